@@ -1,0 +1,133 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's CalSurfG hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
+ * The product library (dsurftomo_amd/csrc) never includes, links or calls it.
+ *
+ * Parity status: PINNED. Every function below is checked bit-for-bit (fp32 fields) against the
+ * reference's own Fortran compiled by oracle/Makefile (target `ref`) -- see
+ * tests/test_oracle_vs_ref.py -- and against the golden vectors in tests/golden/ that were
+ * produced by that build (tests/golden/make_golden.py).
+ *
+ * Conventions: arrays keep the reference's column-major layout, 2-D fields are (nnz, nnx) with
+ * z (longitude) fastest: element (iz, ix), 1-based, lives at [(ix-1)*ld + (iz-1)].
+ */
+#ifndef DSURF_ORACLE_H
+#define DSURF_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* geometry of the propagation grid; CalSurfG.f90:1032-1065 (gd = 8) / :2487-2520 (gd = 5) */
+typedef struct {
+    int nx, ny;            /* velocity-vertex grid incl. the one-vertex rim */
+    int nvx, nvz;          /* nx-2, ny-2 */
+    int gdx, gdz;          /* dicing */
+    int sgdl, sgs;         /* source-grid dicing level, source-grid half extent (both 8) */
+    int nnx, nnz;          /* propagation grid nodes */
+    float goxd, gozd, dvxd, dvzd;
+    float gox, goz, dvx, dvz, dnx, dnz;
+    float earth;
+} dso_grid;
+
+/* refined source box; CalSurfG.f90:1227-1246 */
+typedef struct {
+    int vnl, vnr, vnt, vnb;    /* coarse-node bounds of the box (1-based) */
+    int nnx, nnz;              /* refined node counts */
+    float gox, goz, dnx, dnz;  /* refined origin/spacing */
+} dso_box;
+
+void dso_grid_init(dso_grid *g, int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd);
+
+/* gridder, CalSurfG.f90:1460-1553. pv: nx*ny doubles (lat index fastest); veln: (nnz,nnx) floats */
+void dso_gridder(const dso_grid *g, const double *pv, float *veln);
+
+/* box geometry for a source; returns 0, or -1 if the source is outside the grid (:1209-1246) */
+int dso_source_box(const dso_grid *g, float x, float z, dso_box *b);
+
+/* bsplrefine, CalSurfG.f90:1562-1628. velr: (b->nnz, b->nnx) floats, ld = b->nnz */
+void dso_bsplrefine(const dso_grid *g, const double *pv, const dso_box *b, float *velr);
+
+/* One (period, source) eikonal solve: refined stage + hand-off + coarse stage (:1192-1356).
+ *   veln   in : coarse velocities (nnz,nnx)
+ *   ttn    out: coarse travel times (nnz,nnx)
+ *   ttnr, nstsr out (may be NULL): refined snapshot (b.nnz, b.nnx); nstsr: -1 far, 0 alive, >0 close
+ *   inj_t, inj_s out (may be NULL): coarse field/status right before travel(urg=2)
+ * returns 0 or -1 (source outside) */
+int dso_solve_source(const dso_grid *g, const double *pv, const float *veln, float x, float z,
+                     dso_box *b, float *ttn, float *ttnr, int *nstsr, float *inj_t, int *inj_s);
+
+/* Plain FMM on an arbitrary field (travel with urg=0, CalSurfG.f90:288-487), no source refinement */
+int dso_travel_plain(int nnx, int nnz, float gox, float goz, float dnx, float dnz, float earth,
+                     const float *veln, float x, float z, float *ttn);
+
+/* fouds2 (CalSurfG.f90:587-759) evaluated at one node with an explicit alive mask (alive[.] != 0) */
+float dso_fouds2_masked(int nnx, int nnz, int ld, float gox, float dnx, float dnz, float earth,
+                        const float *veln, const float *ttn, const unsigned char *alive, int iz, int ix);
+
+/* srtimes, CalSurfG.f90:1636-1759; returns 0 or -1 (receiver outside) */
+int dso_srtimes(const dso_grid *g, const float *veln, const float *ttn,
+                float sx, float sz, float rx, float rz, float *t);
+
+/* rpaths, CalSurfG.f90:1771-2318. fdm: (nvz+2, nvx+2) floats column-major (0-based vertex indices),
+ * zeroed here. returns 0, -1 (receiver outside); *rbint set to 1 when a ray is clamped at the edge */
+int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const float *ttn,
+               const float *ttnr, const int *nstsr, float sx, float sz, float rx, float rz,
+               float *fdm, int *rbint, int *nsteps);
+
+/* dispersion side (surfdisp_oracle.c) ------------------------------------------------------- */
+
+/* surfdisp96, surfdisp96.f:52-350. thk/vp/vs/rho: nlayer floats; t: kmax doubles; cg out */
+void dso_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                    int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                    const double *t, double *cg);
+
+/* refineGrid2LayerMdl, CalSurfG.f90:2352-2411 */
+void dso_refine_layers(float minthk0, int mmax, const float *dep, const float *vp, const float *vs,
+                       const float *rho, int *rmax, float *rdep, float *rvp, float *rvs,
+                       float *rrho, float *rthk);
+
+/* caldespersion (:2866-2927): pv (nx*ny, kmax) */
+void dso_caldespersion(int nx, int ny, int nz, const float *vel, double *pv, int iwave, int igr,
+                       int kmax, const double *t, const float *depz, float minthk);
+
+/* depthkernel (:1-169): pv (nx*ny,kmax), sen_* (nx*ny,kmax,nz) */
+void dso_depthkernel(int nx, int ny, int nz, const float *vel, double *pv, double *sen_vs,
+                     double *sen_vp, double *sen_rho, int iwave, int igr, int kmax,
+                     const double *t, const float *depz, float minthk);
+
+/* Whole-boundary restatements with the reference's argument lists (CalSurfG.f90:939-943, :2412-2415).
+ * All arguments by pointer exactly like the Fortran symbols calsurfg_ / synthetic_.
+ * Return 0, or a negative code where the reference would STOP. */
+int dso_calsurfg(const int *nx, const int *ny, const int *nz, const int *nparpi, const float *vels,
+                 int *iw, float *rw, int *col, float *dsurf,
+                 const float *goxdf, const float *gozdf, const float *dvxdf, const float *dvzdf,
+                 const int *kmaxRc, const int *kmaxRg, const int *kmaxLc, const int *kmaxLg,
+                 const double *tRc, const double *tRg, const double *tLc, const double *tLg,
+                 const int *wavetype, const int *igrt, const int *periods, const float *depz,
+                 const float *minthk, const float *scxf, const float *sczf, const float *rcxf,
+                 const float *rczf, const int *nrc1, const int *nsrcsurf1, const int *kmax,
+                 const int *nsrcsurf, const int *nrcf, int *nar);
+
+int dso_synthetic(const int *nx, const int *ny, const int *nz, const int *nparpi, const float *vels,
+                  float *obst,
+                  const float *goxdf, const float *gozdf, const float *dvxdf, const float *dvzdf,
+                  const int *kmaxRc, const int *kmaxRg, const int *kmaxLc, const int *kmaxLg,
+                  const double *tRc, const double *tRg, const double *tLc, const double *tLg,
+                  const int *wavetype, const int *igrt, const int *periods, const float *depz,
+                  const float *minthk, const float *scxf, const float *sczf, const float *rcxf,
+                  const float *rczf, const int *nrc1, const int *nsrcsurf1, const int *kmax,
+                  const int *nsrcsurf, const int *nrcf, const float *noiselevel);
+
+/* Engine-level entry used for parity at synthetic configs: pv maps are given per period slot
+ * (bypasses the dispersion stage), travel times only. pv: (nx*ny, kmax) doubles.
+ * dsurf gets sum(nrc1) values in (knumi, srcnum, istep) order. */
+int dso_traveltimes(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd,
+                    int kmax, int nsrcsurf, int nrcf, const double *pv, const int *nsrcsurf1,
+                    const int *nrc1, const float *scxf, const float *sczf, const float *rcxf,
+                    const float *rczf, float *dsurf, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

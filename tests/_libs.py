@@ -1,0 +1,202 @@
+"""ctypes access to the two checker libraries used by the tests.
+
+  oracle/libdsurf_oracle.so   C restatement (always buildable: gcc)
+  oracle/_ref/libdsurf_ref.so the reference's own Fortran + white-box handles (only where
+                              /root/reference exists, or where a prebuilt copy travelled)
+
+Test infrastructure only: nothing under dsurftomo_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libdsurf_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libdsurf_ref.so")
+REFERENCE_SRC = "/root/reference/src"
+
+f32, f64, i32 = C.c_float, C.c_double, C.c_int
+vp = C.c_void_p
+
+
+class Grid(C.Structure):
+    _fields_ = [(n, i32) for n in ("nx", "ny", "nvx", "nvz", "gdx", "gdz", "sgdl", "sgs", "nnx", "nnz")] + \
+               [(n, f32) for n in ("goxd", "gozd", "dvxd", "dvzd", "gox", "goz", "dvx", "dvz", "dnx", "dnz", "earth")]
+
+
+class Box(C.Structure):
+    _fields_ = [(n, i32) for n in ("vnl", "vnr", "vnt", "vnb", "nnx", "nnz")] + \
+               [(n, f32) for n in ("gox", "goz", "dnx", "dnz")]
+
+
+def ptr(a):
+    return a.ctypes.data_as(vp) if a is not None else None
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
+
+
+def build_oracle():
+    srcs = [os.path.join(ORACLE_DIR, n) for n in ("dsurf_oracle.c", "surfdisp_oracle.c", "dsurf_oracle.h")]
+    if _stale(ORACLE_SO, srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+def build_ref():
+    """Build oracle/_ref from the reference sources when they are present; else use a prebuilt copy."""
+    if os.path.isdir(REFERENCE_SRC):
+        if _stale(REF_SO, [os.path.join(ORACLE_DIR, "ref_whitebox.f90")]):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+    return REF_SO if os.path.exists(REF_SO) else None
+
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        L = C.CDLL(build_oracle())
+        L.dso_grid_init.argtypes = [C.POINTER(Grid), i32, i32, f32, f32, f32, f32, i32]
+        L.dso_gridder.argtypes = [C.POINTER(Grid), vp, vp]
+        L.dso_source_box.argtypes = [C.POINTER(Grid), f32, f32, C.POINTER(Box)]
+        L.dso_bsplrefine.argtypes = [C.POINTER(Grid), vp, C.POINTER(Box), vp]
+        L.dso_solve_source.argtypes = [C.POINTER(Grid), vp, vp, f32, f32, C.POINTER(Box), vp, vp, vp, vp, vp]
+        L.dso_travel_plain.argtypes = [i32, i32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
+        L.dso_fouds2_masked.argtypes = [i32, i32, i32, f32, f32, f32, f32, vp, vp, vp, i32, i32]
+        L.dso_fouds2_masked.restype = f32
+        L.dso_srtimes.argtypes = [C.POINTER(Grid), vp, vp, f32, f32, f32, f32, C.POINTER(f32)]
+        L.dso_rpaths.argtypes = [C.POINTER(Grid), C.POINTER(Box), vp, vp, vp, vp, f32, f32, f32, f32, vp,
+                                 C.POINTER(i32), C.POINTER(i32)]
+        _oracle = L
+    return _oracle
+
+
+def ref():
+    """The reference library, or None when it is neither buildable nor prebuilt here."""
+    global _ref
+    if _ref is None:
+        so = build_ref()
+        if so is None:
+            return None
+        L = C.CDLL(so)
+        L.ref_wb_init.argtypes = [i32, i32, f32, f32, f32, f32, i32]
+        L.ref_wb_solve.argtypes = [f32, f32]
+        L.ref_wb_srtimes.argtypes = [f32] * 4
+        L.ref_wb_srtimes.restype = f32
+        L.ref_wb_rpaths.argtypes = [f32, f32, f32, f32, vp]
+        L.ref_wb_rbint.restype = i32
+        _ref = L
+    return _ref
+
+
+# ---------------------------------------------------------------------------------------------
+# convenience wrappers (numpy in / numpy out). 2-D fields come back as arrays indexed [ix, iz].
+
+def grid(nx, ny, goxd, gozd, dvxd, dvzd, gd=8):
+    g = Grid()
+    oracle().dso_grid_init(C.byref(g), nx, ny, goxd, gozd, dvxd, dvzd, gd)
+    return g
+
+
+def o_gridder(g, pv):
+    pv = np.ascontiguousarray(pv, np.float64)
+    veln = np.zeros((g.nnx, g.nnz), np.float32)
+    oracle().dso_gridder(C.byref(g), ptr(pv), ptr(veln))
+    return veln
+
+
+def o_solve(g, pv, veln, x, z):
+    pv = np.ascontiguousarray(pv, np.float64)
+    b = Box()
+    T = np.zeros((g.nnx, g.nnz), np.float32)
+    Tr = np.zeros(129 * 129, np.float32)
+    Sr = np.zeros(129 * 129, np.int32)
+    it = np.zeros((g.nnx, g.nnz), np.float32)
+    is_ = np.zeros((g.nnx, g.nnz), np.int32)
+    rc = oracle().dso_solve_source(C.byref(g), ptr(pv), ptr(veln), x, z, C.byref(b), ptr(T), ptr(Tr), ptr(Sr),
+                                   ptr(it), ptr(is_))
+    if rc != 0:
+        raise ValueError("source outside grid")
+    n = b.nnx * b.nnz
+    return dict(box=b, T=T, Tr=Tr[:n].reshape(b.nnx, b.nnz).copy(), Sr=Sr[:n].reshape(b.nnx, b.nnz).copy(),
+                inj_t=it, inj_s=is_)
+
+
+def o_srtimes(g, veln, T, sx, sz, rx, rz):
+    t = f32()
+    rc = oracle().dso_srtimes(C.byref(g), ptr(veln), ptr(T), sx, sz, rx, rz, C.byref(t))
+    if rc != 0:
+        raise ValueError("receiver outside grid")
+    return np.float32(t.value)
+
+
+def o_rpaths(g, sol, veln, sx, sz, rx, rz):
+    fdm = np.zeros((g.nvx + 2, g.nvz + 2), np.float32)
+    rb, ns = i32(0), i32(0)
+    Tr = np.ascontiguousarray(sol["Tr"])
+    Sr = np.ascontiguousarray(sol["Sr"])
+    rc = oracle().dso_rpaths(C.byref(g), C.byref(sol["box"]), ptr(veln), ptr(sol["T"]), ptr(Tr), ptr(Sr),
+                             sx, sz, rx, rz, ptr(fdm), C.byref(rb), C.byref(ns))
+    if rc != 0:
+        raise ValueError("receiver outside grid")
+    return fdm, rb.value, ns.value
+
+
+class RefWB:
+    """White-box session on the reference library (module-global state: one at a time)."""
+
+    def __init__(self, nx, ny, goxd, gozd, dvxd, dvzd, gd=8):
+        self.L = ref()
+        assert self.L is not None
+        self.L.ref_wb_init(nx, ny, goxd, gozd, dvxd, dvzd, gd)
+        nnx, nnz = i32(), i32()
+        a = [f32() for _ in range(4)]
+        self.L.ref_wb_dims(C.byref(nnx), C.byref(nnz), *[C.byref(v) for v in a])
+        self.nnx, self.nnz = nnx.value, nnz.value
+        self.gox, self.goz, self.dnx, self.dnz = [np.float32(v.value) for v in a]
+        self.nvx, self.nvz = nx - 2, ny - 2
+
+    def gridder(self, pv):
+        pv = np.ascontiguousarray(pv, np.float64)
+        self.L.ref_wb_gridder(ptr(pv))
+        out = np.zeros((self.nnx, self.nnz), np.float32)
+        self.L.ref_wb_get_veln(ptr(out))
+        return out
+
+    def solve(self, x, z):
+        self.L.ref_wb_solve(x, z)
+        T = np.zeros((self.nnx, self.nnz), np.float32)
+        self.L.ref_wb_get_ttn(ptr(T))
+        it = np.zeros((self.nnx, self.nnz), np.float32)
+        is_ = np.zeros((self.nnx, self.nnz), np.int32)
+        self.L.ref_wb_get_injected(ptr(it), ptr(is_))
+        rnx, rnz = i32(), i32()
+        a = [f32() for _ in range(4)]
+        bnd = [i32() for _ in range(4)]
+        self.L.ref_wb_refined_dims(C.byref(rnx), C.byref(rnz), *[C.byref(v) for v in a], *[C.byref(v) for v in bnd])
+        Tr = np.zeros((rnx.value, rnz.value), np.float32)
+        Sr = np.zeros((rnx.value, rnz.value), np.int32)
+        self.L.ref_wb_get_refined(ptr(Tr), ptr(Sr))
+        return dict(T=T, Tr=Tr, Sr=Sr, inj_t=it, inj_s=is_, rdims=(rnx.value, rnz.value),
+                    rgeom=[np.float32(v.value) for v in a], bounds=[v.value for v in bnd])
+
+    def srtimes(self, sx, sz, rx, rz):
+        return np.float32(self.L.ref_wb_srtimes(sx, sz, rx, rz))
+
+    def rpaths(self, sx, sz, rx, rz):
+        fdm = np.zeros((self.nvx + 2, self.nvz + 2), np.float32)
+        self.L.ref_wb_rpaths(sx, sz, rx, rz, ptr(fdm))
+        return fdm
+
+    def close(self):
+        self.L.ref_wb_release()
