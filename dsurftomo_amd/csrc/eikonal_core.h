@@ -1,0 +1,389 @@
+// Per-node eikonal arithmetic shared by every kernel of the CalSurfG path.
+//
+// Everything in here is a pure function on values (no global state), written once for device
+// code; the same header compiles for the host so that tests can drive the serial/per-node logic
+// on a CPU and compare it with the oracle (tests/hostcheck.cpp).  The product never runs it on
+// the host.
+//
+// Arithmetic contract: fp32, one rounding per operation, NO fused multiply-add (build with
+// -ffp-contract=off), IEEE divide and sqrt.  Expression order follows the reference's upwind
+// stencil `fouds2` (reference CalSurfG.f90:612-758) term by term, because the travel-time field
+// has to land on the reference's Fast-Marching answer to <= 1e-4 s and one ulp at T ~ 100 s is
+// already 8e-6 s.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DSA_HD __host__ __device__ __forceinline__
+#else
+#define DSA_HD static inline
+#endif
+
+namespace dsa {
+
+constexpr float kInf = __builtin_inff();
+
+// Travel times are non-negative, so the sign bit of a stored T is free: a set sign bit marks a
+// node that is "alive from the start" (accepted by the serial prologue, never recomputed).
+DSA_HD bool t_pinned(float t) { return __builtin_signbit(t); }
+DSA_HD float t_value(float t) { return __builtin_fabsf(t); }
+
+// Geometry of one node column (depends on ix only); reference CalSurfG.f90:613-615.
+struct NodeGeom {
+    float ri;     // earth radius
+    float risti;  // ri * sin(theta_ix), supplied by a host-computed table (device sinf != libm sinf)
+    float dnx;    // node spacing in colatitude (radians)
+    float dnz;    // node spacing in longitude (radians)
+};
+
+// The 9-point upwind neighbourhood of a node. Index 0 = lower index (ix-1 / iz-1), 1 = higher.
+struct Stencil {
+    float tj[2], tj2[2];  // x neighbours (iz, ix-+1) and their outer neighbours (iz, ix-+2)
+    float tk[2], tk2[2];  // z neighbours (iz-+1, ix) and outer (iz-+2, ix)
+    bool ej[2], ek[2];    // neighbour lies inside the grid
+    bool aj[2], ak[2];    // neighbour is alive
+    bool oj[2], ok[2];    // outer neighbour is alive (and inside the grid)
+};
+
+DSA_HD float sq(float x) { return x * x; }
+
+// One evaluation of the mixed first/second-order upwind update; returns +inf when no quadrant
+// has an alive neighbour.  Quadrant order and the running minimum follow CalSurfG.f90:616-757;
+// a quadrant whose j or k neighbour lies outside the grid is skipped entirely (not "not alive").
+DSA_HD float fouds2(const Stencil& s, float slown, const NodeGeom& g)
+{
+    bool have = false;
+    float travm = kInf;
+    const float ri = g.ri, risti = g.risti, dnx = g.dnx, dnz = g.dnz;
+    for (int j = 0; j < 2; ++j) {
+        if (!s.ej[j]) continue;
+        const bool swj = s.aj[j] && s.oj[j] && (s.tj[j] > s.tj2[j]);
+        for (int k = 0; k < 2; ++k) {
+            if (!s.ek[k]) continue;
+            const bool swk = s.ak[k] && s.ok[k] && (s.tk[k] > s.tk2[k]);
+            float a, b, c, tref, tdiv;
+            bool sol = true;
+            if (swj) {
+                if (swk) {
+                    const float u = 2.0f * ri * dnx;
+                    const float v = 2.0f * risti * dnz;
+                    float em = 4.0f * s.tj[j] - s.tj2[j] - 4.0f * s.tk[k];
+                    em = em + s.tk2[k];
+                    a = sq(v) + sq(u);
+                    b = 2.0f * em * sq(u);
+                    c = sq(u) * (sq(em) - sq(slown) * sq(v));
+                    tref = 4.0f * s.tj[j] - s.tj2[j];
+                    tdiv = 3.0f;
+                } else if (s.ak[k]) {
+                    const float u = risti * dnz;
+                    const float v = 2.0f * ri * dnx;
+                    const float em = 3.0f * s.tk[k] - 4.0f * s.tj[j] + s.tj2[j];
+                    a = sq(v) + 9.0f * sq(u);
+                    b = 6.0f * em * sq(u);
+                    c = sq(u) * (sq(em) - sq(slown) * sq(v));
+                    tref = s.tk[k];
+                    tdiv = 1.0f;
+                } else {
+                    const float u = 2.0f * ri * dnx;
+                    a = 1.0f;
+                    b = 0.0f;
+                    c = -(sq(u) * sq(slown));
+                    tref = 4.0f * s.tj[j] - s.tj2[j];
+                    tdiv = 3.0f;
+                }
+            } else if (s.aj[j]) {
+                if (swk) {
+                    const float u = ri * dnx;
+                    const float v = 2.0f * risti * dnz;
+                    const float em = 3.0f * s.tj[j] - 4.0f * s.tk[k] + s.tk2[k];
+                    a = sq(v) + 9.0f * sq(u);
+                    b = 6.0f * em * sq(u);
+                    c = sq(u) * (sq(em) - sq(v) * sq(slown));
+                    tref = s.tj[j];
+                    tdiv = 1.0f;
+                } else if (s.ak[k]) {
+                    const float u = ri * dnx;
+                    const float v = risti * dnz;
+                    const float em = s.tk[k] - s.tj[j];
+                    a = sq(u) + sq(v);
+                    b = -(2.0f * sq(u) * em);
+                    c = sq(u) * (sq(em) - sq(v) * sq(slown));
+                    tref = s.tj[j];
+                    tdiv = 1.0f;
+                } else {
+                    a = 1.0f;
+                    b = 0.0f;
+                    c = -(sq(slown) * sq(ri) * sq(dnx));
+                    tref = s.tj[j];
+                    tdiv = 1.0f;
+                }
+            } else {
+                if (swk) {
+                    const float u = 2.0f * risti * dnz;
+                    a = 1.0f;
+                    b = 0.0f;
+                    c = -(sq(u) * sq(slown));
+                    tref = 4.0f * s.tk[k] - s.tk2[k];
+                    tdiv = 3.0f;
+                } else if (s.ak[k]) {
+                    a = 1.0f;
+                    b = 0.0f;
+                    c = -(sq(slown) * sq(risti) * sq(dnz));
+                    tref = s.tk[k];
+                    tdiv = 1.0f;
+                } else {
+                    sol = false;
+                    a = 1.0f; b = 0.0f; c = 0.0f; tref = 0.0f; tdiv = 1.0f;
+                }
+            }
+            if (sol) {
+                float rd1 = sq(b) - 4.0f * a * c;
+                if (rd1 < 0.0f) rd1 = 0.0f;
+                const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+                const float trav = (tref + tdsh) / tdiv;
+                if (have) travm = (trav < travm) ? trav : travm;
+                else { travm = trav; have = true; }
+            }
+        }
+    }
+    return travm;
+}
+
+// Raw neighbourhood of a node as stored in a travel-time field (sign bit = pinned, +inf = not
+// reached). Order: [0]=x-, [1]=x+, [2]=z-, [3]=z+; `outer` are the nodes two steps away.
+struct Hood {
+    float near_[4];
+    float outer[4];
+    bool in[4];       // near neighbour inside the grid
+    bool in_outer[4]; // outer neighbour inside the grid
+};
+
+// Local solver H: the value Fast Marching would have *accepted* at this node, as a pure function
+// of the neighbours' times.  FMM recomputes a trial value each time a neighbour is accepted and
+// freezes it when the node itself is popped, i.e. when its trial value is no later than the next
+// neighbour's time.  So: neighbours that are pinned are alive from the start; the others are
+// taken in order of increasing time, and the walk stops at the first trial value c with
+// c <= T(next neighbour).  An outer node counts as alive when it is pinned or was accepted
+// before the neighbour most recently added ("now").  Ties stop the walk (c <= T): the reference's
+// own tie order depends on its heap layout and cannot be derived locally ("ties").
+DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g)
+{
+    Stencil s;
+    float tn[4];
+    bool pin[4];
+    int order[4];
+    int no = 0;
+    bool any_alive = false;
+    for (int q = 0; q < 4; ++q) {
+        const bool in = h.in[q];
+        const float raw = in ? h.near_[q] : kInf;
+        tn[q] = t_value(raw);
+        pin[q] = in && t_pinned(raw);
+        if (pin[q]) any_alive = true;
+        else if (in && tn[q] < kInf) order[no++] = q;
+    }
+    // insertion sort of at most 4 candidates by time
+    for (int i = 1; i < no; ++i) {
+        const int q = order[i];
+        int j = i;
+        while (j > 0 && tn[order[j - 1]] > tn[q]) { order[j] = order[j - 1]; --j; }
+        order[j] = q;
+    }
+    bool alive[4] = { pin[0], pin[1], pin[2], pin[3] };
+    float tnow = -kInf;
+
+    auto fill = [&](void) {
+        for (int d = 0; d < 2; ++d) {
+            s.tj[d] = tn[d];           s.tk[d] = tn[2 + d];
+            s.ej[d] = h.in[d];         s.ek[d] = h.in[2 + d];
+            s.aj[d] = alive[d];        s.ak[d] = alive[2 + d];
+            const float oxr = h.in_outer[d] ? h.outer[d] : kInf;
+            const float ozr = h.in_outer[2 + d] ? h.outer[2 + d] : kInf;
+            s.tj2[d] = t_value(oxr);   s.tk2[d] = t_value(ozr);
+            s.oj[d] = h.in_outer[d] && (t_pinned(oxr) || t_value(oxr) < tnow);
+            s.ok[d] = h.in_outer[2 + d] && (t_pinned(ozr) || t_value(ozr) < tnow);
+        }
+    };
+
+    float c = kInf;
+    if (any_alive) { fill(); c = fouds2(s, slown, g); }
+    for (int i = 0; i < no; ++i) {
+        const int q = order[i];
+        if (c <= tn[q]) break;
+        alive[q] = true;
+        tnow = tn[q];
+        fill();
+        c = fouds2(s, slown, g);
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Serial narrow-band march used only for the few dozen accept steps around a source where the
+// reference's behaviour depends on its heap (source-cell start-up and the refined->coarse band;
+// reference CalSurfG.f90:288-487 with the tree of :768-921, whose update step only ever moves an
+// entry towards the root).  One lane runs it per source; all state lives in caller-provided
+// arrays.  `status`: -1 far, 0 alive, >0 slot in the tree.
+// ---------------------------------------------------------------------------------------------
+struct MarchView {
+    float* T;             // travel times, (ldT, *) column-major, indexed by full-grid (iz, ix), 1-based
+    int ldT;
+    const float* slow;    // slowness, same indexing
+    int ldS;
+    const float* risti;   // per-ix table, 1-based index ix -> risti[ix-1]
+    int16_t* status;      // window-local status, (wnz, wnx) column-major
+    int wz0, wx0;         // full-grid index of window element (1,1) minus 1
+    int wnz, wnx;         // window extent
+    int nnz, nnx;         // full grid extent
+    float ri, dnx, dnz;
+    int32_t* heap;        // packed (iz << 16 | ix), 1-based slots, capacity `cap`
+    int cap;
+    int ntr;
+    int error;            // 1: window overflow, 2: tree overflow
+};
+
+DSA_HD float& mv_T(MarchView& m, int iz, int ix) { return m.T[(size_t)(ix - 1) * (size_t)m.ldT + (size_t)(iz - 1)]; }
+DSA_HD float mv_slow(const MarchView& m, int iz, int ix) { return m.slow[(size_t)(ix - 1) * (size_t)m.ldS + (size_t)(iz - 1)]; }
+DSA_HD bool mv_inwin(const MarchView& m, int iz, int ix)
+{
+    return iz > m.wz0 && iz <= m.wz0 + m.wnz && ix > m.wx0 && ix <= m.wx0 + m.wnx;
+}
+// status of a node; nodes outside the window but inside the grid read as far (and raise the
+// overflow error if the march ever needs to write them)
+DSA_HD int mv_get(const MarchView& m, int iz, int ix)
+{
+    if (!mv_inwin(m, iz, ix)) return -1;
+    return m.status[(size_t)(ix - 1 - m.wx0) * (size_t)m.wnz + (size_t)(iz - 1 - m.wz0)];
+}
+DSA_HD void mv_set(MarchView& m, int iz, int ix, int v)
+{
+    if (!mv_inwin(m, iz, ix)) { m.error = 1; return; }
+    m.status[(size_t)(ix - 1 - m.wx0) * (size_t)m.wnz + (size_t)(iz - 1 - m.wz0)] = (int16_t)v;
+}
+DSA_HD int hp_iz(int32_t p) { return p >> 16; }
+DSA_HD int hp_ix(int32_t p) { return p & 0xffff; }
+DSA_HD float mv_key(MarchView& m, int slot) { return mv_T(m, hp_iz(m.heap[slot]), hp_ix(m.heap[slot])); }
+
+DSA_HD void mv_sift_up(MarchView& m, int iz, int ix, int tpc)
+{
+    int tpp = tpc / 2;
+    while (tpp > 0) {
+        if (mv_T(m, iz, ix) < mv_key(m, tpp)) {
+            mv_set(m, iz, ix, tpp);
+            mv_set(m, hp_iz(m.heap[tpp]), hp_ix(m.heap[tpp]), tpc);
+            const int32_t e = m.heap[tpc]; m.heap[tpc] = m.heap[tpp]; m.heap[tpp] = e;
+            tpc = tpp;
+            tpp = tpc / 2;
+        } else tpp = 0;
+    }
+}
+DSA_HD void mv_add(MarchView& m, int iz, int ix)
+{
+    if (m.ntr + 1 >= m.cap) { m.error = 2; return; }
+    m.ntr += 1;
+    mv_set(m, iz, ix, m.ntr);
+    m.heap[m.ntr] = (iz << 16) | ix;
+    mv_sift_up(m, iz, ix, m.ntr);
+}
+DSA_HD void mv_pop_root(MarchView& m)
+{
+    if (m.ntr == 1) { m.ntr = 0; return; }
+    mv_set(m, hp_iz(m.heap[m.ntr]), hp_ix(m.heap[m.ntr]), 1);
+    m.heap[1] = m.heap[m.ntr];
+    m.ntr -= 1;
+    int tpp = 1, tpc = 2;
+    while (tpc < m.ntr) {
+        if (mv_key(m, tpc) > mv_key(m, tpc + 1)) tpc += 1;
+        if (mv_key(m, tpc) < mv_key(m, tpp)) {
+            mv_set(m, hp_iz(m.heap[tpp]), hp_ix(m.heap[tpp]), tpc);
+            mv_set(m, hp_iz(m.heap[tpc]), hp_ix(m.heap[tpc]), tpp);
+            const int32_t e = m.heap[tpc]; m.heap[tpc] = m.heap[tpp]; m.heap[tpp] = e;
+            tpp = tpc;
+            tpc = 2 * tpp;
+        } else tpc = m.ntr + 1;
+    }
+    if (tpc == m.ntr) {
+        if (mv_key(m, tpc) < mv_key(m, tpp)) {
+            mv_set(m, hp_iz(m.heap[tpp]), hp_ix(m.heap[tpp]), tpc);
+            mv_set(m, hp_iz(m.heap[tpc]), hp_ix(m.heap[tpc]), tpp);
+            const int32_t e = m.heap[tpc]; m.heap[tpc] = m.heap[tpp]; m.heap[tpp] = e;
+        }
+    }
+}
+
+// trial value at (iz, ix) from the march's own alive set (status == 0)
+DSA_HD float mv_trial(MarchView& m, int iz, int ix)
+{
+    Stencil s;
+    const int jx[2] = { ix - 1, ix + 1 }, jx2[2] = { ix - 2, ix + 2 };
+    const int kz[2] = { iz - 1, iz + 1 }, kz2[2] = { iz - 2, iz + 2 };
+    for (int d = 0; d < 2; ++d) {
+        s.ej[d] = jx[d] >= 1 && jx[d] <= m.nnx;
+        s.aj[d] = s.ej[d] && mv_get(m, iz, jx[d]) == 0;
+        s.tj[d] = s.aj[d] ? mv_T(m, iz, jx[d]) : kInf;
+        const bool o = jx2[d] >= 1 && jx2[d] <= m.nnx && mv_get(m, iz, jx2[d]) == 0;
+        s.oj[d] = o;
+        s.tj2[d] = o ? mv_T(m, iz, jx2[d]) : kInf;
+        s.ek[d] = kz[d] >= 1 && kz[d] <= m.nnz;
+        s.ak[d] = s.ek[d] && mv_get(m, kz[d], ix) == 0;
+        s.tk[d] = s.ak[d] ? mv_T(m, kz[d], ix) : kInf;
+        const bool p = kz2[d] >= 1 && kz2[d] <= m.nnz && mv_get(m, kz2[d], ix) == 0;
+        s.ok[d] = p;
+        s.tk2[d] = p ? mv_T(m, kz2[d], ix) : kInf;
+    }
+    NodeGeom g = { m.ri, m.risti[ix - 1], m.dnx, m.dnz };
+    return fouds2(s, mv_slow(m, iz, ix), g);
+}
+
+// accept the root and update its four neighbours; returns false on error
+DSA_HD bool mv_accept_root(MarchView& m)
+{
+    const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
+    mv_set(m, iz, ix, 0);
+    mv_pop_root(m);
+    for (int i = ix - 1; i <= ix + 1; i += 2) {
+        if (i < 1 || i > m.nnx) continue;
+        const int st = mv_get(m, iz, i);
+        if (st == -1) {
+            if (!mv_inwin(m, iz, i)) { m.error = 1; return false; }
+            mv_T(m, iz, i) = mv_trial(m, iz, i); mv_add(m, iz, i);
+        } else if (st > 0) { mv_T(m, iz, i) = mv_trial(m, iz, i); mv_sift_up(m, iz, i, st); }
+    }
+    for (int i = iz - 1; i <= iz + 1; i += 2) {
+        if (i < 1 || i > m.nnz) continue;
+        const int st = mv_get(m, i, ix);
+        if (st == -1) {
+            if (!mv_inwin(m, i, ix)) { m.error = 1; return false; }
+            mv_T(m, i, ix) = mv_trial(m, i, ix); mv_add(m, i, ix);
+        } else if (st > 0) { mv_T(m, i, ix) = mv_trial(m, i, ix); mv_sift_up(m, i, ix, st); }
+    }
+    return m.error == 0;
+}
+
+// bilinear weight sum of reference CalSurfG.f90:2328-2349; nv[i][j]: i = x offset, j = z offset
+DSA_HD float bilinear4(const float nv[2][2], float dnx, float dnz, float dsx, float dsz)
+{
+    float biv = 0.0f;
+    for (int i = 1; i <= 2; ++i)
+        for (int j = 1; j <= 2; ++j) {
+            const float produ = (1.0f - fabsf(((float)(i - 1) * dnx - dsx) / dnx)) *
+                                (1.0f - fabsf(((float)(j - 1) * dnz - dsz) / dnz));
+            biv = biv + nv[i - 1][j - 1] * produ;
+        }
+    return biv;
+}
+
+// cubic B-spline basis, reference CalSurfG.f90:1509-1512
+DSA_HD void bspline4(float u, float w[4])
+{
+    const float u2 = u * u, u3 = u * (u * u);
+    const float m = 1.0f - u;
+    w[0] = (m * (m * m)) / 6.0f;
+    w[1] = (4.0f - 6.0f * u2 + 3.0f * u3) / 6.0f;
+    w[2] = (1.0f + 3.0f * u + 3.0f * u2 - 3.0f * u3) / 6.0f;
+    w[3] = u3 / 6.0f;
+}
+
+}  // namespace dsa

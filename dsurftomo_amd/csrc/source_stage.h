@@ -1,0 +1,263 @@
+// Per-source stages around the two fixed-point solves of one (period, source) unit:
+//
+//   refine velocities in the source box -> start-up march (serial, a few accepts)
+//     -> fixed point on the refined box -> hand-off (first open-edge arrival, alive/close/far,
+//        trial values, every 8th node onto the coarse grid, band promotion)
+//     -> band march on the coarse grid (serial, a few dozen accepts) -> fixed point on the coarse grid
+//
+// It mirrors what the reference does inline per source (CalSurfG.f90:1192-1356) including the
+// behaviours that are load-bearing for parity: source-cell start values in radians (:369-375),
+// the literal open-edge test that compares coarse box bounds with refined extents (:396-407 with
+// :1241-1242), injection of status and value for status >= 0 (:1293-1303) and promotion of alive
+// nodes that touch a far node (:1332-1349).
+//
+// Functions are __host__ __device__ so tests can run them on a CPU; kernels only wrap them.
+#pragma once
+
+#include "eikonal_core.h"
+
+namespace dsa {
+
+constexpr int kSgdl = 8;        // source-grid dicing level (reference sgdl)
+constexpr int kSgs = 8;         // source-grid half extent in coarse nodes (reference sgs)
+constexpr int kRefMax = 129;    // (2*sgs)*sgdl + 1
+constexpr int kRWin = 32;       // status window (nodes) of the refined start-up march
+constexpr int kCMargin = 24;    // margin (coarse nodes) of the coarse band-march window around the box
+constexpr int kCWinMax = 2 * kSgs + 1 + 2 * kCMargin;  // 65
+constexpr int kHeapCap = 1024;
+
+// coarse propagation grid of one call (shared by all periods)
+struct GridDesc {
+    int nx, ny, nvx, nvz, gdx, gdz;
+    int nnx, nnz;
+    float gox, goz, dvx, dvz, dnx, dnz, earth;
+    int nbx, nbz;          // 8x8-node blocks per side
+};
+
+// one (period slot, source); everything here is exact fp32/int arithmetic done once on the host
+struct SourceDesc {
+    float scx, scz;
+    int period;                   // index of the velocity map
+    int vnl, vnr, vnt, vnb;       // refined box in coarse node indices (1-based)
+    int rnx, rnz;                 // refined node counts
+    float rgox, rgoz, rdnx, rdnz; // refined origin / spacing
+    int isx_r, isz_r;             // source cell in the refined grid
+    float dsx_r, dsz_r;           // source offset inside that cell
+    int open_xlo, open_xhi, open_zlo, open_zhi;  // literal open-edge flags of the refined stage
+    int rwz0, rwx0;               // refined march window origin (0-based offset of element (1,1))
+    int cwz0, cwx0, cwnz, cwnx;   // coarse march window
+    int nbx_r, nbz_r;             // 8x8 blocks of the refined grid
+    int first_ray, nrec;          // receivers of this source: rays [first_ray, first_ray+nrec)
+};
+
+// per-source scratch in device memory (all sources of a batch laid out back to back)
+struct SourceScratch {
+    float* slow_r;      // kRefMax*kRefMax, ld = rnz
+    float* T_r;         // same; during the refined solve: sign bit = pinned, +inf = not reached
+    int8_t* S_r;        // final refined status: -1 far, 0 alive, 1 close (kept for the ray tracer)
+    float* risti_r;     // kRefMax
+    float* vcorner;     // 4 refined velocities of the source cell, [i][j] i = x offset
+    int16_t* rst;       // kRWin*kRWin status window of the start-up march
+    int16_t* cst;       // kCWinMax*kCWinMax status window of the band march
+    int8_t* cinit;      // same extent: node was in the tree when the band march started
+    int32_t* heap;      // kHeapCap
+    int32_t* flags;     // [0] refined stage ended inside the start-up march, [1] error code
+};
+
+// ---------------------------------------------------------------------------------------------
+// refined velocity at refined node (k, l) = (z, x) 1-based of the box; reference bsplrefine
+// (CalSurfG.f90:1596-1623). velv: (ny, nx) vertex values as fp32, velv(i,j) = velv[i*nx + j].
+// ub/vb: 65x4 basis tables (u = (l-1)/64).
+DSA_HD float refined_velocity(const GridDesc& g, const SourceDesc& s, const float* velv,
+                              const float* basis, int kz, int lx)
+{
+    const int nr = g.gdx * kSgdl;                 // refined nodes per vertex cell (gdx == gdz)
+    const int gz = (s.vnt - 1) * kSgdl + kz;      // global refined index, 1-based
+    const int gx = (s.vnl - 1) * kSgdl + lx;
+    int ci = (gz - 1) / nr + 1, k = (gz - 1) % nr + 1;    // vertex cell i (1..nvz-1), in-cell index
+    int cj = (gx - 1) / nr + 1, l = (gx - 1) % nr + 1;
+    if (ci > g.nvz - 1) { ci = g.nvz - 1; k = nr + 1; }   // last node belongs to the last cell
+    if (cj > g.nvx - 1) { cj = g.nvx - 1; l = nr + 1; }
+    const float* ub = basis + 4 * (l - 1);
+    const float* vb = basis + 4 * (k - 1);
+    float sum[4];
+    for (int i1 = 1; i1 <= 4; ++i1) {
+        float acc = 0.0f;
+        for (int j1 = 1; j1 <= 4; ++j1)
+            acc = acc + ub[j1 - 1] * velv[(ci - 2 + i1) * g.nx + (cj - 2 + j1)];
+        sum[i1 - 1] = vb[i1 - 1] * acc;
+    }
+    return sum[0] + sum[1] + sum[2] + sum[3];
+}
+
+// coarse velocity at node (iz, ix); reference gridder (CalSurfG.f90:1526-1548)
+DSA_HD float coarse_velocity(const GridDesc& g, const float* velv, const float* basis, int iz, int ix)
+{
+    int ci = (iz - 1) / g.gdz + 1, l = (iz - 1) % g.gdz + 1;
+    int cj = (ix - 1) / g.gdx + 1, m = (ix - 1) % g.gdx + 1;
+    if (ci > g.nvz - 1) { ci = g.nvz - 1; l = g.gdz + 1; }
+    if (cj > g.nvx - 1) { cj = g.nvx - 1; m = g.gdx + 1; }
+    const float* ui = basis + 4 * (m - 1);
+    const float* vi = basis + 4 * (l - 1);
+    float sumi = 0.0f;
+    for (int i1 = 1; i1 <= 4; ++i1) {
+        float sumj = 0.0f;
+        for (int j1 = 1; j1 <= 4; ++j1)
+            sumj = sumj + ui[j1 - 1] * velv[(ci - 2 + i1) * g.nx + (cj - 2 + j1)];
+        sumi = sumi + vi[i1 - 1] * sumj;
+    }
+    return sumi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Start-up march on the refined grid: travel(urg=1) from its beginning until the four corners of
+// the source cell are alive (then the regular fixed-point solve takes over), or until the
+// reference's own exit fires.  Returns 1 if the refined stage is finished (exit fired / tree
+// empty), 0 for hand-over.  On return T_r holds plain values where status >= 0.
+DSA_HD int refined_startup(const GridDesc& g, const SourceDesc& s, SourceScratch& w)
+{
+    MarchView m;
+    m.T = w.T_r; m.ldT = s.rnz; m.slow = w.slow_r; m.ldS = s.rnz; m.risti = w.risti_r;
+    m.status = w.rst; m.wz0 = s.rwz0; m.wx0 = s.rwx0; m.wnz = kRWin; m.wnx = kRWin;
+    m.nnz = s.rnz; m.nnx = s.rnx; m.ri = g.earth; m.dnx = s.rdnx; m.dnz = s.rdnz;
+    m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0;
+    for (int q = 0; q < kRWin * kRWin; ++q) w.rst[q] = -1;
+    const int isx = s.isx_r, isz = s.isz_r;
+    float vss[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) vss[i][j] = w.vcorner[i * 2 + j];
+    const float vsrc = bilinear4(vss, s.rdnx, s.rdnz, s.dsx_r, s.dsz_r);
+    for (int i = 1; i <= 2; ++i)
+        for (int j = 1; j <= 2; ++j) {
+            // distances in radians, as the reference has them
+            const float ds = sqrtf(sq(s.dsx_r - (float)(i - 1) * s.rdnx) + sq(s.dsz_r - (float)(j - 1) * s.rdnz));
+            mv_T(m, isz - 1 + j, isx - 1 + i) = 2.0f * ds / (vss[i - 1][j - 1] + vsrc);
+            mv_add(m, isz - 1 + j, isx - 1 + i);
+        }
+    int ended = 1;
+    while (m.ntr > 0 && m.error == 0) {
+        if (mv_get(m, isz, isx) == 0 && mv_get(m, isz + 1, isx) == 0 && mv_get(m, isz, isx + 1) == 0 &&
+            mv_get(m, isz + 1, isx + 1) == 0) { ended = 0; break; }
+        const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
+        bool out = false;
+        if (ix == 1 && s.open_xlo) out = true;
+        if (ix == s.rnx && s.open_xhi) out = true;
+        if (iz == 1 && s.open_zlo) out = true;
+        if (iz == s.rnz && s.open_zhi) out = true;
+        if (out) { mv_set(m, iz, ix, 0); break; }
+        if (!mv_accept_root(m)) break;
+    }
+    w.flags[0] = ended;
+    if (m.error) w.flags[1] = m.error;
+    return ended;
+}
+
+// After the start-up march: encode the march state into the refined field for the fixed-point
+// solve (alive -> pinned sign bit; everything else +inf unless the stage already ended, in which
+// case close nodes keep their trial value).  Serial over the small window.
+DSA_HD void refined_encode(const SourceDesc& s, SourceScratch& w, int ended)
+{
+    for (int lx = 0; lx < kRWin; ++lx)
+        for (int lz = 0; lz < kRWin; ++lz) {
+            const int ix = s.rwx0 + lx + 1, iz = s.rwz0 + lz + 1;
+            if (ix < 1 || ix > s.rnx || iz < 1 || iz > s.rnz) continue;
+            const int st = w.rst[lx * kRWin + lz];
+            float& t = w.T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)];
+            if (st == 0) t = -t;                 // -0.0f for an exact zero keeps the sign bit
+            else if (st > 0 && ended) { /* keep trial value */ }
+            else t = kInf;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hand-off, per refined node, after the fixed point on the box (or after an early end).
+// tstar: first arrival on an open edge; (ez, ex): the node that carried it (0 if none).
+DSA_HD bool is_open_edge(const SourceDesc& s, int iz, int ix)
+{
+    return (ix == 1 && s.open_xlo) || (ix == s.rnx && s.open_xhi) || (iz == 1 && s.open_zlo) ||
+           (iz == s.rnz && s.open_zhi);
+}
+
+DSA_HD bool ref_alive(const SourceDesc& s, const float* T_r, float tstar, int iz, int ix)
+{
+    const float t = T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)];
+    return t_pinned(t) || t_value(t) < tstar;
+}
+
+// classify node (iz, ix): returns status (-1, 0, 1) and the value to keep in *tout
+DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScratch& w, int ended,
+                        float tstar, int ez, int ex, int iz, int ix, float* tout)
+{
+    const float raw = w.T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)];
+    if (ended) {
+        if (t_pinned(raw)) { *tout = t_value(raw); return 0; }
+        if (t_value(raw) < kInf) { *tout = raw; return 1; }
+        *tout = kInf; return -1;
+    }
+    if (ref_alive(s, w.T_r, tstar, iz, ix)) { *tout = t_value(raw); return 0; }
+    // not alive: close iff it touches an alive node; its value is the trial value from the alive
+    // set (the edge node that ended the stage is alive but was never propagated)
+    Stencil st;
+    const int jx[2] = { ix - 1, ix + 1 }, jx2[2] = { ix - 2, ix + 2 };
+    const int kz[2] = { iz - 1, iz + 1 }, kz2[2] = { iz - 2, iz + 2 };
+    bool touch = false;
+    for (int d = 0; d < 2; ++d) {
+        st.ej[d] = jx[d] >= 1 && jx[d] <= s.rnx;
+        st.aj[d] = st.ej[d] && ref_alive(s, w.T_r, tstar, iz, jx[d]);
+        st.tj[d] = st.aj[d] ? t_value(w.T_r[(size_t)(jx[d] - 1) * s.rnz + (iz - 1)]) : kInf;
+        const bool o = jx2[d] >= 1 && jx2[d] <= s.rnx && ref_alive(s, w.T_r, tstar, iz, jx2[d]);
+        st.oj[d] = o;
+        st.tj2[d] = o ? t_value(w.T_r[(size_t)(jx2[d] - 1) * s.rnz + (iz - 1)]) : kInf;
+        st.ek[d] = kz[d] >= 1 && kz[d] <= s.rnz;
+        st.ak[d] = st.ek[d] && ref_alive(s, w.T_r, tstar, kz[d], ix);
+        st.tk[d] = st.ak[d] ? t_value(w.T_r[(size_t)(ix - 1) * s.rnz + (kz[d] - 1)]) : kInf;
+        const bool p = kz2[d] >= 1 && kz2[d] <= s.rnz && ref_alive(s, w.T_r, tstar, kz2[d], ix);
+        st.ok[d] = p;
+        st.tk2[d] = p ? t_value(w.T_r[(size_t)(ix - 1) * s.rnz + (kz2[d] - 1)]) : kInf;
+        touch = touch || st.aj[d] || st.ak[d];
+    }
+    if (!touch) { *tout = kInf; return -1; }
+    NodeGeom ng = { g.earth, w.risti_r[ix - 1], s.rdnx, s.rdnz };
+    *tout = fouds2(st, w.slow_r[(size_t)(ix - 1) * s.rnz + (iz - 1)], ng);
+    if (iz == ez && ix == ex) return 0;
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Band march on the coarse grid: travel(urg=2) from the injected state until every node that
+// started in the tree has been accepted.  T_c is the coarse field of this source (plain values
+// inside the window on entry for status >= 0), slow_c/risti_c the period's coarse tables.
+// Serial.  On return: alive nodes of the window are pinned (sign bit), all others +inf.
+DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, float* T_c,
+                              const float* slow_c, const float* risti_c)
+{
+    MarchView m;
+    m.T = T_c; m.ldT = g.nnz; m.slow = slow_c; m.ldS = g.nnz; m.risti = risti_c;
+    m.status = w.cst; m.wz0 = s.cwz0; m.wx0 = s.cwx0; m.wnz = s.cwnz; m.wnx = s.cwnx;
+    m.nnz = g.nnz; m.nnx = g.nnx; m.ri = g.earth; m.dnx = g.dnx; m.dnz = g.dnz;
+    m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0;
+    int ninit = 0;
+    // tree start order of the reference: ix outer, iz inner (:341-347)
+    for (int lx = 0; lx < s.cwnx; ++lx)
+        for (int lz = 0; lz < s.cwnz; ++lz) {
+            const int q = lx * s.cwnz + lz;
+            w.cinit[q] = 0;
+            if (w.cst[q] > 0) { w.cinit[q] = 1; ++ninit; mv_add(m, s.cwz0 + lz + 1, s.cwx0 + lx + 1); }
+        }
+    while (m.ntr > 0 && ninit > 0 && m.error == 0) {
+        const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
+        const int q = (ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0);
+        if (w.cinit[q]) { w.cinit[q] = 0; --ninit; }
+        if (!mv_accept_root(m)) break;
+    }
+    if (m.error) w.flags[1] = 16 + m.error;
+    for (int lx = 0; lx < s.cwnx; ++lx)
+        for (int lz = 0; lz < s.cwnz; ++lz) {
+            const int ix = s.cwx0 + lx + 1, iz = s.cwz0 + lz + 1;
+            float& t = T_c[(size_t)(ix - 1) * g.nnz + (iz - 1)];
+            const int st = w.cst[lx * s.cwnz + lz];
+            if (st == 0) t = -t_value(t);
+            else t = kInf;
+        }
+}
+
+}  // namespace dsa

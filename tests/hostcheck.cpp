@@ -1,0 +1,206 @@
+// TEST HARNESS (not product): drives the product's __host__ __device__ per-node / per-source
+// logic (dsurftomo_amd/csrc/{eikonal_core,source_stage,host_geometry}.h) on the CPU so that it
+// can be compared with the oracle without a GPU.  The device iteration (block list, LDS tiles,
+// ballots) is replaced by a plain worklist here; the fixed point it reaches is schedule
+// independent, which is exactly what tests/test_hostcheck.py asserts against the oracle.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../dsurftomo_amd/csrc/host_geometry.h"
+
+using namespace dsa;
+
+namespace {
+
+struct Field {
+    int nnx, nnz;
+    float* T;
+    const float* slow;
+    const float* risti;
+    float ri, dnx, dnz;
+};
+
+Hood load_hood(const Field& f, int iz, int ix)
+{
+    Hood h;
+    const int nz[4] = { iz, iz, iz - 1, iz + 1 }, nx[4] = { ix - 1, ix + 1, ix, ix };
+    const int oz[4] = { iz, iz, iz - 2, iz + 2 }, ox[4] = { ix - 2, ix + 2, ix, ix };
+    for (int q = 0; q < 4; ++q) {
+        h.in[q] = nx[q] >= 1 && nx[q] <= f.nnx && nz[q] >= 1 && nz[q] <= f.nnz;
+        h.in_outer[q] = ox[q] >= 1 && ox[q] <= f.nnx && oz[q] >= 1 && oz[q] <= f.nnz;
+        h.near_[q] = h.in[q] ? f.T[(size_t)(nx[q] - 1) * f.nnz + (nz[q] - 1)] : kInf;
+        h.outer[q] = h.in_outer[q] ? f.T[(size_t)(ox[q] - 1) * f.nnz + (oz[q] - 1)] : kInf;
+    }
+    return h;
+}
+
+long fixed_point(Field& f)
+{
+    const size_t n = (size_t)f.nnx * f.nnz;
+    std::vector<int> q(n * 2 + 64);
+    std::vector<unsigned char> inq(n, 0);
+    size_t head = 0, tail = 0, cap = q.size();
+    long evals = 0;
+    auto push = [&](int iz, int ix) {
+        if (ix < 1 || ix > f.nnx || iz < 1 || iz > f.nnz) return;
+        const size_t id = (size_t)(ix - 1) * f.nnz + (iz - 1);
+        if (t_pinned(f.T[id]) || inq[id]) return;
+        inq[id] = 1; q[tail] = (int)id; tail = (tail + 1) % cap;
+    };
+    for (int ix = 1; ix <= f.nnx; ++ix)
+        for (int iz = 1; iz <= f.nnz; ++iz)
+            if (t_pinned(f.T[(size_t)(ix - 1) * f.nnz + (iz - 1)])) {
+                push(iz, ix - 1); push(iz, ix + 1); push(iz - 1, ix); push(iz + 1, ix);
+            }
+    while (head != tail) {
+        const size_t id = (size_t)q[head]; head = (head + 1) % cap; inq[id] = 0;
+        const int ix = (int)(id / f.nnz) + 1, iz = (int)(id % f.nnz) + 1;
+        const Hood h = load_hood(f, iz, ix);
+        const NodeGeom g = { f.ri, f.risti[ix - 1], f.dnx, f.dnz };
+        const float c = solve_node(h, f.slow[id], g);
+        ++evals;
+        if (std::memcmp(&c, &f.T[id], 4) != 0) {
+            f.T[id] = c;
+            push(iz, ix - 1); push(iz, ix + 1); push(iz - 1, ix); push(iz + 1, ix);
+            push(iz, ix - 2); push(iz, ix + 2); push(iz - 2, ix); push(iz + 2, ix);
+        }
+        if (evals > 400L * (long)n) return -1;
+    }
+    return evals;
+}
+
+}  // namespace
+
+extern "C" {
+
+// fouds2 on a field with an explicit alive mask; mirrors oracle dso_fouds2_masked for unit tests
+float hc_fouds2_masked(int nnx, int nnz, float gox, float dnx, float dnz, float earth, const float* veln,
+                       const float* ttn, const unsigned char* alive, int iz, int ix)
+{
+    Stencil s;
+    auto al = [&](int z, int x) { return x >= 1 && x <= nnx && z >= 1 && z <= nnz && alive[(size_t)(x - 1) * nnz + (z - 1)] != 0; };
+    auto tt = [&](int z, int x) { return ttn[(size_t)(x - 1) * nnz + (z - 1)]; };
+    const int jx[2] = { ix - 1, ix + 1 }, jx2[2] = { ix - 2, ix + 2 }, kz[2] = { iz - 1, iz + 1 }, kz2[2] = { iz - 2, iz + 2 };
+    for (int d = 0; d < 2; ++d) {
+        s.ej[d] = jx[d] >= 1 && jx[d] <= nnx;
+        s.aj[d] = al(iz, jx[d]); s.tj[d] = s.aj[d] ? tt(iz, jx[d]) : kInf;
+        s.oj[d] = al(iz, jx2[d]); s.tj2[d] = s.oj[d] ? tt(iz, jx2[d]) : kInf;
+        s.ek[d] = kz[d] >= 1 && kz[d] <= nnz;
+        s.ak[d] = al(kz[d], ix); s.tk[d] = s.ak[d] ? tt(kz[d], ix) : kInf;
+        s.ok[d] = al(kz2[d], ix); s.tk2[d] = s.ok[d] ? tt(kz2[d], ix) : kInf;
+    }
+    const NodeGeom g = { earth, earth * sinf(gox + (float)(ix - 1) * dnx), dnx, dnz };
+    return fouds2(s, 1.0f / veln[(size_t)(ix - 1) * nnz + (iz - 1)], g);
+}
+
+// coarse velocity field through the product's per-node gridder
+void hc_gridder(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const double* pv, float* veln)
+{
+    GridDesc g; make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
+    std::vector<float> velv((size_t)nx * ny), basis(4 * (gd + 1));
+    for (int k = 0; k < nx * ny; ++k) velv[k] = (float)pv[k];
+    basis_table(gd, basis.data());
+    for (int ix = 1; ix <= g.nnx; ++ix)
+        for (int iz = 1; iz <= g.nnz; ++iz)
+            veln[(size_t)(ix - 1) * g.nnz + (iz - 1)] = coarse_velocity(g, velv.data(), basis.data(), iz, ix);
+}
+
+// one (period, source) unit; outputs as oracle dso_solve_source. stats: [0] start-up ended early,
+// [1] error flags, [2] evals refined, [3] evals coarse. Returns 0 / -1 (outside)
+int hc_solve_source(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const double* pv,
+                    float x, float z, float* ttn, float* ttnr_out, int* nstsr_out, float* inj_t, int* inj_s,
+                    int* box_out, long* stats)
+{
+    GridDesc g; make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
+    SourceDesc s;
+    if (make_source(g, x, z, s) != 0) return -1;
+    const size_t nc = (size_t)g.nnx * g.nnz, nr = (size_t)s.rnx * s.rnz;
+    std::vector<float> velv((size_t)nx * ny), cbasis(4 * (gd + 1)), rbasis(4 * (gd * kSgdl + 1));
+    for (int k = 0; k < nx * ny; ++k) velv[k] = (float)pv[k];
+    basis_table(gd, cbasis.data());
+    basis_table(gd * kSgdl, rbasis.data());
+    std::vector<float> slow_c(nc), risti_c(g.nnx), slow_r(nr), T_r(nr, kInf), risti_r(kRefMax), vcorner(4);
+    for (int ix = 1; ix <= g.nnx; ++ix)
+        for (int iz = 1; iz <= g.nnz; ++iz)
+            slow_c[(size_t)(ix - 1) * g.nnz + (iz - 1)] = 1.0f / coarse_velocity(g, velv.data(), cbasis.data(), iz, ix);
+    risti_table(g.gox, g.dnx, g.earth, g.nnx, risti_c.data());
+    risti_table(s.rgox, s.rdnx, g.earth, s.rnx, risti_r.data());
+    for (int lx = 1; lx <= s.rnx; ++lx)
+        for (int kz = 1; kz <= s.rnz; ++kz) {
+            const float v = refined_velocity(g, s, velv.data(), rbasis.data(), kz, lx);
+            slow_r[(size_t)(lx - 1) * s.rnz + (kz - 1)] = 1.0f / v;
+            if ((lx == s.isx_r || lx == s.isx_r + 1) && (kz == s.isz_r || kz == s.isz_r + 1))
+                vcorner[(lx - s.isx_r) * 2 + (kz - s.isz_r)] = v;
+        }
+    std::vector<int16_t> rst(kRWin * kRWin), cst((size_t)kCWinMax * kCWinMax);
+    std::vector<int8_t> S_r(nr), cinit((size_t)kCWinMax * kCWinMax);
+    std::vector<int32_t> heap(kHeapCap), flags(2, 0);
+    SourceScratch w;
+    w.slow_r = slow_r.data(); w.T_r = T_r.data(); w.S_r = S_r.data(); w.risti_r = risti_r.data();
+    w.vcorner = vcorner.data(); w.rst = rst.data(); w.cst = cst.data(); w.cinit = cinit.data();
+    w.heap = heap.data(); w.flags = flags.data();
+
+    const int ended = refined_startup(g, s, w);
+    refined_encode(s, w, ended);
+    stats[2] = 0;
+    if (!ended) {
+        Field fr = { s.rnx, s.rnz, T_r.data(), slow_r.data(), risti_r.data(), g.earth, s.rdnx, s.rdnz };
+        stats[2] = fixed_point(fr);
+    }
+    // first arrival on an open edge (scan order: ix outer, iz inner; first minimum wins)
+    float tstar = kInf; int ez = 0, ex = 0;
+    if (!ended)
+        for (int ix = 1; ix <= s.rnx; ++ix)
+            for (int iz = 1; iz <= s.rnz; ++iz)
+                if (is_open_edge(s, iz, ix)) {
+                    const float t = t_value(T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)]);
+                    if (t < tstar) { tstar = t; ez = iz; ex = ix; }
+                }
+    std::vector<float> Tfin(nr);
+    for (int ix = 1; ix <= s.rnx; ++ix)
+        for (int iz = 1; iz <= s.rnz; ++iz) {
+            const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
+            S_r[id] = (int8_t)handoff_node(g, s, w, ended, tstar, ez, ex, iz, ix, &Tfin[id]);
+        }
+    if (ttnr_out) std::memcpy(ttnr_out, Tfin.data(), 4 * nr);
+    if (nstsr_out) for (size_t k = 0; k < nr; ++k) nstsr_out[k] = S_r[k];
+
+    // injection + band promotion into the coarse window / field
+    for (size_t k = 0; k < nc; ++k) ttn[k] = kInf;
+    for (int q = 0; q < s.cwnx * s.cwnz; ++q) cst[q] = -1;
+    auto cs = [&](int iz, int ix) -> int16_t& { return cst[(size_t)(ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0)]; };
+    for (int k = 1; k <= s.rnz; k += kSgdl)
+        for (int l = 1; l <= s.rnx; l += kSgdl) {
+            const int cz = s.vnt + (k - 1) / kSgdl, cx = s.vnl + (l - 1) / kSgdl;
+            const size_t id = (size_t)(l - 1) * s.rnz + (k - 1);
+            cs(cz, cx) = S_r[id];
+            if (S_r[id] >= 0) ttn[(size_t)(cx - 1) * g.nnz + (cz - 1)] = Tfin[id];
+        }
+    auto far = [&](int iz, int ix) {
+        if (ix < 1 || ix > g.nnx || iz < 1 || iz > g.nnz) return false;
+        if (!(iz > s.cwz0 && iz <= s.cwz0 + s.cwnz && ix > s.cwx0 && ix <= s.cwx0 + s.cwnx)) return true;
+        return cs(iz, ix) == -1;
+    };
+    // the reference promotes in place while scanning ix outer / iz inner; promoted nodes become
+    // status 1, which is not "far", so the scan order does not matter
+    for (int ix = s.vnl; ix <= s.vnr; ++ix)
+        for (int iz = s.vnt; iz <= s.vnb; ++iz)
+            if (cs(iz, ix) == 0 && (far(iz - 1, ix) || far(iz + 1, ix) || far(iz, ix - 1) || far(iz, ix + 1))) cs(iz, ix) = 1;
+    if (inj_t) std::memcpy(inj_t, ttn, 4 * nc);
+    if (inj_s) {
+        for (size_t k = 0; k < nc; ++k) inj_s[k] = -1;
+        for (int ix = s.cwx0 + 1; ix <= s.cwx0 + s.cwnx; ++ix)
+            for (int iz = s.cwz0 + 1; iz <= s.cwz0 + s.cwnz; ++iz) inj_s[(size_t)(ix - 1) * g.nnz + (iz - 1)] = cs(iz, ix);
+    }
+    coarse_band_march(g, s, w, ttn, slow_c.data(), risti_c.data());
+    Field fc = { g.nnx, g.nnz, ttn, slow_c.data(), risti_c.data(), g.earth, g.dnx, g.dnz };
+    stats[3] = fixed_point(fc);
+    for (size_t k = 0; k < nc; ++k) ttn[k] = t_value(ttn[k]);
+    stats[0] = ended; stats[1] = flags[1];
+    if (box_out) { box_out[0] = s.vnl; box_out[1] = s.vnr; box_out[2] = s.vnt; box_out[3] = s.vnb; box_out[4] = s.rnx; box_out[5] = s.rnz; }
+    return 0;
+}
+
+}  // extern "C"
