@@ -1,0 +1,78 @@
+// Engine state behind the opaque dsa_engine handle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "host_geometry.h"
+#include "kernels.h"
+
+namespace dsa {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+};
+
+struct Engine {
+    int device = 0;
+    std::string arch;
+    hipStream_t stream = nullptr;
+    hipEvent_t events[8] = {};
+    std::string error;
+    int status = 0;
+
+    // model
+    GridDesc g{};
+    int nmaps = 0;
+    size_t nfield = 0;
+    bool have_maps = false;
+    float dpl = 0.0f;          // minimum cell width (km)
+    float hmin_slow = 0.0f;    // smallest slowness of the maps (window scale)
+    DevBuf<float> velv, veln, slow, risti_c, cbasis, rbasis;
+
+    // plan
+    bool planned = false;
+    bool keep_fields = false;
+    std::vector<SourceDesc> h_src;
+    std::vector<float> h_risti_r;
+    std::vector<RayDesc> h_rays;
+    size_t mem_budget = 0;
+    size_t per_unit_bytes = 0;
+    int chunk = 0;
+    int max_chunk = 0;
+    float window_cells = 8.0f;
+    int last_chunk_first = -1, last_chunk_n = 0;
+
+    DevBuf<SourceDesc> src;
+    DevBuf<RayDesc> rays;
+    DevBuf<float> out;
+    DevBuf<int32_t> err;
+    DevBuf<float> slow_r, T_r, Tfin_r, risti_r, vcorner, key_r, tstar, T_c, key_c;
+    DevBuf<int8_t> S_r, cinit;
+    DevBuf<unsigned long long> mask_r, mask_c;
+    DevBuf<int16_t> rst, cst;
+    DevBuf<int32_t> heap, flags, info;
+    DevBuf<FimProblem> prob_r, prob_c;
+
+    double stats[16] = {};
+
+    ~Engine();
+    void fail(int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+    template <class T> int ensure(DevBuf<T>& b, size_t n);
+    int init(int device_index);
+    int set_maps(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int dicing, int nm, const double* pv);
+    int plan(int nunits, const int* map_index, const float* scx, const float* scz, const int* nrec, const float* rcx, const float* rcz);
+    int solve(float* dsurf);
+    BatchPtrs batch() const;
+    int list_cap_for(size_t nblocks) const;
+    void launch_srtimes_chunk(int r0, int nr, int first_unit);
+    int get_field(int unit, float* ttn);
+    int get_refined(int unit, int* rnx, int* rnz, float* ttnr, int8_t* st);
+    int get_velocity(int map, float* out_v);
+};
+
+}  // namespace dsa

@@ -1,0 +1,78 @@
+// Internal interface between the engine (host) and the HIP kernels of the CalSurfG path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "source_stage.h"
+
+namespace dsa {
+
+// One fixed-point problem: a travel-time field on an (nnz, nnx) grid, column-major with z fastest.
+// T carries the boundary condition: pinned nodes (sign bit) are never recomputed, every other
+// node is +inf or a previous estimate.  mask/key are per 8x8-node block (block id = bx*nbz + bz):
+// mask bit (lx*8 + lz) marks a node whose neighbourhood changed since it was last evaluated,
+// key is a lower bound on the time at which the block's dirty nodes can be accepted.
+struct FimProblem {
+    float* T;
+    const float* slow;
+    const float* risti;
+    unsigned long long* mask;
+    float* key;
+    int nnx, nnz, nbx, nbz;
+    float ri, dnx, dnz;
+    float window;          // causal window (seconds of travel time) evaluated per round
+    int32_t* info;         // [0] rounds, [1] block visits, [2] list overflows, [3] error
+};
+
+struct FimLaunch {
+    int list_cap;          // entries per active list (LDS)
+    int max_blocks;        // max blocks of any problem in the launch (sizes the membership bitset)
+};
+
+size_t fim_lds_bytes(const FimLaunch& l, int nwaves);
+void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream);
+
+// period-level tables ---------------------------------------------------------------------------
+// velv: fp32 vertex values (ny, nx); basis: (gd+1) x 4; outputs veln / slow (nnz, nnx)
+void launch_gridder(const GridDesc& g, const float* d_velv, const float* d_basis, float* d_veln, float* d_slow,
+                    hipStream_t stream);
+
+// per-source stages ------------------------------------------------------------------------------
+struct BatchPtrs {
+    const SourceDesc* src;       // [nsrc]
+    // refined, per source, stride kRefMax*kRefMax unless noted
+    float* slow_r; float* T_r; float* Tfin_r; int8_t* S_r;
+    float* risti_r;              // stride kRefMax (uploaded by the host)
+    float* vcorner;              // stride 4
+    unsigned long long* mask_r; float* key_r;     // stride kRefBlocks
+    int16_t* rst;                // stride kRWin*kRWin
+    int16_t* cst; int8_t* cinit; // stride kCWinMax*kCWinMax
+    int32_t* heap;               // stride kHeapCap
+    int32_t* flags;              // stride 4: [0] ended early, [1] error, [2] e* iz, [3] e* ix
+    float* tstar;                // stride 1
+    // coarse, per source
+    float* T_c;                  // stride nnx*nnz
+    unsigned long long* mask_c; float* key_c;     // stride nbx*nbz
+};
+constexpr int kRefBlocks = 17 * 17;
+
+void launch_fill(float* d, size_t n, float v, hipStream_t stream);
+void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_velv_all, size_t velv_stride,
+                   const float* d_rbasis, hipStream_t stream);
+void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);
+void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);
+void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
+                         size_t field_stride, const float* d_risti_c, hipStream_t stream);
+void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
+                          size_t field_stride, const float* d_risti_c, float window_r, float window_c,
+                          FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, hipStream_t stream);
+
+// receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
+struct RayDesc { int src; float rx, rz; float sin_rx; };   // sin_rx = libm sinf(rx), made on the host
+// RayDesc::src is a global unit index; unit_base is the first unit held by the batch arrays
+void launch_srtimes(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, int nrays,
+                    const float* d_veln_all, size_t field_stride, float dpl, float* d_out, int32_t* d_err,
+                    hipStream_t stream);
+
+}  // namespace dsa

@@ -1,0 +1,353 @@
+// Kernels around the fixed-point solve: period-level velocity tables, the per-source stages of
+// source_stage.h, and the receiver gather.  See kernels.h for the data layout.
+#include "kernels.h"
+
+namespace dsa {
+
+namespace {
+
+__device__ __forceinline__ SourceScratch scratch_of(const BatchPtrs& b, int s)
+{
+    SourceScratch w;
+    const size_t rr = (size_t)kRefMax * kRefMax;
+    w.slow_r = b.slow_r + s * rr;
+    w.T_r = b.T_r + s * rr;
+    w.S_r = b.S_r + s * rr;
+    w.risti_r = b.risti_r + (size_t)s * kRefMax;
+    w.vcorner = b.vcorner + (size_t)s * 4;
+    w.rst = b.rst + (size_t)s * kRWin * kRWin;
+    w.cst = b.cst + (size_t)s * kCWinMax * kCWinMax;
+    w.cinit = b.cinit + (size_t)s * kCWinMax * kCWinMax;
+    w.heap = b.heap + (size_t)s * kHeapCap;
+    w.flags = b.flags + (size_t)s * 4;
+    return w;
+}
+
+// mark node (iz, ix) (1-based) dirty in a block-mask array; single writer per source
+__device__ __forceinline__ void mark_dirty(unsigned long long* mask, float* key, int nbz, int iz, int ix, float t)
+{
+    const int bx = (ix - 1) >> 3, bz = (iz - 1) >> 3;
+    const int bit = ((ix - 1) & 7) * 8 + ((iz - 1) & 7);
+    const int b = bx * nbz + bz;
+    mask[b] |= 1ull << bit;
+    if (t < key[b]) key[b] = t;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fill(float* __restrict__ d, size_t n, float v)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
+}
+
+void launch_fill(float* d, size_t n, float v, hipStream_t stream)
+{
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, stream, d, n, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: dice one period's vertex map onto the propagation grid; z fastest -> lanes walk iz
+__global__ void k_gridder(GridDesc g, const float* __restrict__ velv, const float* __restrict__ basis,
+                          float* __restrict__ veln, float* __restrict__ slow)
+{
+    const size_t n = (size_t)g.nnx * g.nnz;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const int ix = (int)(id / g.nnz) + 1, iz = (int)(id % g.nnz) + 1;
+    const float v = coarse_velocity(g, velv, basis, iz, ix);
+    veln[id] = v;
+    slow[id] = 1.0f / v;
+}
+
+void launch_gridder(const GridDesc& g, const float* d_velv, const float* d_basis, float* d_veln, float* d_slow,
+                    hipStream_t stream)
+{
+    const size_t n = (size_t)g.nnx * g.nnz;
+    hipLaunchKernelGGL(k_gridder, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, d_velv, d_basis, d_veln, d_slow);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a: refined velocities of every source box; also resets the refined field and block state
+__global__ void k_refine(GridDesc g, BatchPtrs b, const float* __restrict__ velv_all, size_t velv_stride,
+                         const float* __restrict__ rbasis)
+{
+    const int s = blockIdx.y;
+    const SourceDesc sd = b.src[s];
+    const int n = sd.rnx * sd.rnz;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rr = (size_t)kRefMax * kRefMax;
+    if (id < kRefBlocks) { b.mask_r[(size_t)s * kRefBlocks + id] = 0ull; b.key_r[(size_t)s * kRefBlocks + id] = kInf; }
+    if (id < 4 && blockIdx.x == 0) b.flags[(size_t)s * 4 + id] = 0;
+    if (id >= n) return;
+    const int lx = id / sd.rnz + 1, kz = id % sd.rnz + 1;
+    const float* velv = velv_all + (size_t)sd.period * velv_stride;
+    const float v = refined_velocity(g, sd, velv, rbasis, kz, lx);
+    b.slow_r[s * rr + id] = 1.0f / v;
+    b.T_r[s * rr + id] = kInf;
+    if ((lx == sd.isx_r || lx == sd.isx_r + 1) && (kz == sd.isz_r || kz == sd.isz_r + 1))
+        b.vcorner[(size_t)s * 4 + (lx - sd.isx_r) * 2 + (kz - sd.isz_r)] = v;
+}
+
+void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_velv_all, size_t velv_stride,
+                   const float* d_rbasis, hipStream_t stream)
+{
+    if (nsrc <= 0) return;
+    const int per = (kRefMax * kRefMax + 255) / 256;
+    hipLaunchKernelGGL(k_refine, dim3(per, nsrc), dim3(256), 0, stream, g, b, d_velv_all, velv_stride, d_rbasis);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2b: start-up march, one lane per source (a few accept steps each; the control flow is the same
+// for every source, so the lanes of a wave stay together)
+__global__ void k_refined_startup(GridDesc g, BatchPtrs b, int nsrc)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    const SourceDesc sd = b.src[s];
+    SourceScratch w = scratch_of(b, s);
+    const int ended = refined_startup(g, sd, w);
+    refined_encode(sd, w, ended);
+    if (ended) return;
+    // the unpinned neighbours of every pinned node start the fixed-point solve
+    unsigned long long* mask = b.mask_r + (size_t)s * kRefBlocks;
+    float* key = b.key_r + (size_t)s * kRefBlocks;
+    for (int lx = 0; lx < kRWin; ++lx)
+        for (int lz = 0; lz < kRWin; ++lz) {
+            if (w.rst[lx * kRWin + lz] != 0) continue;
+            const int ix = sd.rwx0 + lx + 1, iz = sd.rwz0 + lz + 1;
+            const float t = t_value(w.T_r[(size_t)(ix - 1) * sd.rnz + (iz - 1)]);
+            const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
+            for (int q = 0; q < 4; ++q) {
+                if (nx[q] < 1 || nx[q] > sd.rnx || nz[q] < 1 || nz[q] > sd.rnz) continue;
+                if (t_pinned(w.T_r[(size_t)(nx[q] - 1) * sd.rnz + (nz[q] - 1)])) continue;
+                mark_dirty(mask, key, sd.nbz_r, nz[q], nx[q], t);
+            }
+        }
+}
+
+void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream)
+{
+    if (nsrc <= 0) return;
+    hipLaunchKernelGGL(k_refined_startup, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2c: hand-off, one workgroup per source
+__global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
+{
+    __shared__ unsigned long long s_best;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const SourceDesc sd = b.src[s];
+    SourceScratch w = scratch_of(b, s);
+    const int ended = w.flags[0];
+    const int n = sd.rnx * sd.rnz;
+    const size_t rr = (size_t)kRefMax * kRefMax;
+    if (tid == 0) s_best = ~0ull;
+    __syncthreads();
+    // first arrival on an open edge; ties resolved by scan order (ix outer, iz inner)
+    if (!ended) {
+        for (int id = tid; id < n; id += 256) {
+            const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
+            if (!is_open_edge(sd, iz, ix)) continue;
+            const float t = t_value(w.T_r[id]);
+            const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id;
+            atomicMin(&s_best, k);
+        }
+    }
+    __syncthreads();
+    float tstar = kInf;
+    int ez = 0, ex = 0;
+    if (!ended && s_best != ~0ull) {
+        tstar = __uint_as_float((unsigned)(s_best >> 32));
+        const int id = (int)(s_best & 0xffffffffu);
+        ex = id / sd.rnz + 1; ez = id % sd.rnz + 1;
+        if (!(tstar < kInf)) { ez = 0; ex = 0; }
+    }
+    if (tid == 0) { b.tstar[s] = tstar; w.flags[2] = ez; w.flags[3] = ex; }
+    float* Tfin = b.Tfin_r + s * rr;
+    for (int id = tid; id < n; id += 256) {
+        const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
+        float t;
+        const int st = handoff_node(g, sd, w, ended, tstar, ez, ex, iz, ix, &t);
+        w.S_r[id] = (int8_t)st;
+        Tfin[id] = t;
+    }
+    // coarse window: everything far, then every 8th refined node, then band promotion
+    const int wn = sd.cwnx * sd.cwnz;
+    for (int q = tid; q < wn; q += 256) w.cst[q] = -1;
+    __syncthreads();
+    float* T_c = b.T_c + (size_t)s * g.nnx * g.nnz;
+    const int bxn = (sd.rnx - 1) / kSgdl + 1, bzn = (sd.rnz - 1) / kSgdl + 1;
+    for (int q = tid; q < bxn * bzn; q += 256) {
+        const int l = (q / bzn) * kSgdl + 1, k = (q % bzn) * kSgdl + 1;
+        const int cz = sd.vnt + (k - 1) / kSgdl, cx = sd.vnl + (l - 1) / kSgdl;
+        const int id = (l - 1) * sd.rnz + (k - 1);
+        const int st = w.S_r[id];
+        w.cst[(cx - 1 - sd.cwx0) * sd.cwnz + (cz - 1 - sd.cwz0)] = (int16_t)st;
+        if (st >= 0) T_c[(size_t)(cx - 1) * g.nnz + (cz - 1)] = Tfin[id];
+    }
+    __syncthreads();
+    // alive nodes that touch a far node go back into the band. A promoted node reads as "not far"
+    // before and after, so concurrent promotion is order independent.
+    for (int q = tid; q < bxn * bzn; q += 256) {
+        const int cx = sd.vnl + q / bzn, cz = sd.vnt + q % bzn;
+        int16_t* me = &w.cst[(cx - 1 - sd.cwx0) * sd.cwnz + (cz - 1 - sd.cwz0)];
+        if (*me != 0) continue;
+        const int nx[4] = { cx - 1, cx + 1, cx, cx }, nz[4] = { cz, cz, cz - 1, cz + 1 };
+        bool band = false;
+        for (int d = 0; d < 4; ++d) {
+            if (nx[d] < 1 || nx[d] > g.nnx || nz[d] < 1 || nz[d] > g.nnz) continue;
+            const bool inwin = nz[d] > sd.cwz0 && nz[d] <= sd.cwz0 + sd.cwnz && nx[d] > sd.cwx0 && nx[d] <= sd.cwx0 + sd.cwnx;
+            if (!inwin || w.cst[(nx[d] - 1 - sd.cwx0) * sd.cwnz + (nz[d] - 1 - sd.cwz0)] == -1) band = true;
+        }
+        if (band) *me = 1;
+    }
+}
+
+void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream)
+{
+    if (nsrc <= 0) return;
+    hipLaunchKernelGGL(k_handoff, dim3(nsrc), dim3(256), 0, stream, g, b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2d: band march on the coarse grid, one lane per source, then seed the coarse solve
+__global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* __restrict__ slow_all,
+                               size_t field_stride, const float* __restrict__ risti_c)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    const SourceDesc sd = b.src[s];
+    SourceScratch w = scratch_of(b, s);
+    float* T_c = b.T_c + (size_t)s * g.nnx * g.nnz;
+    const float* slow_c = slow_all + (size_t)sd.period * field_stride;
+    coarse_band_march(g, sd, w, T_c, slow_c, risti_c);
+    unsigned long long* mask = b.mask_c + (size_t)s * g.nbx * g.nbz;
+    float* key = b.key_c + (size_t)s * g.nbx * g.nbz;
+    for (int lx = 0; lx < sd.cwnx; ++lx)
+        for (int lz = 0; lz < sd.cwnz; ++lz) {
+            if (w.cst[lx * sd.cwnz + lz] != 0) continue;
+            const int ix = sd.cwx0 + lx + 1, iz = sd.cwz0 + lz + 1;
+            const float t = t_value(T_c[(size_t)(ix - 1) * g.nnz + (iz - 1)]);
+            const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
+            for (int q = 0; q < 4; ++q) {
+                if (nx[q] < 1 || nx[q] > g.nnx || nz[q] < 1 || nz[q] > g.nnz) continue;
+                if (t_pinned(T_c[(size_t)(nx[q] - 1) * g.nnz + (nz[q] - 1)])) continue;
+                mark_dirty(mask, key, g.nbz, nz[q], nx[q], t);
+            }
+        }
+}
+
+void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
+                         size_t field_stride, const float* d_risti_c, hipStream_t stream)
+{
+    if (nsrc <= 0) return;
+    hipLaunchKernelGGL(k_coarse_march, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all, field_stride, d_risti_c);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* slow_all, size_t field_stride,
+                                const float* risti_c, float window_r, float window_c, FimProblem* prob_r,
+                                FimProblem* prob_c, int32_t* info)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    const SourceDesc sd = b.src[s];
+    const size_t rr = (size_t)kRefMax * kRefMax;
+    FimProblem r;
+    r.T = b.T_r + s * rr; r.slow = b.slow_r + s * rr; r.risti = b.risti_r + (size_t)s * kRefMax;
+    r.mask = b.mask_r + (size_t)s * kRefBlocks; r.key = b.key_r + (size_t)s * kRefBlocks;
+    r.nnx = sd.rnx; r.nnz = sd.rnz; r.nbx = sd.nbx_r; r.nbz = sd.nbz_r;
+    r.ri = g.earth; r.dnx = sd.rdnx; r.dnz = sd.rdnz; r.window = window_r;
+    r.info = info + (size_t)s * 8;
+    prob_r[s] = r;
+    FimProblem c;
+    c.T = b.T_c + (size_t)s * g.nnx * g.nnz; c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
+    c.mask = b.mask_c + (size_t)s * g.nbx * g.nbz; c.key = b.key_c + (size_t)s * g.nbx * g.nbz;
+    c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
+    c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = window_c;
+    c.info = info + (size_t)s * 8 + 4;
+    prob_c[s] = c;
+    for (int q = 0; q < 8; ++q) info[(size_t)s * 8 + q] = 0;
+}
+
+void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
+                          size_t field_stride, const float* d_risti_c, float window_r, float window_c,
+                          FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, hipStream_t stream)
+{
+    if (nsrc <= 0) return;
+    hipLaunchKernelGGL(k_make_problems, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all,
+                       field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: receiver travel times, one thread per ray; reference srtimes (CalSurfG.f90:1681-1754)
+__global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc* __restrict__ rays, int nrays,
+                          const float* __restrict__ veln_all, size_t field_stride, float dpl,
+                          float* __restrict__ out, int32_t* __restrict__ err)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrays) return;
+    const RayDesc rd = rays[r];
+    const int slot = rd.src - unit_base;
+    const SourceDesc sd = b.src[slot];
+    const float* T = b.T_c + (size_t)slot * g.nnx * g.nnz;
+    const float* veln = veln_all + (size_t)sd.period * field_stride;
+    const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, earth = g.earth;
+    const float rcx1 = rd.rx, rcz1 = rd.rz, scx = sd.scx, scz = sd.scz;
+    int irx = (int)((rcx1 - gox) / dnx) + 1;
+    int irz = (int)((rcz1 - goz) / dnz) + 1;
+    if (irx < 1 || irx > g.nnx || irz < 1 || irz > g.nnz) { atomicExch(err, r + 1); out[r] = 0.0f; return; }
+    if (irx == g.nnx) irx -= 1;
+    if (irz == g.nnz) irz -= 1;
+    const int isx = (int)((scx - gox) / dnx) + 1;
+    const int isz = (int)((scz - goz) / dnz) + 1;
+    float sred = sq((scx - rcx1) * earth);
+    sred = sred + sq((scz - rcz1) * earth * rd.sin_rx);
+    sred = sqrtf(sred);
+    bool nearsrc = sred < dpl;
+    if (isx == irx && isz == irz) nearsrc = true;
+    float trr;
+    const size_t ld = g.nnz;
+    if (nearsrc) {
+        float vss[2][2];
+        for (int k = 1; k <= 2; ++k)
+            for (int l = 1; l <= 2; ++l) vss[k - 1][l - 1] = veln[(size_t)(isx - 1 + k - 1) * ld + (isz - 1 + l - 1)];
+        float drx = (scx - gox) - (float)(isx - 1) * dnx;
+        float drz = (scz - goz) - (float)(isz - 1) * dnz;
+        const float vels = bilinear4(vss, dnx, dnz, drx, drz);
+        for (int k = 1; k <= 2; ++k)
+            for (int l = 1; l <= 2; ++l) vss[k - 1][l - 1] = veln[(size_t)(irx - 1 + k - 1) * ld + (irz - 1 + l - 1)];
+        drx = (rcx1 - gox) - (float)(irx - 1) * dnx;
+        drz = (rcz1 - goz) - (float)(irz - 1) * dnz;
+        const float velr = bilinear4(vss, dnx, dnz, drx, drz);
+        trr = 2.0f * sred / (vels + velr);
+    } else {
+        const float drx = (rcx1 - gox) - (float)(irx - 1) * dnx;
+        const float drz = (rcz1 - goz) - (float)(irz - 1) * dnz;
+        trr = 0.0f;
+        for (int k = 1; k <= 2; ++k)
+            for (int l = 1; l <= 2; ++l) {
+                const float produ = (1.0f - fabsf(((float)(l - 1) * dnz - drz) / dnz)) *
+                                    (1.0f - fabsf(((float)(k - 1) * dnx - drx) / dnx));
+                trr = trr + t_value(T[(size_t)(irx - 1 + k - 1) * ld + (irz - 1 + l - 1)]) * produ;
+            }
+    }
+    out[r] = trr;
+}
+
+void launch_srtimes(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, int nrays,
+                    const float* d_veln_all, size_t field_stride, float dpl, float* d_out, int32_t* d_err,
+                    hipStream_t stream)
+{
+    if (nrays <= 0) return;
+    hipLaunchKernelGGL(k_srtimes, dim3((nrays + 255) / 256), dim3(256), 0, stream, g, b, unit_base, d_rays, nrays,
+                       d_veln_all, field_stride, dpl, d_out, d_err);
+}
+
+}  // namespace dsa

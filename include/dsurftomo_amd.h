@@ -1,0 +1,111 @@
+/* dsurftomo_amd -- C ABI of the MI355X forward-modelling engine for DSurfTomo's CalSurfG path.
+ *
+ * Plain C, pointers and sizes only.  Two levels:
+ *
+ *   (1) Drop-in level: dsa_calsurfg / dsa_synthetic take exactly the argument lists of the
+ *       reference's Fortran subroutines CalSurfG (reference src/CalSurfG.f90:939-943, argument
+ *       declarations :987-1002) and synthetic (:2412-2415, :2460-2472): every argument by
+ *       pointer, arrays column-major, 1-based indices in iw/col.  The Fortran shim
+ *       dsurftomo_amd/fortran/calsurfg_shim.f90 exports the link symbols `calsurfg_` and
+ *       `synthetic_` that the reference's main program imports (main.f90:355-359, :338-342) and
+ *       forwards to these two functions.  See INTEGRATION.md.
+ *
+ *   (2) Engine level (own design): an explicit context, phase-velocity maps given per period
+ *       slot (this is what the benchmark and the parity tests at synthetic sizes use: "identical
+ *       grids" by construction), and batched (period, source) units.
+ *
+ * All functions return 0 on success or a negative dsa_status; dsa_error_string() gives the text.
+ * Where the reference prints a message and STOPs (source or receiver outside the model,
+ * CalSurfG.f90:1214-1220, :1686-1692, :1898-1904) the engine returns DSA_ERR_OUTSIDE and the shim
+ * prints the reference's message and stops the program, so callers see the same behaviour.
+ * There is no CPU fallback: without a usable GPU every entry point fails with DSA_ERR_DEVICE.
+ */
+#ifndef DSURFTOMO_AMD_H
+#define DSURFTOMO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsa_engine dsa_engine;
+
+enum dsa_status {
+    DSA_OK = 0,
+    DSA_ERR_DEVICE = -1,     /* no GPU / HIP runtime error */
+    DSA_ERR_ARGUMENT = -2,
+    DSA_ERR_OUTSIDE = -3,    /* a source or receiver lies outside the model */
+    DSA_ERR_INTERNAL = -4,   /* a device-side guard fired (window / tree overflow, no convergence) */
+    DSA_ERR_STATE = -5       /* call order (e.g. solve before plan) */
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+int dsa_create(dsa_engine** out, int device_index);
+void dsa_destroy(dsa_engine* e);
+const char* dsa_error_string(const dsa_engine* e);   /* e may be NULL: last creation error */
+/* memory the engine may use for per-source fields (bytes, 0 = default: 60 % of free HBM) */
+int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
+
+/* ---- engine level --------------------------------------------------------------------------- */
+/* Grid of reference CalSurfG.f90:1032-1065 (dicing 8) / :2487-2520 (dicing 5) and `nmaps`
+ * velocity maps pv[m][nx*ny] (fp64, latitude index fastest: pv[(jj-1)*nx + ii - 1], the layout
+ * of the reference's pvRc etc.).  Runs the dicing kernel once per map (the reference repeats it
+ * per source, :1186). */
+int dsa_set_maps(dsa_engine* e, int nx, int ny, float goxd, float gozd, float dvxd, float dvzd,
+                 int dicing, int nmaps, const double* pv);
+
+/* Describe the (map, source) units and their receivers (colatitude / longitude in radians, the
+ * convention of scxf/sczf/rcxf/rczf).  Receivers of unit u are rcx[first .. first+nrec[u]) with
+ * first = sum of nrec over earlier units.  Host-side preparation and upload only. */
+int dsa_plan(dsa_engine* e, int nunits, const int* map_index, const float* scx, const float* scz,
+             const int* nrec, const float* rcx, const float* rcz);
+
+/* Solve every planned unit: eikonal field per unit, then receiver times into dsurf (host,
+ * sum(nrec) floats, unit-major order == the reference's (knumi, srcnum, istep) order). */
+int dsa_solve(dsa_engine* e, float* dsurf);
+
+/* copy one unit's coarse travel-time field (nnz, nnx column-major) back; valid after dsa_solve
+ * for units of the last chunk only unless keep_fields was requested */
+int dsa_get_dims(const dsa_engine* e, int* nnx, int* nnz);
+int dsa_keep_fields(dsa_engine* e, int on);
+int dsa_get_field(dsa_engine* e, int unit, float* ttn);
+int dsa_get_velocity(dsa_engine* e, int map, float* veln);
+/* refined snapshot of a unit: ttnr (rnz, rnx) and status (-1 far, 0 alive, 1 close) */
+int dsa_get_refined(dsa_engine* e, int unit, int* rnx, int* rnz, float* ttnr, int8_t* status);
+
+/* counters of the last dsa_solve: see DSA_STAT_* */
+enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, DSA_STAT_MS_STAGES,
+       DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_VISITS_TOTAL,
+       DSA_STAT_CHUNK, DSA_STAT_COUNT };
+int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT */);
+
+/* ---- drop-in level -------------------------------------------------------------------------- */
+int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,
+                 int* iw, float* rw, int* col, float* dsurf,
+                 const float* goxdf, const float* gozdf, const float* dvxdf, const float* dvzdf,
+                 const int* kmaxRc, const int* kmaxRg, const int* kmaxLc, const int* kmaxLg,
+                 const double* tRc, const double* tRg, const double* tLc, const double* tLg,
+                 const int* wavetype, const int* igrt, const int* periods, const float* depz,
+                 const float* minthk, const float* scxf, const float* sczf, const float* rcxf,
+                 const float* rczf, const int* nrc1, const int* nsrcsurf1, const int* kmax,
+                 const int* nsrcsurf, const int* nrcf, int* nar);
+
+int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,
+                  float* obst,
+                  const float* goxdf, const float* gozdf, const float* dvxdf, const float* dvzdf,
+                  const int* kmaxRc, const int* kmaxRg, const int* kmaxLc, const int* kmaxLg,
+                  const double* tRc, const double* tRg, const double* tLc, const double* tLg,
+                  const int* wavetype, const int* igrt, const int* periods, const float* depz,
+                  const float* minthk, const float* scxf, const float* sczf, const float* rcxf,
+                  const float* rczf, const int* nrc1, const int* nsrcsurf1, const int* kmax,
+                  const int* nsrcsurf, const int* nrcf, const float* noiselevel);
+
+/* text of the last error of the process-wide engine used by the drop-in level */
+const char* dsa_dropin_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
