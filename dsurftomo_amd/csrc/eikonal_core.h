@@ -151,27 +151,43 @@ DSA_HD float fouds2(const Stencil& s, float slown, const NodeGeom& g)
     return travm;
 }
 
-// Raw neighbourhood of a node as stored in a travel-time field (sign bit = pinned, +inf = not
-// reached). Order: [0]=x-, [1]=x+, [2]=z-, [3]=z+; `outer` are the nodes two steps away.
+// Per-node state of the fixed-point solve: the travel time T and the acceptance time tau.
+//
+// Fast Marching accepts nodes in the order of a clock that never runs backwards, but the value a
+// node is accepted with can be *smaller* than the clock: when a neighbour Y is accepted at time
+// t and the update of X from Y gives c < t (two fronts meeting head-on with second-order
+// stencils), X is accepted right away, at clock time t, with value c.  Its other neighbours must
+// then treat X as "accepted at t", not "accepted at c".  So every node carries
+//     T   = its travel time (what the stencil uses),
+//     tau = max(T, tau of the last neighbour it used) = when it was accepted (what orders things).
+// With T alone the update has no fixed point at such nodes and the iteration cycles forever; with
+// (T, tau) the reference's field is a fixed point everywhere except at exact time ties.
+//
+// Storage: T with sign bit = pinned (accepted by the serial march, never recomputed); tau with
+// sign bit = "queued" (the node is in an active list).  +inf = not reached.
+constexpr uint32_t kQueuedBit = 0x80000000u;
+DSA_HD float tau_value(float t) { return __builtin_fabsf(t); }
+
+// Raw neighbourhood of a node. Order: [0]=x-, [1]=x+, [2]=z-, [3]=z+; `*_outer` two steps away.
 struct Hood {
-    float near_[4];
-    float outer[4];
+    float near_[4], near_tau[4];
+    float outer[4], outer_tau[4];
     bool in[4];       // near neighbour inside the grid
     bool in_outer[4]; // outer neighbour inside the grid
 };
 
-// Local solver H: the value Fast Marching would have *accepted* at this node, as a pure function
-// of the neighbours' times.  FMM recomputes a trial value each time a neighbour is accepted and
+// Local solver: the (T, tau) Fast Marching would have accepted at this node, as a pure function
+// of the neighbours' states.  FMM recomputes a trial value each time a neighbour is accepted and
 // freezes it when the node itself is popped, i.e. when its trial value is no later than the next
-// neighbour's time.  So: neighbours that are pinned are alive from the start; the others are
-// taken in order of increasing time, and the walk stops at the first trial value c with
-// c <= T(next neighbour).  An outer node counts as alive when it is pinned or was accepted
-// before the neighbour most recently added ("now").  Ties stop the walk (c <= T): the reference's
-// own tie order depends on its heap layout and cannot be derived locally ("ties").
-DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g)
+// neighbour's acceptance.  So: pinned neighbours are alive from the start; the others are taken in
+// order of increasing tau, and the walk stops at the first trial value c with c <= tau(next).
+// An outer node counts as alive when it is pinned or was accepted before the neighbour most
+// recently added ("now").  Ties stop the walk (c <= tau): the reference's own tie order depends on
+// its heap layout and cannot be derived locally ("ties").
+DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* tau_out)
 {
     Stencil s;
-    float tn[4];
+    float tn[4], kn[4];
     bool pin[4];
     int order[4];
     int no = 0;
@@ -180,15 +196,16 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g)
         const bool in = h.in[q];
         const float raw = in ? h.near_[q] : kInf;
         tn[q] = t_value(raw);
+        kn[q] = in ? tau_value(h.near_tau[q]) : kInf;
         pin[q] = in && t_pinned(raw);
         if (pin[q]) any_alive = true;
-        else if (in && tn[q] < kInf) order[no++] = q;
+        else if (in && kn[q] < kInf) order[no++] = q;
     }
-    // insertion sort of at most 4 candidates by time
+    // insertion sort of at most 4 candidates by acceptance time
     for (int i = 1; i < no; ++i) {
         const int q = order[i];
         int j = i;
-        while (j > 0 && tn[order[j - 1]] > tn[q]) { order[j] = order[j - 1]; --j; }
+        while (j > 0 && kn[order[j - 1]] > kn[q]) { order[j] = order[j - 1]; --j; }
         order[j] = q;
     }
     bool alive[4] = { pin[0], pin[1], pin[2], pin[3] };
@@ -202,8 +219,8 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g)
             const float oxr = h.in_outer[d] ? h.outer[d] : kInf;
             const float ozr = h.in_outer[2 + d] ? h.outer[2 + d] : kInf;
             s.tj2[d] = t_value(oxr);   s.tk2[d] = t_value(ozr);
-            s.oj[d] = h.in_outer[d] && (t_pinned(oxr) || t_value(oxr) < tnow);
-            s.ok[d] = h.in_outer[2 + d] && (t_pinned(ozr) || t_value(ozr) < tnow);
+            s.oj[d] = h.in_outer[d] && (t_pinned(oxr) || tau_value(h.outer_tau[d]) < tnow);
+            s.ok[d] = h.in_outer[2 + d] && (t_pinned(ozr) || tau_value(h.outer_tau[2 + d]) < tnow);
         }
     };
 
@@ -211,12 +228,13 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g)
     if (any_alive) { fill(); c = fouds2(s, slown, g); }
     for (int i = 0; i < no; ++i) {
         const int q = order[i];
-        if (c <= tn[q]) break;
+        if (c <= kn[q]) break;
         alive[q] = true;
-        tnow = tn[q];
+        tnow = kn[q];
         fill();
         c = fouds2(s, slown, g);
     }
+    *tau_out = (c > tnow) ? c : tnow;
     return c;
 }
 

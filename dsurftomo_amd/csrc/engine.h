@@ -44,16 +44,17 @@ struct Engine {
     size_t per_unit_bytes = 0;
     int chunk = 0;
     int max_chunk = 0;
-    float window_cells = 8.0f;
+    float window_cells = 3.0f;
+    int list_cap = 0, ready_cap = 0;   // 0 = derive from the grid
     int last_chunk_first = -1, last_chunk_n = 0;
 
     DevBuf<SourceDesc> src;
     DevBuf<RayDesc> rays;
     DevBuf<float> out;
     DevBuf<int32_t> err;
-    DevBuf<float> slow_r, T_r, Tfin_r, risti_r, vcorner, key_r, tstar, T_c, key_c;
+    DevBuf<float> slow_r, T_r, tau_r, Tfin_r, risti_r, vcorner, T_c, tau_c;
+    DevBuf<int> seed_r, nseed_r, seed_c, nseed_c;
     DevBuf<int8_t> S_r, cinit;
-    DevBuf<unsigned long long> mask_r, mask_c;
     DevBuf<int16_t> rst, cst;
     DevBuf<int32_t> heap, flags, info;
     DevBuf<FimProblem> prob_r, prob_c;
@@ -68,7 +69,7 @@ struct Engine {
     int plan(int nunits, const int* map_index, const float* scx, const float* scz, const int* nrec, const float* rcx, const float* rcz);
     int solve(float* dsurf);
     BatchPtrs batch() const;
-    int list_cap_for(size_t nblocks) const;
+    FimLaunch launch_shape(int nnx, int nnz) const;
     void launch_srtimes_chunk(int r0, int nr, int first_unit);
     int get_field(int unit, float* ttn);
     int get_refined(int unit, int* rnx, int* rnz, float* ttnr, int8_t* st);

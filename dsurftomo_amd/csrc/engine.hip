@@ -54,8 +54,8 @@ Engine::~Engine()
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     rel(velv); rel(veln); rel(slow); rel(risti_c); rel(cbasis); rel(rbasis);
     rel(src); rel(rays); rel(out); rel(err);
-    rel(slow_r); rel(T_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(mask_r); rel(key_r);
-    rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(tstar); rel(T_c); rel(mask_c); rel(key_c);
+    rel(slow_r); rel(T_r); rel(tau_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
+    rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(T_c); rel(tau_c); rel(seed_c); rel(nseed_c);
     rel(prob_r); rel(prob_c); rel(info);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
@@ -153,8 +153,8 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     size_t free_b = 0, total_b = 0;
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
     size_t budget = mem_budget ? mem_budget : (size_t)(0.6 * (double)free_b);
-    const size_t nb = (size_t)g.nbx * g.nbz, rr = (size_t)kRefMax * kRefMax;
-    per_unit_bytes = nfield * 4 + nb * 12 + rr * 13 + kRefMax * 4 + kRefBlocks * 12 + kRWin * kRWin * 2 +
+    const size_t rr = (size_t)kRefMax * kRefMax;
+    per_unit_bytes = nfield * 8 + rr * 17 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
                      (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(SourceDesc);
     size_t c = budget / per_unit_bytes;
     if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B)", budget, per_unit_bytes); return DSA_ERR_DEVICE; }
@@ -162,11 +162,11 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
     const size_t C = (size_t)chunk;
     if (ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(nr, 1)) || ensure(err, 4) ||
-        ensure(slow_r, C * rr) || ensure(T_r, C * rr) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
-        ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(mask_r, C * kRefBlocks) || ensure(key_r, C * kRefBlocks) ||
+        ensure(slow_r, C * rr) || ensure(T_r, C * rr) || ensure(tau_r, C * rr) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
+        ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
-        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(tstar, C) || ensure(T_c, C * nfield) ||
-        ensure(mask_c, C * nb) || ensure(key_c, C * nb) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 8)) return status;
+        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, C * nfield) || ensure(tau_c, C * nfield) ||
+        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16)) return status;
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = true;
@@ -177,9 +177,9 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
 BatchPtrs Engine::batch() const
 {
     BatchPtrs b;
-    b.src = src.p; b.slow_r = slow_r.p; b.T_r = T_r.p; b.Tfin_r = Tfin_r.p; b.S_r = S_r.p; b.risti_r = risti_r.p;
-    b.vcorner = vcorner.p; b.mask_r = mask_r.p; b.key_r = key_r.p; b.rst = rst.p; b.cst = cst.p; b.cinit = cinit.p;
-    b.heap = heap.p; b.flags = flags.p; b.tstar = tstar.p; b.T_c = T_c.p; b.mask_c = mask_c.p; b.key_c = key_c.p;
+    b.src = src.p; b.slow_r = slow_r.p; b.T_r = T_r.p; b.tau_r = tau_r.p; b.Tfin_r = Tfin_r.p; b.S_r = S_r.p; b.risti_r = risti_r.p;
+    b.vcorner = vcorner.p; b.seed_r = seed_r.p; b.nseed_r = nseed_r.p; b.rst = rst.p; b.cst = cst.p; b.cinit = cinit.p;
+    b.heap = heap.p; b.flags = flags.p; b.T_c = T_c.p; b.tau_c = tau_c.p; b.seed_c = seed_c.p; b.nseed_c = nseed_c.p;
     return b;
 }
 
@@ -188,12 +188,11 @@ int Engine::solve(float* dsurf)
     if (!planned) { fail(DSA_ERR_STATE, "solve: call dsa_plan first"); return DSA_ERR_STATE; }
     HIP_TRY(this, hipSetDevice(device));
     const int nunits = (int)h_src.size();
-    const size_t nb = (size_t)g.nbx * g.nbz;
     std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
     stats[DSA_STAT_UNITS] = nunits;
     stats[DSA_STAT_CHUNK] = chunk;
-    // causal window: a few cells' worth of travel time at the fastest velocity of the model
-    const float cell_c = std::min(g.dnx, g.dnz) * g.earth * 0.5f * hmin_slow;
+    // causal window: a few cells' worth of travel time (narrowest cell, fastest velocity of the model)
+    const float cell_c = dpl * hmin_slow;
     const float window_c = window_cells * cell_c;
     const float window_r = window_cells * cell_c / (float)kSgdl;
     HIP_TRY(this, hipMemsetAsync(err.p, 0, 4 * sizeof(int32_t), stream));
@@ -206,20 +205,17 @@ int Engine::solve(float* dsurf)
         HIP_TRY(this, hipMemcpyAsync(risti_r.p, h_risti_r.data() + (size_t)first * kRefMax, (size_t)n * kRefMax * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipEventRecord(events[1], stream));
         launch_fill(T_c.p, (size_t)n * nfield, kInf, stream);
-        launch_fill(key_c.p, (size_t)n * nb, kInf, stream);
-        HIP_TRY(this, hipMemsetAsync(mask_c.p, 0, (size_t)n * nb * 8, stream));
+        launch_fill(tau_c.p, (size_t)n * nfield, kInf, stream);
         launch_make_problems(g, b, n, slow.p, nfield, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));
-        FimLaunch lr; lr.max_blocks = kRefBlocks; lr.list_cap = 512;
-        launch_fim(prob_r.p, n, lr, stream);
+        launch_fim(prob_r.p, n, launch_shape(kRefMax, kRefMax), stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         launch_handoff(g, b, n, stream);
         launch_coarse_march(g, b, n, slow.p, nfield, risti_c.p, stream);
         HIP_TRY(this, hipEventRecord(events[4], stream));
-        FimLaunch lc; lc.max_blocks = (int)nb; lc.list_cap = list_cap_for(nb);
-        launch_fim(prob_c.p, n, lc, stream);
+        launch_fim(prob_c.p, n, launch_shape(g.nnx, g.nnz), stream);
         HIP_TRY(this, hipEventRecord(events[5], stream));
         // receivers of this chunk
         const int r0 = h_src[first].first_ray;
@@ -227,9 +223,9 @@ int Engine::solve(float* dsurf)
         if (r1 > r0) launch_srtimes_chunk(r0, r1 - r0, first);
         HIP_TRY(this, hipEventRecord(events[6], stream));
         HIP_TRY(this, hipGetLastError());
-        h_info.resize((size_t)n * 8);
+        h_info.resize((size_t)n * 16);
         h_flags.resize((size_t)n * 4);
-        HIP_TRY(this, hipMemcpyAsync(h_info.data(), info.p, (size_t)n * 8 * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(this, hipMemcpyAsync(h_info.data(), info.p, (size_t)n * 16 * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipMemcpyAsync(h_flags.data(), flags.p, (size_t)n * 4 * 4, hipMemcpyDeviceToHost, stream));
         if (dsurf && r1 > r0)
             HIP_TRY(this, hipMemcpyAsync(dsurf + r0, out.p + r0, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, stream));
@@ -243,11 +239,16 @@ int Engine::solve(float* dsurf)
         HIP_TRY(this, hipEventElapsedTime(&d, events[5], events[6]));
         stats[DSA_STAT_MS_STAGES] += a + c2 + d;
         stats[DSA_STAT_LAUNCHES_FIM_COARSE] += 1;
+        last_chunk_first = first;
+        last_chunk_n = n;
         for (int u = 0; u < n; ++u) {
-            const int32_t* fi = &h_info[(size_t)u * 8];
-            stats[DSA_STAT_ROUNDS_MAX] = std::max(stats[DSA_STAT_ROUNDS_MAX], (double)fi[4]);
-            stats[DSA_STAT_VISITS_TOTAL] += fi[5];
-            if (fi[3] || fi[7]) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge", first + u); return DSA_ERR_INTERNAL; }
+            const int32_t* fi = &h_info[(size_t)u * 16];
+            stats[DSA_STAT_ROUNDS_MAX] = std::max(stats[DSA_STAT_ROUNDS_MAX], (double)fi[8]);
+            unsigned long long ev;
+            std::memcpy(&ev, fi + 12, 8);
+            stats[DSA_STAT_EVALS_TOTAL] += (double)ev;
+            stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
+            if (fi[2] < 0 || fi[10] < 0) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
             if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
         }
         last_chunk_first = first;
@@ -264,15 +265,17 @@ int Engine::solve(float* dsurf)
     return 0;
 }
 
-int Engine::list_cap_for(size_t nblocks) const
+FimLaunch Engine::launch_shape(int nnx, int nnz) const
 {
-    // the active band is a few block rows along the front's perimeter
-    size_t cap = 8 * (size_t)(g.nbx + g.nbz) + 256;
-    if (cap > nblocks + 64) cap = nblocks + 64;
-    // LDS: 2 lists + bitset + tiles must stay below 160 KiB; leave room for 2 workgroups per CU
-    const size_t limit = (64 * 1024 - (nblocks + 31) / 32 * 4 - 8 * 144 * 4 - 64) / 8;
-    if (cap > limit) cap = limit;
-    return (int)cap;
+    // the active band is a few node layers along the front's perimeter; everything lives in LDS
+    FimLaunch l;
+    size_t cap = list_cap > 0 ? (size_t)list_cap : (size_t)6 * (size_t)(nnx + nnz) + 1024;
+    size_t rcap = ready_cap > 0 ? (size_t)ready_cap : (size_t)2 * (size_t)(nnx + nnz) + 1024;
+    const size_t limit = (150 * 1024) / 4;                  // ints of LDS left for lists
+    if (2 * cap + rcap > limit) { cap = limit * 3 / 8; rcap = limit / 4; }
+    l.list_cap = (int)cap;
+    l.ready_cap = (int)rcap;
+    return l;
 }
 
 void Engine::launch_srtimes_chunk(int r0, int nr, int first_unit)
@@ -342,6 +345,19 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes)
     return 0;
 }
 
+int dsa_set_option(dsa_engine* e, const char* name, double value)
+{
+    if (!e || !name) return DSA_ERR_ARGUMENT;
+    Engine* en = reinterpret_cast<Engine*>(e);
+    const std::string n(name);
+    if (n == "window_cells" && value > 0) { en->window_cells = (float)value; return 0; }
+    if (n == "max_chunk" && value >= 0) { en->max_chunk = (int)value; return 0; }
+    if (n == "list_cap" && value >= 0) { en->list_cap = (int)value; return 0; }
+    if (n == "ready_cap" && value >= 0) { en->ready_cap = (int)value; return 0; }
+    en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
+    return DSA_ERR_ARGUMENT;
+}
+
 int dsa_set_maps(dsa_engine* e, int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int dicing, int nmaps, const double* pv)
 {
     if (!e) return DSA_ERR_ARGUMENT;
@@ -392,6 +408,18 @@ int dsa_get_refined(dsa_engine* e, int unit, int* rnx, int* rnz, float* ttnr, in
 {
     if (!e || !rnx || !rnz || !ttnr || !status) return DSA_ERR_ARGUMENT;
     return reinterpret_cast<Engine*>(e)->get_refined(unit, rnx, rnz, ttnr, status);
+}
+
+int dsa_debug_field(dsa_engine* e, int unit, int which, float* out)
+{
+    if (!e || !out) return DSA_ERR_ARGUMENT;
+    Engine* en = reinterpret_cast<Engine*>(e);
+    if (en->last_chunk_first < 0 || unit < en->last_chunk_first || unit >= en->last_chunk_first + en->last_chunk_n) return DSA_ERR_STATE;
+    const size_t slot = (size_t)(unit - en->last_chunk_first), rr = (size_t)dsa::kRefMax * dsa::kRefMax;
+    const float* src = which == 0 ? en->T_c.p + slot * en->nfield : which == 1 ? en->tau_c.p + slot * en->nfield
+                     : which == 2 ? en->T_r.p + slot * rr : en->tau_r.p + slot * rr;
+    const size_t n = which < 2 ? en->nfield : rr;
+    return hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : DSA_ERR_DEVICE;
 }
 
 int dsa_get_stats(const dsa_engine* e, double* out)

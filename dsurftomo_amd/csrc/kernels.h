@@ -9,28 +9,29 @@
 namespace dsa {
 
 // One fixed-point problem: a travel-time field on an (nnz, nnx) grid, column-major with z fastest.
-// T carries the boundary condition: pinned nodes (sign bit) are never recomputed, every other
-// node is +inf or a previous estimate.  mask/key are per 8x8-node block (block id = bx*nbz + bz):
-// mask bit (lx*8 + lz) marks a node whose neighbourhood changed since it was last evaluated,
-// key is a lower bound on the time at which the block's dirty nodes can be accepted.
+// T / tau carry the boundary condition (eikonal_core.h): pinned nodes (sign bit of T) are never
+// recomputed, every other node starts at +inf.  `seed` lists the nodes to evaluate first (their
+// queued bit, the sign bit of tau, is already set).
 struct FimProblem {
     float* T;
+    float* tau;
     const float* slow;
     const float* risti;
-    unsigned long long* mask;
-    float* key;
-    int nnx, nnz, nbx, nbz;
+    const int* seed;
+    const int* seed_count;
+    int nnx, nnz;
     float ri, dnx, dnz;
     float window;          // causal window (seconds of travel time) evaluated per round
-    int32_t* info;         // [0] rounds, [1] block visits, [2] list overflows, [3] error
+    int max_rounds;
+    int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [4..5] evaluations (u64)
 };
 
 struct FimLaunch {
     int list_cap;          // entries per active list (LDS)
-    int max_blocks;        // max blocks of any problem in the launch (sizes the membership bitset)
+    int ready_cap;         // entries of the dense ready list (LDS)
 };
 
-size_t fim_lds_bytes(const FimLaunch& l, int nwaves);
+size_t fim_lds_bytes(const FimLaunch& l);
 void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream);
 
 // period-level tables ---------------------------------------------------------------------------
@@ -42,20 +43,20 @@ void launch_gridder(const GridDesc& g, const float* d_velv, const float* d_basis
 struct BatchPtrs {
     const SourceDesc* src;       // [nsrc]
     // refined, per source, stride kRefMax*kRefMax unless noted
-    float* slow_r; float* T_r; float* Tfin_r; int8_t* S_r;
+    float* slow_r; float* T_r; float* tau_r; float* Tfin_r; int8_t* S_r;
     float* risti_r;              // stride kRefMax (uploaded by the host)
     float* vcorner;              // stride 4
-    unsigned long long* mask_r; float* key_r;     // stride kRefBlocks
+    int* seed_r; int* nseed_r;   // stride kSeedR / 1
     int16_t* rst;                // stride kRWin*kRWin
     int16_t* cst; int8_t* cinit; // stride kCWinMax*kCWinMax
     int32_t* heap;               // stride kHeapCap
     int32_t* flags;              // stride 4: [0] ended early, [1] error, [2] e* iz, [3] e* ix
-    float* tstar;                // stride 1
     // coarse, per source
-    float* T_c;                  // stride nnx*nnz
-    unsigned long long* mask_c; float* key_c;     // stride nbx*nbz
+    float* T_c; float* tau_c;    // stride nnx*nnz
+    int* seed_c; int* nseed_c;   // stride kSeedC / 1
 };
-constexpr int kRefBlocks = 17 * 17;
+constexpr int kSeedR = kRWin * kRWin;              // the start-up march cannot pin more than its window
+constexpr int kSeedC = kCWinMax * kCWinMax;
 
 void launch_fill(float* d, size_t n, float v, hipStream_t stream);
 void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_velv_all, size_t velv_stride,

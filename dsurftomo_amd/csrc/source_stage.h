@@ -54,6 +54,7 @@ struct SourceDesc {
 struct SourceScratch {
     float* slow_r;      // kRefMax*kRefMax, ld = rnz
     float* T_r;         // same; during the refined solve: sign bit = pinned, +inf = not reached
+    float* tau_r;       // acceptance times of the refined solve (eikonal_core.h)
     int8_t* S_r;        // final refined status: -1 far, 0 alive, 1 close (kept for the ray tracer)
     float* risti_r;     // kRefMax
     float* vcorner;     // 4 refined velocities of the source cell, [i][j] i = x offset
@@ -161,31 +162,46 @@ DSA_HD void refined_encode(const SourceDesc& s, SourceScratch& w, int ended)
             const int ix = s.rwx0 + lx + 1, iz = s.rwz0 + lz + 1;
             if (ix < 1 || ix > s.rnx || iz < 1 || iz > s.rnz) continue;
             const int st = w.rst[lx * kRWin + lz];
-            float& t = w.T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)];
-            if (st == 0) t = -t;                 // -0.0f for an exact zero keeps the sign bit
-            else if (st > 0 && ended) { /* keep trial value */ }
-            else t = kInf;
+            const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
+            float& t = w.T_r[id];
+            if (st == 0) { w.tau_r[id] = t; t = -t; }          // -0.0f for an exact zero keeps the sign bit
+            else if (st > 0 && ended) w.tau_r[id] = t;          // keep the trial value
+            else { t = kInf; w.tau_r[id] = kInf; }
         }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Hand-off, per refined node, after the fixed point on the box (or after an early end).
-// tstar: first arrival on an open edge; (ez, ex): the node that carried it (0 if none).
+// rstar: acceptance rank of the first open-edge node; (ez, ex): that node (0 if none).
 DSA_HD bool is_open_edge(const SourceDesc& s, int iz, int ix)
 {
     return (ix == 1 && s.open_xlo) || (ix == s.rnx && s.open_xhi) || (iz == 1 && s.open_zlo) ||
            (iz == s.rnz && s.open_zhi);
 }
 
-DSA_HD bool ref_alive(const SourceDesc& s, const float* T_r, float tstar, int iz, int ix)
+// Acceptance order of the refined solve: by tau; among nodes accepted at the same clock value the
+// causal one (T == tau) goes first, then the non-causal ones by value.  Packed so that unsigned
+// comparison orders it (all values are >= 0).
+DSA_HD uint64_t accept_rank(float t_raw, float tau_raw)
 {
-    const float t = T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)];
-    return t_pinned(t) || t_value(t) < tstar;
+    const float t = t_value(t_raw), k = tau_value(tau_raw);
+    union { float f; uint32_t u; } a, b;
+    a.f = k; b.f = t;
+    const uint32_t sec = (t < k) ? b.u + 1u : 0u;
+    return ((uint64_t)a.u << 32) | sec;
+}
+
+// rstar: rank of the open-edge node that ended the refined stage (~0 if none)
+DSA_HD bool ref_alive(const SourceDesc& s, const SourceScratch& w, uint64_t rstar, int iz, int ix)
+{
+    const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
+    const float t = w.T_r[id];
+    return t_pinned(t) || accept_rank(t, w.tau_r[id]) < rstar;
 }
 
 // classify node (iz, ix): returns status (-1, 0, 1) and the value to keep in *tout
 DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScratch& w, int ended,
-                        float tstar, int ez, int ex, int iz, int ix, float* tout)
+                        uint64_t rstar, int ez, int ex, int iz, int ix, float* tout)
 {
     const float raw = w.T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)];
     if (ended) {
@@ -193,7 +209,7 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
         if (t_value(raw) < kInf) { *tout = raw; return 1; }
         *tout = kInf; return -1;
     }
-    if (ref_alive(s, w.T_r, tstar, iz, ix)) { *tout = t_value(raw); return 0; }
+    if (ref_alive(s, w, rstar, iz, ix)) { *tout = t_value(raw); return 0; }
     // not alive: close iff it touches an alive node; its value is the trial value from the alive
     // set (the edge node that ended the stage is alive but was never propagated)
     Stencil st;
@@ -202,15 +218,15 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
     bool touch = false;
     for (int d = 0; d < 2; ++d) {
         st.ej[d] = jx[d] >= 1 && jx[d] <= s.rnx;
-        st.aj[d] = st.ej[d] && ref_alive(s, w.T_r, tstar, iz, jx[d]);
+        st.aj[d] = st.ej[d] && ref_alive(s, w, rstar, iz, jx[d]);
         st.tj[d] = st.aj[d] ? t_value(w.T_r[(size_t)(jx[d] - 1) * s.rnz + (iz - 1)]) : kInf;
-        const bool o = jx2[d] >= 1 && jx2[d] <= s.rnx && ref_alive(s, w.T_r, tstar, iz, jx2[d]);
+        const bool o = jx2[d] >= 1 && jx2[d] <= s.rnx && ref_alive(s, w, rstar, iz, jx2[d]);
         st.oj[d] = o;
         st.tj2[d] = o ? t_value(w.T_r[(size_t)(jx2[d] - 1) * s.rnz + (iz - 1)]) : kInf;
         st.ek[d] = kz[d] >= 1 && kz[d] <= s.rnz;
-        st.ak[d] = st.ek[d] && ref_alive(s, w.T_r, tstar, kz[d], ix);
+        st.ak[d] = st.ek[d] && ref_alive(s, w, rstar, kz[d], ix);
         st.tk[d] = st.ak[d] ? t_value(w.T_r[(size_t)(ix - 1) * s.rnz + (kz[d] - 1)]) : kInf;
-        const bool p = kz2[d] >= 1 && kz2[d] <= s.rnz && ref_alive(s, w.T_r, tstar, kz2[d], ix);
+        const bool p = kz2[d] >= 1 && kz2[d] <= s.rnz && ref_alive(s, w, rstar, kz2[d], ix);
         st.ok[d] = p;
         st.tk2[d] = p ? t_value(w.T_r[(size_t)(ix - 1) * s.rnz + (kz2[d] - 1)]) : kInf;
         touch = touch || st.aj[d] || st.ak[d];
@@ -226,8 +242,8 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
 // Band march on the coarse grid: travel(urg=2) from the injected state until every node that
 // started in the tree has been accepted.  T_c is the coarse field of this source (plain values
 // inside the window on entry for status >= 0), slow_c/risti_c the period's coarse tables.
-// Serial.  On return: alive nodes of the window are pinned (sign bit), all others +inf.
-DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, float* T_c,
+// Serial.  On return: alive nodes of the window are pinned (sign bit), all others +inf (T and tau).
+DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, float* T_c, float* tau_c,
                               const float* slow_c, const float* risti_c)
 {
     MarchView m;
@@ -253,10 +269,11 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
     for (int lx = 0; lx < s.cwnx; ++lx)
         for (int lz = 0; lz < s.cwnz; ++lz) {
             const int ix = s.cwx0 + lx + 1, iz = s.cwz0 + lz + 1;
-            float& t = T_c[(size_t)(ix - 1) * g.nnz + (iz - 1)];
+            const size_t id = (size_t)(ix - 1) * g.nnz + (iz - 1);
+            float& t = T_c[id];
             const int st = w.cst[lx * s.cwnz + lz];
-            if (st == 0) t = -t_value(t);
-            else t = kInf;
+            if (st == 0) { tau_c[id] = t_value(t); t = -t_value(t); }
+            else { t = kInf; tau_c[id] = kInf; }
         }
 }
 

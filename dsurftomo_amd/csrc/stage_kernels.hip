@@ -12,6 +12,7 @@ __device__ __forceinline__ SourceScratch scratch_of(const BatchPtrs& b, int s)
     const size_t rr = (size_t)kRefMax * kRefMax;
     w.slow_r = b.slow_r + s * rr;
     w.T_r = b.T_r + s * rr;
+    w.tau_r = b.tau_r + s * rr;
     w.S_r = b.S_r + s * rr;
     w.risti_r = b.risti_r + (size_t)s * kRefMax;
     w.vcorner = b.vcorner + (size_t)s * 4;
@@ -23,14 +24,15 @@ __device__ __forceinline__ SourceScratch scratch_of(const BatchPtrs& b, int s)
     return w;
 }
 
-// mark node (iz, ix) (1-based) dirty in a block-mask array; single writer per source
-__device__ __forceinline__ void mark_dirty(unsigned long long* mask, float* key, int nbz, int iz, int ix, float t)
+// queue node (iz, ix) (1-based) as a seed of the fixed-point solve; single writer per source
+__device__ __forceinline__ void seed_node(float* tau, int ld, int* seed, int* nseed, int cap, int iz, int ix)
 {
-    const int bx = (ix - 1) >> 3, bz = (iz - 1) >> 3;
-    const int bit = ((ix - 1) & 7) * 8 + ((iz - 1) & 7);
-    const int b = bx * nbz + bz;
-    mask[b] |= 1ull << bit;
-    if (t < key[b]) key[b] = t;
+    const size_t id = (size_t)(ix - 1) * ld + (iz - 1);
+    unsigned* bits = reinterpret_cast<unsigned*>(tau);
+    if (bits[id] & kQueuedBit) return;
+    bits[id] |= kQueuedBit;
+    if (*nseed < cap) seed[*nseed] = (int)id;
+    *nseed += 1;      // a count above cap makes the solve kernel rescan the field
 }
 
 }  // namespace
@@ -81,14 +83,15 @@ __global__ void k_refine(GridDesc g, BatchPtrs b, const float* __restrict__ velv
     const int n = sd.rnx * sd.rnz;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t rr = (size_t)kRefMax * kRefMax;
-    if (id < kRefBlocks) { b.mask_r[(size_t)s * kRefBlocks + id] = 0ull; b.key_r[(size_t)s * kRefBlocks + id] = kInf; }
     if (id < 4 && blockIdx.x == 0) b.flags[(size_t)s * 4 + id] = 0;
+    if (id == 0 && blockIdx.x == 0) { b.nseed_r[s] = 0; b.nseed_c[s] = 0; }
     if (id >= n) return;
     const int lx = id / sd.rnz + 1, kz = id % sd.rnz + 1;
     const float* velv = velv_all + (size_t)sd.period * velv_stride;
     const float v = refined_velocity(g, sd, velv, rbasis, kz, lx);
     b.slow_r[s * rr + id] = 1.0f / v;
     b.T_r[s * rr + id] = kInf;
+    b.tau_r[s * rr + id] = kInf;
     if ((lx == sd.isx_r || lx == sd.isx_r + 1) && (kz == sd.isz_r || kz == sd.isz_r + 1))
         b.vcorner[(size_t)s * 4 + (lx - sd.isx_r) * 2 + (kz - sd.isz_r)] = v;
 }
@@ -114,20 +117,20 @@ __global__ void k_refined_startup(GridDesc g, BatchPtrs b, int nsrc)
     refined_encode(sd, w, ended);
     if (ended) return;
     // the unpinned neighbours of every pinned node start the fixed-point solve
-    unsigned long long* mask = b.mask_r + (size_t)s * kRefBlocks;
-    float* key = b.key_r + (size_t)s * kRefBlocks;
+    int* seed = b.seed_r + (size_t)s * kSeedR;
+    int nseed = 0;
     for (int lx = 0; lx < kRWin; ++lx)
         for (int lz = 0; lz < kRWin; ++lz) {
             if (w.rst[lx * kRWin + lz] != 0) continue;
             const int ix = sd.rwx0 + lx + 1, iz = sd.rwz0 + lz + 1;
-            const float t = t_value(w.T_r[(size_t)(ix - 1) * sd.rnz + (iz - 1)]);
             const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
             for (int q = 0; q < 4; ++q) {
                 if (nx[q] < 1 || nx[q] > sd.rnx || nz[q] < 1 || nz[q] > sd.rnz) continue;
                 if (t_pinned(w.T_r[(size_t)(nx[q] - 1) * sd.rnz + (nz[q] - 1)])) continue;
-                mark_dirty(mask, key, sd.nbz_r, nz[q], nx[q], t);
+                seed_node(w.tau_r, sd.rnz, seed, &nseed, kSeedR, nz[q], nx[q]);
             }
         }
+    b.nseed_r[s] = nseed;
 }
 
 void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream)
@@ -141,39 +144,41 @@ void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hip
 __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
 {
     __shared__ unsigned long long s_best;
+    __shared__ int s_first;
     const int s = blockIdx.x, tid = threadIdx.x;
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
     const int ended = w.flags[0];
     const int n = sd.rnx * sd.rnz;
     const size_t rr = (size_t)kRefMax * kRefMax;
-    if (tid == 0) s_best = ~0ull;
+    if (tid == 0) { s_best = ~0ull; s_first = 0x7fffffff; }
     __syncthreads();
-    // first arrival on an open edge; ties resolved by scan order (ix outer, iz inner)
+    // first open-edge node in acceptance order; exact ties resolved by scan order (ix outer, iz inner)
     if (!ended) {
         for (int id = tid; id < n; id += 256) {
             const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
-            if (!is_open_edge(sd, iz, ix)) continue;
-            const float t = t_value(w.T_r[id]);
-            const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id;
-            atomicMin(&s_best, k);
+            if (!is_open_edge(sd, iz, ix) || !(t_value(w.T_r[id]) < kInf)) continue;
+            atomicMin(&s_best, (unsigned long long)accept_rank(w.T_r[id], w.tau_r[id]));
         }
+        __syncthreads();
+        const unsigned long long best = s_best;
+        if (best != ~0ull)
+            for (int id = tid; id < n; id += 256) {
+                const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
+                if (!is_open_edge(sd, iz, ix) || !(t_value(w.T_r[id]) < kInf)) continue;
+                if ((unsigned long long)accept_rank(w.T_r[id], w.tau_r[id]) == best) atomicMin(&s_first, id);
+            }
     }
     __syncthreads();
-    float tstar = kInf;
+    const uint64_t rstar = ended ? ~0ull : (uint64_t)s_best;
     int ez = 0, ex = 0;
-    if (!ended && s_best != ~0ull) {
-        tstar = __uint_as_float((unsigned)(s_best >> 32));
-        const int id = (int)(s_best & 0xffffffffu);
-        ex = id / sd.rnz + 1; ez = id % sd.rnz + 1;
-        if (!(tstar < kInf)) { ez = 0; ex = 0; }
-    }
-    if (tid == 0) { b.tstar[s] = tstar; w.flags[2] = ez; w.flags[3] = ex; }
+    if (!ended && s_first != 0x7fffffff) { ex = s_first / sd.rnz + 1; ez = s_first % sd.rnz + 1; }
+    if (tid == 0) { w.flags[2] = ez; w.flags[3] = ex; }
     float* Tfin = b.Tfin_r + s * rr;
     for (int id = tid; id < n; id += 256) {
         const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
         float t;
-        const int st = handoff_node(g, sd, w, ended, tstar, ez, ex, iz, ix, &t);
+        const int st = handoff_node(g, sd, w, ended, rstar, ez, ex, iz, ix, &t);
         w.S_r[id] = (int8_t)st;
         Tfin[id] = t;
     }
@@ -225,22 +230,23 @@ __global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* _
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
     float* T_c = b.T_c + (size_t)s * g.nnx * g.nnz;
+    float* tau_c = b.tau_c + (size_t)s * g.nnx * g.nnz;
     const float* slow_c = slow_all + (size_t)sd.period * field_stride;
-    coarse_band_march(g, sd, w, T_c, slow_c, risti_c);
-    unsigned long long* mask = b.mask_c + (size_t)s * g.nbx * g.nbz;
-    float* key = b.key_c + (size_t)s * g.nbx * g.nbz;
+    coarse_band_march(g, sd, w, T_c, tau_c, slow_c, risti_c);
+    int* seed = b.seed_c + (size_t)s * kSeedC;
+    int nseed = 0;
     for (int lx = 0; lx < sd.cwnx; ++lx)
         for (int lz = 0; lz < sd.cwnz; ++lz) {
             if (w.cst[lx * sd.cwnz + lz] != 0) continue;
             const int ix = sd.cwx0 + lx + 1, iz = sd.cwz0 + lz + 1;
-            const float t = t_value(T_c[(size_t)(ix - 1) * g.nnz + (iz - 1)]);
             const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
             for (int q = 0; q < 4; ++q) {
                 if (nx[q] < 1 || nx[q] > g.nnx || nz[q] < 1 || nz[q] > g.nnz) continue;
                 if (t_pinned(T_c[(size_t)(nx[q] - 1) * g.nnz + (nz[q] - 1)])) continue;
-                mark_dirty(mask, key, g.nbz, nz[q], nx[q], t);
+                seed_node(tau_c, g.nnz, seed, &nseed, kSeedC, nz[q], nx[q]);
             }
         }
+    b.nseed_c[s] = nseed;
 }
 
 void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
@@ -260,20 +266,23 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     const SourceDesc sd = b.src[s];
     const size_t rr = (size_t)kRefMax * kRefMax;
     FimProblem r;
-    r.T = b.T_r + s * rr; r.slow = b.slow_r + s * rr; r.risti = b.risti_r + (size_t)s * kRefMax;
-    r.mask = b.mask_r + (size_t)s * kRefBlocks; r.key = b.key_r + (size_t)s * kRefBlocks;
-    r.nnx = sd.rnx; r.nnz = sd.rnz; r.nbx = sd.nbx_r; r.nbz = sd.nbz_r;
+    r.T = b.T_r + s * rr; r.tau = b.tau_r + s * rr; r.slow = b.slow_r + s * rr; r.risti = b.risti_r + (size_t)s * kRefMax;
+    r.seed = b.seed_r + (size_t)s * kSeedR; r.seed_count = b.nseed_r + s;
+    r.nnx = sd.rnx; r.nnz = sd.rnz;
     r.ri = g.earth; r.dnx = sd.rdnx; r.dnz = sd.rdnz; r.window = window_r;
-    r.info = info + (size_t)s * 8;
+    r.max_rounds = 64 * (sd.rnx + sd.rnz) + 4096;
+    r.info = info + (size_t)s * 16;
     prob_r[s] = r;
     FimProblem c;
-    c.T = b.T_c + (size_t)s * g.nnx * g.nnz; c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
-    c.mask = b.mask_c + (size_t)s * g.nbx * g.nbz; c.key = b.key_c + (size_t)s * g.nbx * g.nbz;
-    c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
+    c.T = b.T_c + (size_t)s * g.nnx * g.nnz; c.tau = b.tau_c + (size_t)s * g.nnx * g.nnz;
+    c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
+    c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s;
+    c.nnx = g.nnx; c.nnz = g.nnz;
     c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = window_c;
-    c.info = info + (size_t)s * 8 + 4;
+    c.max_rounds = 64 * (g.nnx + g.nnz) + 4096;
+    c.info = info + (size_t)s * 16 + 8;
     prob_c[s] = c;
-    for (int q = 0; q < 8; ++q) info[(size_t)s * 8 + q] = 0;
+    for (int q = 0; q < 16; ++q) info[(size_t)s * 16 + q] = 0;
 }
 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsurftomo_amd.so")
 
 STAT_NAMES = ("ms_total", "ms_fim_coarse", "ms_fim_refined", "ms_stages", "launches_fim_coarse", "units",
-              "rounds_max", "visits_total", "chunk")
+              "rounds_max", "evals_total", "chunk", "rescans")
 
 _f32, _i32, _vp = C.c_float, C.c_int, C.c_void_p
 _lib = None
@@ -39,6 +39,7 @@ def load_library():
     L.dsa_error_string.argtypes = [_vp]
     L.dsa_error_string.restype = C.c_char_p
     L.dsa_set_memory_budget.argtypes = [_vp, C.c_size_t]
+    L.dsa_set_option.argtypes = [_vp, C.c_char_p, C.c_double]
     L.dsa_set_maps.argtypes = [_vp, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _i32, _vp]
     L.dsa_plan.argtypes = [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
     L.dsa_solve.argtypes = [_vp, _vp]
@@ -48,6 +49,7 @@ def load_library():
     L.dsa_get_velocity.argtypes = [_vp, _i32, _vp]
     L.dsa_get_refined.argtypes = [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]
     L.dsa_get_stats.argtypes = [_vp, _vp]
+    L.dsa_debug_field.argtypes = [_vp, _i32, _i32, _vp]
     L.dsa_dropin_error.restype = C.c_char_p
     _lib = L
     return L
@@ -81,6 +83,9 @@ class Engine:
 
     def set_memory_budget(self, nbytes):
         self._check(self._L.dsa_set_memory_budget(self._h, int(nbytes)))
+
+    def set_option(self, name, value):
+        self._check(self._L.dsa_set_option(self._h, name.encode(), float(value)))
 
     def set_maps(self, nx, ny, goxd, gozd, dvxd, dvzd, pv, dicing=8):
         """pv: (nmaps, nx*ny) float64, latitude index fastest inside a map."""
@@ -132,6 +137,12 @@ class Engine:
         self._check(self._L.dsa_get_refined(self._h, int(unit), C.byref(a), C.byref(b), _p(t), _p(s)))
         n = a.value * b.value
         return t[:n].reshape(a.value, b.value).copy(), s[:n].reshape(a.value, b.value).copy()
+
+    def debug_field(self, unit, which):
+        """raw device state of a resident unit (see dsa_debug_field); coarse fields come back [ix, iz]"""
+        out = np.zeros((self.nnx, self.nnz) if which < 2 else (129 * 129,), np.float32)
+        self._check(self._L.dsa_debug_field(self._h, int(unit), int(which), _p(out)))
+        return out
 
     def stats(self):
         out = np.zeros(16, np.float64)

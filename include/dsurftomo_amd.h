@@ -48,6 +48,11 @@ const char* dsa_error_string(const dsa_engine* e);   /* e may be NULL: last crea
 /* memory the engine may use for per-source fields (bytes, 0 = default: 60 % of free HBM) */
 int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 
+/* tuning knobs: "window_cells" (causal window of the fixed-point solve, in cell travel times,
+ * default 3), "max_chunk" (cap on sources resident per chunk, 0 = memory budget only),
+ * "list_cap" / "ready_cap" (LDS list sizes of the solve kernel, 0 = derived from the grid) */
+int dsa_set_option(dsa_engine* e, const char* name, double value);
+
 /* ---- engine level --------------------------------------------------------------------------- */
 /* Grid of reference CalSurfG.f90:1032-1065 (dicing 8) / :2487-2520 (dicing 5) and `nmaps`
  * velocity maps pv[m][nx*ny] (fp64, latitude index fastest: pv[(jj-1)*nx + ii - 1], the layout
@@ -75,10 +80,14 @@ int dsa_get_velocity(dsa_engine* e, int map, float* veln);
 /* refined snapshot of a unit: ttnr (rnz, rnx) and status (-1 far, 0 alive, 1 close) */
 int dsa_get_refined(dsa_engine* e, int unit, int* rnx, int* rnz, float* ttnr, int8_t* status);
 
+/* raw state of a resident unit for diagnostics: which = 0 coarse T (sign bit = pinned), 1 coarse
+ * tau (sign bit = queued), 2 refined T, 3 refined tau (129*129 floats, leading dimension rnz) */
+int dsa_debug_field(dsa_engine* e, int unit, int which, float* out);
+
 /* counters of the last dsa_solve: see DSA_STAT_* */
 enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, DSA_STAT_MS_STAGES,
-       DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_VISITS_TOTAL,
-       DSA_STAT_CHUNK, DSA_STAT_COUNT };
+       DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_EVALS_TOTAL,
+       DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */

@@ -1,0 +1,26 @@
+"""Throughput / scheduling probe for the fixed-point kernel (not a benchmark: see bench.py)."""
+import sys, time, os, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import synth
+from dsurftomo_amd.engine import Engine
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 131
+nsrc = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+windows = [float(w) for w in sys.argv[3].split(',')] if len(sys.argv) > 3 else [2, 4, 8, 16, 32]
+kind = sys.argv[4] if len(sys.argv) > 4 else 'smooth'
+e = Engine(0)
+nper = 2
+pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)])
+e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+nb = ((e.nnx + 7) // 8) ** 2
+u = synth.units(nx, nsrc, nper, 32)
+ref = None
+for wc in windows:
+    e.set_option('window_cells', wc)
+    e.plan(**u)
+    t0 = time.time(); t = e.solve(); dt = time.time() - t0
+    st = e.stats(); n = nsrc * nper
+    same = 'first' if ref is None else f'identical={np.array_equal(ref.view(np.uint32), t.view(np.uint32))} maxdiff={np.abs(ref - t).max():.2g}'
+    if ref is None: ref = t
+    print(f'N={e.nnx} {kind} units {n:5d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
+          f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} | {same}', flush=True)
