@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the CalSurfG hot path on MI355X: (period, source) eikonal solves per second.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2] / configs[3]): 1025x1025 propagation grid
+(nx = ny = 131 velocity vertices), 16 periods, 1000 sources, 32 receivers per source, smooth
+2-D phase-velocity maps pv_p = (2.8 + 0.05 p)(1 + 0.10 sin(4 pi i/nx) cos(4 pi j/ny)).  A "step"
+is one pass of the hot path over the whole set: 16 000 solves (refine + two fixed-point solves)
+plus 512 000 receiver times.  Velocity maps and source/receiver descriptors are resident in HBM
+before the timed region; the receiver times come back to the host inside it.
+
+With N > 1 the 16 000 units are split into N contiguous slices (whole periods per rank), every
+rank solves its slice, and the receiver-time vector is completed on every rank by an RCCL
+all-gather: total work is fixed ("strong" scaling, as configs[3] states).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the coarse fixed-point
+solve) from HIP events recorded on the engine's own stream; `cpu_baseline` times the reference's
+own Fortran (oracle/_ref, single core) -- or the C oracle if that library is absent -- on a
+bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+NX = 131
+NPER = 16
+NSRC = 1000
+NREC = 32
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def bytes_per_solve(n):
+    """Algorithmic HBM bytes of one solve: fp32 velocity read + fp32 travel-time
+    write over the coarse grid, plus the 129x129 refined box (slowness + time)."""
+    return 8.0 * n * n + 129 * 129 * 8.0
+
+
+def cpu_baseline(budget_units=48):
+    """Reference CPU path on a bounded sample: per unit dicing (the reference re-dices per source,
+    CalSurfG.f90:1186), refined + coarse Fast Marching and the 32 receiver times; one core."""
+    import _libs as L
+    import synth
+    units = synth.units(NX, NSRC, NPER, NREC)
+    pick = np.linspace(0, NSRC * NPER - 1, budget_units).astype(int)
+    ref = L.ref()
+    if ref is not None:
+        wb = L.RefWB(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+        t0 = time.perf_counter()
+        for u in pick:
+            p = int(units["map_index"][u])
+            wb.L.ref_wb_gridder(L.ptr(np.ascontiguousarray(synth.medium(NX, "smooth", p))))
+            wb.L.ref_wb_solve(float(units["scx"][u]), float(units["scz"][u]))
+            for r in range(NREC):
+                wb.L.ref_wb_srtimes(float(units["scx"][u]), float(units["scz"][u]),
+                                    float(units["rcx"][u * NREC + r]), float(units["rcz"][u * NREC + r]))
+        dt = time.perf_counter() - t0
+        wb.close()
+        kind = "reference"
+    else:
+        g = L.grid(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+        t0 = time.perf_counter()
+        for u in pick:
+            pv = synth.medium(NX, "smooth", int(units["map_index"][u]))
+            veln = L.o_gridder(g, pv)
+            sol = L.o_solve(g, pv, veln, units["scx"][u], units["scz"][u])
+            for r in range(NREC):
+                L.o_srtimes(g, veln, sol["T"], units["scx"][u], units["scz"][u], units["rcx"][u * NREC + r], units["rcz"][u * NREC + r])
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": round(len(pick) / dt, 4), "unit": "solves/s", "cores": 1, "kind": kind,
+            "sample": "%d of the %d (period, source) units, evenly spaced; dicing + refined/coarse FMM + %d receiver times each" % (len(pick), NSRC * NPER, NREC),
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import synth
+    from dsurftomo_amd import build
+    from dsurftomo_amd.engine import Engine
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        build.build()
+    if dist is not None:
+        dist.barrier()
+
+    # ---- workload, sharded by contiguous unit slices (whole periods per rank for N | 16) ----------
+    units = synth.units(NX, NSRC, NPER, NREC)
+    total_units = NSRC * NPER
+    lo = (total_units * rank) // world
+    hi = (total_units * (rank + 1)) // world
+    sl = slice(lo, hi)
+    rsl = slice(lo * NREC, hi * NREC)
+    pv = np.stack([synth.medium(NX, "smooth", p) for p in range(NPER)])
+
+    eng = Engine(local_rank)
+    if os.environ.get("DSA_MAX_CHUNK"):
+        eng.set_option("max_chunk", int(os.environ["DSA_MAX_CHUNK"]))
+    eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    eng.plan(units["map_index"][sl], units["scx"][sl], units["scz"][sl], units["nrec"][sl], units["rcx"][rsl], units["rcz"][rsl])
+    n = eng.nnx
+
+    dev = torch.device("cuda", local_rank)
+    gathered = torch.zeros(total_units * NREC, dtype=torch.float32, device=dev) if world > 1 else None
+    counts = [((total_units * (r + 1)) // world - (total_units * r) // world) * NREC for r in range(world)]
+
+    def step():
+        t = eng.solve()
+        if world > 1:
+            # the path's one exchange step: every rank ends up with the full receiver-time vector
+            mine = torch.from_numpy(t).to(dev)
+            if len(set(counts)) == 1:
+                dist.all_gather_into_tensor(gathered, mine)
+            else:
+                parts = [gathered[sum(counts[:r]):sum(counts[:r + 1])] for r in range(world)]
+                dist.all_gather(parts, mine)
+        return t
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    acc = {"ms_fim_coarse": 0.0, "launches_fim_coarse": 0.0, "ms_total": 0.0, "ms_fim_refined": 0.0, "ms_stages": 0.0,
+           "evals_total": 0.0, "rounds_max": 0.0}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = eng.stats()
+        for k in acc:
+            acc[k] = max(acc[k], st[k]) if k == "rounds_max" else acc[k] + st[k]
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        solves = total_units * args.steps
+        bps = bytes_per_solve(n)
+        my_units = (hi - lo) * args.steps
+        kernel_s = acc["ms_fim_coarse"] / 1000.0
+        achieved = my_units * bps / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "source-period FMM solves/sec on NxN grid; travel-time max-abs-err vs ref",
+            "value": round(solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: 1025x1025 grid (nx=ny=131, dicing 8), 16 periods x 1000 sources, 32 receivers each, smooth +-10% velocity",
+                       "grid": n, "units_per_step": total_units, "receivers_per_step": total_units * NREC,
+                       "parallelism": "units sharded over %d GPU(s), RCCL all-gather of receiver times" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "k_fim (coarse fixed-point solve)", "bytes_per_solve": bps,
+                         "launches": int(acc["launches_fim_coarse"]),
+                         "avg_launch_ms": round(acc["ms_fim_coarse"] / max(acc["launches_fim_coarse"], 1), 3),
+                         "solves_per_launch": round(my_units / max(acc["launches_fim_coarse"], 1), 1),
+                         "note": "dependency/latency-bound kernel: ~5 evaluations x ~600 fp32 instructions per node; see DESIGN.md"},
+            "kernel_ms_per_step": {"fim_coarse": round(acc["ms_fim_coarse"] / args.steps, 2), "fim_refined": round(acc["ms_fim_refined"] / args.steps, 2),
+                                   "stages": round(acc["ms_stages"] / args.steps, 2)},
+            "evals_per_node": round(acc["evals_total"] / max(my_units, 1) / (n * n), 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

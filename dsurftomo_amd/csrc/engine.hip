@@ -248,6 +248,7 @@ int Engine::solve(float* dsurf)
             std::memcpy(&ev, fi + 12, 8);
             stats[DSA_STAT_EVALS_TOTAL] += (double)ev;
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
+            stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
             if (fi[2] < 0 || fi[10] < 0) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
             if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
         }

@@ -33,7 +33,8 @@ namespace {
 __device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
 
-enum { SC_CUR = 0, SC_NEXT, SC_READY, SC_TMIN, SC_OVERFLOW, SC_THETA, SC_READY_ODD, SC_COUNT = 8 };
+enum { SC_CUR = 0, SC_NEXT, SC_READY, SC_TMIN, SC_OVERFLOW, SC_THETA, SC_READY_ODD, SC_FREEZE, SC_COUNT = 8 };
+constexpr int kStallRounds = 12;
 
 struct Lists {
     int* cur;
@@ -64,16 +65,19 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
     int* sc = L.sc;
     unsigned* tau_bits = reinterpret_cast<unsigned*>(p.tau);
     const int nnz = p.nnz, nnx = p.nnx;
+    const int rhalf = rcap / 2;
 
     const int nseed = *p.seed_count;
     if (tid == 0) {
         sc[SC_CUR] = nseed < cap ? nseed : cap; sc[SC_NEXT] = 0; sc[SC_READY] = 0; sc[SC_READY_ODD] = 0;
         sc[SC_TMIN] = 0x7f800000; sc[SC_OVERFLOW] = nseed > cap ? 1 : 0; sc[SC_THETA] = 0x7f800000;
+        sc[SC_FREEZE] = (int)0xff800000u;      // -inf: nothing frozen
     }
     for (int i = tid; i < nseed && i < cap; i += NT) L.cur[i] = p.seed[i];
     __syncthreads();
 
-    int rounds = 0, rescans = 0;
+    int rounds = 0, rescans = 0, stall = 0, freezes = 0;   // stall bookkeeping is used by thread 0 only
+    float best_tmin = -kInf;
     unsigned long long evals = 0;
     for (;;) {
         int cnt = sc[SC_CUR];
@@ -100,13 +104,17 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
         }
         const float theta = u2f((unsigned)sc[SC_THETA]);
         const bool open = !(theta < kInf);
+        const float freeze = u2f((unsigned)sc[SC_FREEZE]);
+        const bool frozen_any = freeze > -kInf;
 
         // ---- pass A: lower bounds, routing ---------------------------------------------------
         for (int base = 0; base < cnt; base += NT) {
             const int i = base + tid;
-            if (i < cnt) {
+            if (i < cnt) do {
                 const int id = L.cur[i];
                 const int ix = id / nnz, iz = id - ix * nnz;        // 0-based
+                // accepted below the freeze horizon: final (see "stall" at the end of the round)
+                if (frozen_any && tau_value(p.tau[id]) < freeze) { atomicAnd(&tau_bits[id], ~kQueuedBit); continue; }
                 float lb = kInf;
                 if (ix > 0) lb = fminf(lb, tau_value(p.tau[id - nnz]));
                 if (ix + 1 < nnx) lb = fminf(lb, tau_value(p.tau[id + nnz]));
@@ -114,31 +122,31 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
                 if (iz + 1 < nnz) lb = fminf(lb, tau_value(p.tau[id + 1]));
                 bool ready = open || lb < theta;
                 if (ready) {
-                    // even nodes fill the ready buffer from the front, odd nodes from the back
+                    // even nodes use the first half of the ready buffer, odd nodes the second half
                     const bool odd = ((ix + iz) & 1) != 0;
                     const int mine = atomicAdd(&sc[odd ? SC_READY_ODD : SC_READY], 1);
-                    const int other = sc[odd ? SC_READY : SC_READY_ODD];
-                    if (mine + other < rcap - 64) {                 // slack: `other` is read racily
-                        L.ready[odd ? rcap - 1 - mine : mine] = id;
+                    if (mine < rhalf) {
+                        L.ready[odd ? rhalf + mine : mine] = id;
                         atomicAnd(&tau_bits[id], ~kQueuedBit);      // before the barrier: see header
-                    } else { atomicSub(&sc[odd ? SC_READY_ODD : SC_READY], 1); ready = false; }
+                    } else ready = false;                           // counter is clamped when read
                 }
                 if (!ready) {
                     push_next(L, id);
                     atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(lb));
                 }
-            }
+            } while (0);
         }
         __syncthreads();
 
         // ---- pass B: evaluate the ready nodes, even nodes first, then odd ones.  Adjacent nodes are
         // never evaluated in the same sub-pass, so the second half sees the first half's results
         // (red-black Gauss-Seidel: fewer rounds and fewer evaluations than one simultaneous pass).
-        const int nready_even = sc[SC_READY], nready_odd = sc[SC_READY_ODD];
+        const int nready_even = sc[SC_READY] < rhalf ? sc[SC_READY] : rhalf;
+        const int nready_odd = sc[SC_READY_ODD] < rhalf ? sc[SC_READY_ODD] : rhalf;
         for (int half = 0; half < 2; ++half) {
             const int nready = half ? nready_odd : nready_even;
             for (int j = tid; j < nready; j += NT) {
-                const int id = L.ready[half ? rcap - 1 - j : j];
+                const int id = L.ready[half ? rhalf + j : j];
                 const int ix = id / nnz, iz = id - ix * nnz;
                 Hood h;
                 const int off[4] = { -nnz, nnz, -1, 1 };
@@ -190,8 +198,15 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
             // a round that dropped nodes and evaluated nothing is clogged: rebuild from the field
             if (sc[SC_OVERFLOW] && nready_even + nready_odd == 0) sc[SC_CUR] = 0;
             sc[SC_NEXT] = 0; sc[SC_READY] = 0; sc[SC_READY_ODD] = 0;
-            sc[SC_THETA] = (int)f2u(u2f((unsigned)sc[SC_TMIN]) + p.window);
+            const float tmin = u2f((unsigned)sc[SC_TMIN]);
+            sc[SC_THETA] = (int)f2u(tmin + p.window);
             sc[SC_TMIN] = 0x7f800000;
+            // Stall: by causality every node accepted before the earliest pending bound is final, so
+            // that bound must keep rising.  If it does not for kStallRounds rounds, what is left in the
+            // window is a cluster of mutually tied nodes flipping by an ulp (Fast Marching never sees
+            // this: a popped node is frozen).  Freeze everything accepted below the window's edge.
+            if (tmin > best_tmin) { best_tmin = tmin; stall = 0; }
+            else if (tmin < kInf && ++stall >= kStallRounds) { sc[SC_FREEZE] = (int)f2u(best_tmin + p.window); stall = 0; ++freezes; }
         }
         int* t = L.cur; L.cur = L.next; L.next = t;
         ++rounds;
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
     // counters: evaluations summed over threads
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals);
-    if (tid == 0) { p.info[0] = rounds; p.info[1] = rescans; }
+    if (tid == 0) { p.info[0] = rounds; p.info[1] = rescans; p.info[3] = freezes; }
 }
 
 size_t fim_lds_bytes(const FimLaunch& l)

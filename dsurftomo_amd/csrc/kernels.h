@@ -23,7 +23,7 @@ struct FimProblem {
     float ri, dnx, dnz;
     float window;          // causal window (seconds of travel time) evaluated per round
     int max_rounds;
-    int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [4..5] evaluations (u64)
+    int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [3] stall freezes, [4..5] evaluations (u64)
 };
 
 struct FimLaunch {

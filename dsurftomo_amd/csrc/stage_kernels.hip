@@ -324,9 +324,14 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
     float trr;
     const size_t ld = g.nnz;
     if (nearsrc) {
+        // The reference does not clamp the source cell here (CalSurfG.f90:1703-1704), so a source on
+        // the last node row/column makes it read one node past the grid.  Clamp the read instead.
         float vss[2][2];
         for (int k = 1; k <= 2; ++k)
-            for (int l = 1; l <= 2; ++l) vss[k - 1][l - 1] = veln[(size_t)(isx - 1 + k - 1) * ld + (isz - 1 + l - 1)];
+            for (int l = 1; l <= 2; ++l) {
+                const int cx = min(isx - 1 + k - 1, g.nnx - 1), cz = min(isz - 1 + l - 1, g.nnz - 1);
+                vss[k - 1][l - 1] = veln[(size_t)cx * ld + cz];
+            }
         float drx = (scx - gox) - (float)(isx - 1) * dnx;
         float drz = (scz - goz) - (float)(isz - 1) * dnz;
         const float vels = bilinear4(vss, dnx, dnz, drx, drz);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsurftomo_amd.so")
 
 STAT_NAMES = ("ms_total", "ms_fim_coarse", "ms_fim_refined", "ms_stages", "launches_fim_coarse", "units",
-              "rounds_max", "evals_total", "chunk", "rescans")
+              "rounds_max", "evals_total", "chunk", "rescans", "freezes")
 
 _f32, _i32, _vp = C.c_float, C.c_int, C.c_void_p
 _lib = None

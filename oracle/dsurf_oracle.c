@@ -569,9 +569,16 @@ int dso_srtimes(const dso_grid *g, const float *veln, const float *ttn,
     if (isx == irx) { if (isz == irz) sw = 1; }
     float trr;
     if (sw) {
+        /* NOTE: the reference does not clamp isx/isz here (:1703-1704); for a source on the last node
+         * row/column it reads veln one node past the grid (undefined).  Clamped here and in the product. */
         float vss[2][2];
         for (int k = 1; k <= 2; ++k)
-            for (int l = 1; l <= 2; ++l) vss[k - 1][l - 1] = AT(veln, ld, isz - 1 + l, isx - 1 + k);
+            for (int l = 1; l <= 2; ++l) {
+                int cz = isz - 1 + l, cx = isx - 1 + k;
+                if (cz > g->nnz) cz = g->nnz;
+                if (cx > g->nnx) cx = g->nnx;
+                vss[k - 1][l - 1] = AT(veln, ld, cz, cx);
+            }
         float drx = (scx - gox) - (float)(isx - 1) * dnx;
         float drz = (scz - goz) - (float)(isz - 1) * dnz;
         float vels = bilinear(vss, dnx, dnz, drx, drz);
@@ -779,4 +786,62 @@ int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const flo
         rgx = rgx1; rgz = rgz1;
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* engine-level batch: travel times for (period slot, source) units with given velocity maps    */
+
+#include <omp.h>
+
+int dso_traveltimes(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd,
+                    int kmax, int nsrcsurf, int nrcf, const double *pv, const int *nsrcsurf1,
+                    const int *nrc1, const float *scxf, const float *sczf, const float *rcxf,
+                    const float *rczf, float *dsurf, int nthreads)
+{
+    dso_grid g;
+    dso_grid_init(&g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
+    const size_t nc = (size_t)g.nnx * (size_t)g.nnz, nv = (size_t)nx * (size_t)ny;
+    /* flatten the (knumi, srcnum) loop nest of CalSurfG.f90:1144-1145 and prefix-sum the outputs */
+    int nunits = 0;
+    for (int k = 0; k < kmax; ++k) nunits += nsrcsurf1[k];
+    int *uk = (int *)malloc(sizeof(int) * (size_t)(nunits + 1)), *us = (int *)malloc(sizeof(int) * (size_t)(nunits + 1));
+    size_t *first = (size_t *)malloc(sizeof(size_t) * (size_t)(nunits + 1));
+    size_t tot = 0;
+    int u = 0;
+    for (int k = 0; k < kmax; ++k)
+        for (int s = 0; s < nsrcsurf1[k]; ++s) {
+            uk[u] = k; us[u] = s; first[u] = tot;
+            tot += (size_t)nrc1[(size_t)k * nsrcsurf + s];
+            ++u;
+        }
+    /* one diced grid per period slot (the reference re-dices per source; same values) */
+    float *veln = (float *)malloc(sizeof(float) * nc * (size_t)kmax);
+    for (int k = 0; k < kmax; ++k) dso_gridder(&g, pv + nv * (size_t)k, veln + nc * (size_t)k);
+    int rc = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int q = 0; q < nunits; ++q) {
+        const int k = uk[q], s = us[q];
+        float *ttn = (float *)malloc(sizeof(float) * nc);
+        dso_box b;
+        const float x = scxf[(size_t)k * nsrcsurf + s], z = sczf[(size_t)k * nsrcsurf + s];
+        if (dso_solve_source(&g, pv + nv * (size_t)k, veln + nc * (size_t)k, x, z, &b, ttn, NULL, NULL, NULL, NULL) != 0) {
+#pragma omp atomic write
+            rc = -1;
+        } else {
+            const int nr = nrc1[(size_t)k * nsrcsurf + s];
+            for (int r = 0; r < nr; ++r) {
+                const size_t ri = ((size_t)k * nsrcsurf + s) * (size_t)nrcf + (size_t)r;
+                float t = 0.0f;
+                if (dso_srtimes(&g, veln + nc * (size_t)k, ttn, x, z, rcxf[ri], rczf[ri], &t) != 0) {
+#pragma omp atomic write
+                    rc = -2;
+                }
+                dsurf[first[q] + (size_t)r] = t;
+            }
+        }
+        free(ttn);
+    }
+    free(veln); free(uk); free(us); free(first);
+    return rc;
 }

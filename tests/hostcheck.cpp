@@ -4,6 +4,7 @@
 // ballots) is replaced by a plain worklist here; the fixed point it reaches is schedule
 // independent, which is exactly what tests/test_hostcheck.py asserts against the oracle.
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -232,9 +233,12 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* T, float* tau, const
     cur.swap(next);
     float theta = kInf; long rounds = 0, evals = 0;
     std::vector<float> nT, nK;
+    float best_tmin = -kInf, freeze = -kInf; int stall = 0; long freezes = 0;
     while (!cur.empty()) {
         float tmin = kInf; ready.clear();
         for (int id : cur) {
+            // accepted below the freeze horizon: final (see fim_kernel.hip, "stall")
+            if (tau_value(tau[id]) < freeze) { queued[id] = 0; continue; }
             const int ix = id / nnz, iz = id - ix * nnz; float lb = kInf;
             if (ix > 0) lb = fminf(lb, tau_value(tau[id - nnz])); if (ix + 1 < nnx) lb = fminf(lb, tau_value(tau[id + nnz]));
             if (iz > 0) lb = fminf(lb, tau_value(tau[id - 1])); if (iz + 1 < nnz) lb = fminf(lb, tau_value(tau[id + 1]));
@@ -261,11 +265,17 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* T, float* tau, const
                 }
             }
         }
+        if (ncyc < 0 && rounds >= max_rounds - 4) {
+            std::printf("round %ld: theta %.7f tmin %.7f ready %zu next %zu\n", rounds, theta, tmin, ready.size(), next.size());
+            for (size_t k = 0; k < ready.size() && k < 12; ++k) { const int id = ready[k]; std::printf("   ready ix=%d iz=%d T=%.7f tau=%.7f\n", id / nnz + 1, id % nnz + 1, T[id], tau[id]); }
+        }
+        if (tmin > best_tmin) { best_tmin = tmin; stall = 0; }
+        else if (tmin < kInf && ++stall >= 12) { freeze = best_tmin + window; stall = 0; ++freezes; }
         cur.swap(next); next.clear(); theta = tmin + window; ++rounds;
         if (rounds >= max_rounds) break;
     }
-    out[0] = rounds; out[1] = evals; out[2] = (long)cur.size();
-    for (int k = 0; k < ncyc; ++k) cyc_ids[k] = k < (int)cur.size() ? cur[k] : -1;
+    out[0] = rounds; out[1] = evals; out[2] = (long)cur.size(); out[3] = freezes;
+    for (int k = 0; k < (ncyc < 0 ? -ncyc : ncyc); ++k) cyc_ids[k] = k < (int)cur.size() ? cur[k] : -1;
     return cur.empty() ? 0 : -1;
 }
 
