@@ -101,7 +101,7 @@ def main():
 
     import torch
     import synth
-    from dsurftomo_amd import build
+    from dsurftomo_amd import build, sharding
     from dsurftomo_amd.engine import Engine
 
     dist = None
@@ -117,8 +117,7 @@ def main():
     # ---- workload, sharded by contiguous unit slices (whole periods per rank for N | 16) ----------
     units = synth.units(NX, NSRC, NPER, NREC)
     total_units = NSRC * NPER
-    lo = (total_units * rank) // world
-    hi = (total_units * (rank + 1)) // world
+    lo, hi = sharding.unit_range(total_units, world, rank)
     sl = slice(lo, hi)
     rsl = slice(lo * NREC, hi * NREC)
     pv = np.stack([synth.medium(NX, "smooth", p) for p in range(NPER)])
@@ -131,19 +130,13 @@ def main():
     n = eng.nnx
 
     dev = torch.device("cuda", local_rank)
-    gathered = torch.zeros(total_units * NREC, dtype=torch.float32, device=dev) if world > 1 else None
-    counts = [((total_units * (r + 1)) // world - (total_units * r) // world) * NREC for r in range(world)]
+    counts = sharding.ray_counts(units["nrec"], world)
 
     def step():
         t = eng.solve()
         if world > 1:
             # the path's one exchange step: every rank ends up with the full receiver-time vector
-            mine = torch.from_numpy(t).to(dev)
-            if len(set(counts)) == 1:
-                dist.all_gather_into_tensor(gathered, mine)
-            else:
-                parts = [gathered[sum(counts[:r]):sum(counts[:r + 1])] for r in range(world)]
-                dist.all_gather(parts, mine)
+            return sharding.all_gather_times(dist, torch.from_numpy(t).to(dev), counts)
         return t
 
     def fence():

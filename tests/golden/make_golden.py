@@ -1,0 +1,73 @@
+"""Generate the golden vectors in this directory from the reference's own build (oracle/_ref).
+
+    python tests/golden/make_golden.py      # only where /root/reference exists (make -C oracle ref)
+
+Every array comes out of the reference's compiled Fortran through the white-box handles of
+oracle/ref_whitebox.f90 -- nothing here is computed by this repository's code.  The fixtures are
+data only: inputs (grid parameters, phase-velocity map, source / receiver coordinates) and the
+reference's outputs (diced velocity grid, refined snapshot, injected coarse state, final
+travel-time field, receiver times, ray kernels).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _libs as L      # noqa: E402
+import synth           # noqa: E402
+
+CASES = [
+    # name, nx, medium, dicing
+    ("g121_homog", 18, "homog", 8),
+    ("g121_smooth", 18, "smooth", 8),
+    ("g121_checker4", 18, "checker4", 8),
+    ("g076_smooth_d5", 18, "smooth", 5),
+]
+# source positions in node units (fractions <= 1 are relative to N-1): interior off-node, one cell
+# from the low edge, near the high corner (early exit of the refined stage), exactly on a node
+FRAC = [(0.43, 0.61), (1.4, 0.5), (0.985, 0.99), (16.0, 24.0)]
+REC = [(0.10, 0.80), (0.52, 0.18), (0.91, 0.66), (0.45, 0.60)]
+
+
+def coords(nx, gd, frac):
+    gox, goz, dnx, dnz = synth.grid_origin(nx, gd)
+    N = synth.nprop(nx, gd)
+    out = []
+    for fx, fz in frac:
+        fx = np.float32(fx * (N - 1) if fx <= 1.0 else fx)
+        fz = np.float32(fz * (N - 1) if fz <= 1.0 else fz)
+        out.append((np.float32(gox + fx * dnx), np.float32(goz + fz * dnz)))
+    return out
+
+
+def main():
+    assert L.ref() is not None, "reference build not available (make -C oracle ref)"
+    for name, nx, kind, gd in CASES:
+        wb = L.RefWB(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+        pv = synth.medium(nx, kind)
+        out = dict(nx=np.int32(nx), gd=np.int32(gd), goxd=np.float32(synth.GOXD), gozd=np.float32(synth.GOZD),
+                   dvd=np.float32(synth.DVD), pv=pv, veln=wb.gridder(pv))
+        srcs = coords(nx, gd, FRAC)
+        recs = coords(nx, gd, REC)
+        out["src"] = np.array(srcs, np.float32)
+        out["rec"] = np.array(recs, np.float32)
+        for k, (sx, sz) in enumerate(srcs):
+            r = wb.solve(sx, sz)
+            out["T%d" % k] = r["T"]
+            out["Tr%d" % k] = r["Tr"]
+            out["Sr%d" % k] = np.sign(r["Sr"]).clip(-1, 1).astype(np.int8)
+            out["injS%d" % k] = np.sign(r["inj_s"]).clip(-1, 1).astype(np.int8)
+            out["injT%d" % k] = np.where(r["inj_s"] >= 0, r["inj_t"], np.float32(0)).astype(np.float32)
+            out["t%d" % k] = np.array([wb.srtimes(sx, sz, rx, rz) for rx, rz in recs], np.float32)
+            fd = [wb.rpaths(sx, sz, rx, rz) for rx, rz in recs[:3]]
+            out["fdm%d" % k] = np.stack(fd)
+        wb.close()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""The product's host/device-shared logic (eikonal_core.h, source_stage.h, host_geometry.h), driven
+on the CPU by tests/hostcheck.cpp, against the oracle.  No GPU involved: this covers the stencil,
+the (T, tau) local solver, the serial marches, the hand-off, and the device schedule's convergence
+rules (causal window, parity sub-passes, stall freeze) in emulation."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _libs as L
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libhostcheck.so")
+
+
+@pytest.fixture(scope="module")
+def H():
+    src = os.path.join(HERE, "hostcheck.cpp")
+    hdr = [os.path.join(L.ROOT, "dsurftomo_amd", "csrc", n) for n in ("eikonal_core.h", "source_stage.h", "host_geometry.h")]
+    if L._stale(SO, [src] + hdr):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-msse2",
+                               "-mfpmath=sse", "-shared", "-o", SO, src, "-lm"])
+    h = C.CDLL(SO)
+    h.hc_solve_source.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.f32, L.f32] + [L.vp] * 7
+    h.hc_gridder.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.vp]
+    h.hc_fouds2_masked.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.vp, L.vp, L.vp, L.i32, L.i32]
+    h.hc_fouds2_masked.restype = L.f32
+    h.hc_coarse_problem.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.f32, L.f32] + [L.vp] * 5
+    h.hc_device_schedule.argtypes = [L.i32, L.i32, L.vp, L.vp, L.vp, L.vp, L.f32, L.f32, L.f32, L.f32, L.i32, L.i32, L.vp, L.vp, L.i32]
+    h.hc_device_schedule.restype = C.c_long
+    return h
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_stencil_bitwise_against_oracle(H):
+    """fouds2 on random alive masks over a real travel-time field"""
+    nx, gd = 18, 8
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+    pv = synth.medium(nx, "smooth")
+    veln = L.o_gridder(g, pv)
+    N = g.nnx
+    sx = np.float32(g.gox + np.float32(40.3) * g.dnx)
+    sz = np.float32(g.goz + np.float32(71.6) * g.dnz)
+    T = L.o_solve(g, pv, veln, sx, sz)["T"]
+    u = synth.LCG(5).uniform(N * N + 4000)
+    alive = (u[:N * N] < 0.6).astype(np.uint8).reshape(N, N)
+    pick = (u[N * N:] * (N * N)).astype(int)
+    O = L.oracle()
+    nmis = 0
+    for p in pick[:2000]:
+        ix, iz = p // N + 1, p % N + 1
+        a = np.float32(O.dso_fouds2_masked(N, N, N, g.gox, g.dnx, g.dnz, g.earth, L.ptr(veln), L.ptr(T), L.ptr(alive), iz, ix))
+        b = np.float32(H.hc_fouds2_masked(N, N, g.gox, g.dnx, g.dnz, g.earth, L.ptr(veln), L.ptr(T), L.ptr(alive), iz, ix))
+        # the oracle returns 0 when no neighbour is alive, the product +inf
+        if not np.isfinite(b):
+            continue
+        nmis += int(a.view(np.uint32) != b.view(np.uint32))
+    assert nmis == 0
+
+
+@pytest.mark.parametrize("nx,kind,gd", [(18, "homog", 8), (18, "smooth", 8), (18, "smooth", 5), (35, "checker4", 8)])
+def test_pipeline_against_oracle(H, nx, kind, gd):
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+    pv = synth.medium(nx, kind)
+    veln = L.o_gridder(g, pv)
+    N = g.nnx
+    vh = np.zeros((N, N), np.float32)
+    H.hc_gridder(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd, L.ptr(pv), L.ptr(vh))
+    assert (bits(vh) != bits(veln)).sum() == 0
+    frac = [(0.43 * N + 0.3, 0.61 * N + 0.6), (1.4, N / 2 + 0.2), (N - 2.5, N - 3.3), (N - 1.0, N - 1.0), (0.0, 0.0), (N * 0.7, N * 0.2)]
+    worst, nbad = 0.0, 0
+    for fx, fz in frac:
+        sx = np.float32(g.gox + np.float32(fx) * g.dnx)
+        sz = np.float32(g.goz + np.float32(fz) * g.dnz)
+        o = L.o_solve(g, pv, veln, sx, sz)
+        T = np.zeros((N, N), np.float32); Tr = np.zeros(129 * 129, np.float32); Sr = np.zeros(129 * 129, np.int32)
+        it = np.zeros((N, N), np.float32); is_ = np.zeros((N, N), np.int32); box = np.zeros(6, np.int32); st = np.zeros(4, np.int64)
+        assert H.hc_solve_source(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd, L.ptr(pv), sx, sz, L.ptr(T), L.ptr(Tr),
+                                 L.ptr(Sr), L.ptr(it), L.ptr(is_), L.ptr(box), L.ptr(st)) == 0
+        assert st[1] == 0, "serial march guard fired"
+        n = box[4] * box[5]
+        cls_o = np.sign(o["Sr"]).clip(-1, 1)
+        cls_h = np.sign(Sr[:n].reshape(box[4], box[5])).clip(-1, 1)
+        assert (cls_o != cls_h).sum() <= 4            # exact ties only (symmetric media)
+        assert (np.sign(o["inj_s"]).clip(-1, 1) != np.sign(is_).clip(-1, 1)).sum() <= 2
+        worst = max(worst, float(np.abs(T - o["T"]).max()))
+        nbad += int((bits(T) != bits(o["T"])).sum())
+    assert worst <= 1e-4 and nbad <= 0.002 * len(frac) * N * N
+
+
+def test_device_schedule_converges_and_is_schedule_independent(H):
+    """emulated device rounds (both evaluation modes, several windows) reach one and the same field"""
+    nx = 35
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    N = g.nnx
+    pv = synth.medium(nx, "rough")
+    sx, sz = synth.sources(nx, 8)
+    fields = []
+    for mode, wc in ((1, 3.0), (0, 3.0), (1, 1.0), (1, 8.0)):
+        T = np.zeros((N, N), np.float32); tau = np.zeros((N, N), np.float32); slow = np.zeros((N, N), np.float32)
+        ris = np.zeros(N, np.float32); geom = np.zeros(4, np.float32)
+        assert H.hc_coarse_problem(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8, L.ptr(pv), sx[3], sz[3], L.ptr(T), L.ptr(tau),
+                                   L.ptr(slow), L.ptr(ris), L.ptr(geom)) == 0
+        out = np.zeros(4, np.int64); cyc = np.zeros(4, np.int32)
+        rc = H.hc_device_schedule(N, N, L.ptr(T), L.ptr(tau), L.ptr(slow), L.ptr(ris), geom[0], geom[1], geom[2],
+                                  np.float32(wc * geom[3]), mode, 20000, L.ptr(out), L.ptr(cyc), 4)
+        assert rc == 0, "no convergence"
+        assert out[1] / (N * N) < 12.0, "evaluations per node out of the expected range"
+        fields.append(np.abs(T))
+    for f in fields[1:]:
+        assert (bits(f) != bits(fields[0])).sum() == 0
