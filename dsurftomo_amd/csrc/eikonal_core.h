@@ -50,105 +50,116 @@ struct Stencil {
 DSA_HD float sq(float x) { return x * x; }
 
 // One evaluation of the mixed first/second-order upwind update; returns +inf when no quadrant
-// has an alive neighbour.  Quadrant order and the running minimum follow CalSurfG.f90:616-757;
-// a quadrant whose j or k neighbour lies outside the grid is skipped entirely (not "not alive").
+// has an alive neighbour.
+//
+// The reference (CalSurfG.f90:616-757) loops over the four (j, k) quadrants, picks one of eight
+// coefficient sets per quadrant, solves a quadratic and keeps the running minimum; a quadrant whose
+// j or k neighbour lies outside the grid is skipped entirely (not "not alive").  This is the same
+// arithmetic, reorganised so that lanes of a wave do not walk through every variant:
+//   * the minimum is order independent, so candidates are enumerated per neighbour;
+//   * the one-sided variants have a = 1, b = 0, for which (-b + sqrt(b*b - 4ac)) / (2a) is exactly
+//     sqrt(-c) (scaling by 4 and by 1/2 is exact, sqrt is correctly rounded), and dividing by
+//     tdiv = 1 is the identity -- so they cost one sqrt and no division, bit for bit;
+//   * a one-sided candidate from neighbour j exists iff some k inside the grid is not alive (that
+//     is the quadrant the reference would have produced it in), and vice versa;
+//   * only quadrants with both neighbours alive need the full quadratic.
+// tests/test_hostcheck.py pins this bitwise against the oracle's literal restatement.
 DSA_HD float fouds2(const Stencil& s, float slown, const NodeGeom& g)
 {
-    bool have = false;
-    float travm = kInf;
     const float ri = g.ri, risti = g.risti, dnx = g.dnx, dnz = g.dnz;
-    for (int j = 0; j < 2; ++j) {
-        if (!s.ej[j]) continue;
-        const bool swj = s.aj[j] && s.oj[j] && (s.tj[j] > s.tj2[j]);
+    const float s2 = sq(slown);
+    float best = kInf;
+    bool swj[2], swk[2];
+    for (int d = 0; d < 2; ++d) {
+        swj[d] = s.ej[d] && s.aj[d] && s.oj[d] && (s.tj[d] > s.tj2[d]);
+        swk[d] = s.ek[d] && s.ak[d] && s.ok[d] && (s.tk[d] > s.tk2[d]);
+    }
+    const bool k_dead = (s.ek[0] && !s.ak[0]) || (s.ek[1] && !s.ak[1]);   // some k quadrant without k
+    const bool j_dead = (s.ej[0] && !s.aj[0]) || (s.ej[1] && !s.aj[1]);
+    const bool any_k = s.ek[0] || s.ek[1], any_j = s.ej[0] || s.ej[1];
+
+    // one-sided candidates
+    if (k_dead)
+        for (int j = 0; j < 2; ++j) {
+            if (!(s.ej[j] && s.aj[j])) continue;
+            float trav;
+            if (swj[j]) {
+                const float u = 2.0f * ri * dnx;
+                trav = ((4.0f * s.tj[j] - s.tj2[j]) + sqrtf(sq(u) * s2)) / 3.0f;
+            } else {
+                trav = s.tj[j] + sqrtf(s2 * sq(ri) * sq(dnx));
+            }
+            best = (trav < best) ? trav : best;
+        }
+    if (j_dead)
         for (int k = 0; k < 2; ++k) {
-            if (!s.ek[k]) continue;
-            const bool swk = s.ak[k] && s.ok[k] && (s.tk[k] > s.tk2[k]);
-            float a, b, c, tref, tdiv;
-            bool sol = true;
-            if (swj) {
-                if (swk) {
+            if (!(s.ek[k] && s.ak[k])) continue;
+            float trav;
+            if (swk[k]) {
+                const float u = 2.0f * risti * dnz;
+                trav = ((4.0f * s.tk[k] - s.tk2[k]) + sqrtf(sq(u) * s2)) / 3.0f;
+            } else {
+                trav = s.tk[k] + sqrtf(s2 * sq(risti) * sq(dnz));
+            }
+            best = (trav < best) ? trav : best;
+        }
+    (void)any_k; (void)any_j;
+
+    // two-sided candidates
+    for (int j = 0; j < 2; ++j) {
+        if (!(s.ej[j] && s.aj[j])) continue;
+        for (int k = 0; k < 2; ++k) {
+            if (!(s.ek[k] && s.ak[k])) continue;
+            float a, b, c, tref;
+            bool third = false;
+            if (swj[j]) {
+                if (swk[k]) {
                     const float u = 2.0f * ri * dnx;
                     const float v = 2.0f * risti * dnz;
                     float em = 4.0f * s.tj[j] - s.tj2[j] - 4.0f * s.tk[k];
                     em = em + s.tk2[k];
                     a = sq(v) + sq(u);
                     b = 2.0f * em * sq(u);
-                    c = sq(u) * (sq(em) - sq(slown) * sq(v));
+                    c = sq(u) * (sq(em) - s2 * sq(v));
                     tref = 4.0f * s.tj[j] - s.tj2[j];
-                    tdiv = 3.0f;
-                } else if (s.ak[k]) {
+                    third = true;
+                } else {
                     const float u = risti * dnz;
                     const float v = 2.0f * ri * dnx;
                     const float em = 3.0f * s.tk[k] - 4.0f * s.tj[j] + s.tj2[j];
                     a = sq(v) + 9.0f * sq(u);
                     b = 6.0f * em * sq(u);
-                    c = sq(u) * (sq(em) - sq(slown) * sq(v));
+                    c = sq(u) * (sq(em) - s2 * sq(v));
                     tref = s.tk[k];
-                    tdiv = 1.0f;
-                } else {
-                    const float u = 2.0f * ri * dnx;
-                    a = 1.0f;
-                    b = 0.0f;
-                    c = -(sq(u) * sq(slown));
-                    tref = 4.0f * s.tj[j] - s.tj2[j];
-                    tdiv = 3.0f;
                 }
-            } else if (s.aj[j]) {
-                if (swk) {
+            } else {
+                if (swk[k]) {
                     const float u = ri * dnx;
                     const float v = 2.0f * risti * dnz;
                     const float em = 3.0f * s.tj[j] - 4.0f * s.tk[k] + s.tk2[k];
                     a = sq(v) + 9.0f * sq(u);
                     b = 6.0f * em * sq(u);
-                    c = sq(u) * (sq(em) - sq(v) * sq(slown));
+                    c = sq(u) * (sq(em) - sq(v) * s2);
                     tref = s.tj[j];
-                    tdiv = 1.0f;
-                } else if (s.ak[k]) {
+                } else {
                     const float u = ri * dnx;
                     const float v = risti * dnz;
                     const float em = s.tk[k] - s.tj[j];
                     a = sq(u) + sq(v);
                     b = -(2.0f * sq(u) * em);
-                    c = sq(u) * (sq(em) - sq(v) * sq(slown));
+                    c = sq(u) * (sq(em) - sq(v) * s2);
                     tref = s.tj[j];
-                    tdiv = 1.0f;
-                } else {
-                    a = 1.0f;
-                    b = 0.0f;
-                    c = -(sq(slown) * sq(ri) * sq(dnx));
-                    tref = s.tj[j];
-                    tdiv = 1.0f;
-                }
-            } else {
-                if (swk) {
-                    const float u = 2.0f * risti * dnz;
-                    a = 1.0f;
-                    b = 0.0f;
-                    c = -(sq(u) * sq(slown));
-                    tref = 4.0f * s.tk[k] - s.tk2[k];
-                    tdiv = 3.0f;
-                } else if (s.ak[k]) {
-                    a = 1.0f;
-                    b = 0.0f;
-                    c = -(sq(slown) * sq(risti) * sq(dnz));
-                    tref = s.tk[k];
-                    tdiv = 1.0f;
-                } else {
-                    sol = false;
-                    a = 1.0f; b = 0.0f; c = 0.0f; tref = 0.0f; tdiv = 1.0f;
                 }
             }
-            if (sol) {
-                float rd1 = sq(b) - 4.0f * a * c;
-                if (rd1 < 0.0f) rd1 = 0.0f;
-                const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
-                const float trav = (tref + tdsh) / tdiv;
-                if (have) travm = (trav < travm) ? trav : travm;
-                else { travm = trav; have = true; }
-            }
+            float rd1 = sq(b) - 4.0f * a * c;
+            if (rd1 < 0.0f) rd1 = 0.0f;
+            const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+            float trav = tref + tdsh;
+            if (third) trav = trav / 3.0f;
+            best = (trav < best) ? trav : best;
         }
     }
-    return travm;
+    return best;
 }
 
 // Per-node state of the fixed-point solve: the travel time T and the acceptance time tau.
@@ -184,56 +195,57 @@ struct Hood {
 // An outer node counts as alive when it is pinned or was accepted before the neighbour most
 // recently added ("now").  Ties stop the walk (c <= tau): the reference's own tie order depends on
 // its heap layout and cannot be derived locally ("ties").
+// Everything below is indexed with compile-time constants only: runtime-indexed local arrays would
+// live in scratch memory, and this function is the inner loop of the solve kernel.
 DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* tau_out)
 {
-    Stencil s;
-    float tn[4], kn[4];
-    bool pin[4];
-    int order[4];
-    int no = 0;
-    bool any_alive = false;
+    float tn[4], key[4];
+    int idx[4] = { 0, 1, 2, 3 };
+    unsigned alive = 0u;            // bit q: near neighbour q is alive
     for (int q = 0; q < 4; ++q) {
         const bool in = h.in[q];
         const float raw = in ? h.near_[q] : kInf;
         tn[q] = t_value(raw);
-        kn[q] = in ? tau_value(h.near_tau[q]) : kInf;
-        pin[q] = in && t_pinned(raw);
-        if (pin[q]) any_alive = true;
-        else if (in && kn[q] < kInf) order[no++] = q;
+        const bool pin = in && t_pinned(raw);
+        if (pin) alive |= 1u << q;
+        const float k = in ? tau_value(h.near_tau[q]) : kInf;
+        key[q] = (in && !pin) ? k : kInf;          // +inf: not a candidate of the walk
     }
-    // insertion sort of at most 4 candidates by acceptance time
-    for (int i = 1; i < no; ++i) {
-        const int q = order[i];
-        int j = i;
-        while (j > 0 && kn[order[j - 1]] > kn[q]) { order[j] = order[j - 1]; --j; }
-        order[j] = q;
-    }
-    bool alive[4] = { pin[0], pin[1], pin[2], pin[3] };
-    float tnow = -kInf;
+    // sort the candidates by (acceptance time, index): 5-comparator network, same order as a stable sort
+#define DSA_CE(a, b)                                                                         \
+    do {                                                                                     \
+        const bool sw = key[a] > key[b] || (key[a] == key[b] && idx[a] > idx[b]);            \
+        const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                    \
+        const int ia = sw ? idx[b] : idx[a], ib = sw ? idx[a] : idx[b];                      \
+        key[a] = ka; key[b] = kb; idx[a] = ia; idx[b] = ib;                                  \
+    } while (0)
+    DSA_CE(0, 1); DSA_CE(2, 3); DSA_CE(0, 2); DSA_CE(1, 3); DSA_CE(1, 2);
+#undef DSA_CE
 
-    auto fill = [&](void) {
+    float tnow = -kInf;
+    auto eval = [&](void) -> float {
+        Stencil s;
         for (int d = 0; d < 2; ++d) {
             s.tj[d] = tn[d];           s.tk[d] = tn[2 + d];
             s.ej[d] = h.in[d];         s.ek[d] = h.in[2 + d];
-            s.aj[d] = alive[d];        s.ak[d] = alive[2 + d];
+            s.aj[d] = (alive >> d) & 1u;
+            s.ak[d] = (alive >> (2 + d)) & 1u;
             const float oxr = h.in_outer[d] ? h.outer[d] : kInf;
             const float ozr = h.in_outer[2 + d] ? h.outer[2 + d] : kInf;
             s.tj2[d] = t_value(oxr);   s.tk2[d] = t_value(ozr);
             s.oj[d] = h.in_outer[d] && (t_pinned(oxr) || tau_value(h.outer_tau[d]) < tnow);
             s.ok[d] = h.in_outer[2 + d] && (t_pinned(ozr) || tau_value(h.outer_tau[2 + d]) < tnow);
         }
+        return fouds2(s, slown, g);
     };
 
     float c = kInf;
-    if (any_alive) { fill(); c = fouds2(s, slown, g); }
-    for (int i = 0; i < no; ++i) {
-        const int q = order[i];
-        if (c <= kn[q]) break;
-        alive[q] = true;
-        tnow = kn[q];
-        fill();
-        c = fouds2(s, slown, g);
-    }
+    if (alive) c = eval();
+    bool go = true;
+#define DSA_STEP(i)                                                                          \
+    if (go && key[i] < kInf && c > key[i]) { alive |= 1u << idx[i]; tnow = key[i]; c = eval(); } else go = false
+    DSA_STEP(0); DSA_STEP(1); DSA_STEP(2); DSA_STEP(3);
+#undef DSA_STEP
     *tau_out = (c > tnow) ? c : tnow;
     return c;
 }

@@ -58,6 +58,8 @@ struct Engine {
     DevBuf<int16_t> rst, cst;
     DevBuf<int32_t> heap, flags, info;
     DevBuf<FimProblem> prob_r, prob_c;
+    DevBuf<unsigned long long> clocks;
+    double phase_ticks[8] = {};
 
     double stats[16] = {};
 

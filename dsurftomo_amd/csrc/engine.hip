@@ -56,7 +56,7 @@ Engine::~Engine()
     rel(src); rel(rays); rel(out); rel(err);
     rel(slow_r); rel(T_r); rel(tau_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
     rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(T_c); rel(tau_c); rel(seed_c); rel(nseed_c);
-    rel(prob_r); rel(prob_c); rel(info);
+    rel(prob_r); rel(prob_c); rel(info); rel(clocks);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -166,7 +166,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, C * nfield) || ensure(tau_c, C * nfield) ||
-        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16)) return status;
+        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = true;
@@ -189,6 +189,7 @@ int Engine::solve(float* dsurf)
     HIP_TRY(this, hipSetDevice(device));
     const int nunits = (int)h_src.size();
     std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
+    std::fill(phase_ticks, phase_ticks + 8, 0.0);
     stats[DSA_STAT_UNITS] = nunits;
     stats[DSA_STAT_CHUNK] = chunk;
     // causal window: a few cells' worth of travel time (narrowest cell, fastest velocity of the model)
@@ -206,7 +207,7 @@ int Engine::solve(float* dsurf)
         HIP_TRY(this, hipEventRecord(events[1], stream));
         launch_fill(T_c.p, (size_t)n * nfield, kInf, stream);
         launch_fill(tau_c.p, (size_t)n * nfield, kInf, stream);
-        launch_make_problems(g, b, n, slow.p, nfield, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, stream);
+        launch_make_problems(g, b, n, slow.p, nfield, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));
@@ -229,7 +230,10 @@ int Engine::solve(float* dsurf)
         HIP_TRY(this, hipMemcpyAsync(h_flags.data(), flags.p, (size_t)n * 4 * 4, hipMemcpyDeviceToHost, stream));
         if (dsurf && r1 > r0)
             HIP_TRY(this, hipMemcpyAsync(dsurf + r0, out.p + r0, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, stream));
+        std::vector<unsigned long long> h_clk((size_t)n * 8);
+        HIP_TRY(this, hipMemcpyAsync(h_clk.data(), clocks.p, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipStreamSynchronize(stream));
+        for (int u = 0; u < n; ++u) for (int q = 0; q < 6; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * 8 + q];
         float ms = 0;
         HIP_TRY(this, hipEventElapsedTime(&ms, events[2], events[3])); stats[DSA_STAT_MS_FIM_REFINED] += ms;
         HIP_TRY(this, hipEventElapsedTime(&ms, events[4], events[5])); stats[DSA_STAT_MS_FIM_COARSE] += ms;
@@ -427,6 +431,9 @@ int dsa_get_stats(const dsa_engine* e, double* out)
 {
     if (!e || !out) return DSA_ERR_ARGUMENT;
     std::memcpy(out, reinterpret_cast<const Engine*>(e)->stats, sizeof(double) * DSA_STAT_COUNT);
+    // phase clocks of the coarse solve, summed over units (100 MHz wall clock ticks): pass A, even half,
+    // odd half, round end; then the summed list lengths and ready counts
+    for (int q = 0; q < 6; ++q) out[DSA_STAT_COUNT + q] = reinterpret_cast<const Engine*>(e)->phase_ticks[q];
     return 0;
 }
 

@@ -33,8 +33,8 @@ namespace {
 __device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
 
-enum { SC_CUR = 0, SC_NEXT, SC_READY, SC_TMIN, SC_OVERFLOW, SC_THETA, SC_READY_ODD, SC_FREEZE, SC_COUNT = 8 };
-constexpr int kStallRounds = 12;
+enum { SC_CUR = 0, SC_NEXT, SC_READY, SC_TMIN, SC_OVERFLOW, SC_THETA, SC_READY_ODD, SC_FREEZE, SC_HASH, SC_COUNT = 12 };
+constexpr int kCycleRounds = 8;     // rounds of exactly repeating changes before the window is frozen
 
 struct Lists {
     int* cur;
@@ -44,17 +44,47 @@ struct Lists {
     int* sc;
 };
 
-__device__ __forceinline__ void push_next(const Lists& L, int id)
+// Wave-aggregated slot allocation: one LDS atomic per wave instead of one per lane (same-address LDS
+// atomics serialise lane by lane).  Must be reached by all lanes that are active at the call site;
+// returns the lane's slot, or -1 for lanes that do not want one.
+__device__ __forceinline__ int wave_alloc(int* counter, bool want)
 {
-    const int pos = atomicAdd(&L.sc[SC_NEXT], 1);
-    if (pos < L.cap) L.next[pos] = id;
-    else L.sc[SC_OVERFLOW] = 1;        // the node keeps its queued bit; a rescan picks it up
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+__device__ __forceinline__ void push_next(const Lists& L, int id, bool want)
+{
+    const int pos = wave_alloc(&L.sc[SC_NEXT], want);
+    if (want) {
+        if (pos < L.cap) L.next[pos] = id;
+        else L.sc[SC_OVERFLOW] = 1;    // the node keeps its queued bit; a rescan picks it up
+    }
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
 }  // namespace
 
+// One workgroup of NT threads per problem; the LDS lists allow one workgroup per CU, i.e. 4 waves per
+// SIMD: tell the compiler so, otherwise it targets 8 waves/SIMD (64 VGPRs) and spills the solver.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ problems, int cap, int rcap)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT / 256))) void k_fim(const FimProblem* __restrict__ problems, int cap, int rcap)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const FimProblem p = problems[blockIdx.x];
@@ -72,11 +102,14 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
         sc[SC_CUR] = nseed < cap ? nseed : cap; sc[SC_NEXT] = 0; sc[SC_READY] = 0; sc[SC_READY_ODD] = 0;
         sc[SC_TMIN] = 0x7f800000; sc[SC_OVERFLOW] = nseed > cap ? 1 : 0; sc[SC_THETA] = 0x7f800000;
         sc[SC_FREEZE] = (int)0xff800000u;      // -inf: nothing frozen
+        sc[SC_HASH] = 0;
     }
     for (int i = tid; i < nseed && i < cap; i += NT) L.cur[i] = p.seed[i];
     __syncthreads();
 
-    int rounds = 0, rescans = 0, stall = 0, freezes = 0;   // stall bookkeeping is used by thread 0 only
+    int rounds = 0, rescans = 0, stall = 0, freezes = 0;   // cycle bookkeeping is used by thread 0 only
+    unsigned hist[4] = { 1u, 2u, 3u, 4u };
+    unsigned long long tA = 0, tB0 = 0, tB1 = 0, tE = 0, t0 = wall_clock64(), sum_cnt = 0, sum_ready = 0;   // phase clocks (thread 0)
     float best_tmin = -kInf;
     unsigned long long evals = 0;
     for (;;) {
@@ -107,36 +140,58 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
         const float freeze = u2f((unsigned)sc[SC_FREEZE]);
         const bool frozen_any = freeze > -kInf;
 
-        // ---- pass A: lower bounds, routing ---------------------------------------------------
-        for (int base = 0; base < cnt; base += NT) {
-            const int i = base + tid;
-            if (i < cnt) do {
-                const int id = L.cur[i];
+        // ---- pass A: lower bounds, routing.  Four entries per thread per trip so that their
+        // neighbour loads are in flight together (the pass is pure latency otherwise).
+        constexpr int UA = 4;
+        for (int base = 0; base < cnt; base += NT * UA) {
+            int ids[UA];
+            float lbs[UA], own[UA];
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int i = base + u * NT + tid;
+                ids[u] = i < cnt ? L.cur[i] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                lbs[u] = kInf; own[u] = kInf;
+                if (ids[u] < 0) continue;
+                const int id = ids[u];
                 const int ix = id / nnz, iz = id - ix * nnz;        // 0-based
-                // accepted below the freeze horizon: final (see "stall" at the end of the round)
-                if (frozen_any && tau_value(p.tau[id]) < freeze) { atomicAnd(&tau_bits[id], ~kQueuedBit); continue; }
-                float lb = kInf;
-                if (ix > 0) lb = fminf(lb, tau_value(p.tau[id - nnz]));
-                if (ix + 1 < nnx) lb = fminf(lb, tau_value(p.tau[id + nnz]));
-                if (iz > 0) lb = fminf(lb, tau_value(p.tau[id - 1]));
-                if (iz + 1 < nnz) lb = fminf(lb, tau_value(p.tau[id + 1]));
-                bool ready = open || lb < theta;
-                if (ready) {
-                    // even nodes use the first half of the ready buffer, odd nodes the second half
-                    const bool odd = ((ix + iz) & 1) != 0;
-                    const int mine = atomicAdd(&sc[odd ? SC_READY_ODD : SC_READY], 1);
-                    if (mine < rhalf) {
-                        L.ready[odd ? rhalf + mine : mine] = id;
-                        atomicAnd(&tau_bits[id], ~kQueuedBit);      // before the barrier: see header
-                    } else ready = false;                           // counter is clamped when read
-                }
-                if (!ready) {
-                    push_next(L, id);
-                    atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(lb));
-                }
-            } while (0);
+                const float a = ix > 0 ? p.tau[id - nnz] : kInf;
+                const float b = ix + 1 < nnx ? p.tau[id + nnz] : kInf;
+                const float c = iz > 0 ? p.tau[id - 1] : kInf;
+                const float d = iz + 1 < nnz ? p.tau[id + 1] : kInf;
+                if (frozen_any) own[u] = p.tau[id];
+                lbs[u] = fminf(fminf(tau_value(a), tau_value(b)), fminf(tau_value(c), tau_value(d)));
+            }
+            float tmin_lane = kInf;
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int id = ids[u];
+                const bool have = id >= 0;
+                // accepted below the freeze horizon: final (see "cycle" at the end of the round)
+                const bool frozen = have && frozen_any && tau_value(own[u]) < freeze;
+                const float lb = lbs[u];
+                const bool cand = have && !frozen;
+                const int ix = have ? id / nnz : 0, iz = have ? id - ix * nnz : 0;
+                const bool odd = ((ix + iz) & 1) != 0;
+                // even nodes use the first half of the ready buffer, odd nodes the second half
+                const bool want_e = cand && (open || lb < theta) && !odd;
+                const bool want_o = cand && (open || lb < theta) && odd;
+                const int pe = wave_alloc(&sc[SC_READY], want_e);
+                const int po = wave_alloc(&sc[SC_READY_ODD], want_o);
+                const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);   // counters are clamped when read
+                if (got) L.ready[want_o ? rhalf + po : pe] = id;
+                if (got || frozen) atomicAnd(&tau_bits[id], ~kQueuedBit);            // before the barrier: see header
+                const bool defer = cand && !got;
+                push_next(L, id, defer);
+                if (defer) tmin_lane = fminf(tmin_lane, lb);
+            }
+            tmin_lane = wave_min(tmin_lane);
+            if ((tid & 63) == 0 && tmin_lane < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(tmin_lane));
         }
         __syncthreads();
+        { const unsigned long long t1 = wall_clock64(); tA += t1 - t0; t0 = t1; sum_cnt += cnt; }
 
         // ---- pass B: evaluate the ready nodes, even nodes first, then odd ones.  Adjacent nodes are
         // never evaluated in the same sub-pass, so the second half sees the first half's results
@@ -145,15 +200,17 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
         const int nready_odd = sc[SC_READY_ODD] < rhalf ? sc[SC_READY_ODD] : rhalf;
         for (int half = 0; half < 2; ++half) {
             const int nready = half ? nready_odd : nready_even;
-            for (int j = tid; j < nready; j += NT) {
-                const int id = L.ready[half ? rhalf + j : j];
+            for (int j0 = 0; j0 < nready; j0 += NT) {
+                const int j = j0 + tid;
+                const bool act = j < nready;                         // whole waves stay in the loop body
+                const int id = act ? L.ready[half ? rhalf + j : j] : 0;
                 const int ix = id / nnz, iz = id - ix * nnz;
                 Hood h;
                 const int off[4] = { -nnz, nnz, -1, 1 };
-                h.in[0] = ix > 0;          h.in_outer[0] = ix > 1;
-                h.in[1] = ix + 1 < nnx;    h.in_outer[1] = ix + 2 < nnx;
-                h.in[2] = iz > 0;          h.in_outer[2] = iz > 1;
-                h.in[3] = iz + 1 < nnz;    h.in_outer[3] = iz + 2 < nnz;
+                h.in[0] = act && ix > 0;          h.in_outer[0] = act && ix > 1;
+                h.in[1] = act && ix + 1 < nnx;    h.in_outer[1] = act && ix + 2 < nnx;
+                h.in[2] = act && iz > 0;          h.in_outer[2] = act && iz > 1;
+                h.in[3] = act && iz + 1 < nnz;    h.in_outer[3] = act && iz + 2 < nnz;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     h.near_[q] = h.in[q] ? p.T[id + off[q]] : kInf;
@@ -161,37 +218,55 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
                     h.outer[q] = h.in_outer[q] ? p.T[id + 2 * off[q]] : kInf;
                     h.outer_tau[q] = h.in_outer[q] ? p.tau[id + 2 * off[q]] : kInf;
                 }
-                const float t_old = p.T[id];
-                const float k_old = tau_value(p.tau[id]);
-                if (t_pinned(t_old)) continue;
-                const NodeGeom geom = { p.ri, p.risti[ix], p.dnx, p.dnz };
-                float k;
-                const float c = solve_node(h, p.slow[id], geom, &k);
-                ++evals;
-                if (f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old)) {
+                const float t_old = act ? p.T[id] : -1.0f;            // inactive lanes read as pinned
+                const float k_old = act ? tau_value(p.tau[id]) : 0.0f;
+                bool changed = false;
+                float c = 0.0f, k = kInf;
+                if (!t_pinned(t_old)) {
+                    const NodeGeom geom = { p.ri, p.risti[ix], p.dnx, p.dnz };
+                    c = solve_node(h, p.slow[id], geom, &k);
+                    ++evals;
+                    changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
+                }
+                if (changed) {
                     p.T[id] = c;
                     p.tau[id] = k;                                     // queued bit clear
+                }
+                // Dependents: the 4 near nodes, and the 4 outer nodes whose in-between node is reached
+                // (the node two steps away uses this one only through the node in between; while that
+                // one is unreached the dependency is moot, it will activate the outer node itself when
+                // it changes, and queuing it anyway floods the list with nodes that can never become
+                // ready).  All test-and-sets are issued before any result is consumed, so their L2
+                // round trips overlap; list slots are allocated per wave.
+                bool want[8];
+                unsigned olds[8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (h.in[q] && !t_pinned(h.near_[q]) && !(f2u(h.near_tau[q]) & kQueuedBit)) {
-                            const unsigned old = atomicOr(&tau_bits[id + off[q]], kQueuedBit);
-                            if (!(old & kQueuedBit)) push_next(L, id + off[q]);
-                        }
-                        // The node two steps away uses this one only through the node in between;
-                        // while that one is unreached the dependency is moot (and it will activate
-                        // the outer node itself when it changes).  Queuing it anyway floods the
-                        // list with nodes that can never become ready.
-                        if (h.in_outer[q] && tau_value(h.near_tau[q]) < kInf && !t_pinned(h.outer[q]) &&
-                            !(f2u(h.outer_tau[q]) & kQueuedBit)) {
-                            const unsigned old = atomicOr(&tau_bits[id + 2 * off[q]], kQueuedBit);
-                            if (!(old & kQueuedBit)) push_next(L, id + 2 * off[q]);
-                        }
-                    }
-                    atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(k));
+                for (int q = 0; q < 4; ++q) {
+                    want[q] = changed && h.in[q] && !t_pinned(h.near_[q]) && !(f2u(h.near_tau[q]) & kQueuedBit);
+                    want[4 + q] = changed && h.in_outer[q] && tau_value(h.near_tau[q]) < kInf && !t_pinned(h.outer[q]) &&
+                                  !(f2u(h.outer_tau[q]) & kQueuedBit);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    olds[q] = want[q] ? atomicOr(&tau_bits[id + off[q]], kQueuedBit) : kQueuedBit;
+                    olds[4 + q] = want[4 + q] ? atomicOr(&tau_bits[id + 2 * off[q]], kQueuedBit) : kQueuedBit;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    push_next(L, id + off[q], !(olds[q] & kQueuedBit));
+                    push_next(L, id + 2 * off[q], !(olds[4 + q] & kQueuedBit));
+                }
+                const unsigned hv = wave_sum(changed ? (((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u)) : 0u);
+                const float kmin = wave_min(changed ? k : kInf);
+                if ((tid & 63) == 0) {
+                    if (hv) atomicAdd(reinterpret_cast<unsigned*>(&sc[SC_HASH]), hv);
+                    if (kmin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(kmin));
                 }
             }
             __syncthreads();
+            { const unsigned long long t1 = wall_clock64(); (half ? tB1 : tB0) += t1 - t0; t0 = t1; }
         }
+        sum_ready += nready_even + nready_odd;
         if (tid == 0) {
             const int n = sc[SC_NEXT];
             sc[SC_CUR] = n < cap ? n : cap;
@@ -201,22 +276,33 @@ __global__ __launch_bounds__(NT) void k_fim(const FimProblem* __restrict__ probl
             const float tmin = u2f((unsigned)sc[SC_TMIN]);
             sc[SC_THETA] = (int)f2u(tmin + p.window);
             sc[SC_TMIN] = 0x7f800000;
-            // Stall: by causality every node accepted before the earliest pending bound is final, so
-            // that bound must keep rising.  If it does not for kStallRounds rounds, what is left in the
-            // window is a cluster of mutually tied nodes flipping by an ulp (Fast Marching never sees
-            // this: a popped node is frozen).  Freeze everything accepted below the window's edge.
-            if (tmin > best_tmin) { best_tmin = tmin; stall = 0; }
-            else if (tmin < kInf && ++stall >= kStallRounds) { sc[SC_FREEZE] = (int)f2u(best_tmin + p.window); stall = 0; ++freezes; }
+            // Cycle: a cluster of mutually tied nodes can flip by an ulp forever (Fast Marching never
+            // sees this: a popped node is frozen).  It shows as the complete set of changes repeating
+            // with a short period, which the per-round hash of (node, T, tau) changes detects; settling
+            // along a front never repeats exactly.  When that holds for kCycleRounds rounds, nothing
+            // else inside the window is still moving, and by causality everything accepted before the
+            // window's edge can be frozen.
+            const unsigned hsh = (unsigned)sc[SC_HASH];
+            sc[SC_HASH] = 0;
+            if (tmin > best_tmin) best_tmin = tmin;
+            const bool repeat = hsh != 0u && (hsh == hist[1] || hsh == hist[2] || hsh == hist[3] || hsh == hist[0]);
+            hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = hsh;
+            if (repeat) { if (++stall >= kCycleRounds) { sc[SC_FREEZE] = (int)f2u(best_tmin + p.window); stall = 0; ++freezes; } }
+            else stall = 0;
         }
         int* t = L.cur; L.cur = L.next; L.next = t;
         ++rounds;
         __syncthreads();
+        { const unsigned long long t1 = wall_clock64(); tE += t1 - t0; t0 = t1; }
         if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
     }
     // counters: evaluations summed over threads
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals);
-    if (tid == 0) { p.info[0] = rounds; p.info[1] = rescans; p.info[3] = freezes; }
+    if (tid == 0) {
+        p.info[0] = rounds; p.info[1] = rescans; p.info[3] = freezes;
+        if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; }
+    }
 }
 
 size_t fim_lds_bytes(const FimLaunch& l)

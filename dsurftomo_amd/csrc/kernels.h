@@ -23,6 +23,7 @@ struct FimProblem {
     float ri, dnx, dnz;
     float window;          // causal window (seconds of travel time) evaluated per round
     int max_rounds;
+    unsigned long long* clocks;   // optional, 8 u64: phase clocks of thread 0 (wall_clock64 ticks) + list sizes
     int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [3] stall freezes, [4..5] evaluations (u64)
 };
 
@@ -67,7 +68,8 @@ void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const 
                          size_t field_stride, const float* d_risti_c, hipStream_t stream);
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
-                          FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, hipStream_t stream);
+                          FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
+                          hipStream_t stream);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
 struct RayDesc { int src; float rx, rz; float sin_rx; };   // sin_rx = libm sinf(rx), made on the host

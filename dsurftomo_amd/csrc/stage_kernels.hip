@@ -259,7 +259,7 @@ void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const 
 // ---------------------------------------------------------------------------------------------
 __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* slow_all, size_t field_stride,
                                 const float* risti_c, float window_r, float window_c, FimProblem* prob_r,
-                                FimProblem* prob_c, int32_t* info)
+                                FimProblem* prob_c, int32_t* info, unsigned long long* clocks)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -271,6 +271,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     r.nnx = sd.rnx; r.nnz = sd.rnz;
     r.ri = g.earth; r.dnx = sd.rdnx; r.dnz = sd.rdnz; r.window = window_r;
     r.max_rounds = 64 * (sd.rnx + sd.rnz) + 4096;
+    r.clocks = nullptr;
     r.info = info + (size_t)s * 16;
     prob_r[s] = r;
     FimProblem c;
@@ -280,6 +281,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.nnx = g.nnx; c.nnz = g.nnz;
     c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = window_c;
     c.max_rounds = 64 * (g.nnx + g.nnz) + 4096;
+    c.clocks = clocks ? clocks + (size_t)s * 8 : nullptr;
     c.info = info + (size_t)s * 16 + 8;
     prob_c[s] = c;
     for (int q = 0; q < 16; ++q) info[(size_t)s * 16 + q] = 0;
@@ -287,11 +289,12 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
-                          FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, hipStream_t stream)
+                          FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
+                          hipStream_t stream)
 {
     if (nsrc <= 0) return;
     hipLaunchKernelGGL(k_make_problems, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all,
-                       field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info);
+                       field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -145,6 +145,8 @@ class Engine:
         return out
 
     def stats(self):
-        out = np.zeros(16, np.float64)
+        out = np.zeros(32, np.float64)
         self._check(self._L.dsa_get_stats(self._h, _p(out)))
-        return dict(zip(STAT_NAMES, out[:len(STAT_NAMES)].tolist()))
+        d = dict(zip(STAT_NAMES, out[:len(STAT_NAMES)].tolist()))
+        d["phase_ticks"] = out[len(STAT_NAMES):len(STAT_NAMES) + 6].tolist()
+        return d

@@ -88,7 +88,7 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out);
 enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, DSA_STAT_MS_STAGES,
        DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_EVALS_TOTAL,
        DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_FREEZES, DSA_STAT_COUNT };
-int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT */);
+int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 6: counters, then 6 phase-clock sums */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */
 int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,

@@ -234,6 +234,7 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* T, float* tau, const
     float theta = kInf; long rounds = 0, evals = 0;
     std::vector<float> nT, nK;
     float best_tmin = -kInf, freeze = -kInf; int stall = 0; long freezes = 0;
+    unsigned hist[4] = { 1u, 2u, 3u, 4u }, hsh = 0u;
     while (!cur.empty()) {
         float tmin = kInf; ready.clear();
         for (int id : cur) {
@@ -258,6 +259,7 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* T, float* tau, const
                 const int id = sub[k];
                 if (std::memcmp(&nT[k], &T[id], 4) || std::memcmp(&nK[k], &tau[id], 4)) {
                     T[id] = nT[k]; tau[id] = nK[k];
+                    { unsigned a, b; std::memcpy(&a, &nT[k], 4); std::memcpy(&b, &nK[k], 4); hsh += ((unsigned)id * 2654435761u) ^ (a * 40503u) ^ (b * 2246822519u); }
                     const int ix = id / nnz, iz = id - ix * nnz;
                     if (ix > 0) act(id - nnz); if (ix > 1) act(id - 2 * nnz); if (ix + 1 < nnx) act(id + nnz); if (ix + 2 < nnx) act(id + 2 * nnz);
                     if (iz > 0) act(id - 1); if (iz > 1) act(id - 2); if (iz + 1 < nnz) act(id + 1); if (iz + 2 < nnz) act(id + 2);
@@ -269,8 +271,12 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* T, float* tau, const
             std::printf("round %ld: theta %.7f tmin %.7f ready %zu next %zu\n", rounds, theta, tmin, ready.size(), next.size());
             for (size_t k = 0; k < ready.size() && k < 12; ++k) { const int id = ready[k]; std::printf("   ready ix=%d iz=%d T=%.7f tau=%.7f\n", id / nnz + 1, id % nnz + 1, T[id], tau[id]); }
         }
-        if (tmin > best_tmin) { best_tmin = tmin; stall = 0; }
-        else if (tmin < kInf && ++stall >= 12) { freeze = best_tmin + window; stall = 0; ++freezes; }
+        if (tmin > best_tmin) best_tmin = tmin;
+        {   // same rule as fim_kernel.hip: freeze only when the set of changes repeats exactly
+            const bool repeat = hsh != 0u && (hsh == hist[1] || hsh == hist[2] || hsh == hist[3] || hsh == hist[0]);
+            hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = hsh; hsh = 0u;
+            if (repeat) { if (++stall >= 8) { freeze = best_tmin + window; stall = 0; ++freezes; } } else stall = 0;
+        }
         cur.swap(next); next.clear(); theta = tmin + window; ++rounds;
         if (rounds >= max_rounds) break;
     }
