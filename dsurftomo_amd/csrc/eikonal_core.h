@@ -30,6 +30,29 @@ constexpr float kInf = __builtin_inff();
 DSA_HD bool t_pinned(float t) { return __builtin_signbit(t); }
 DSA_HD float t_value(float t) { return __builtin_fabsf(t); }
 
+// Field layout in HBM.  A node's state is one 8-byte record (T, tau) and records are stored in
+// tiles of 8x8 nodes (512 B = four 128-B lines), tiles in z-fastest order; the slowness field uses
+// the same tiling with 4-byte entries.  Why: the update reads T and tau at x-2..x+2 and z-2..z+2.
+// With plain z-fastest rows the x neighbours are a whole row (4 KB at N = 1025) apart, so one
+// evaluation touches ten separate cache lines for 80 useful bytes, and with one workgroup per CU
+// sharing a 4 MB L2 32 ways the measured HBM traffic was ~360x the algorithmic bytes
+// (profiles/r01_pmc_k_fim_rowmajor.txt).  In a tile the whole stencil sits in 1-3 lines, and the
+// nodes of a front segment crossing the tile share them.
+struct Rec { float T, tau; };
+constexpr int kTileShift = 3, kTile = 8, kTileRecs = 64;
+DSA_HD int tiles_of(int n) { return (n + kTile - 1) >> kTileShift; }
+// record index of node (iz0, ix0), 0-based; nbz = tiles_of(nnz)
+DSA_HD int rec_index(int nbz, int iz0, int ix0)
+{
+    return (((ix0 >> kTileShift) * nbz + (iz0 >> kTileShift)) << 6) + ((ix0 & 7) << 3) + (iz0 & 7);
+}
+DSA_HD void rec_coords(int nbz, int id, int* iz0, int* ix0)
+{
+    const int tile = id >> 6, bx = tile / nbz, bz = tile - bx * nbz;
+    *ix0 = (bx << kTileShift) + ((id >> 3) & 7);
+    *iz0 = (bz << kTileShift) + (id & 7);
+}
+
 // Geometry of one node column (depends on ix only); reference CalSurfG.f90:613-615.
 struct NodeGeom {
     float ri;     // earth radius
@@ -258,10 +281,9 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
 // arrays.  `status`: -1 far, 0 alive, >0 slot in the tree.
 // ---------------------------------------------------------------------------------------------
 struct MarchView {
-    float* T;             // travel times, (ldT, *) column-major, indexed by full-grid (iz, ix), 1-based
-    int ldT;
-    const float* slow;    // slowness, same indexing
-    int ldS;
+    Rec* F;               // tiled (T, tau) records of the full grid; the march uses T only
+    const float* slow;    // tiled slowness
+    int nbz;              // tiles per column of the full grid
     const float* risti;   // per-ix table, 1-based index ix -> risti[ix-1]
     int16_t* status;      // window-local status, (wnz, wnx) column-major
     int wz0, wx0;         // full-grid index of window element (1,1) minus 1
@@ -274,8 +296,8 @@ struct MarchView {
     int error;            // 1: window overflow, 2: tree overflow
 };
 
-DSA_HD float& mv_T(MarchView& m, int iz, int ix) { return m.T[(size_t)(ix - 1) * (size_t)m.ldT + (size_t)(iz - 1)]; }
-DSA_HD float mv_slow(const MarchView& m, int iz, int ix) { return m.slow[(size_t)(ix - 1) * (size_t)m.ldS + (size_t)(iz - 1)]; }
+DSA_HD float& mv_T(MarchView& m, int iz, int ix) { return m.F[rec_index(m.nbz, iz - 1, ix - 1)].T; }
+DSA_HD float mv_slow(const MarchView& m, int iz, int ix) { return m.slow[rec_index(m.nbz, iz - 1, ix - 1)]; }
 DSA_HD bool mv_inwin(const MarchView& m, int iz, int ix)
 {
     return iz > m.wz0 && iz <= m.wz0 + m.wnz && ix > m.wx0 && ix <= m.wx0 + m.wnx;

@@ -28,7 +28,8 @@ struct Engine {
     // model
     GridDesc g{};
     int nmaps = 0;
-    size_t nfield = 0;
+    size_t nfield = 0;         // nodes of the coarse grid
+    size_t nrec_c = 0;         // records of its tiled storage (padded to whole tiles)
     bool have_maps = false;
     float dpl = 0.0f;          // minimum cell width (km)
     float hmin_slow = 0.0f;    // smallest slowness of the maps (window scale)
@@ -52,7 +53,8 @@ struct Engine {
     DevBuf<RayDesc> rays;
     DevBuf<float> out;
     DevBuf<int32_t> err;
-    DevBuf<float> slow_r, T_r, tau_r, Tfin_r, risti_r, vcorner, T_c, tau_c;
+    DevBuf<float> slow_r, Tfin_r, risti_r, vcorner;
+    DevBuf<Rec> F_r, F_c;
     DevBuf<int> seed_r, nseed_r, seed_c, nseed_c;
     DevBuf<int8_t> S_r, cinit;
     DevBuf<int16_t> rst, cst;
@@ -74,6 +76,7 @@ struct Engine {
     FimLaunch launch_shape(int nnx, int nnz) const;
     void launch_srtimes_chunk(int r0, int nr, int first_unit);
     int get_field(int unit, float* ttn);
+    int fetch_tiled(const Rec* dev, int nnx, int nnz, int which, float* out);
     int get_refined(int unit, int* rnx, int* rnz, float* ttnr, int8_t* st);
     int get_velocity(int map, float* out_v);
 };

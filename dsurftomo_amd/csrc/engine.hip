@@ -54,8 +54,8 @@ Engine::~Engine()
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     rel(velv); rel(veln); rel(slow); rel(risti_c); rel(cbasis); rel(rbasis);
     rel(src); rel(rays); rel(out); rel(err);
-    rel(slow_r); rel(T_r); rel(tau_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
-    rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(T_c); rel(tau_c); rel(seed_c); rel(nseed_c);
+    rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
+    rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(F_c); rel(seed_c); rel(nseed_c);
     rel(prob_r); rel(prob_c); rel(info); rel(clocks);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
@@ -88,6 +88,7 @@ int Engine::set_maps(int nx, int ny, float goxd, float gozd, float dvxd, float d
     if (g.nnx > 32767 || g.nnz > 32767) { fail(DSA_ERR_ARGUMENT, "grid %dx%d exceeds the 32767-node index range", g.nnx, g.nnz); return DSA_ERR_ARGUMENT; }
     nmaps = nm;
     nfield = (size_t)g.nnx * g.nnz;
+    nrec_c = (size_t)g.nbx * g.nbz * kTileRecs;
     const size_t nv = (size_t)nx * ny;
     std::vector<float> hv(nv * nm);
     for (size_t k = 0; k < nv * nm; ++k) hv[k] = (float)pv[k];       // velv = real(pv), CalSurfG.f90:1492
@@ -98,14 +99,14 @@ int Engine::set_maps(int nx, int ny, float goxd, float gozd, float dvxd, float d
     basis_table(dicing * kSgdl, rb.data());
     risti_table(g.gox, g.dnx, g.earth, g.nnx, rc.data());
     dpl = min_cell_km(g);
-    if (ensure(velv, hv.size()) || ensure(veln, nfield * nm) || ensure(slow, nfield * nm) || ensure(risti_c, rc.size()) ||
+    if (ensure(velv, hv.size()) || ensure(veln, nfield * nm) || ensure(slow, nrec_c * nm) || ensure(risti_c, rc.size()) ||
         ensure(cbasis, cb.size()) || ensure(rbasis, rb.size())) return status;
     HIP_TRY(this, hipMemcpyAsync(velv.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(cbasis.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(rbasis.p, rb.data(), rb.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(risti_c.p, rc.data(), rc.size() * 4, hipMemcpyHostToDevice, stream));
     for (int m = 0; m < nm; ++m)
-        launch_gridder(g, velv.p + nv * m, cbasis.p, veln.p + nfield * m, slow.p + nfield * m, stream);
+        launch_gridder(g, velv.p + nv * m, cbasis.p, veln.p + nfield * m, slow.p + nrec_c * m, stream);
     HIP_TRY(this, hipGetLastError());
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = false;
@@ -154,7 +155,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
     size_t budget = mem_budget ? mem_budget : (size_t)(0.6 * (double)free_b);
     const size_t rr = (size_t)kRefMax * kRefMax;
-    per_unit_bytes = nfield * 8 + rr * 17 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
+    per_unit_bytes = nrec_c * 8 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
                      (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(SourceDesc);
     size_t c = budget / per_unit_bytes;
     if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B)", budget, per_unit_bytes); return DSA_ERR_DEVICE; }
@@ -162,10 +163,10 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
     const size_t C = (size_t)chunk;
     if (ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(nr, 1)) || ensure(err, 4) ||
-        ensure(slow_r, C * rr) || ensure(T_r, C * rr) || ensure(tau_r, C * rr) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
+        ensure(slow_r, C * kRefRecs) || ensure(F_r, C * kRefRecs) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
-        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, C * nfield) || ensure(tau_c, C * nfield) ||
+        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(F_c, C * nrec_c) ||
         ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
@@ -177,9 +178,9 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
 BatchPtrs Engine::batch() const
 {
     BatchPtrs b;
-    b.src = src.p; b.slow_r = slow_r.p; b.T_r = T_r.p; b.tau_r = tau_r.p; b.Tfin_r = Tfin_r.p; b.S_r = S_r.p; b.risti_r = risti_r.p;
+    b.src = src.p; b.slow_r = slow_r.p; b.F_r = F_r.p; b.Tfin_r = Tfin_r.p; b.S_r = S_r.p; b.risti_r = risti_r.p;
     b.vcorner = vcorner.p; b.seed_r = seed_r.p; b.nseed_r = nseed_r.p; b.rst = rst.p; b.cst = cst.p; b.cinit = cinit.p;
-    b.heap = heap.p; b.flags = flags.p; b.T_c = T_c.p; b.tau_c = tau_c.p; b.seed_c = seed_c.p; b.nseed_c = nseed_c.p;
+    b.heap = heap.p; b.flags = flags.p; b.F_c = F_c.p; b.seed_c = seed_c.p; b.nseed_c = nseed_c.p;
     return b;
 }
 
@@ -205,16 +206,15 @@ int Engine::solve(float* dsurf)
         HIP_TRY(this, hipMemcpyAsync(src.p, h_src.data() + first, (size_t)n * sizeof(SourceDesc), hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipMemcpyAsync(risti_r.p, h_risti_r.data() + (size_t)first * kRefMax, (size_t)n * kRefMax * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipEventRecord(events[1], stream));
-        launch_fill(T_c.p, (size_t)n * nfield, kInf, stream);
-        launch_fill(tau_c.p, (size_t)n * nfield, kInf, stream);
-        launch_make_problems(g, b, n, slow.p, nfield, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, stream);
+        launch_fill(reinterpret_cast<float*>(F_c.p), (size_t)n * nrec_c * 2, kInf, stream);      // (T, tau) = (+inf, +inf)
+        launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));
         launch_fim(prob_r.p, n, launch_shape(kRefMax, kRefMax), stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         launch_handoff(g, b, n, stream);
-        launch_coarse_march(g, b, n, slow.p, nfield, risti_c.p, stream);
+        launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
         HIP_TRY(this, hipEventRecord(events[4], stream));
         launch_fim(prob_c.p, n, launch_shape(g.nnx, g.nnz), stream);
         HIP_TRY(this, hipEventRecord(events[5], stream));
@@ -288,11 +288,25 @@ void Engine::launch_srtimes_chunk(int r0, int nr, int first_unit)
     launch_srtimes(g, batch(), first_unit, rays.p + r0, nr, veln.p, nfield, dpl, out.p + r0, err.p, stream);
 }
 
+// download tiled records and untile on the host: which = 0 -> T (raw), 1 -> tau (raw)
+int Engine::fetch_tiled(const Rec* dev, int nnx, int nnz, int which, float* out)
+{
+    const int nbx = tiles_of(nnx), nbz = tiles_of(nnz);
+    std::vector<Rec> h((size_t)nbx * nbz * kTileRecs);
+    HIP_TRY(this, hipMemcpy(h.data(), dev, h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+    for (int ix = 0; ix < nnx; ++ix)
+        for (int iz = 0; iz < nnz; ++iz) {
+            const Rec r = h[rec_index(nbz, iz, ix)];
+            out[(size_t)ix * nnz + iz] = which ? r.tau : r.T;
+        }
+    return 0;
+}
+
 int Engine::get_field(int unit, float* ttn)
 {
     if (last_chunk_first < 0 || unit < last_chunk_first || unit >= last_chunk_first + last_chunk_n) { fail(DSA_ERR_STATE, "get_field: unit %d is not resident (last chunk covers %d..%d)", unit, last_chunk_first, last_chunk_first + last_chunk_n - 1); return DSA_ERR_STATE; }
     HIP_TRY(this, hipSetDevice(device));
-    HIP_TRY(this, hipMemcpy(ttn, T_c.p + (size_t)(unit - last_chunk_first) * nfield, nfield * 4, hipMemcpyDeviceToHost));
+    if (fetch_tiled(F_c.p + (size_t)(unit - last_chunk_first) * nrec_c, g.nnx, g.nnz, 0, ttn)) return status;
     for (size_t k = 0; k < nfield; ++k) ttn[k] = fabsf(ttn[k]);
     return 0;
 }
@@ -420,11 +434,10 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out)
     if (!e || !out) return DSA_ERR_ARGUMENT;
     Engine* en = reinterpret_cast<Engine*>(e);
     if (en->last_chunk_first < 0 || unit < en->last_chunk_first || unit >= en->last_chunk_first + en->last_chunk_n) return DSA_ERR_STATE;
-    const size_t slot = (size_t)(unit - en->last_chunk_first), rr = (size_t)dsa::kRefMax * dsa::kRefMax;
-    const float* src = which == 0 ? en->T_c.p + slot * en->nfield : which == 1 ? en->tau_c.p + slot * en->nfield
-                     : which == 2 ? en->T_r.p + slot * rr : en->tau_r.p + slot * rr;
-    const size_t n = which < 2 ? en->nfield : rr;
-    return hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : DSA_ERR_DEVICE;
+    const size_t slot = (size_t)(unit - en->last_chunk_first);
+    if (which < 2) return en->fetch_tiled(en->F_c.p + slot * en->nrec_c, en->g.nnx, en->g.nnz, which, out);
+    const dsa::SourceDesc& s = en->h_src[unit];
+    return en->fetch_tiled(en->F_r.p + slot * dsa::kRefRecs, s.rnx, s.rnz, which - 2, out);
 }
 
 int dsa_get_stats(const dsa_engine* e, double* out)

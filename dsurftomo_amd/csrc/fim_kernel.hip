@@ -93,8 +93,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
     L.cur = smem; L.next = smem + cap; L.ready = smem + 2 * cap; L.sc = smem + 2 * cap + rcap;
     L.cap = cap; L.rcap = rcap;
     int* sc = L.sc;
-    unsigned* tau_bits = reinterpret_cast<unsigned*>(p.tau);
-    const int nnz = p.nnz, nnx = p.nnx;
+    Rec* const F = p.F;
+    const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
+    auto tau_word = [&](int id) { return reinterpret_cast<unsigned*>(&F[id].tau); };
     const int rhalf = rcap / 2;
 
     const int nseed = *p.seed_count;
@@ -120,10 +121,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
             __syncthreads();
             if (tid == 0) { sc[SC_OVERFLOW] = 0; sc[SC_NEXT] = 0; }
             __syncthreads();
-            const int n = nnx * nnz;
+            const int n = p.nbx * nbz * kTileRecs;
             for (int id = tid; id < n; id += NT)
-                if ((__hip_atomic_load(&tau_bits[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kQueuedBit) &&
-                    !t_pinned(p.T[id])) {
+                if ((__hip_atomic_load(tau_word(id), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kQueuedBit) &&
+                    !t_pinned(F[id].T)) {
                     const int pos = atomicAdd(&sc[SC_NEXT], 1);
                     if (pos < cap) L.cur[pos] = id; else sc[SC_OVERFLOW] = 1;
                 }
@@ -156,12 +157,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
                 lbs[u] = kInf; own[u] = kInf;
                 if (ids[u] < 0) continue;
                 const int id = ids[u];
-                const int ix = id / nnz, iz = id - ix * nnz;        // 0-based
-                const float a = ix > 0 ? p.tau[id - nnz] : kInf;
-                const float b = ix + 1 < nnx ? p.tau[id + nnz] : kInf;
-                const float c = iz > 0 ? p.tau[id - 1] : kInf;
-                const float d = iz + 1 < nnz ? p.tau[id + 1] : kInf;
-                if (frozen_any) own[u] = p.tau[id];
+                int iz, ix;                                         // 0-based
+                rec_coords(nbz, id, &iz, &ix);
+                const float a = ix > 0 ? F[rec_index(nbz, iz, ix - 1)].tau : kInf;
+                const float b = ix + 1 < nnx ? F[rec_index(nbz, iz, ix + 1)].tau : kInf;
+                const float c = iz > 0 ? F[rec_index(nbz, iz - 1, ix)].tau : kInf;
+                const float d = iz + 1 < nnz ? F[rec_index(nbz, iz + 1, ix)].tau : kInf;
+                if (frozen_any) own[u] = F[id].tau;
                 lbs[u] = fminf(fminf(tau_value(a), tau_value(b)), fminf(tau_value(c), tau_value(d)));
             }
             float tmin_lane = kInf;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
                 const bool frozen = have && frozen_any && tau_value(own[u]) < freeze;
                 const float lb = lbs[u];
                 const bool cand = have && !frozen;
-                const int ix = have ? id / nnz : 0, iz = have ? id - ix * nnz : 0;
+                int iz = 0, ix = 0;
+                if (have) rec_coords(nbz, id, &iz, &ix);
                 const bool odd = ((ix + iz) & 1) != 0;
                 // even nodes use the first half of the ready buffer, odd nodes the second half
                 const bool want_e = cand && (open || lb < theta) && !odd;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
                 const int po = wave_alloc(&sc[SC_READY_ODD], want_o);
                 const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);   // counters are clamped when read
                 if (got) L.ready[want_o ? rhalf + po : pe] = id;
-                if (got || frozen) atomicAnd(&tau_bits[id], ~kQueuedBit);            // before the barrier: see header
+                if (got || frozen) atomicAnd(tau_word(id), ~kQueuedBit);             // before the barrier: see header
                 const bool defer = cand && !got;
                 push_next(L, id, defer);
                 if (defer) tmin_lane = fminf(tmin_lane, lb);
@@ -204,22 +207,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
                 const int j = j0 + tid;
                 const bool act = j < nready;                         // whole waves stay in the loop body
                 const int id = act ? L.ready[half ? rhalf + j : j] : 0;
-                const int ix = id / nnz, iz = id - ix * nnz;
+                int iz, ix;
+                rec_coords(nbz, id, &iz, &ix);
                 Hood h;
-                const int off[4] = { -nnz, nnz, -1, 1 };
                 h.in[0] = act && ix > 0;          h.in_outer[0] = act && ix > 1;
                 h.in[1] = act && ix + 1 < nnx;    h.in_outer[1] = act && ix + 2 < nnx;
                 h.in[2] = act && iz > 0;          h.in_outer[2] = act && iz > 1;
                 h.in[3] = act && iz + 1 < nnz;    h.in_outer[3] = act && iz + 2 < nnz;
+                // record indices of the 8 stencil nodes (x-, x+, z-, z+; near then outer)
+                int nid[8];
+                nid[0] = rec_index(nbz, iz, ix - 1); nid[4] = rec_index(nbz, iz, ix - 2);
+                nid[1] = rec_index(nbz, iz, ix + 1); nid[5] = rec_index(nbz, iz, ix + 2);
+                nid[2] = rec_index(nbz, iz - 1, ix); nid[6] = rec_index(nbz, iz - 2, ix);
+                nid[3] = rec_index(nbz, iz + 1, ix); nid[7] = rec_index(nbz, iz + 2, ix);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    h.near_[q] = h.in[q] ? p.T[id + off[q]] : kInf;
-                    h.near_tau[q] = h.in[q] ? p.tau[id + off[q]] : kInf;
-                    h.outer[q] = h.in_outer[q] ? p.T[id + 2 * off[q]] : kInf;
-                    h.outer_tau[q] = h.in_outer[q] ? p.tau[id + 2 * off[q]] : kInf;
+                    const Rec a = h.in[q] ? F[nid[q]] : Rec{ kInf, kInf };
+                    const Rec b = h.in_outer[q] ? F[nid[4 + q]] : Rec{ kInf, kInf };
+                    h.near_[q] = a.T; h.near_tau[q] = a.tau;
+                    h.outer[q] = b.T; h.outer_tau[q] = b.tau;
                 }
-                const float t_old = act ? p.T[id] : -1.0f;            // inactive lanes read as pinned
-                const float k_old = act ? tau_value(p.tau[id]) : 0.0f;
+                const Rec own = act ? F[id] : Rec{ -1.0f, 0.0f };     // inactive lanes read as pinned
+                const float t_old = own.T;
+                const float k_old = tau_value(own.tau);
                 bool changed = false;
                 float c = 0.0f, k = kInf;
                 if (!t_pinned(t_old)) {
@@ -228,10 +238,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
                     ++evals;
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
-                if (changed) {
-                    p.T[id] = c;
-                    p.tau[id] = k;                                     // queued bit clear
-                }
+                if (changed) F[id] = Rec{ c, k };                       // one 8-byte store; queued bit clear
                 // Dependents: the 4 near nodes, and the 4 outer nodes whose in-between node is reached
                 // (the node two steps away uses this one only through the node in between; while that
                 // one is unreached the dependency is moot, it will activate the outer node itself when
@@ -248,13 +255,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    olds[q] = want[q] ? atomicOr(&tau_bits[id + off[q]], kQueuedBit) : kQueuedBit;
-                    olds[4 + q] = want[4 + q] ? atomicOr(&tau_bits[id + 2 * off[q]], kQueuedBit) : kQueuedBit;
+                    olds[q] = want[q] ? atomicOr(tau_word(nid[q]), kQueuedBit) : kQueuedBit;
+                    olds[4 + q] = want[4 + q] ? atomicOr(tau_word(nid[4 + q]), kQueuedBit) : kQueuedBit;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    push_next(L, id + off[q], !(olds[q] & kQueuedBit));
-                    push_next(L, id + 2 * off[q], !(olds[4 + q] & kQueuedBit));
+                    push_next(L, nid[q], !(olds[q] & kQueuedBit));
+                    push_next(L, nid[4 + q], !(olds[4 + q] & kQueuedBit));
                 }
                 const unsigned hv = wave_sum(changed ? (((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u)) : 0u);
                 const float kmin = wave_min(changed ? k : kInf);

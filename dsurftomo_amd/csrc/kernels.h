@@ -8,18 +8,17 @@
 
 namespace dsa {
 
-// One fixed-point problem: a travel-time field on an (nnz, nnx) grid, column-major with z fastest.
-// T / tau carry the boundary condition (eikonal_core.h): pinned nodes (sign bit of T) are never
-// recomputed, every other node starts at +inf.  `seed` lists the nodes to evaluate first (their
-// queued bit, the sign bit of tau, is already set).
+// One fixed-point problem: a travel-time field on an (nnz, nnx) grid stored as tiled (T, tau)
+// records (eikonal_core.h).  The records carry the boundary condition: pinned nodes (sign bit of T)
+// are never recomputed, every other node starts at +inf.  `seed` lists the record indices to
+// evaluate first (their queued bit, the sign bit of tau, is already set).
 struct FimProblem {
-    float* T;
-    float* tau;
-    const float* slow;
+    Rec* F;
+    const float* slow;     // tiled like F
     const float* risti;
     const int* seed;
     const int* seed_count;
-    int nnx, nnz;
+    int nnx, nnz, nbx, nbz;
     float ri, dnx, dnz;
     float window;          // causal window (seconds of travel time) evaluated per round
     int max_rounds;
@@ -36,15 +35,16 @@ size_t fim_lds_bytes(const FimLaunch& l);
 void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream);
 
 // period-level tables ---------------------------------------------------------------------------
-// velv: fp32 vertex values (ny, nx); basis: (gd+1) x 4; outputs veln / slow (nnz, nnx)
+// velv: fp32 vertex values (ny, nx); basis: (gd+1) x 4; outputs veln (nnz, nnx row-major, for the
+// receiver / ray kernels) and slow (tiled, for the solve)
 void launch_gridder(const GridDesc& g, const float* d_velv, const float* d_basis, float* d_veln, float* d_slow,
                     hipStream_t stream);
 
 // per-source stages ------------------------------------------------------------------------------
 struct BatchPtrs {
     const SourceDesc* src;       // [nsrc]
-    // refined, per source, stride kRefMax*kRefMax unless noted
-    float* slow_r; float* T_r; float* tau_r; float* Tfin_r; int8_t* S_r;
+    // refined, per source: tiled slowness / records (stride kRefRecs), row-major results (stride kRefMax^2)
+    float* slow_r; Rec* F_r; float* Tfin_r; int8_t* S_r;
     float* risti_r;              // stride kRefMax (uploaded by the host)
     float* vcorner;              // stride 4
     int* seed_r; int* nseed_r;   // stride kSeedR / 1
@@ -53,7 +53,7 @@ struct BatchPtrs {
     int32_t* heap;               // stride kHeapCap
     int32_t* flags;              // stride 4: [0] ended early, [1] error, [2] e* iz, [3] e* ix
     // coarse, per source
-    float* T_c; float* tau_c;    // stride nnx*nnz
+    Rec* F_c;                    // stride nbx*nbz*64 (tiled records)
     int* seed_c; int* nseed_c;   // stride kSeedC / 1
 };
 constexpr int kSeedR = kRWin * kRWin;              // the start-up march cannot pin more than its window

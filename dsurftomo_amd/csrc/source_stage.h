@@ -21,6 +21,8 @@ namespace dsa {
 constexpr int kSgdl = 8;        // source-grid dicing level (reference sgdl)
 constexpr int kSgs = 8;         // source-grid half extent in coarse nodes (reference sgs)
 constexpr int kRefMax = 129;    // (2*sgs)*sgdl + 1
+constexpr int kRefTiles = (kRefMax + 7) / 8;                       // 17
+constexpr int kRefRecs = kRefTiles * kRefTiles * 64;               // tiled storage of the largest box
 constexpr int kRWin = 32;       // status window (nodes) of the refined start-up march
 constexpr int kCMargin = 24;    // margin (coarse nodes) of the coarse band-march window around the box
 constexpr int kCWinMax = 2 * kSgs + 1 + 2 * kCMargin;  // 65
@@ -46,15 +48,14 @@ struct SourceDesc {
     int open_xlo, open_xhi, open_zlo, open_zhi;  // literal open-edge flags of the refined stage
     int rwz0, rwx0;               // refined march window origin (0-based offset of element (1,1))
     int cwz0, cwx0, cwnz, cwnx;   // coarse march window
-    int nbx_r, nbz_r;             // 8x8 blocks of the refined grid
+    int nbx_r, nbz_r;             // 8x8 tiles of the refined grid
     int first_ray, nrec;          // receivers of this source: rays [first_ray, first_ray+nrec)
 };
 
 // per-source scratch in device memory (all sources of a batch laid out back to back)
 struct SourceScratch {
-    float* slow_r;      // kRefMax*kRefMax, ld = rnz
-    float* T_r;         // same; during the refined solve: sign bit = pinned, +inf = not reached
-    float* tau_r;       // acceptance times of the refined solve (eikonal_core.h)
+    float* slow_r;      // kRefRecs tiled slowness of the refined box
+    Rec* F_r;           // kRefRecs tiled (T, tau) records of the refined solve (eikonal_core.h)
     int8_t* S_r;        // final refined status: -1 far, 0 alive, 1 close (kept for the ray tracer)
     float* risti_r;     // kRefMax
     float* vcorner;     // 4 refined velocities of the source cell, [i][j] i = x offset
@@ -118,7 +119,7 @@ DSA_HD float coarse_velocity(const GridDesc& g, const float* velv, const float* 
 DSA_HD int refined_startup(const GridDesc& g, const SourceDesc& s, SourceScratch& w)
 {
     MarchView m;
-    m.T = w.T_r; m.ldT = s.rnz; m.slow = w.slow_r; m.ldS = s.rnz; m.risti = w.risti_r;
+    m.F = w.F_r; m.slow = w.slow_r; m.nbz = s.nbz_r; m.risti = w.risti_r;
     m.status = w.rst; m.wz0 = s.rwz0; m.wx0 = s.rwx0; m.wnz = kRWin; m.wnx = kRWin;
     m.nnz = s.rnz; m.nnx = s.rnx; m.ri = g.earth; m.dnx = s.rdnx; m.dnz = s.rdnz;
     m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0;
@@ -162,11 +163,10 @@ DSA_HD void refined_encode(const SourceDesc& s, SourceScratch& w, int ended)
             const int ix = s.rwx0 + lx + 1, iz = s.rwz0 + lz + 1;
             if (ix < 1 || ix > s.rnx || iz < 1 || iz > s.rnz) continue;
             const int st = w.rst[lx * kRWin + lz];
-            const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
-            float& t = w.T_r[id];
-            if (st == 0) { w.tau_r[id] = t; t = -t; }          // -0.0f for an exact zero keeps the sign bit
-            else if (st > 0 && ended) w.tau_r[id] = t;          // keep the trial value
-            else { t = kInf; w.tau_r[id] = kInf; }
+            Rec& r = w.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)];
+            if (st == 0) { r.tau = r.T; r.T = -r.T; }              // -0.0f for an exact zero keeps the sign bit
+            else if (st > 0 && ended) r.tau = r.T;                 // keep the trial value
+            else { r.T = kInf; r.tau = kInf; }
         }
 }
 
@@ -194,16 +194,15 @@ DSA_HD uint64_t accept_rank(float t_raw, float tau_raw)
 // rstar: rank of the open-edge node that ended the refined stage (~0 if none)
 DSA_HD bool ref_alive(const SourceDesc& s, const SourceScratch& w, uint64_t rstar, int iz, int ix)
 {
-    const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
-    const float t = w.T_r[id];
-    return t_pinned(t) || accept_rank(t, w.tau_r[id]) < rstar;
+    const Rec r = w.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)];
+    return t_pinned(r.T) || accept_rank(r.T, r.tau) < rstar;
 }
 
 // classify node (iz, ix): returns status (-1, 0, 1) and the value to keep in *tout
 DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScratch& w, int ended,
                         uint64_t rstar, int ez, int ex, int iz, int ix, float* tout)
 {
-    const float raw = w.T_r[(size_t)(ix - 1) * s.rnz + (iz - 1)];
+    const float raw = w.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)].T;
     if (ended) {
         if (t_pinned(raw)) { *tout = t_value(raw); return 0; }
         if (t_value(raw) < kInf) { *tout = raw; return 1; }
@@ -219,21 +218,21 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
     for (int d = 0; d < 2; ++d) {
         st.ej[d] = jx[d] >= 1 && jx[d] <= s.rnx;
         st.aj[d] = st.ej[d] && ref_alive(s, w, rstar, iz, jx[d]);
-        st.tj[d] = st.aj[d] ? t_value(w.T_r[(size_t)(jx[d] - 1) * s.rnz + (iz - 1)]) : kInf;
+        st.tj[d] = st.aj[d] ? t_value(w.F_r[rec_index(s.nbz_r, iz - 1, jx[d] - 1)].T) : kInf;
         const bool o = jx2[d] >= 1 && jx2[d] <= s.rnx && ref_alive(s, w, rstar, iz, jx2[d]);
         st.oj[d] = o;
-        st.tj2[d] = o ? t_value(w.T_r[(size_t)(jx2[d] - 1) * s.rnz + (iz - 1)]) : kInf;
+        st.tj2[d] = o ? t_value(w.F_r[rec_index(s.nbz_r, iz - 1, jx2[d] - 1)].T) : kInf;
         st.ek[d] = kz[d] >= 1 && kz[d] <= s.rnz;
         st.ak[d] = st.ek[d] && ref_alive(s, w, rstar, kz[d], ix);
-        st.tk[d] = st.ak[d] ? t_value(w.T_r[(size_t)(ix - 1) * s.rnz + (kz[d] - 1)]) : kInf;
+        st.tk[d] = st.ak[d] ? t_value(w.F_r[rec_index(s.nbz_r, kz[d] - 1, ix - 1)].T) : kInf;
         const bool p = kz2[d] >= 1 && kz2[d] <= s.rnz && ref_alive(s, w, rstar, kz2[d], ix);
         st.ok[d] = p;
-        st.tk2[d] = p ? t_value(w.T_r[(size_t)(ix - 1) * s.rnz + (kz2[d] - 1)]) : kInf;
+        st.tk2[d] = p ? t_value(w.F_r[rec_index(s.nbz_r, kz2[d] - 1, ix - 1)].T) : kInf;
         touch = touch || st.aj[d] || st.ak[d];
     }
     if (!touch) { *tout = kInf; return -1; }
     NodeGeom ng = { g.earth, w.risti_r[ix - 1], s.rdnx, s.rdnz };
-    *tout = fouds2(st, w.slow_r[(size_t)(ix - 1) * s.rnz + (iz - 1)], ng);
+    *tout = fouds2(st, w.slow_r[rec_index(s.nbz_r, iz - 1, ix - 1)], ng);
     if (iz == ez && ix == ex) return 0;
     return 1;
 }
@@ -241,13 +240,13 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
 // ---------------------------------------------------------------------------------------------
 // Band march on the coarse grid: travel(urg=2) from the injected state until every node that
 // started in the tree has been accepted.  T_c is the coarse field of this source (plain values
-// inside the window on entry for status >= 0), slow_c/risti_c the period's coarse tables.
+// inside the window on entry for status >= 0), slow_c (tiled) / risti_c the period's coarse tables.
 // Serial.  On return: alive nodes of the window are pinned (sign bit), all others +inf (T and tau).
-DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, float* T_c, float* tau_c,
+DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, Rec* F_c,
                               const float* slow_c, const float* risti_c)
 {
     MarchView m;
-    m.T = T_c; m.ldT = g.nnz; m.slow = slow_c; m.ldS = g.nnz; m.risti = risti_c;
+    m.F = F_c; m.slow = slow_c; m.nbz = g.nbz; m.risti = risti_c;
     m.status = w.cst; m.wz0 = s.cwz0; m.wx0 = s.cwx0; m.wnz = s.cwnz; m.wnx = s.cwnx;
     m.nnz = g.nnz; m.nnx = g.nnx; m.ri = g.earth; m.dnx = g.dnx; m.dnz = g.dnz;
     m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0;
@@ -269,11 +268,10 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
     for (int lx = 0; lx < s.cwnx; ++lx)
         for (int lz = 0; lz < s.cwnz; ++lz) {
             const int ix = s.cwx0 + lx + 1, iz = s.cwz0 + lz + 1;
-            const size_t id = (size_t)(ix - 1) * g.nnz + (iz - 1);
-            float& t = T_c[id];
+            Rec& r = F_c[rec_index(g.nbz, iz - 1, ix - 1)];
             const int st = w.cst[lx * s.cwnz + lz];
-            if (st == 0) { tau_c[id] = t_value(t); t = -t_value(t); }
-            else { t = kInf; tau_c[id] = kInf; }
+            if (st == 0) { r.tau = t_value(r.T); r.T = -t_value(r.T); }
+            else { r.T = kInf; r.tau = kInf; }
         }
 }
 

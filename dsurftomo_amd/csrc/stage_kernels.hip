@@ -10,9 +10,8 @@ __device__ __forceinline__ SourceScratch scratch_of(const BatchPtrs& b, int s)
 {
     SourceScratch w;
     const size_t rr = (size_t)kRefMax * kRefMax;
-    w.slow_r = b.slow_r + s * rr;
-    w.T_r = b.T_r + s * rr;
-    w.tau_r = b.tau_r + s * rr;
+    w.slow_r = b.slow_r + (size_t)s * kRefRecs;
+    w.F_r = b.F_r + (size_t)s * kRefRecs;
     w.S_r = b.S_r + s * rr;
     w.risti_r = b.risti_r + (size_t)s * kRefMax;
     w.vcorner = b.vcorner + (size_t)s * 4;
@@ -25,12 +24,12 @@ __device__ __forceinline__ SourceScratch scratch_of(const BatchPtrs& b, int s)
 }
 
 // queue node (iz, ix) (1-based) as a seed of the fixed-point solve; single writer per source
-__device__ __forceinline__ void seed_node(float* tau, int ld, int* seed, int* nseed, int cap, int iz, int ix)
+__device__ __forceinline__ void seed_node(Rec* F, int nbz, int* seed, int* nseed, int cap, int iz, int ix)
 {
-    const size_t id = (size_t)(ix - 1) * ld + (iz - 1);
-    unsigned* bits = reinterpret_cast<unsigned*>(tau);
-    if (bits[id] & kQueuedBit) return;
-    bits[id] |= kQueuedBit;
+    const int id = rec_index(nbz, iz - 1, ix - 1);
+    unsigned* bits = reinterpret_cast<unsigned*>(&F[id].tau);
+    if (*bits & kQueuedBit) return;
+    *bits |= kQueuedBit;
     if (*nseed < cap) seed[*nseed] = (int)id;
     *nseed += 1;      // a count above cap makes the solve kernel rescan the field
 }
@@ -57,20 +56,22 @@ void launch_fill(float* d, size_t n, float v, hipStream_t stream)
 __global__ void k_gridder(GridDesc g, const float* __restrict__ velv, const float* __restrict__ basis,
                           float* __restrict__ veln, float* __restrict__ slow)
 {
-    const size_t n = (size_t)g.nnx * g.nnz;
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n) return;
-    const int ix = (int)(id / g.nnz) + 1, iz = (int)(id % g.nnz) + 1;
-    const float v = coarse_velocity(g, velv, basis, iz, ix);
-    veln[id] = v;
+    const int nrec = g.nbx * g.nbz * kTileRecs;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;      // tiled record index: lanes walk a tile
+    if (id >= nrec) return;
+    int iz0, ix0;
+    rec_coords(g.nbz, id, &iz0, &ix0);
+    if (iz0 >= g.nnz || ix0 >= g.nnx) { slow[id] = 1.0f; return; }        // padding of the last tiles
+    const float v = coarse_velocity(g, velv, basis, iz0 + 1, ix0 + 1);
+    veln[(size_t)ix0 * g.nnz + iz0] = v;
     slow[id] = 1.0f / v;
 }
 
 void launch_gridder(const GridDesc& g, const float* d_velv, const float* d_basis, float* d_veln, float* d_slow,
                     hipStream_t stream)
 {
-    const size_t n = (size_t)g.nnx * g.nnz;
-    hipLaunchKernelGGL(k_gridder, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, d_velv, d_basis, d_veln, d_slow);
+    const int nrec = g.nbx * g.nbz * kTileRecs;
+    hipLaunchKernelGGL(k_gridder, dim3((nrec + 255) / 256), dim3(256), 0, stream, g, d_velv, d_basis, d_veln, d_slow);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -80,18 +81,19 @@ __global__ void k_refine(GridDesc g, BatchPtrs b, const float* __restrict__ velv
 {
     const int s = blockIdx.y;
     const SourceDesc sd = b.src[s];
-    const int n = sd.rnx * sd.rnz;
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t rr = (size_t)kRefMax * kRefMax;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;       // tiled record index inside the box storage
     if (id < 4 && blockIdx.x == 0) b.flags[(size_t)s * 4 + id] = 0;
     if (id == 0 && blockIdx.x == 0) { b.nseed_r[s] = 0; b.nseed_c[s] = 0; }
-    if (id >= n) return;
-    const int lx = id / sd.rnz + 1, kz = id % sd.rnz + 1;
+    if (id >= kRefRecs) return;
+    const size_t at = (size_t)s * kRefRecs + id;
+    b.F_r[at] = Rec{ kInf, kInf };
+    int kz0, lx0;
+    rec_coords(sd.nbz_r, id, &kz0, &lx0);
+    if (id >= sd.nbx_r * sd.nbz_r * kTileRecs || kz0 >= sd.rnz || lx0 >= sd.rnx) { b.slow_r[at] = 1.0f; return; }
+    const int lx = lx0 + 1, kz = kz0 + 1;
     const float* velv = velv_all + (size_t)sd.period * velv_stride;
     const float v = refined_velocity(g, sd, velv, rbasis, kz, lx);
-    b.slow_r[s * rr + id] = 1.0f / v;
-    b.T_r[s * rr + id] = kInf;
-    b.tau_r[s * rr + id] = kInf;
+    b.slow_r[at] = 1.0f / v;
     if ((lx == sd.isx_r || lx == sd.isx_r + 1) && (kz == sd.isz_r || kz == sd.isz_r + 1))
         b.vcorner[(size_t)s * 4 + (lx - sd.isx_r) * 2 + (kz - sd.isz_r)] = v;
 }
@@ -100,7 +102,7 @@ void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float*
                    const float* d_rbasis, hipStream_t stream)
 {
     if (nsrc <= 0) return;
-    const int per = (kRefMax * kRefMax + 255) / 256;
+    const int per = (kRefRecs + 255) / 256;
     hipLaunchKernelGGL(k_refine, dim3(per, nsrc), dim3(256), 0, stream, g, b, d_velv_all, velv_stride, d_rbasis);
 }
 
@@ -126,8 +128,8 @@ __global__ void k_refined_startup(GridDesc g, BatchPtrs b, int nsrc)
             const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
             for (int q = 0; q < 4; ++q) {
                 if (nx[q] < 1 || nx[q] > sd.rnx || nz[q] < 1 || nz[q] > sd.rnz) continue;
-                if (t_pinned(w.T_r[(size_t)(nx[q] - 1) * sd.rnz + (nz[q] - 1)])) continue;
-                seed_node(w.tau_r, sd.rnz, seed, &nseed, kSeedR, nz[q], nx[q]);
+                if (t_pinned(w.F_r[rec_index(sd.nbz_r, nz[q] - 1, nx[q] - 1)].T)) continue;
+                seed_node(w.F_r, sd.nbz_r, seed, &nseed, kSeedR, nz[q], nx[q]);
             }
         }
     b.nseed_r[s] = nseed;
@@ -157,16 +159,20 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     if (!ended) {
         for (int id = tid; id < n; id += 256) {
             const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
-            if (!is_open_edge(sd, iz, ix) || !(t_value(w.T_r[id]) < kInf)) continue;
-            atomicMin(&s_best, (unsigned long long)accept_rank(w.T_r[id], w.tau_r[id]));
+            if (!is_open_edge(sd, iz, ix)) continue;
+            const Rec r = w.F_r[rec_index(sd.nbz_r, iz - 1, ix - 1)];
+            if (!(t_value(r.T) < kInf)) continue;
+            atomicMin(&s_best, (unsigned long long)accept_rank(r.T, r.tau));
         }
         __syncthreads();
         const unsigned long long best = s_best;
         if (best != ~0ull)
             for (int id = tid; id < n; id += 256) {
                 const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
-                if (!is_open_edge(sd, iz, ix) || !(t_value(w.T_r[id]) < kInf)) continue;
-                if ((unsigned long long)accept_rank(w.T_r[id], w.tau_r[id]) == best) atomicMin(&s_first, id);
+                if (!is_open_edge(sd, iz, ix)) continue;
+                const Rec r = w.F_r[rec_index(sd.nbz_r, iz - 1, ix - 1)];
+                if (!(t_value(r.T) < kInf)) continue;
+                if ((unsigned long long)accept_rank(r.T, r.tau) == best) atomicMin(&s_first, id);
             }
     }
     __syncthreads();
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     const int wn = sd.cwnx * sd.cwnz;
     for (int q = tid; q < wn; q += 256) w.cst[q] = -1;
     __syncthreads();
-    float* T_c = b.T_c + (size_t)s * g.nnx * g.nnz;
+    Rec* F_c = b.F_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
     const int bxn = (sd.rnx - 1) / kSgdl + 1, bzn = (sd.rnz - 1) / kSgdl + 1;
     for (int q = tid; q < bxn * bzn; q += 256) {
         const int l = (q / bzn) * kSgdl + 1, k = (q % bzn) * kSgdl + 1;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
         const int id = (l - 1) * sd.rnz + (k - 1);
         const int st = w.S_r[id];
         w.cst[(cx - 1 - sd.cwx0) * sd.cwnz + (cz - 1 - sd.cwz0)] = (int16_t)st;
-        if (st >= 0) T_c[(size_t)(cx - 1) * g.nnz + (cz - 1)] = Tfin[id];
+        if (st >= 0) F_c[rec_index(g.nbz, cz - 1, cx - 1)].T = Tfin[id];
     }
     __syncthreads();
     // alive nodes that touch a far node go back into the band. A promoted node reads as "not far"
@@ -229,10 +235,9 @@ __global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* _
     if (s >= nsrc) return;
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
-    float* T_c = b.T_c + (size_t)s * g.nnx * g.nnz;
-    float* tau_c = b.tau_c + (size_t)s * g.nnx * g.nnz;
-    const float* slow_c = slow_all + (size_t)sd.period * field_stride;
-    coarse_band_march(g, sd, w, T_c, tau_c, slow_c, risti_c);
+    Rec* F_c = b.F_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
+    const float* slow_c = slow_all + (size_t)sd.period * field_stride;      // tiled slowness of this period
+    coarse_band_march(g, sd, w, F_c, slow_c, risti_c);
     int* seed = b.seed_c + (size_t)s * kSeedC;
     int nseed = 0;
     for (int lx = 0; lx < sd.cwnx; ++lx)
@@ -242,8 +247,8 @@ __global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* _
             const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
             for (int q = 0; q < 4; ++q) {
                 if (nx[q] < 1 || nx[q] > g.nnx || nz[q] < 1 || nz[q] > g.nnz) continue;
-                if (t_pinned(T_c[(size_t)(nx[q] - 1) * g.nnz + (nz[q] - 1)])) continue;
-                seed_node(tau_c, g.nnz, seed, &nseed, kSeedC, nz[q], nx[q]);
+                if (t_pinned(F_c[rec_index(g.nbz, nz[q] - 1, nx[q] - 1)].T)) continue;
+                seed_node(F_c, g.nbz, seed, &nseed, kSeedC, nz[q], nx[q]);
             }
         }
     b.nseed_c[s] = nseed;
@@ -264,21 +269,20 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
     const SourceDesc sd = b.src[s];
-    const size_t rr = (size_t)kRefMax * kRefMax;
     FimProblem r;
-    r.T = b.T_r + s * rr; r.tau = b.tau_r + s * rr; r.slow = b.slow_r + s * rr; r.risti = b.risti_r + (size_t)s * kRefMax;
+    r.F = b.F_r + (size_t)s * kRefRecs; r.slow = b.slow_r + (size_t)s * kRefRecs; r.risti = b.risti_r + (size_t)s * kRefMax;
     r.seed = b.seed_r + (size_t)s * kSeedR; r.seed_count = b.nseed_r + s;
-    r.nnx = sd.rnx; r.nnz = sd.rnz;
+    r.nnx = sd.rnx; r.nnz = sd.rnz; r.nbx = sd.nbx_r; r.nbz = sd.nbz_r;
     r.ri = g.earth; r.dnx = sd.rdnx; r.dnz = sd.rdnz; r.window = window_r;
     r.max_rounds = 64 * (sd.rnx + sd.rnz) + 4096;
     r.clocks = nullptr;
     r.info = info + (size_t)s * 16;
     prob_r[s] = r;
     FimProblem c;
-    c.T = b.T_c + (size_t)s * g.nnx * g.nnz; c.tau = b.tau_c + (size_t)s * g.nnx * g.nnz;
+    c.F = b.F_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
     c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
     c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s;
-    c.nnx = g.nnx; c.nnz = g.nnz;
+    c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
     c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = window_c;
     c.max_rounds = 64 * (g.nnx + g.nnz) + 4096;
     c.clocks = clocks ? clocks + (size_t)s * 8 : nullptr;
@@ -308,7 +312,7 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
     const RayDesc rd = rays[r];
     const int slot = rd.src - unit_base;
     const SourceDesc sd = b.src[slot];
-    const float* T = b.T_c + (size_t)slot * g.nnx * g.nnz;
+    const Rec* F = b.F_c + (size_t)slot * g.nbx * g.nbz * kTileRecs;
     const float* veln = veln_all + (size_t)sd.period * field_stride;
     const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, earth = g.earth;
     const float rcx1 = rd.rx, rcz1 = rd.rz, scx = sd.scx, scz = sd.scz;
@@ -352,7 +356,7 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
             for (int l = 1; l <= 2; ++l) {
                 const float produ = (1.0f - fabsf(((float)(l - 1) * dnz - drz) / dnz)) *
                                     (1.0f - fabsf(((float)(k - 1) * dnx - drx) / dnx));
-                trr = trr + t_value(T[(size_t)(irx - 1 + k - 1) * ld + (irz - 1 + l - 1)]) * produ;
+                trr = trr + t_value(F[rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1)].T) * produ;
             }
     }
     out[r] = trr;

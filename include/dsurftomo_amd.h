@@ -81,7 +81,7 @@ int dsa_get_velocity(dsa_engine* e, int map, float* veln);
 int dsa_get_refined(dsa_engine* e, int unit, int* rnx, int* rnz, float* ttnr, int8_t* status);
 
 /* raw state of a resident unit for diagnostics: which = 0 coarse T (sign bit = pinned), 1 coarse
- * tau (sign bit = queued), 2 refined T, 3 refined tau (129*129 floats, leading dimension rnz) */
+ * tau (sign bit = queued), 2 refined T, 3 refined tau (rnx*rnz floats, leading dimension rnz) */
 int dsa_debug_field(dsa_engine* e, int unit, int which, float* out);
 
 /* counters of the last dsa_solve: see DSA_STAT_* */

@@ -16,13 +16,14 @@ using namespace dsa;
 namespace {
 
 struct Field {
-    int nnx, nnz;
-    float* T;
-    float* tau;
-    const float* slow;
+    int nnx, nnz, nbz;
+    Rec* F;                 // tiled records
+    const float* slow;      // tiled slowness
     const float* risti;
     float ri, dnx, dnz;
 };
+
+inline int ridx(const Field& f, int iz, int ix) { return rec_index(f.nbz, iz - 1, ix - 1); }   // 1-based
 
 Hood load_hood(const Field& f, int iz, int ix)
 {
@@ -32,48 +33,164 @@ Hood load_hood(const Field& f, int iz, int ix)
     for (int q = 0; q < 4; ++q) {
         h.in[q] = nx[q] >= 1 && nx[q] <= f.nnx && nz[q] >= 1 && nz[q] <= f.nnz;
         h.in_outer[q] = ox[q] >= 1 && ox[q] <= f.nnx && oz[q] >= 1 && oz[q] <= f.nnz;
-        h.near_[q] = h.in[q] ? f.T[(size_t)(nx[q] - 1) * f.nnz + (nz[q] - 1)] : kInf;
-        h.outer[q] = h.in_outer[q] ? f.T[(size_t)(ox[q] - 1) * f.nnz + (oz[q] - 1)] : kInf;
-        h.near_tau[q] = h.in[q] ? f.tau[(size_t)(nx[q] - 1) * f.nnz + (nz[q] - 1)] : kInf;
-        h.outer_tau[q] = h.in_outer[q] ? f.tau[(size_t)(ox[q] - 1) * f.nnz + (oz[q] - 1)] : kInf;
+        const Rec a = h.in[q] ? f.F[ridx(f, nz[q], nx[q])] : Rec{ kInf, kInf };
+        const Rec b = h.in_outer[q] ? f.F[ridx(f, oz[q], ox[q])] : Rec{ kInf, kInf };
+        h.near_[q] = a.T; h.near_tau[q] = a.tau; h.outer[q] = b.T; h.outer_tau[q] = b.tau;
     }
     return h;
+}
+
+// tiled <-> row-major helpers
+std::vector<Rec> tile_fill(int nnx, int nnz)
+{
+    return std::vector<Rec>((size_t)tiles_of(nnx) * tiles_of(nnz) * kTileRecs, Rec{ kInf, kInf });
+}
+void untile(int nnx, int nnz, const Rec* F, float* T, float* tau)
+{
+    const int nbz = tiles_of(nnz);
+    for (int ix = 0; ix < nnx; ++ix)
+        for (int iz = 0; iz < nnz; ++iz) {
+            const Rec r = F[rec_index(nbz, iz, ix)];
+            if (T) T[(size_t)ix * nnz + iz] = r.T;
+            if (tau) tau[(size_t)ix * nnz + iz] = r.tau;
+        }
 }
 
 long fixed_point(Field& f)
 {
     const size_t n = (size_t)f.nnx * f.nnz;
-    std::vector<int> q(n * 2 + 64);
+    std::vector<int> qx(n * 2 + 64), qz(n * 2 + 64);
     std::vector<unsigned char> inq(n, 0);
-    size_t head = 0, tail = 0, cap = q.size();
+    size_t head = 0, tail = 0, cap = qx.size();
     long evals = 0;
     auto push = [&](int iz, int ix) {
         if (ix < 1 || ix > f.nnx || iz < 1 || iz > f.nnz) return;
         const size_t id = (size_t)(ix - 1) * f.nnz + (iz - 1);
-        if (t_pinned(f.T[id]) || inq[id]) return;
-        inq[id] = 1; q[tail] = (int)id; tail = (tail + 1) % cap;
+        if (t_pinned(f.F[ridx(f, iz, ix)].T) || inq[id]) return;
+        inq[id] = 1; qx[tail] = ix; qz[tail] = iz; tail = (tail + 1) % cap;
     };
     for (int ix = 1; ix <= f.nnx; ++ix)
         for (int iz = 1; iz <= f.nnz; ++iz)
-            if (t_pinned(f.T[(size_t)(ix - 1) * f.nnz + (iz - 1)])) {
-                push(iz, ix - 1); push(iz, ix + 1); push(iz - 1, ix); push(iz + 1, ix);
-            }
+            if (t_pinned(f.F[ridx(f, iz, ix)].T)) { push(iz, ix - 1); push(iz, ix + 1); push(iz - 1, ix); push(iz + 1, ix); }
     while (head != tail) {
-        const size_t id = (size_t)q[head]; head = (head + 1) % cap; inq[id] = 0;
-        const int ix = (int)(id / f.nnz) + 1, iz = (int)(id % f.nnz) + 1;
+        const int ix = qx[head], iz = qz[head]; head = (head + 1) % cap;
+        inq[(size_t)(ix - 1) * f.nnz + (iz - 1)] = 0;
         const Hood h = load_hood(f, iz, ix);
         const NodeGeom g = { f.ri, f.risti[ix - 1], f.dnx, f.dnz };
+        Rec& r = f.F[ridx(f, iz, ix)];
         float k;
-        const float c = solve_node(h, f.slow[id], g, &k);
+        const float c = solve_node(h, f.slow[ridx(f, iz, ix)], g, &k);
         ++evals;
-        if (std::memcmp(&c, &f.T[id], 4) != 0 || std::memcmp(&k, &f.tau[id], 4) != 0) {
-            f.T[id] = c; f.tau[id] = k;
+        if (std::memcmp(&c, &r.T, 4) != 0 || std::memcmp(&k, &r.tau, 4) != 0) {
+            r.T = c; r.tau = k;
             push(iz, ix - 1); push(iz, ix + 1); push(iz - 1, ix); push(iz + 1, ix);
             push(iz, ix - 2); push(iz, ix + 2); push(iz - 2, ix); push(iz + 2, ix);
         }
         if (evals > 400L * (long)n) return -1;
     }
     return evals;
+}
+
+// everything up to (not including) the coarse fixed-point solve, on tiled storage
+struct Prepared {
+    GridDesc g; SourceDesc s;
+    std::vector<Rec> F_c, F_r;
+    std::vector<float> slow_c, slow_r, risti_c, risti_r, Tfin;
+    std::vector<int8_t> S_r;
+    std::vector<int16_t> cst;
+    int ended = 0, err = 0; long evals_r = 0; float hmin = 0;
+};
+
+int prepare(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const double* pv, float x, float z,
+            Prepared& P, float* inj_t, int* inj_s)
+{
+    GridDesc& g = P.g; SourceDesc& s = P.s;
+    make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
+    if (make_source(g, x, z, s) != 0) return -1;
+    const size_t nr = (size_t)s.rnx * s.rnz;
+    std::vector<float> velv((size_t)nx * ny), cbasis(4 * (gd + 1)), rbasis(4 * (gd * kSgdl + 1)), vcorner(4);
+    for (int k = 0; k < nx * ny; ++k) velv[k] = (float)pv[k];
+    basis_table(gd, cbasis.data());
+    basis_table(gd * kSgdl, rbasis.data());
+    P.F_c = tile_fill(g.nnx, g.nnz); P.F_r = tile_fill(s.rnx, s.rnz);
+    P.slow_c.assign(P.F_c.size(), 1.0f); P.slow_r.assign(P.F_r.size(), 1.0f);
+    P.risti_c.resize(g.nnx); P.risti_r.resize(kRefMax);
+    P.hmin = 1e30f;
+    for (int ix = 1; ix <= g.nnx; ++ix)
+        for (int iz = 1; iz <= g.nnz; ++iz) {
+            const float sl = 1.0f / coarse_velocity(g, velv.data(), cbasis.data(), iz, ix);
+            P.slow_c[rec_index(g.nbz, iz - 1, ix - 1)] = sl;
+            if (sl < P.hmin) P.hmin = sl;
+        }
+    risti_table(g.gox, g.dnx, g.earth, g.nnx, P.risti_c.data());
+    risti_table(s.rgox, s.rdnx, g.earth, s.rnx, P.risti_r.data());
+    for (int lx = 1; lx <= s.rnx; ++lx)
+        for (int kz = 1; kz <= s.rnz; ++kz) {
+            const float v = refined_velocity(g, s, velv.data(), rbasis.data(), kz, lx);
+            P.slow_r[rec_index(s.nbz_r, kz - 1, lx - 1)] = 1.0f / v;
+            if ((lx == s.isx_r || lx == s.isx_r + 1) && (kz == s.isz_r || kz == s.isz_r + 1))
+                vcorner[(lx - s.isx_r) * 2 + (kz - s.isz_r)] = v;
+        }
+    std::vector<int16_t> rst(kRWin * kRWin);
+    P.cst.assign((size_t)kCWinMax * kCWinMax, -1);
+    P.S_r.assign(nr, -1);
+    std::vector<int8_t> cinit((size_t)kCWinMax * kCWinMax);
+    std::vector<int32_t> heap(kHeapCap), flags(4, 0);
+    SourceScratch w;
+    w.slow_r = P.slow_r.data(); w.F_r = P.F_r.data(); w.S_r = P.S_r.data(); w.risti_r = P.risti_r.data();
+    w.vcorner = vcorner.data(); w.rst = rst.data(); w.cst = P.cst.data(); w.cinit = cinit.data();
+    w.heap = heap.data(); w.flags = flags.data();
+
+    const int ended = refined_startup(g, s, w);
+    refined_encode(s, w, ended);
+    P.ended = ended;
+    if (!ended) {
+        Field fr = { s.rnx, s.rnz, s.nbz_r, P.F_r.data(), P.slow_r.data(), P.risti_r.data(), g.earth, s.rdnx, s.rdnz };
+        P.evals_r = fixed_point(fr);
+    }
+    // first open-edge node in acceptance order (scan order ix outer, iz inner breaks exact ties)
+    uint64_t rstar = ~0ull; int ez = 0, ex = 0;
+    if (!ended)
+        for (int ix = 1; ix <= s.rnx; ++ix)
+            for (int iz = 1; iz <= s.rnz; ++iz)
+                if (is_open_edge(s, iz, ix)) {
+                    const Rec r = P.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)];
+                    if (!(t_value(r.T) < kInf)) continue;
+                    const uint64_t rk = accept_rank(r.T, r.tau);
+                    if (rk < rstar) { rstar = rk; ez = iz; ex = ix; }
+                }
+    P.Tfin.assign(nr, kInf);
+    for (int ix = 1; ix <= s.rnx; ++ix)
+        for (int iz = 1; iz <= s.rnz; ++iz) {
+            const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
+            P.S_r[id] = (int8_t)handoff_node(g, s, w, ended, rstar, ez, ex, iz, ix, &P.Tfin[id]);
+        }
+    // injection + band promotion into the coarse window / field
+    auto cs = [&](int iz, int ix) -> int16_t& { return P.cst[(size_t)(ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0)]; };
+    for (int k = 1; k <= s.rnz; k += kSgdl)
+        for (int l = 1; l <= s.rnx; l += kSgdl) {
+            const int cz = s.vnt + (k - 1) / kSgdl, cx = s.vnl + (l - 1) / kSgdl;
+            const size_t id = (size_t)(l - 1) * s.rnz + (k - 1);
+            cs(cz, cx) = P.S_r[id];
+            if (P.S_r[id] >= 0) P.F_c[rec_index(g.nbz, cz - 1, cx - 1)].T = P.Tfin[id];
+        }
+    auto far = [&](int iz, int ix) {
+        if (ix < 1 || ix > g.nnx || iz < 1 || iz > g.nnz) return false;
+        if (!(iz > s.cwz0 && iz <= s.cwz0 + s.cwnz && ix > s.cwx0 && ix <= s.cwx0 + s.cwnx)) return true;
+        return cs(iz, ix) == -1;
+    };
+    for (int ix = s.vnl; ix <= s.vnr; ++ix)
+        for (int iz = s.vnt; iz <= s.vnb; ++iz)
+            if (cs(iz, ix) == 0 && (far(iz - 1, ix) || far(iz + 1, ix) || far(iz, ix - 1) || far(iz, ix + 1))) cs(iz, ix) = 1;
+    if (inj_t) untile(g.nnx, g.nnz, P.F_c.data(), inj_t, nullptr);
+    if (inj_s) {
+        for (size_t k = 0; k < (size_t)g.nnx * g.nnz; ++k) inj_s[k] = -1;
+        for (int ix = s.cwx0 + 1; ix <= s.cwx0 + s.cwnx; ++ix)
+            for (int iz = s.cwz0 + 1; iz <= s.cwz0 + s.cwnz; ++iz) inj_s[(size_t)(ix - 1) * g.nnz + (iz - 1)] = cs(iz, ix);
+    }
+    coarse_band_march(g, s, w, P.F_c.data(), P.slow_c.data(), P.risti_c.data());
+    P.err = flags[1];
+    return 0;
 }
 
 }  // namespace
@@ -118,94 +235,17 @@ int hc_solve_source(int nx, int ny, float goxd, float gozd, float dvxd, float dv
                     float x, float z, float* ttn, float* ttnr_out, int* nstsr_out, float* inj_t, int* inj_s,
                     int* box_out, long* stats)
 {
-    GridDesc g; make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
-    SourceDesc s;
-    if (make_source(g, x, z, s) != 0) return -1;
-    const size_t nc = (size_t)g.nnx * g.nnz, nr = (size_t)s.rnx * s.rnz;
-    std::vector<float> velv((size_t)nx * ny), cbasis(4 * (gd + 1)), rbasis(4 * (gd * kSgdl + 1));
-    for (int k = 0; k < nx * ny; ++k) velv[k] = (float)pv[k];
-    basis_table(gd, cbasis.data());
-    basis_table(gd * kSgdl, rbasis.data());
-    std::vector<float> slow_c(nc), risti_c(g.nnx), slow_r(nr), T_r(nr, kInf), tau_r(nr, kInf), tau_c(nc, kInf), risti_r(kRefMax), vcorner(4);
-    for (int ix = 1; ix <= g.nnx; ++ix)
-        for (int iz = 1; iz <= g.nnz; ++iz)
-            slow_c[(size_t)(ix - 1) * g.nnz + (iz - 1)] = 1.0f / coarse_velocity(g, velv.data(), cbasis.data(), iz, ix);
-    risti_table(g.gox, g.dnx, g.earth, g.nnx, risti_c.data());
-    risti_table(s.rgox, s.rdnx, g.earth, s.rnx, risti_r.data());
-    for (int lx = 1; lx <= s.rnx; ++lx)
-        for (int kz = 1; kz <= s.rnz; ++kz) {
-            const float v = refined_velocity(g, s, velv.data(), rbasis.data(), kz, lx);
-            slow_r[(size_t)(lx - 1) * s.rnz + (kz - 1)] = 1.0f / v;
-            if ((lx == s.isx_r || lx == s.isx_r + 1) && (kz == s.isz_r || kz == s.isz_r + 1))
-                vcorner[(lx - s.isx_r) * 2 + (kz - s.isz_r)] = v;
-        }
-    std::vector<int16_t> rst(kRWin * kRWin), cst((size_t)kCWinMax * kCWinMax);
-    std::vector<int8_t> S_r(nr), cinit((size_t)kCWinMax * kCWinMax);
-    std::vector<int32_t> heap(kHeapCap), flags(2, 0);
-    SourceScratch w;
-    w.slow_r = slow_r.data(); w.T_r = T_r.data(); w.tau_r = tau_r.data(); w.S_r = S_r.data(); w.risti_r = risti_r.data();
-    w.vcorner = vcorner.data(); w.rst = rst.data(); w.cst = cst.data(); w.cinit = cinit.data();
-    w.heap = heap.data(); w.flags = flags.data();
-
-    const int ended = refined_startup(g, s, w);
-    refined_encode(s, w, ended);
-    stats[2] = 0;
-    if (!ended) {
-        Field fr = { s.rnx, s.rnz, T_r.data(), tau_r.data(), slow_r.data(), risti_r.data(), g.earth, s.rdnx, s.rdnz };
-        stats[2] = fixed_point(fr);
-    }
-    // first open-edge node in acceptance order (scan order ix outer, iz inner breaks exact ties)
-    uint64_t rstar = ~0ull; int ez = 0, ex = 0;
-    if (!ended)
-        for (int ix = 1; ix <= s.rnx; ++ix)
-            for (int iz = 1; iz <= s.rnz; ++iz)
-                if (is_open_edge(s, iz, ix)) {
-                    const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
-                    if (!(t_value(T_r[id]) < kInf)) continue;
-                    const uint64_t r = accept_rank(T_r[id], tau_r[id]);
-                    if (r < rstar) { rstar = r; ez = iz; ex = ix; }
-                }
-    std::vector<float> Tfin(nr);
-    for (int ix = 1; ix <= s.rnx; ++ix)
-        for (int iz = 1; iz <= s.rnz; ++iz) {
-            const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
-            S_r[id] = (int8_t)handoff_node(g, s, w, ended, rstar, ez, ex, iz, ix, &Tfin[id]);
-        }
-    if (ttnr_out) std::memcpy(ttnr_out, Tfin.data(), 4 * nr);
-    if (nstsr_out) for (size_t k = 0; k < nr; ++k) nstsr_out[k] = S_r[k];
-
-    // injection + band promotion into the coarse window / field
-    for (size_t k = 0; k < nc; ++k) ttn[k] = kInf;
-    for (int q = 0; q < s.cwnx * s.cwnz; ++q) cst[q] = -1;
-    auto cs = [&](int iz, int ix) -> int16_t& { return cst[(size_t)(ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0)]; };
-    for (int k = 1; k <= s.rnz; k += kSgdl)
-        for (int l = 1; l <= s.rnx; l += kSgdl) {
-            const int cz = s.vnt + (k - 1) / kSgdl, cx = s.vnl + (l - 1) / kSgdl;
-            const size_t id = (size_t)(l - 1) * s.rnz + (k - 1);
-            cs(cz, cx) = S_r[id];
-            if (S_r[id] >= 0) ttn[(size_t)(cx - 1) * g.nnz + (cz - 1)] = Tfin[id];
-        }
-    auto far = [&](int iz, int ix) {
-        if (ix < 1 || ix > g.nnx || iz < 1 || iz > g.nnz) return false;
-        if (!(iz > s.cwz0 && iz <= s.cwz0 + s.cwnz && ix > s.cwx0 && ix <= s.cwx0 + s.cwnx)) return true;
-        return cs(iz, ix) == -1;
-    };
-    // the reference promotes in place while scanning ix outer / iz inner; promoted nodes become
-    // status 1, which is not "far", so the scan order does not matter
-    for (int ix = s.vnl; ix <= s.vnr; ++ix)
-        for (int iz = s.vnt; iz <= s.vnb; ++iz)
-            if (cs(iz, ix) == 0 && (far(iz - 1, ix) || far(iz + 1, ix) || far(iz, ix - 1) || far(iz, ix + 1))) cs(iz, ix) = 1;
-    if (inj_t) std::memcpy(inj_t, ttn, 4 * nc);
-    if (inj_s) {
-        for (size_t k = 0; k < nc; ++k) inj_s[k] = -1;
-        for (int ix = s.cwx0 + 1; ix <= s.cwx0 + s.cwnx; ++ix)
-            for (int iz = s.cwz0 + 1; iz <= s.cwz0 + s.cwnz; ++iz) inj_s[(size_t)(ix - 1) * g.nnz + (iz - 1)] = cs(iz, ix);
-    }
-    coarse_band_march(g, s, w, ttn, tau_c.data(), slow_c.data(), risti_c.data());
-    Field fc = { g.nnx, g.nnz, ttn, tau_c.data(), slow_c.data(), risti_c.data(), g.earth, g.dnx, g.dnz };
+    Prepared P;
+    if (prepare(nx, ny, goxd, gozd, dvxd, dvzd, gd, pv, x, z, P, inj_t, inj_s) != 0) return -1;
+    const GridDesc& g = P.g; const SourceDesc& s = P.s;
+    const size_t nr = (size_t)s.rnx * s.rnz;
+    if (ttnr_out) std::memcpy(ttnr_out, P.Tfin.data(), 4 * nr);
+    if (nstsr_out) for (size_t k = 0; k < nr; ++k) nstsr_out[k] = P.S_r[k];
+    Field fc = { g.nnx, g.nnz, g.nbz, P.F_c.data(), P.slow_c.data(), P.risti_c.data(), g.earth, g.dnx, g.dnz };
     stats[3] = fixed_point(fc);
-    for (size_t k = 0; k < nc; ++k) ttn[k] = t_value(ttn[k]);
-    stats[0] = ended; stats[1] = flags[1];
+    untile(g.nnx, g.nnz, P.F_c.data(), ttn, nullptr);
+    for (size_t k = 0; k < (size_t)g.nnx * g.nnz; ++k) ttn[k] = t_value(ttn[k]);
+    stats[0] = P.ended; stats[1] = P.err; stats[2] = P.evals_r;
     if (box_out) { box_out[0] = s.vnl; box_out[1] = s.vnr; box_out[2] = s.vnt; box_out[3] = s.vnb; box_out[4] = s.rnx; box_out[5] = s.rnz; }
     return 0;
 }
@@ -213,63 +253,74 @@ int hc_solve_source(int nx, int ny, float goxd, float gozd, float dvxd, float dv
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
-// Emulation of the device schedule of fim_kernel.hip (same routing, same theta update, the whole
-// ready set evaluated from the old states), used to study convergence on the CPU.
+// Emulation of the device schedule of fim_kernel.hip (same routing, same theta update, same cycle
+// rule; the ready set is evaluated from the old states), used to study convergence on the CPU.
+// Interface arrays are row-major (nnz fastest); storage inside is tiled like on the device.
 // mode 0: all ready nodes at once; mode 1: two sub-passes by node parity (even first).
-extern "C" long hc_device_schedule(int nnx, int nnz, float* T, float* tau, const float* slow, const float* risti,
+extern "C" long hc_device_schedule(int nnx, int nnz, float* Tio, float* tauio, const float* slow_rm, const float* risti,
                                    float ri, float dnx, float dnz, float window, int mode, int max_rounds,
-                                   long* out /* rounds, evals, last list size */, int* cyc_ids, int ncyc)
+                                   long* out /* rounds, evals, last list size, freezes */, int* cyc_ids, int ncyc)
 {
-    Field f = { nnx, nnz, T, tau, slow, risti, ri, dnx, dnz };
-    const size_t n = (size_t)nnx * nnz;
+    const int nbz = tiles_of(nnz);
+    std::vector<Rec> F = tile_fill(nnx, nnz);
+    std::vector<float> slow(F.size(), 1.0f);
+    for (int ix = 0; ix < nnx; ++ix)
+        for (int iz = 0; iz < nnz; ++iz) {
+            const int id = rec_index(nbz, iz, ix);
+            F[id] = Rec{ Tio[(size_t)ix * nnz + iz], tauio[(size_t)ix * nnz + iz] };
+            slow[id] = slow_rm[(size_t)ix * nnz + iz];
+        }
+    Field f = { nnx, nnz, nbz, F.data(), slow.data(), risti, ri, dnx, dnz };
+    const size_t n = F.size();
     std::vector<int> cur, next, ready;
     std::vector<unsigned char> queued(n, 0);
-    auto act = [&](long id) { if (id < 0 || (size_t)id >= n) return; if (t_pinned(T[id]) || queued[id]) return; queued[id] = 1; next.push_back((int)id); };
-    for (int ix = 1; ix <= nnx; ++ix) for (int iz = 1; iz <= nnz; ++iz) {
-        const size_t id = (size_t)(ix - 1) * nnz + (iz - 1);
-        if (!t_pinned(T[id])) continue;
-        if (ix > 1) act(id - nnz); if (ix < nnx) act(id + nnz); if (iz > 1) act(id - 1); if (iz < nnz) act(id + 1);
-    }
+    auto act = [&](int iz0, int ix0) {
+        if (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) return;
+        const int id = rec_index(nbz, iz0, ix0);
+        if (t_pinned(F[id].T) || queued[id]) return;
+        queued[id] = 1; next.push_back(id);
+    };
+    for (int ix = 0; ix < nnx; ++ix) for (int iz = 0; iz < nnz; ++iz)
+        if (t_pinned(F[rec_index(nbz, iz, ix)].T)) { act(iz, ix - 1); act(iz, ix + 1); act(iz - 1, ix); act(iz + 1, ix); }
     cur.swap(next);
     float theta = kInf; long rounds = 0, evals = 0;
     std::vector<float> nT, nK;
     float best_tmin = -kInf, freeze = -kInf; int stall = 0; long freezes = 0;
     unsigned hist[4] = { 1u, 2u, 3u, 4u }, hsh = 0u;
+    auto tv = [&](int iz0, int ix0) { return (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) ? kInf : tau_value(F[rec_index(nbz, iz0, ix0)].tau); };
     while (!cur.empty()) {
         float tmin = kInf; ready.clear();
         for (int id : cur) {
-            // accepted below the freeze horizon: final (see fim_kernel.hip, "stall")
-            if (tau_value(tau[id]) < freeze) { queued[id] = 0; continue; }
-            const int ix = id / nnz, iz = id - ix * nnz; float lb = kInf;
-            if (ix > 0) lb = fminf(lb, tau_value(tau[id - nnz])); if (ix + 1 < nnx) lb = fminf(lb, tau_value(tau[id + nnz]));
-            if (iz > 0) lb = fminf(lb, tau_value(tau[id - 1])); if (iz + 1 < nnz) lb = fminf(lb, tau_value(tau[id + 1]));
+            if (tau_value(F[id].tau) < freeze) { queued[id] = 0; continue; }       // accepted below the freeze horizon: final
+            int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
+            const float lb = fminf(fminf(tv(iz0, ix0 - 1), tv(iz0, ix0 + 1)), fminf(tv(iz0 - 1, ix0), tv(iz0 + 1, ix0)));
             if (!(theta < kInf) || lb < theta) { ready.push_back(id); queued[id] = 0; }
             else { next.push_back(id); tmin = fminf(tmin, lb); }
         }
         for (int pass = 0; pass < (mode == 1 ? 2 : 1); ++pass) {
             std::vector<int> sub;
-            for (int id : ready) { const int ix = id / nnz, iz = id - ix * nnz; if (mode == 0 || ((ix + iz) & 1) == pass) sub.push_back(id); }
+            for (int id : ready) { int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0); if (mode == 0 || ((ix0 + iz0) & 1) == pass) sub.push_back(id); }
             nT.resize(sub.size()); nK.resize(sub.size());
             for (size_t k = 0; k < sub.size(); ++k) {
-                const int id = sub[k]; const int ix = id / nnz + 1, iz = id % nnz + 1;
-                const Hood h = load_hood(f, iz, ix); const NodeGeom g = { ri, risti[ix - 1], dnx, dnz };
-                nT[k] = solve_node(h, slow[id], g, &nK[k]); ++evals;
+                int iz0, ix0; rec_coords(nbz, sub[k], &iz0, &ix0);
+                const Hood h = load_hood(f, iz0 + 1, ix0 + 1); const NodeGeom g = { ri, risti[ix0], dnx, dnz };
+                nT[k] = solve_node(h, slow[sub[k]], g, &nK[k]); ++evals;
             }
             for (size_t k = 0; k < sub.size(); ++k) {
                 const int id = sub[k];
-                if (std::memcmp(&nT[k], &T[id], 4) || std::memcmp(&nK[k], &tau[id], 4)) {
-                    T[id] = nT[k]; tau[id] = nK[k];
+                if (std::memcmp(&nT[k], &F[id].T, 4) || std::memcmp(&nK[k], &F[id].tau, 4)) {
+                    F[id].T = nT[k]; F[id].tau = nK[k];
                     { unsigned a, b; std::memcpy(&a, &nT[k], 4); std::memcpy(&b, &nK[k], 4); hsh += ((unsigned)id * 2654435761u) ^ (a * 40503u) ^ (b * 2246822519u); }
-                    const int ix = id / nnz, iz = id - ix * nnz;
-                    if (ix > 0) act(id - nnz); if (ix > 1) act(id - 2 * nnz); if (ix + 1 < nnx) act(id + nnz); if (ix + 2 < nnx) act(id + 2 * nnz);
-                    if (iz > 0) act(id - 1); if (iz > 1) act(id - 2); if (iz + 1 < nnz) act(id + 1); if (iz + 2 < nnz) act(id + 2);
+                    int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
+                    act(iz0, ix0 - 1); act(iz0, ix0 + 1); act(iz0 - 1, ix0); act(iz0 + 1, ix0);
+                    // outer dependents only through a reached in-between node (as the kernel does)
+                    if (tv(iz0, ix0 - 1) < kInf) act(iz0, ix0 - 2);
+                    if (tv(iz0, ix0 + 1) < kInf) act(iz0, ix0 + 2);
+                    if (tv(iz0 - 1, ix0) < kInf) act(iz0 - 2, ix0);
+                    if (tv(iz0 + 1, ix0) < kInf) act(iz0 + 2, ix0);
                     tmin = fminf(tmin, nK[k]);
                 }
             }
-        }
-        if (ncyc < 0 && rounds >= max_rounds - 4) {
-            std::printf("round %ld: theta %.7f tmin %.7f ready %zu next %zu\n", rounds, theta, tmin, ready.size(), next.size());
-            for (size_t k = 0; k < ready.size() && k < 12; ++k) { const int id = ready[k]; std::printf("   ready ix=%d iz=%d T=%.7f tau=%.7f\n", id / nnz + 1, id % nnz + 1, T[id], tau[id]); }
         }
         if (tmin > best_tmin) best_tmin = tmin;
         {   // same rule as fim_kernel.hip: freeze only when the set of changes repeats exactly
@@ -280,52 +331,23 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* T, float* tau, const
         cur.swap(next); next.clear(); theta = tmin + window; ++rounds;
         if (rounds >= max_rounds) break;
     }
+    untile(nnx, nnz, F.data(), Tio, tauio);
     out[0] = rounds; out[1] = evals; out[2] = (long)cur.size(); out[3] = freezes;
     for (int k = 0; k < (ncyc < 0 ? -ncyc : ncyc); ++k) cyc_ids[k] = k < (int)cur.size() ? cur[k] : -1;
     return cur.empty() ? 0 : -1;
 }
 
-// set-up helper: coarse problem of one source after the serial stages (T, tau, slow, risti filled)
+// set-up helper: coarse problem of one source after the serial stages, row-major outputs
 extern "C" int hc_coarse_problem(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const double* pv,
                                  float x, float z, float* T, float* tau, float* slow_c, float* risti_c, float* geom /* ri dnx dnz cell */)
 {
-    GridDesc g; make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
-    SourceDesc s; if (make_source(g, x, z, s) != 0) return -1;
-    const size_t nc = (size_t)g.nnx * g.nnz, nr = (size_t)s.rnx * s.rnz;
-    std::vector<float> velv((size_t)nx * ny), cbasis(4 * (gd + 1)), rbasis(4 * (gd * kSgdl + 1));
-    for (int k = 0; k < nx * ny; ++k) velv[k] = (float)pv[k];
-    basis_table(gd, cbasis.data()); basis_table(gd * kSgdl, rbasis.data());
-    std::vector<float> slow_r(nr), T_r(nr, kInf), tau_r(nr, kInf), risti_r(kRefMax), vcorner(4);
-    float hmin = 1e30f;
-    for (int ix = 1; ix <= g.nnx; ++ix) for (int iz = 1; iz <= g.nnz; ++iz) { float sl = 1.0f / coarse_velocity(g, velv.data(), cbasis.data(), iz, ix); slow_c[(size_t)(ix - 1) * g.nnz + (iz - 1)] = sl; if (sl < hmin) hmin = sl; }
-    risti_table(g.gox, g.dnx, g.earth, g.nnx, risti_c);
-    risti_table(s.rgox, s.rdnx, g.earth, s.rnx, risti_r.data());
-    for (int lx = 1; lx <= s.rnx; ++lx) for (int kz = 1; kz <= s.rnz; ++kz) {
-        const float v = refined_velocity(g, s, velv.data(), rbasis.data(), kz, lx);
-        slow_r[(size_t)(lx - 1) * s.rnz + (kz - 1)] = 1.0f / v;
-        if ((lx == s.isx_r || lx == s.isx_r + 1) && (kz == s.isz_r || kz == s.isz_r + 1)) vcorner[(lx - s.isx_r) * 2 + (kz - s.isz_r)] = v; }
-    std::vector<int16_t> rst(kRWin * kRWin), cst((size_t)kCWinMax * kCWinMax); std::vector<int8_t> S_r(nr), cinit((size_t)kCWinMax * kCWinMax);
-    std::vector<int32_t> heap(kHeapCap), flags(2, 0);
-    SourceScratch w; w.slow_r = slow_r.data(); w.T_r = T_r.data(); w.tau_r = tau_r.data(); w.S_r = S_r.data(); w.risti_r = risti_r.data();
-    w.vcorner = vcorner.data(); w.rst = rst.data(); w.cst = cst.data(); w.cinit = cinit.data(); w.heap = heap.data(); w.flags = flags.data();
-    const int ended = refined_startup(g, s, w); refined_encode(s, w, ended);
-    if (!ended) { Field fr = { s.rnx, s.rnz, T_r.data(), tau_r.data(), slow_r.data(), risti_r.data(), g.earth, s.rdnx, s.rdnz }; fixed_point(fr); }
-    uint64_t rstar = ~0ull; int ez = 0, ex = 0;
-    if (!ended) for (int ix = 1; ix <= s.rnx; ++ix) for (int iz = 1; iz <= s.rnz; ++iz) if (is_open_edge(s, iz, ix)) {
-        const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1); if (!(t_value(T_r[id]) < kInf)) continue;
-        const uint64_t r = accept_rank(T_r[id], tau_r[id]); if (r < rstar) { rstar = r; ez = iz; ex = ix; } }
-    std::vector<float> Tfin(nr);
-    for (int ix = 1; ix <= s.rnx; ++ix) for (int iz = 1; iz <= s.rnz; ++iz) { const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1); S_r[id] = (int8_t)handoff_node(g, s, w, ended, rstar, ez, ex, iz, ix, &Tfin[id]); }
-    for (size_t k = 0; k < nc; ++k) { T[k] = kInf; tau[k] = kInf; }
-    for (int q = 0; q < s.cwnx * s.cwnz; ++q) cst[q] = -1;
-    auto cs = [&](int iz, int ix) -> int16_t& { return cst[(size_t)(ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0)]; };
-    for (int k = 1; k <= s.rnz; k += kSgdl) for (int l = 1; l <= s.rnx; l += kSgdl) { const int cz = s.vnt + (k - 1) / kSgdl, cx = s.vnl + (l - 1) / kSgdl;
-        const size_t id = (size_t)(l - 1) * s.rnz + (k - 1); cs(cz, cx) = S_r[id]; if (S_r[id] >= 0) T[(size_t)(cx - 1) * g.nnz + (cz - 1)] = Tfin[id]; }
-    auto far = [&](int iz, int ix) { if (ix < 1 || ix > g.nnx || iz < 1 || iz > g.nnz) return false;
-        if (!(iz > s.cwz0 && iz <= s.cwz0 + s.cwnz && ix > s.cwx0 && ix <= s.cwx0 + s.cwnx)) return true; return cs(iz, ix) == -1; };
-    for (int ix = s.vnl; ix <= s.vnr; ++ix) for (int iz = s.vnt; iz <= s.vnb; ++iz)
-        if (cs(iz, ix) == 0 && (far(iz - 1, ix) || far(iz + 1, ix) || far(iz, ix - 1) || far(iz, ix + 1))) cs(iz, ix) = 1;
-    coarse_band_march(g, s, w, T, tau, slow_c, risti_c);
-    geom[0] = g.earth; geom[1] = g.dnx; geom[2] = g.dnz; geom[3] = min_cell_km(g) * hmin;
+    Prepared P;
+    if (prepare(nx, ny, goxd, gozd, dvxd, dvzd, gd, pv, x, z, P, nullptr, nullptr) != 0) return -1;
+    const GridDesc& g = P.g;
+    untile(g.nnx, g.nnz, P.F_c.data(), T, tau);
+    for (int ix = 0; ix < g.nnx; ++ix)
+        for (int iz = 0; iz < g.nnz; ++iz) slow_c[(size_t)ix * g.nnz + iz] = P.slow_c[rec_index(g.nbz, iz, ix)];
+    std::memcpy(risti_c, P.risti_c.data(), 4 * (size_t)g.nnx);
+    geom[0] = g.earth; geom[1] = g.dnx; geom[2] = g.dnz; geom[3] = min_cell_km(g) * P.hmin;
     return 0;
 }
