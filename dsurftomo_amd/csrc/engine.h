@@ -55,7 +55,9 @@ struct Engine {
     DevBuf<int32_t> err;
     DevBuf<float> slow_r, Tfin_r, risti_r, vcorner;
     DevBuf<Rec> F_r, F_c;
-    DevBuf<int> seed_r, nseed_r, seed_c, nseed_c;
+    DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists;
+    size_t lists_stride = 0;
+    int fim_threads = 256;
     DevBuf<int8_t> S_r, cinit;
     DevBuf<int16_t> rst, cst;
     DevBuf<int32_t> heap, flags, info;

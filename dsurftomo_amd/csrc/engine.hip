@@ -56,7 +56,7 @@ Engine::~Engine()
     rel(src); rel(rays); rel(out); rel(err);
     rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
     rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(F_c); rel(seed_c); rel(nseed_c);
-    rel(prob_r); rel(prob_c); rel(info); rel(clocks);
+    rel(prob_r); rel(prob_c); rel(info); rel(clocks); rel(lists);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -155,14 +155,15 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
     size_t budget = mem_budget ? mem_budget : (size_t)(0.6 * (double)free_b);
     const size_t rr = (size_t)kRefMax * kRefMax;
-    per_unit_bytes = nrec_c * 8 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
+    per_unit_bytes = nrec_c * 8 + (size_t)(40 * (g.nnx + g.nnz) + 10240) * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
                      (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(SourceDesc);
     size_t c = budget / per_unit_bytes;
     if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B)", budget, per_unit_bytes); return DSA_ERR_DEVICE; }
     chunk = (int)std::min<size_t>(c, (size_t)std::max(nunits, 1));
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
     const size_t C = (size_t)chunk;
-    if (ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(nr, 1)) || ensure(err, 4) ||
+    { const FimLaunch lc = launch_shape(g.nnx, g.nnz); lists_stride = (size_t)2 * lc.list_cap + lc.ready_cap; }
+    if (ensure(lists, C * lists_stride) || ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(nr, 1)) || ensure(err, 4) ||
         ensure(slow_r, C * kRefRecs) || ensure(F_r, C * kRefRecs) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
@@ -181,6 +182,7 @@ BatchPtrs Engine::batch() const
     b.src = src.p; b.slow_r = slow_r.p; b.F_r = F_r.p; b.Tfin_r = Tfin_r.p; b.S_r = S_r.p; b.risti_r = risti_r.p;
     b.vcorner = vcorner.p; b.seed_r = seed_r.p; b.nseed_r = nseed_r.p; b.rst = rst.p; b.cst = cst.p; b.cinit = cinit.p;
     b.heap = heap.p; b.flags = flags.p; b.F_c = F_c.p; b.seed_c = seed_c.p; b.nseed_c = nseed_c.p;
+    b.lists = lists.p; b.lists_stride = lists_stride;
     return b;
 }
 
@@ -233,7 +235,10 @@ int Engine::solve(float* dsurf)
         std::vector<unsigned long long> h_clk((size_t)n * 8);
         HIP_TRY(this, hipMemcpyAsync(h_clk.data(), clocks.p, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipStreamSynchronize(stream));
-        for (int u = 0; u < n; ++u) for (int q = 0; q < 6; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * 8 + q];
+        for (int u = 0; u < n; ++u) {
+            for (int q = 0; q < 6; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * 8 + q];
+            phase_ticks[6] = std::max(phase_ticks[6], (double)h_clk[(size_t)u * 8 + 6]);
+        }
         float ms = 0;
         HIP_TRY(this, hipEventElapsedTime(&ms, events[2], events[3])); stats[DSA_STAT_MS_FIM_REFINED] += ms;
         HIP_TRY(this, hipEventElapsedTime(&ms, events[4], events[5])); stats[DSA_STAT_MS_FIM_COARSE] += ms;
@@ -272,14 +277,11 @@ int Engine::solve(float* dsurf)
 
 FimLaunch Engine::launch_shape(int nnx, int nnz) const
 {
-    // the active band is a few node layers along the front's perimeter; everything lives in LDS
+    // the active band is a few node layers along the front's perimeter (peak ~13 k nodes at 1025^2)
     FimLaunch l;
-    size_t cap = list_cap > 0 ? (size_t)list_cap : (size_t)6 * (size_t)(nnx + nnz) + 1024;
-    size_t rcap = ready_cap > 0 ? (size_t)ready_cap : (size_t)2 * (size_t)(nnx + nnz) + 1024;
-    const size_t limit = (150 * 1024) / 4;                  // ints of LDS left for lists
-    if (2 * cap + rcap > limit) { cap = limit * 3 / 8; rcap = limit / 4; }
-    l.list_cap = (int)cap;
-    l.ready_cap = (int)rcap;
+    l.list_cap = list_cap > 0 ? list_cap : 16 * (nnx + nnz) + 4096;
+    l.ready_cap = ready_cap > 0 ? ready_cap : 8 * (nnx + nnz) + 2048;
+    l.threads = fim_threads;
     return l;
 }
 
@@ -373,6 +375,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "max_chunk" && value >= 0) { en->max_chunk = (int)value; return 0; }
     if (n == "list_cap" && value >= 0) { en->list_cap = (int)value; return 0; }
     if (n == "ready_cap" && value >= 0) { en->ready_cap = (int)value; return 0; }
+    if (n == "fim_threads" && (value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;
 }
@@ -446,7 +449,7 @@ int dsa_get_stats(const dsa_engine* e, double* out)
     std::memcpy(out, reinterpret_cast<const Engine*>(e)->stats, sizeof(double) * DSA_STAT_COUNT);
     // phase clocks of the coarse solve, summed over units (100 MHz wall clock ticks): pass A, even half,
     // odd half, round end; then the summed list lengths and ready counts
-    for (int q = 0; q < 6; ++q) out[DSA_STAT_COUNT + q] = reinterpret_cast<const Engine*>(e)->phase_ticks[q];
+    for (int q = 0; q < 7; ++q) out[DSA_STAT_COUNT + q] = reinterpret_cast<const Engine*>(e)->phase_ticks[q];
     return 0;
 }
 

@@ -18,6 +18,7 @@ struct FimProblem {
     const float* risti;
     const int* seed;
     const int* seed_count;
+    int* lists;            // scratch for the active lists: 2 * list_cap + ready_cap ints
     int nnx, nnz, nbx, nbz;
     float ri, dnx, dnz;
     float window;          // causal window (seconds of travel time) evaluated per round
@@ -27,8 +28,9 @@ struct FimProblem {
 };
 
 struct FimLaunch {
-    int list_cap;          // entries per active list (LDS)
-    int ready_cap;         // entries of the dense ready list (LDS)
+    int list_cap;          // entries per active list
+    int ready_cap;         // entries of the dense ready list
+    int threads;           // workgroup size: 256, 512 or 1024
 };
 
 size_t fim_lds_bytes(const FimLaunch& l);
@@ -55,6 +57,7 @@ struct BatchPtrs {
     // coarse, per source
     Rec* F_c;                    // stride nbx*nbz*64 (tiled records)
     int* seed_c; int* nseed_c;   // stride kSeedC / 1
+    int* lists; size_t lists_stride;   // active-list scratch, shared by the refined and the coarse solve
 };
 constexpr int kSeedR = kRWin * kRWin;              // the start-up march cannot pin more than its window
 constexpr int kSeedC = kCWinMax * kCWinMax;

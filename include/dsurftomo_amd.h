@@ -50,7 +50,8 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 
 /* tuning knobs: "window_cells" (causal window of the fixed-point solve, in cell travel times,
  * default 3), "max_chunk" (cap on sources resident per chunk, 0 = memory budget only),
- * "list_cap" / "ready_cap" (LDS list sizes of the solve kernel, 0 = derived from the grid) */
+ * "list_cap" / "ready_cap" (active-list sizes of the solve kernel, 0 = derived from the grid),
+ * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024) */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
 
 /* ---- engine level --------------------------------------------------------------------------- */

@@ -257,6 +257,7 @@ int hc_solve_source(int nx, int ny, float goxd, float gozd, float dvxd, float dv
 // rule; the ready set is evaluated from the old states), used to study convergence on the CPU.
 // Interface arrays are row-major (nnz fastest); storage inside is tiled like on the device.
 // mode 0: all ready nodes at once; mode 1: two sub-passes by node parity (even first).
+extern "C" { int g_prune = 1; }
 extern "C" long hc_device_schedule(int nnx, int nnz, float* Tio, float* tauio, const float* slow_rm, const float* risti,
                                    float ri, float dnx, float dnz, float window, int mode, int max_rounds,
                                    long* out /* rounds, evals, last list size, freezes */, int* cyc_ids, int ncyc)
@@ -309,15 +310,22 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* Tio, float* tauio, c
             for (size_t k = 0; k < sub.size(); ++k) {
                 const int id = sub[k];
                 if (std::memcmp(&nT[k], &F[id].T, 4) || std::memcmp(&nK[k], &F[id].tau, 4)) {
+                    const float t_lo = fminf(t_value(F[id].T), nT[k]), k_lo = fminf(tau_value(F[id].tau), nK[k]);
                     F[id].T = nT[k]; F[id].tau = nK[k];
                     { unsigned a, b; std::memcpy(&a, &nT[k], 4); std::memcpy(&b, &nK[k], 4); hsh += ((unsigned)id * 2654435761u) ^ (a * 40503u) ^ (b * 2246822519u); }
                     int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
-                    act(iz0, ix0 - 1); act(iz0, ix0 + 1); act(iz0 - 1, ix0); act(iz0 + 1, ix0);
-                    // outer dependents only through a reached in-between node (as the kernel does)
-                    if (tv(iz0, ix0 - 1) < kInf) act(iz0, ix0 - 2);
-                    if (tv(iz0, ix0 + 1) < kInf) act(iz0, ix0 + 2);
-                    if (tv(iz0 - 1, ix0) < kInf) act(iz0 - 2, ix0);
-                    if (tv(iz0 + 1, ix0) < kInf) act(iz0 + 2, ix0);
+                    // dependents that can be affected (same tests as fim_kernel.hip, see there)
+                    const int dz[4] = { 0, 0, -1, 1 }, dx[4] = { -1, 1, 0, 0 };
+                    for (int q = 0; q < 4; ++q) {
+                        const int yz = iz0 + dz[q], yx = ix0 + dx[q], zz = iz0 + 2 * dz[q], zx = ix0 + 2 * dx[q];
+                        if (yx < 0 || yx >= nnx || yz < 0 || yz >= nnz) continue;
+                        const Rec y = F[rec_index(nbz, yz, yx)];
+                        if (!g_prune || k_lo <= tau_value(y.tau)) act(yz, yx);
+                        if (zx < 0 || zx >= nnx || zz < 0 || zz >= nnz) continue;
+                        if (!(tau_value(y.tau) < kInf)) continue;          // through a reached in-between node only
+                        const Rec zr = F[rec_index(nbz, zz, zx)];
+                        if (!g_prune || (t_value(y.T) > t_lo && k_lo < tau_value(zr.tau))) act(zz, zx);
+                    }
                     tmin = fminf(tmin, nK[k]);
                 }
             }

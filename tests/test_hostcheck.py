@@ -115,3 +115,27 @@ def test_device_schedule_converges_and_is_schedule_independent(H):
         fields.append(np.abs(T))
     for f in fields[1:]:
         assert (bits(f) != bits(fields[0])).sum() == 0
+
+
+def test_dependency_pruning_is_exact(H):
+    """activating only the dependents that can be affected gives the same (T, tau), with far fewer evaluations"""
+    nx = 35
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    N = g.nnx
+    sx, sz = synth.sources(nx, 8)
+    for kind, src in (("rough", 1), ("checker4", 5), ("homog", 2)):
+        pv = synth.medium(nx, kind)
+        res = []
+        for prune in (0, 1):
+            C.c_int.in_dll(H, "g_prune").value = prune
+            T = np.zeros((N, N), np.float32); tau = np.zeros((N, N), np.float32); slow = np.zeros((N, N), np.float32)
+            ris = np.zeros(N, np.float32); geom = np.zeros(4, np.float32)
+            assert H.hc_coarse_problem(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8, L.ptr(pv), sx[src], sz[src], L.ptr(T),
+                                       L.ptr(tau), L.ptr(slow), L.ptr(ris), L.ptr(geom)) == 0
+            out = np.zeros(4, np.int64); cyc = np.zeros(4, np.int32)
+            assert H.hc_device_schedule(N, N, L.ptr(T), L.ptr(tau), L.ptr(slow), L.ptr(ris), geom[0], geom[1], geom[2],
+                                        np.float32(3.0 * geom[3]), 1, 20000, L.ptr(out), L.ptr(cyc), 4) == 0
+            res.append((np.abs(T), np.abs(tau), out[1] / (N * N)))
+        C.c_int.in_dll(H, "g_prune").value = 1
+        assert (bits(res[0][0]) != bits(res[1][0])).sum() == 0 and (bits(res[0][1]) != bits(res[1][1])).sum() == 0
+        assert res[1][2] < 0.6 * res[0][2]

@@ -8,6 +8,7 @@ nx = int(sys.argv[1]) if len(sys.argv) > 1 else 131
 nsrc = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 windows = [float(w) for w in sys.argv[3].split(',')] if len(sys.argv) > 3 else [2, 4, 8, 16, 32]
 kind = sys.argv[4] if len(sys.argv) > 4 else 'smooth'
+threads = [int(t) for t in sys.argv[5].split(',')] if len(sys.argv) > 5 else [512]
 e = Engine(0)
 nper = 2
 pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)])
@@ -15,15 +16,15 @@ e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
 nb = ((e.nnx + 7) // 8) ** 2
 u = synth.units(nx, nsrc, nper, 32)
 ref = None
-for wc in windows:
-    e.set_option('window_cells', wc)
+for wc, nt in [(w, t) for t in threads for w in windows]:
+    e.set_option('window_cells', wc); e.set_option('fim_threads', nt)
     e.plan(**u)
     t0 = time.time(); t = e.solve(); dt = time.time() - t0
     st = e.stats(); n = nsrc * nper
     same = 'first' if ref is None else f'identical={np.array_equal(ref.view(np.uint32), t.view(np.uint32))} maxdiff={np.abs(ref - t).max():.2g}'
     if ref is None: ref = t
-    print(f'N={e.nnx} {kind} units {n:5d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
+    print(f'N={e.nnx} {kind} units {n:5d} wg {nt:4d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
           f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} freezes {st["freezes"]:.0f} | {same}', flush=True)
     pt = np.array(st["phase_ticks"]); tot = pt[:4].sum()
     if tot > 0:
-        print(f'      phase share: passA {pt[0]/tot:.2f} evalEven {pt[1]/tot:.2f} evalOdd {pt[2]/tot:.2f} roundEnd {pt[3]/tot:.2f} | us/unit {tot/n/100:.0f} | avg list {pt[4]/n/max(st["rounds_max"],1):.0f} avg ready/round {pt[5]/n/max(st["rounds_max"],1):.0f}', flush=True)
+        print(f'      phase share: passA {pt[0]/tot:.2f} evalEven {pt[1]/tot:.2f} evalOdd {pt[2]/tot:.2f} roundEnd {pt[3]/tot:.2f} | us/unit {tot/n/100:.0f} | avg list {pt[4]/n/max(st["rounds_max"],1):.0f} avg ready/round {pt[5]/n/max(st["rounds_max"],1):.0f} max list {pt[6]:.0f}', flush=True)
