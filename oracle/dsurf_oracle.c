@@ -1,9 +1,9 @@
 /* TEST INFRASTRUCTURE ONLY -- see dsurf_oracle.h.
  *
  * Eikonal / ray / Frechet side of the CalSurfG hot path, restated in C with the reference's
- * fp32 operation order (compile with -ffp-contract=off, SSE math).  Integer powers follow the
- * binary-exponentiation order the reference's compiler emits (x**3 = x*(x*x), x**4 = (x*x)*(x*x),
- * x**5 = x*((x*x)*(x*x))); this is part of what tests/test_oracle_vs_ref.py pins bitwise.
+ * fp32 operation order (compile with -ffp-contract=off, SSE math).  Integer powers follow what the
+ * reference's compiler emits (positive powers are left-to-right chains, x**3 = (x*x)*x); this is
+ * part of what tests/test_oracle_vs_ref.py pins bitwise.
  */
 #include "dsurf_oracle.h"
 
@@ -843,5 +843,187 @@ int dso_traveltimes(int nx, int ny, float goxd, float gozd, float dvxd, float dv
         free(ttn);
     }
     free(veln); free(uk); free(us); free(first);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* whole boundary: CalSurfG (CalSurfG.f90:939-1459) and synthetic (:2412-2865)                  */
+
+static inline float r2(float x) { return x * x; }
+static inline float r3(float x) { return (x * x) * x; }
+static inline float r4(float x) { return ((x * x) * x) * x; }
+
+/* Frechet row of one ray from its vertex kernel fdm; CalSurfG.f90:1383-1432.
+ * sen_*: (nx*ny, kmax, nz) doubles; slot: 0-based period slot. Appends to rw/iw/col. */
+static void assemble_row(int nx, int ny, int nz, const float *vels, const float *depz, const float *fdm,
+                         const double *sen_vs, const double *sen_vp, const double *sen_rho, int kmax, int slot,
+                         float *row, int rownum, float *rw, int *iw, int *col, int *nar)
+{
+    const int nvx = nx - 2, nvz = ny - 2, nparpi = nvx * nvz * (nz - 1);
+    const size_t ncol = (size_t)nx * ny;
+    const float ftol = 1e-4f;
+    const int shallow = depz[nz - 2] < 35.0f;
+    for (int n = 0; n < nparpi; ++n) row[n] = 0.0f;
+    for (int jj = 1; jj <= nvz; ++jj)
+        for (int kk = 1; kk <= nvx; ++kk) {
+            const float f = fdm[(size_t)kk * (nvz + 2) + jj];
+            if (!(fabsf(f) >= ftol)) continue;
+            const size_t c = (size_t)jj * nx + kk;            /* 0-based column of vertex (kk+1, jj+1) */
+            for (int k = 1; k <= nz - 1; ++k) {
+                const float v = vels[(size_t)(k - 1) * ncol + c];
+                float coe_a, vpft;
+                if (shallow) {
+                    coe_a = 2.0947f - (0.8206f * 2.0f) * v + (0.2683f * 3.0f) * r2(v) - (0.0251f * 4.0f) * r3(v);
+                    vpft = 0.9409f + 2.0947f * v - 0.8206f * r2(v) + 0.2683f * r3(v) - 0.0251f * r4(v);
+                } else {
+                    coe_a = 2.2110f - (0.8984f * 2.0f) * v + (0.2786f * 3.0f) * r2(v) - (0.02412f * 4.0f) * r3(v);
+                    vpft = 0.9098f + 2.2110f * v - 0.8984f * r2(v) + 0.2786f * r3(v) - 0.02412f * r4(v);
+                }
+                const float coe_rho = coe_a * (1.6612f - (0.4721f * 2.0f) * vpft + (0.0671f * 3.0f) * r2(vpft) -
+                                               (0.0043f * 4.0f) * r3(vpft) + (0.000106f * 5.0f) * r4(vpft));
+                const size_t si = ((size_t)(k - 1) * kmax + slot) * ncol + c;
+                const double val = (sen_vp[si] * (double)coe_a + sen_rho[si] * (double)coe_rho + sen_vs[si]) * (double)f;
+                row[(size_t)(k - 1) * nvx * nvz + (size_t)(jj - 1) * nvx + (kk - 1)] = (float)val;
+            }
+        }
+    for (int n = 1; n <= nparpi; ++n)
+        if (fabsf(row[n - 1]) > ftol) {
+            *nar += 1;
+            rw[*nar - 1] = row[n - 1];
+            iw[*nar] = rownum;          /* iw(nar+1) */
+            col[*nar - 1] = n;
+        }
+}
+
+int dso_calsurfg(const int *pnx, const int *pny, const int *pnz, const int *pnparpi, const float *vels,
+                 int *iw, float *rw, int *col, float *dsurf,
+                 const float *goxdf, const float *gozdf, const float *dvxdf, const float *dvzdf,
+                 const int *pkmaxRc, const int *pkmaxRg, const int *pkmaxLc, const int *pkmaxLg,
+                 const double *tRc, const double *tRg, const double *tLc, const double *tLg,
+                 const int *wavetype, const int *igrt, const int *periods, const float *depz,
+                 const float *pminthk, const float *scxf, const float *sczf, const float *rcxf,
+                 const float *rczf, const int *nrc1, const int *nsrcsurf1, const int *pkmax,
+                 const int *pnsrcsurf, const int *pnrcf, int *nar)
+{
+    const int nx = *pnx, ny = *pny, nz = *pnz, kmax = *pkmax, nsrcsurf = *pnsrcsurf, nrcf = *pnrcf;
+    const int kmaxRc = *pkmaxRc, kmaxRg = *pkmaxRg, kmaxLc = *pkmaxLc, kmaxLg = *pkmaxLg;
+    const float minthk = *pminthk;
+    const size_t ncol = (size_t)nx * ny;
+    (void)pnparpi;
+    dso_grid g;
+    dso_grid_init(&g, nx, ny, *goxdf, *gozdf, *dvxdf, *dvzdf, 8);
+    const size_t nc = (size_t)g.nnx * g.nnz;
+    const int kmx = kmax > 0 ? kmax : 1;
+    double *pvRc = calloc(ncol * kmx, 8), *pvRg = calloc(ncol * (kmaxRg > 0 ? kmaxRg : 1), 8);
+    double *pvLc = calloc(ncol * kmx, 8), *pvLg = calloc(ncol * (kmaxLg > 0 ? kmaxLg : 1), 8);
+    /* combined sensitivity arrays sen_*(nx*ny, kmax, nz), filled per type at their slot offsets */
+    double *sen_vs = calloc(ncol * kmx * nz, 8), *sen_vp = calloc(ncol * kmx * nz, 8), *sen_rho = calloc(ncol * kmx * nz, 8);
+    const int kmax1 = kmaxRc, kmax2 = kmaxRc + kmaxRg, kmax3 = kmaxRc + kmaxRg + kmaxLc;
+    struct { int n, off, iwave, igr; const double *t; double *pv; } ty[4] = {
+        { kmaxRc, 0, 2, 0, tRc, pvRc }, { kmaxRg, kmax1, 2, 1, tRg, pvRg }, { kmaxLc, kmax2, 1, 0, tLc, pvLc }, { kmaxLg, kmax3, 1, 1, tLg, pvLg } };
+    for (int q = 0; q < 4; ++q) {
+        if (ty[q].n <= 0) continue;
+        if (ty[q].igr == 1)   /* phase velocities at the group periods overwrite the head of pvRc / pvLc (:1110, :1128) */
+            dso_caldespersion(nx, ny, nz, vels, q == 1 ? pvRc : pvLc, ty[q].iwave, 0, ty[q].n, ty[q].t, depz, minthk);
+        double *svs = malloc(ncol * ty[q].n * nz * 8), *svp = malloc(ncol * ty[q].n * nz * 8), *srh = malloc(ncol * ty[q].n * nz * 8);
+        dso_depthkernel(nx, ny, nz, vels, ty[q].pv, svs, svp, srh, ty[q].iwave, ty[q].igr, ty[q].n, ty[q].t, depz, minthk);
+        for (int k = 0; k < nz; ++k)
+            for (int p = 0; p < ty[q].n; ++p) {
+                const size_t src = ((size_t)k * ty[q].n + p) * ncol, dst = ((size_t)k * kmax + ty[q].off + p) * ncol;
+                memcpy(sen_vs + dst, svs + src, ncol * 8); memcpy(sen_vp + dst, svp + src, ncol * 8); memcpy(sen_rho + dst, srh + src, ncol * 8);
+            }
+        free(svs); free(svp); free(srh);
+    }
+    *nar = 0;
+    int count1 = 0, rc = 0, rbint = 0;
+    float *veln = malloc(4 * nc), *ttn = malloc(4 * nc), *ttnr = malloc(4 * 129 * 129), *fdm = malloc(4 * ncol);
+    int *nstsr = malloc(4 * 129 * 129);
+    float *row = malloc(4 * (size_t)(nx - 2) * (ny - 2) * (nz > 1 ? nz - 1 : 1));
+    for (int knumi = 1; knumi <= kmax && rc == 0; ++knumi)
+        for (int srcnum = 1; srcnum <= nsrcsurf1[knumi - 1] && rc == 0; ++srcnum) {
+            const size_t sk = (size_t)(knumi - 1) * nsrcsurf + (srcnum - 1);
+            const int wt = wavetype[sk], gr = igrt[sk], per = periods[sk];
+            const double *velf = NULL;
+            if (wt == 2 && gr == 0) velf = pvRc + ncol * (size_t)(per - 1);
+            if (wt == 2 && gr == 1) velf = pvRg + ncol * (size_t)(per - 1);
+            if (wt == 1 && gr == 0) velf = pvLc + ncol * (size_t)(per - 1);
+            if (wt == 1 && gr == 1) velf = pvLg + ncol * (size_t)(per - 1);
+            if (!velf) { rc = -4; break; }
+            const int igroup = gr == 1 ? 2 : 1;
+            int count11 = count1;
+            const float x = scxf[sk], z = sczf[sk];
+            for (int ig = 1; ig <= igroup && rc == 0; ++ig) {
+                if (ig == 2 && wt == 2) velf = pvRc + ncol * (size_t)(per - 1);
+                if (ig == 2 && wt == 1) velf = pvLc + ncol * (size_t)(per - 1);
+                dso_gridder(&g, velf, veln);
+                dso_box b;
+                if (dso_solve_source(&g, velf, veln, x, z, &b, ttn, ttnr, nstsr, NULL, NULL) != 0) { rc = -3; break; }
+                for (int istep = 1; istep <= nrc1[sk]; ++istep) {
+                    const size_t ri = sk * (size_t)nrcf + (size_t)(istep - 1);
+                    if (ig == 1) {
+                        float t;
+                        if (dso_srtimes(&g, veln, ttn, x, z, rcxf[ri], rczf[ri], &t) != 0) { rc = -3; break; }
+                        count1 += 1;
+                        dsurf[count1 - 1] = t;
+                    }
+                    if (gr == 0 || (ig == 2 && gr == 1)) {
+                        count11 += 1;
+                        if (dso_rpaths(&g, &b, veln, ttn, ttnr, nstsr, x, z, rcxf[ri], rczf[ri], fdm, &rbint, NULL) != 0) { rc = -3; break; }
+                        assemble_row(nx, ny, nz, vels, depz, fdm, sen_vs, sen_vp, sen_rho, kmax, knumi - 1, row, count11, rw, iw, col, nar);
+                    }
+                }
+            }
+        }
+    free(pvRc); free(pvRg); free(pvLc); free(pvLg); free(sen_vs); free(sen_vp); free(sen_rho);
+    free(veln); free(ttn); free(ttnr); free(fdm); free(nstsr); free(row);
+    return rc;
+}
+
+int dso_synthetic(const int *pnx, const int *pny, const int *pnz, const int *pnparpi, const float *vels,
+                  float *obst,
+                  const float *goxdf, const float *gozdf, const float *dvxdf, const float *dvzdf,
+                  const int *pkmaxRc, const int *pkmaxRg, const int *pkmaxLc, const int *pkmaxLg,
+                  const double *tRc, const double *tRg, const double *tLc, const double *tLg,
+                  const int *wavetype, const int *igrt, const int *periods, const float *depz,
+                  const float *pminthk, const float *scxf, const float *sczf, const float *rcxf,
+                  const float *rczf, const int *nrc1, const int *nsrcsurf1, const int *pkmax,
+                  const int *pnsrcsurf, const int *pnrcf, const float *noiselevel)
+{
+    /* noise: obst = t + t*gaussian()*noiselevel with an unseeded generator in the reference (:2840);
+     * the oracle supports noiselevel == 0 only (deterministic part) */
+    const int nx = *pnx, ny = *pny, nz = *pnz, kmax = *pkmax, nsrcsurf = *pnsrcsurf, nrcf = *pnrcf;
+    const size_t ncol = (size_t)nx * ny;
+    (void)pnparpi; (void)noiselevel;
+    dso_grid g;
+    dso_grid_init(&g, nx, ny, *goxdf, *gozdf, *dvxdf, *dvzdf, 5);
+    const size_t nc = (size_t)g.nnx * g.nnz;
+    const int n4[4] = { *pkmaxRc, *pkmaxRg, *pkmaxLc, *pkmaxLg };
+    const int iw4[4] = { 2, 2, 1, 1 }, ig4[4] = { 0, 1, 0, 1 };
+    const double *t4[4] = { tRc, tRg, tLc, tLg };
+    double *pv4[4];
+    for (int q = 0; q < 4; ++q) {
+        pv4[q] = calloc(ncol * (n4[q] > 0 ? n4[q] : 1), 8);
+        if (n4[q] > 0) dso_caldespersion(nx, ny, nz, vels, pv4[q], iw4[q], ig4[q], n4[q], t4[q], depz, *pminthk);
+    }
+    float *veln = malloc(4 * nc), *ttn = malloc(4 * nc);
+    int count1 = 0, rc = 0;
+    for (int knumi = 1; knumi <= kmax && rc == 0; ++knumi)
+        for (int srcnum = 1; srcnum <= nsrcsurf1[knumi - 1] && rc == 0; ++srcnum) {
+            const size_t sk = (size_t)(knumi - 1) * nsrcsurf + (srcnum - 1);
+            const int wt = wavetype[sk], gr = igrt[sk], per = periods[sk];
+            const int q = (wt == 2 ? 0 : 2) + (gr == 1 ? 1 : 0);
+            const double *velf = pv4[q] + ncol * (size_t)(per - 1);
+            dso_gridder(&g, velf, veln);
+            dso_box b;
+            if (dso_solve_source(&g, velf, veln, scxf[sk], sczf[sk], &b, ttn, NULL, NULL, NULL, NULL) != 0) { rc = -3; break; }
+            for (int istep = 1; istep <= nrc1[sk]; ++istep) {
+                const size_t ri = sk * (size_t)nrcf + (size_t)(istep - 1);
+                float t;
+                if (dso_srtimes(&g, veln, ttn, scxf[sk], sczf[sk], rcxf[ri], rczf[ri], &t) != 0) { rc = -3; break; }
+                obst[count1++] = t;
+            }
+        }
+    for (int q = 0; q < 4; ++q) free(pv4[q]);
+    free(veln); free(ttn);
     return rc;
 }

@@ -200,3 +200,110 @@ class RefWB:
 
     def close(self):
         self.L.ref_wb_release()
+
+
+def call_boundary(fn, c, synthetic=False, noise=0.0):
+    """Call a CalSurfG-shaped entry point (reference `calsurfg_` / oracle `dso_calsurfg` / product
+    `dsa_calsurfg`: every argument by reference, CalSurfG.f90:939-943) on synth.boundary_case() data."""
+    i32 = lambda v: C.byref(C.c_int(int(v)))
+    f32 = lambda v: C.byref(C.c_float(float(v)))
+    nd, npar = c["ndata"], c["nparpi"]
+    head = [i32(c["nx"]), i32(c["ny"]), i32(c["nz"]), i32(npar), ptr(c["vels"])]
+    tail = [f32(c["goxd"]), f32(c["gozd"]), f32(c["dvxd"]), f32(c["dvzd"]), i32(c["kRc"]), i32(c["kRg"]), i32(c["kLc"]), i32(c["kLg"]),
+            ptr(c["tRc"]), ptr(c["tRg"]), ptr(c["tLc"]), ptr(c["tLg"]), ptr(c["wavetype"]), ptr(c["igrt"]), ptr(c["periods"]),
+            ptr(c["depz"]), f32(c["minthk"]), ptr(c["scxf"]), ptr(c["sczf"]), ptr(c["rcxf"]), ptr(c["rczf"]), ptr(c["nrc1"]),
+            ptr(c["nsrcsurf1"]), i32(c["kmax"]), i32(c["nsrcsurf"]), i32(c["nrcf"])]
+    if synthetic:
+        obst = np.zeros(nd, np.float32)
+        fn(*head, ptr(obst), *tail, f32(noise))
+        return obst
+    cap = nd * npar + 1
+    iw = np.zeros(cap + 1, np.int32)
+    rw = np.zeros(cap, np.float32)
+    col = np.zeros(cap, np.int32)
+    dsurf = np.zeros(nd, np.float32)
+    nar = C.c_int(0)
+    fn(*head, ptr(iw), ptr(rw), ptr(col), ptr(dsurf), *tail, C.byref(nar))
+    n = nar.value
+    return dict(dsurf=dsurf, nar=n, rw=rw[:n].copy(), iw=iw[1:n + 1].copy(), col=col[:n].copy())
+
+
+# ---------------------------------------------------------------------------------------------
+# dispersion side: the same call on the oracle (by value) and the reference (Fortran, by reference)
+
+def _ib(v):
+    return C.byref(C.c_int(int(v)))
+
+
+def brocher(vs):
+    """vp, rho from vs in fp32 the way the reference's column drivers build their layer model
+    (CalSurfG.f90:2340-2346); used to make inputs for surfdisp96 tests"""
+    f = np.float32
+    vs = np.asarray(vs, f)
+    v2 = vs * vs; v3 = v2 * vs; v4 = v3 * vs
+    p = f(0.9409) + f(2.0947) * vs - f(0.8206) * v2 + f(0.2683) * v3 - f(0.0251) * v4
+    p2 = p * p; p3 = p2 * p; p4 = p3 * p; p5 = p4 * p
+    rho = f(1.6612) * p - f(0.4721) * p2 + f(0.0671) * p3 - f(0.0043) * p4 + f(0.000106) * p5
+    return p.astype(f), rho.astype(f)
+
+
+def surfdisp96(which, thk, vpv, vs, rho, iflsph, iwave, mode, igr, t):
+    """phase / group velocities for one layered model; which = 'oracle' | 'ref'"""
+    kmax = len(t)
+    tt = np.zeros(max(kmax, 60), np.float64); tt[:kmax] = t
+    cg = np.zeros(max(kmax, 60), np.float64)
+    a = [np.ascontiguousarray(x, np.float32).copy() for x in (thk, vpv, vs, rho)]
+    if which == "oracle":
+        O = oracle()
+        O.dso_surfdisp96.argtypes = [vp] * 4 + [i32] * 6 + [vp, vp]
+        O.dso_surfdisp96(*[ptr(x) for x in a], len(thk), iflsph, iwave, mode, igr, kmax, ptr(tt), ptr(cg))
+    else:
+        ref().surfdisp96_(*[ptr(x) for x in a], _ib(len(thk)), _ib(iflsph), _ib(iwave), _ib(mode), _ib(igr), _ib(kmax), ptr(tt), ptr(cg))
+    return cg[:kmax].copy()
+
+
+def depthkernel(which, vel, depz, minthk, iwave, igr, t, kernels=True):
+    """vel: (nz, ny, nx) fp32 [= Fortran vel(nx,ny,nz)]. Returns pv (kmax, ny*nx) and, with kernels,
+    sen_vs/vp/rho (nz, kmax, ny*nx) -- caldespersion when kernels is False"""
+    nz, ny, nx = vel.shape
+    kmax = len(t)
+    t = np.ascontiguousarray(t, np.float64)
+    depz = np.ascontiguousarray(depz, np.float32)
+    vel = np.ascontiguousarray(vel, np.float32)
+    pv = np.zeros((kmax, ny * nx))
+    sen = [np.zeros((nz, kmax, ny * nx)) for _ in range(3)] if kernels else []
+    if which == "oracle":
+        O = oracle()
+        O.dso_caldespersion.argtypes = [i32] * 3 + [vp, vp, i32, i32, i32, vp, vp, f32]
+        O.dso_depthkernel.argtypes = [i32] * 3 + [vp] * 5 + [i32, i32, i32, vp, vp, f32]
+        if kernels:
+            O.dso_depthkernel(nx, ny, nz, ptr(vel), ptr(pv), *[ptr(s) for s in sen], iwave, igr, kmax, ptr(t), ptr(depz), minthk)
+        else:
+            O.dso_caldespersion(nx, ny, nz, ptr(vel), ptr(pv), iwave, igr, kmax, ptr(t), ptr(depz), minthk)
+    else:
+        R = ref()
+        mt = C.byref(C.c_float(minthk))
+        if kernels:
+            R.depthkernel_(_ib(nx), _ib(ny), _ib(nz), ptr(vel), ptr(pv), *[ptr(s) for s in sen], _ib(iwave), _ib(igr), _ib(kmax), ptr(t), ptr(depz), mt)
+        else:
+            R.caldespersion_(_ib(nx), _ib(ny), _ib(nz), ptr(vel), ptr(pv), _ib(iwave), _ib(igr), _ib(kmax), ptr(t), ptr(depz), mt)
+    return (pv, *sen) if kernels else pv
+
+
+def layered_models(n, seed=4):
+    """n random layered models (thk, vp, vs, rho, periods) for surfdisp96 tests; some with a mild
+    low-velocity zone"""
+    import synth
+    r = synth.LCG(seed)
+    out = []
+    for trial in range(n):
+        nl = 3 + int(r.uniform(1)[0] * 37)
+        thk = (0.5 + 5.5 * r.uniform(nl)).astype(np.float32); thk[-1] = 0
+        vs = np.sort(1.5 + 3.1 * r.uniform(nl)).astype(np.float32)
+        if trial % 5 == 0:
+            vs[1:3] = vs[1:3][::-1].copy()
+        vpv, rho = brocher(vs)
+        kmax = 3 + int(r.uniform(1)[0] * 27)
+        t = np.sort(0.5 + 39.5 * r.uniform(kmax))
+        out.append((thk, vpv, vs, rho, t))
+    return out

@@ -69,5 +69,29 @@ def main():
         print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def main_dispersion():
+    """b_disp.npz: surfdisp96 on 12 layered models; b_boundary.npz: one whole CalSurfG / synthetic
+    call (the inputs are regenerated from synth.boundary_case(), only the reference's outputs are stored)"""
+    out = {}
+    for m, (thk, vpv, vs, rho, t) in enumerate(L.layered_models(12, seed=21)):
+        out["thk%d" % m], out["vp%d" % m], out["vs%d" % m], out["rho%d" % m], out["t%d" % m] = thk, vpv, vs, rho, t
+        for iwave in (1, 2):
+            for igr in (0, 1):
+                out["c%d_%d%d" % (m, iwave, igr)] = L.surfdisp96("ref", thk, vpv, vs, rho, 1, iwave, 1, igr, t)
+    path = os.path.join(HERE, "b_disp.npz")
+    np.savez_compressed(path, **out)
+    print("b_disp ->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+    c = synth.boundary_case()
+    a = L.call_boundary(L.ref().calsurfg_, c)
+    obst = L.call_boundary(L.ref().synthetic_, c, synthetic=True)
+    vel = np.ascontiguousarray(c["vels"].T)
+    pv, svs, svp, srho = L.depthkernel("ref", vel, c["depz"], float(c["minthk"]), 2, 1, c["tRg"])
+    path = os.path.join(HERE, "b_boundary.npz")
+    np.savez_compressed(path, dsurf=a["dsurf"], nar=np.int32(a["nar"]), rw=a["rw"], iw=a["iw"], col=a["col"], obst=obst,
+                        pvRg=pv, sen_vsRg=svs, sen_vpRg=svp, sen_rhoRg=srho)
+    print("b_boundary ->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
 if __name__ == "__main__":
     main()
+    main_dispersion()

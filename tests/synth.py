@@ -83,3 +83,57 @@ def units(nx, nsrc, nper, nrec, gd=8, seed=SEED):
     rcz = np.tile(sz[idx].reshape(-1), nper)
     nr = np.full(nsrc * nper, nrec, np.int32)
     return dict(map_index=map_index, scx=scx, scz=scz, nrec=nr, rcx=rcx, rcz=rcz)
+
+
+def boundary_case(nx=12, ny=11, nz=5, kRc=3, kRg=2, kLc=2, kLg=1, nsrc=4, nrcf=5, dvd=0.05, seed=SEED, deep=False,
+                  ragged=True):
+    """Arguments of one CalSurfG / synthetic call (CalSurfG.f90:939-943) as a dict of numpy arrays in
+    Fortran memory order. Period slots run Rc, Rg, Lc, Lg like main.f90:215-245."""
+    f = np.float32
+    r = LCG(seed + 101)
+    kmax = kRc + kRg + kLc + kLg
+    depz = (np.array([0.0, 3.0, 7.0, 12.0, 18.0, 26.0, 36.0, 48.0, 62.0])[:nz] * (2.0 if deep else 1.0)).astype(f)
+    i = np.arange(nx, dtype=np.float64)[:, None, None]
+    j = np.arange(ny, dtype=np.float64)[None, :, None]
+    k = np.arange(nz, dtype=np.float64)[None, None, :]
+    vels = (2.6 + 0.28 * k) * (1.0 + 0.06 * np.sin(2.2 * np.pi * i / nx + 0.3 * k) * np.cos(1.7 * np.pi * j / ny))
+    vels = np.asfortranarray(vels.astype(f))                      # vels(nx, ny, nz)
+    tRc = np.array([4.0, 6.0, 9.0, 12.0][:kRc], np.float64)
+    tRg = np.array([5.0, 8.0, 11.0][:kRg], np.float64)
+    tLc = np.array([4.5, 7.0, 10.0][:kLc], np.float64)
+    tLg = np.array([6.0, 9.0][:kLg], np.float64)
+    wavetype = np.zeros((nsrc, kmax), np.int32, order="F")
+    igrt = np.zeros((nsrc, kmax), np.int32, order="F")
+    periods = np.zeros((nsrc, kmax), np.int32, order="F")
+    nrc1 = np.zeros((nsrc, kmax), np.int32, order="F")
+    nsrcsurf1 = np.zeros(kmax, np.int32)
+    scxf = np.zeros((nsrc, kmax), f, order="F")
+    sczf = np.zeros((nsrc, kmax), f, order="F")
+    rcxf = np.zeros((nrcf, nsrc, kmax), f, order="F")
+    rczf = np.zeros((nrcf, nsrc, kmax), f, order="F")
+    goxd, gozd = f(24.0), f(121.0)
+    # stations inside the propagation grid: latitude goxd - [0, nx-3] dvd, longitude gozd + [0, ny-3] dvd
+    slot = 0
+    for wt, gr, n in ((2, 0, kRc), (2, 1, kRg), (1, 0, kLc), (1, 1, kLg)):
+        for p in range(n):
+            ns = nsrc - (slot % 2 if ragged else 0)
+            nsrcsurf1[slot] = ns
+            for s in range(ns):
+                u = r.uniform(2 + 2 * nrcf)
+                lat = lambda q: float(goxd) - (0.3 + q * (nx - 3.6)) * dvd
+                lon = lambda q: float(gozd) + (0.3 + q * (ny - 3.6)) * dvd
+                wavetype[s, slot], igrt[s, slot], periods[s, slot] = wt, gr, p + 1
+                scxf[s, slot] = f((90.0 - lat(u[0])) * np.pi / 180.0)
+                sczf[s, slot] = f(lon(u[1]) * np.pi / 180.0)
+                nr = nrcf - ((s + slot) % 3 if ragged else 0)
+                nrc1[s, slot] = nr
+                for q in range(nr):
+                    rcxf[q, s, slot] = f((90.0 - lat(u[2 + 2 * q])) * np.pi / 180.0)
+                    rczf[q, s, slot] = f(lon(u[3 + 2 * q]) * np.pi / 180.0)
+            slot += 1
+    ndata = int(nrc1.sum())
+    return dict(nx=nx, ny=ny, nz=nz, nparpi=(nx - 2) * (ny - 2) * (nz - 1), vels=vels, goxd=goxd, gozd=gozd,
+                dvxd=f(dvd), dvzd=f(dvd), kRc=kRc, kRg=kRg, kLc=kLc, kLg=kLg, tRc=tRc, tRg=tRg, tLc=tLc, tLg=tLg,
+                wavetype=wavetype, igrt=igrt, periods=periods, depz=depz, minthk=f((depz[1] - depz[0]) / 3.0),
+                scxf=scxf, sczf=sczf, rcxf=rcxf, rczf=rczf, nrc1=nrc1, nsrcsurf1=nsrcsurf1, kmax=kmax,
+                nsrcsurf=nsrc, nrcf=nrcf, ndata=ndata)

@@ -8,7 +8,8 @@ import pytest
 
 import _libs as L
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = sorted(glob.glob(os.path.join(GDIR, "g*.npz")))
 
 
 def bits(a):
@@ -44,3 +45,31 @@ def test_oracle_matches_golden(path):
         for r, (rx, rz) in enumerate(z["rec"][:3]):
             fdm, _, _ = L.o_rpaths(g, o, veln, sx, sz, rx, rz)
             assert (bits(fdm) != bits(z["fdm%d" % k][r])).sum() == 0
+
+
+def bits64(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def test_surfdisp96_golden():
+    z = np.load(os.path.join(GDIR, "b_disp.npz"))
+    for m in range(12):
+        for iwave in (1, 2):
+            for igr in (0, 1):
+                o = L.surfdisp96("oracle", z["thk%d" % m], z["vp%d" % m], z["vs%d" % m], z["rho%d" % m], 1, iwave, 1, igr, z["t%d" % m])
+                assert (bits64(o) != bits64(z["c%d_%d%d" % (m, iwave, igr)])).sum() == 0
+
+
+def test_boundary_golden():
+    """one whole CalSurfG + synthetic call and one depthkernel call against the reference's outputs"""
+    import synth
+    z = np.load(os.path.join(GDIR, "b_boundary.npz"))
+    c = synth.boundary_case()
+    b = L.call_boundary(L.oracle().dso_calsurfg, c)
+    assert b["nar"] == int(z["nar"])
+    assert (bits(b["dsurf"]) != bits(z["dsurf"])).sum() == 0 and (bits(b["rw"]) != bits(z["rw"])).sum() == 0
+    assert (b["iw"] != z["iw"]).sum() == 0 and (b["col"] != z["col"]).sum() == 0
+    assert (bits(L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)) != bits(z["obst"])).sum() == 0
+    vel = np.ascontiguousarray(c["vels"].T)
+    for a, k in zip(L.depthkernel("oracle", vel, c["depz"], float(c["minthk"]), 2, 1, c["tRg"]), ("pvRg", "sen_vsRg", "sen_vpRg", "sen_rhoRg")):
+        assert (bits64(a) != bits64(z[k])).sum() == 0

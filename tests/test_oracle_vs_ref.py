@@ -45,3 +45,51 @@ def test_fields_rays_bitwise(nx, kind, gd):
                 assert (bits(wb.rpaths(sx, sz, rx, rz)) != bits(fo)).sum() == 0
     finally:
         wb.close()
+
+
+def bits64(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def test_surfdisp96_bitwise():
+    """surfdisp96.f:52-350 on 40 random layered models x (Love, Rayleigh) x (phase, group), spherical"""
+    for thk, vpv, vs, rho, t in L.layered_models(40):
+        for iwave in (1, 2):
+            for igr in (0, 1):
+                o = L.surfdisp96("oracle", thk, vpv, vs, rho, 1, iwave, 1, igr, t)
+                r = L.surfdisp96("ref", thk, vpv, vs, rho, 1, iwave, 1, igr, t)
+                assert (bits64(o) != bits64(r)).sum() == 0
+    thk, vpv, vs, rho, t = L.layered_models(1, seed=9)[0]       # flat-earth branch
+    for iwave in (1, 2):
+        assert (bits64(L.surfdisp96("oracle", thk, vpv, vs, rho, 0, iwave, 1, 0, t)) !=
+                bits64(L.surfdisp96("ref", thk, vpv, vs, rho, 0, iwave, 1, 0, t))).sum() == 0
+
+
+@pytest.mark.parametrize("iwave,igr", [(2, 0), (2, 1), (1, 0), (1, 1)])
+def test_depth_kernels_bitwise(iwave, igr):
+    """caldespersion (CalSurfG.f90:2320-2368) and depthkernel (:1461-1597) on a 6x5x7 model"""
+    c = synth.boundary_case(nx=6, ny=5, nz=7)
+    vel = np.ascontiguousarray(c["vels"].T)
+    t = np.array([1.0, 2.0, 4.0, 7.0, 11.0, 16.0])
+    po = L.depthkernel("oracle", vel, c["depz"], 1.0, iwave, igr, t, kernels=False)
+    pr = L.depthkernel("ref", vel, c["depz"], 1.0, iwave, igr, t, kernels=False)
+    assert (bits64(po) != bits64(pr)).sum() == 0
+    for a, b in zip(L.depthkernel("oracle", vel, c["depz"], 1.0, iwave, igr, t), L.depthkernel("ref", vel, c["depz"], 1.0, iwave, igr, t)):
+        assert (bits64(a) != bits64(b)).sum() == 0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(deep=True, nz=7, nx=10, ny=13, seed=5), dict(kRc=0, kRg=2, kLc=0, kLg=1)])
+def test_boundary_bitwise(kw):
+    """The whole boundary: CalSurfG (:939-1459) -> dsurf + CSR-ish rows (rw, iw, col, nar) and
+    synthetic (:2412-2865, noiselevel 0) -> obst; all four wave types, ragged source/receiver
+    counts, the pvRc overwrite by the group-velocity periods"""
+    c = synth.boundary_case(**kw)
+    a = L.call_boundary(L.ref().calsurfg_, c)
+    b = L.call_boundary(L.oracle().dso_calsurfg, c)
+    assert a["nar"] == b["nar"] and a["nar"] > 0
+    assert (bits(a["dsurf"]) != bits(b["dsurf"])).sum() == 0
+    assert (bits(a["rw"]) != bits(b["rw"])).sum() == 0
+    assert (a["iw"] != b["iw"]).sum() == 0 and (a["col"] != b["col"]).sum() == 0
+    sa = L.call_boundary(L.ref().synthetic_, c, synthetic=True)
+    sb = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
+    assert (bits(sa) != bits(sb)).sum() == 0
