@@ -1,0 +1,102 @@
+// K7: dispersion curves and depth kernels for every column of the Vs model (reference depthkernel
+// CalSurfG.f90:1-169, caldespersion :2866-2927, on top of surfdisp96.f).
+//
+// One lane per curve: (column, perturbation) with perturbation 0 = the model itself and
+// 1 + 6 i + 2 q + s = parameter q (Vs, Vp, rho) of depth i scaled by 1 -+ 0.005.  Columns vary
+// fastest so that a wavefront holds neighbouring columns under the same perturbation: similar
+// models, similar trip counts.  The curves land in a (perturbation, period, column) buffer and a
+// second, trivial kernel turns them into pv and the central differences.
+#include "kernels.h"
+#include "dispersion_core.h"
+
+namespace dsa {
+
+constexpr int kMaxDepths = 64;
+
+template <int IFUNC>
+__global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__ G, const float* __restrict__ vels, int ncol,
+                                                   int npert, int igr, int kmax, const double* __restrict__ t,
+                                                   float* __restrict__ ws, size_t nlanes, double* __restrict__ curves)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (size_t)ncol * npert) return;
+    const int p = (int)(tid / ncol), c = (int)(tid - (size_t)p * ncol);
+    const int nz = G->nz;
+    float vs[kMaxDepths], vp[kMaxDepths], rho[kMaxDepths];
+    for (int k = 0; k < nz; ++k) {
+        vs[k] = vels[(size_t)k * ncol + c];
+        brocher_vp_rho(vs[k], &vp[k], &rho[k]);
+    }
+    if (p > 0) {
+        const int idx = p - 1, i = idx / 6, q = (idx % 6) >> 1, s = idx & 1;
+        float* arr = q == 0 ? vs : (q == 1 ? vp : rho);
+        const float base = arr[i];
+        const float dln = 0.01f;
+        arr[i] = s ? base + 0.5f * dln * base : base - 0.5f * dln * base;
+    }
+    Layers m;
+    const size_t plane = (size_t)G->rmax * nlanes;
+    m.d = ws + tid; m.a = ws + plane + tid; m.b = ws + 2 * plane + tid; m.rho = ws + 3 * plane + tid;
+    m.stride = nlanes;
+    build_layers<IFUNC>(*G, vs, vp, rho, m);
+    dispersion_curve<IFUNC>(m, igr, kmax, t, curves + (size_t)p * kmax * ncol + c, (size_t)ncol);
+}
+
+void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
+                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, hipStream_t stream)
+{
+    const size_t n = (size_t)ncol * npert;
+    if (n == 0) return;
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, 0, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves);
+    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, 0, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves);
+}
+
+// pv(c, k) = curve 0; sen_q(c, slot0 + k, i) = (cg(+) - cg(-)) / dble(dln * base_q(i)), CalSurfG.f90:76-150
+__global__ void k_depth_kernels(const float* __restrict__ vels, int ncol, int nz, int kmax, const double* __restrict__ curves,
+                                int with_kernels, double* __restrict__ pv, double* __restrict__ sen_vs, double* __restrict__ sen_vp,
+                                double* __restrict__ sen_rho, int kmax_total, int slot0)
+{
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)ncol * kmax) return;
+    const int k = (int)(id / ncol), c = (int)(id - (size_t)k * ncol);
+    pv[id] = curves[id];
+    if (!with_kernels) return;
+    const float dln = 0.01f;
+    for (int i = 0; i < nz; ++i) {
+        const float v = vels[(size_t)i * ncol + c];
+        float base[3];
+        base[0] = v;
+        brocher_vp_rho(v, &base[1], &base[2]);
+        double* out[3] = { sen_vs, sen_vp, sen_rho };
+        for (int q = 0; q < 3; ++q) {
+            const size_t pm = (size_t)(1 + 6 * i + 2 * q) * kmax * ncol + id;
+            const double cg1 = curves[pm], cg2 = curves[pm + (size_t)kmax * ncol];
+            out[q][((size_t)i * kmax_total + slot0 + k) * ncol + c] = (cg2 - cg1) / (double)(dln * base[q]);
+        }
+    }
+}
+
+void launch_depth_kernels(const float* d_vels, int ncol, int nz, int kmax, const double* d_curves, int with_kernels, double* d_pv,
+                          double* d_sen_vs, double* d_sen_vp, double* d_sen_rho, int kmax_total, int slot0, hipStream_t stream)
+{
+    const size_t n = (size_t)ncol * kmax;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_depth_kernels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_vels, ncol, nz, kmax, d_curves,
+                       with_kernels, d_pv, d_sen_vs, d_sen_vp, d_sen_rho, kmax_total, slot0);
+}
+
+// velv = real(pv) for the maps of a call (CalSurfG.f90:1492)
+__global__ void k_to_float(const double* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+void launch_to_float(const double* d_in, float* d_out, size_t n, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_to_float, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_in, d_out, n);
+}
+
+}  // namespace dsa

@@ -1,0 +1,468 @@
+// Surface-wave dispersion of one layered column: fundamental-mode phase / group velocity at a list
+// of periods (reference surfdisp96.f:52-1062 as driven by CalSurfG.f90 depthkernel :1-169 and
+// caldespersion :2866-2927: spherical earth, mode 1, one wave type per call).
+//
+// One curve is a serial chain (the root search at period k starts from the root at k-1), so the
+// device runs one curve per lane and gets its parallelism from columns x perturbations.  The layer
+// arrays of a lane live in a strided workspace (element l of lane t at [l * stride + t]) so that
+// the lanes of a wavefront read consecutive addresses.
+//
+// Arithmetic contract: fp64 secular functions with the reference's operation order; the
+// single-precision temporaries of the F77 original (implicit REAL*4: cc1, betmx, t1a, t1b, cc0,
+// gvel, ...) are kept single.  Everything that does not depend on the velocities -- the flattened
+// layer thicknesses (logs), the flattening factors and the density exponent (powf) -- comes from
+// the host in LayerGeom, computed with libm, so the only device transcendentals are the
+// sin / cos / exp inside the secular functions.
+#pragma once
+
+#include "eikonal_core.h"
+
+namespace dsa {
+
+constexpr int kMaxLayers = 200;     // reference NL
+constexpr int kMaxPeriods = 60;     // reference NP
+
+// velocity-independent part of the layered model of a call (host-made, refineGrid2LayerMdl
+// CalSurfG.f90:2352-2411 + sphere surfdisp96.f:480-547)
+struct LayerGeom {
+    int nz;                 // grid depths
+    int rmax;               // layers after refinement, incl. the half space
+    int nsub[kMaxLayers];   // sublayers of grid interval i (0-based, nz-1 of them)
+    float dflat[kMaxLayers];    // flattened thickness of layer l
+    double tmp[kMaxLayers];     // velocity flattening factor (ar+ar)/(r0+r1)
+    float rhofac_love[kMaxLayers], rhofac_rayl[kMaxLayers];   // btp**(-5), btp**(-2.275)
+};
+
+// strided view of one lane's layers
+struct Layers {
+    float* d; float* a; float* b; float* rho;
+    size_t stride;
+    int mmax, llw;
+    DSA_HDM float D(int k) const { return d[(size_t)k * stride]; }      // k 0-based
+    DSA_HDM float A(int k) const { return a[(size_t)k * stride]; }
+    DSA_HDM float B(int k) const { return b[(size_t)k * stride]; }
+    DSA_HDM float R(int k) const { return rho[(size_t)k * stride]; }
+};
+
+DSA_HD double sign1(double x) { return __builtin_copysign(1.0, x); }
+
+// Love: Thomson-Haskell, surfdisp96.f:704-763
+DSA_HD double dltar1(const Layers& m, double wvno, double omega)
+{
+    const int mmax = m.mmax;
+    double beta1 = (double)m.B(mmax - 1);
+    double rho1 = (double)m.R(mmax - 1);
+    double xkb = omega / beta1;
+    double wvnop = wvno + xkb;
+    double wvnom = fabs(wvno - xkb);
+    double rb = sqrt(wvnop * wvnom);
+    double e1 = rho1 * rb;
+    double e2 = 1.0 / (beta1 * beta1);
+    for (int k = mmax - 1; k >= m.llw; --k) {
+        beta1 = (double)m.B(k - 1);
+        rho1 = (double)m.R(k - 1);
+        const double dk = (double)m.D(k - 1);
+        const double xmu = rho1 * beta1 * beta1;
+        xkb = omega / beta1;
+        wvnop = wvno + xkb;
+        wvnom = fabs(wvno - xkb);
+        rb = sqrt(wvnop * wvnom);
+        const double q = dk * rb;
+        double sinq, y, z, cosq;
+        if (wvno < xkb) {
+            sinq = sin(q); y = sinq / rb; z = -rb * sinq; cosq = cos(q);
+        } else if (wvno == xkb) {
+            cosq = 1.0; y = dk; z = 0.0;
+        } else {
+            double fac = 0.0;
+            if (q < 16) fac = exp(-2.0 * q);
+            cosq = (1.0 + fac) * 0.5;
+            sinq = (1.0 - fac) * 0.5;
+            y = sinq / rb; z = rb * sinq;
+        }
+        const double e10 = e1 * cosq + e2 * xmu * z;
+        const double e20 = e1 * y / xmu + e2 * cosq;
+        double xnor = fabs(e10);
+        const double ynor = fabs(e20);
+        if (ynor > xnor) xnor = ynor;
+        if (xnor < 1.e-40) xnor = 1.0;
+        e1 = e10 / xnor;
+        e2 = e20 / xnor;
+    }
+    return e1;
+}
+
+// products of the P / SV eigenfunctions over one layer, surfdisp96.f:868-985
+struct LayerTerms { double a0, cpcq, cpy, cpz, cqw, cqx, xy, xz, wy, wz, w, cosp; };
+
+DSA_HD void layer_terms(double p, double q, double ra, double rb, double wvno, double xka, double xkb, double dpth, LayerTerms& o)
+{
+    double pex = 0.0, sex = 0.0, sinp, x, sinq, y, z, cosq, fac, w, cosp;
+    if (wvno < xka) {
+        sinp = sin(p); w = sinp / ra; x = -ra * sinp; cosp = cos(p);
+    } else if (wvno == xka) {
+        cosp = 1.0; w = dpth; x = 0.0;
+    } else {
+        pex = p; fac = 0.0;
+        if (p < 16) fac = exp(-2.0 * p);
+        cosp = (1.0 + fac) * 0.5;
+        sinp = (1.0 - fac) * 0.5;
+        w = sinp / ra; x = ra * sinp;
+    }
+    if (wvno < xkb) {
+        sinq = sin(q); y = sinq / rb; z = -rb * sinq; cosq = cos(q);
+    } else if (wvno == xkb) {
+        cosq = 1.0; y = dpth; z = 0.0;
+    } else {
+        sex = q; fac = 0.0;
+        if (q < 16) fac = exp(-2.0 * q);
+        cosq = (1.0 + fac) * 0.5;
+        sinq = (1.0 - fac) * 0.5;
+        y = sinq / rb; z = rb * sinq;
+    }
+    const double exa = pex + sex;
+    o.a0 = 0.0;
+    if (exa < 60.0) o.a0 = exp(-exa);
+    o.cpcq = cosp * cosq;
+    o.cpy = cosp * y;
+    o.cpz = cosp * z;
+    o.cqw = cosq * w;
+    o.cqx = cosq * x;
+    o.xy = x * y;
+    o.xz = x * z;
+    o.wy = w * y;
+    o.wz = w * z;
+    o.w = w;
+    o.cosp = cosp;
+}
+
+// Rayleigh: Dunkin's compound matrix, surfdisp96.f:767-865 with dnka :1018-1062 and normc :989-1014
+DSA_HD double dltar4(const Layers& m, double wvno, double omga)
+{
+    const int mmax = m.mmax;
+    double e0, e1, e2, e3, e4;
+    LayerTerms o;
+    double omega = omga;
+    if (omega < 1.0e-4) omega = 1.0e-4;
+    const double wvno2 = wvno * wvno;
+    double xka = omega / (double)m.A(mmax - 1);
+    double xkb = omega / (double)m.B(mmax - 1);
+    double wvnop = wvno + xka;
+    double wvnom = fabs(wvno - xka);
+    double ra = sqrt(wvnop * wvnom);
+    wvnop = wvno + xkb;
+    wvnom = fabs(wvno - xkb);
+    double rb = sqrt(wvnop * wvnom);
+    double t = (double)m.B(mmax - 1) / omega;
+    double gammk = 2.0 * t * t;
+    double gam = gammk * wvno2;
+    {
+        const double gamm1 = gam - 1.0;
+        const double rho1 = (double)m.R(mmax - 1);
+        e0 = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+        e1 = -rho1 * ra;
+        e2 = rho1 * (gamm1 - gammk * ra * rb);
+        e3 = rho1 * rb;
+        e4 = wvno2 - ra * rb;
+    }
+    for (int k = mmax - 1; k >= m.llw; --k) {
+        const double ak = (double)m.A(k - 1), bk = (double)m.B(k - 1);
+        xka = omega / ak;
+        xkb = omega / bk;
+        t = bk / omega;
+        gammk = 2.0 * t * t;
+        gam = gammk * wvno2;
+        wvnop = wvno + xka;
+        wvnom = fabs(wvno - xka);
+        ra = sqrt(wvnop * wvnom);
+        wvnop = wvno + xkb;
+        wvnom = fabs(wvno - xkb);
+        rb = sqrt(wvnop * wvnom);
+        const double dpth = (double)m.D(k - 1);
+        const double rho = (double)m.R(k - 1);
+        layer_terms(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, o);
+        // compound matrix ca(i, j), named cIJ
+        const double one = 1.0, two = 2.0;
+        const double gamm1 = gam - one;
+        const double twgm1 = gam + gamm1;
+        const double gmgmk = gam * gammk;
+        const double gmgm1 = gam * gamm1;
+        const double gm1sq = gamm1 * gamm1;
+        const double rho2 = rho * rho;
+        const double a0pq = o.a0 - o.cpcq;
+        const double c11 = o.cpcq - two * gmgm1 * a0pq - gmgmk * o.xz - wvno2 * gm1sq * o.wy;
+        const double c12 = (wvno2 * o.cpy - o.cqx) / rho;
+        const double c13 = -(twgm1 * a0pq + gammk * o.xz + wvno2 * gamm1 * o.wy) / rho;
+        const double c14 = (o.cpz - wvno2 * o.cqw) / rho;
+        const double c15 = -(two * wvno2 * a0pq + o.xz + wvno2 * wvno2 * o.wy) / rho2;
+        const double c21 = (gmgmk * o.cpz - gm1sq * o.cqw) * rho;
+        const double c22 = o.cpcq;
+        const double c23 = gammk * o.cpz - gamm1 * o.cqw;
+        const double c24 = -o.wz;
+        const double c25 = c14;
+        const double c41 = (gm1sq * o.cpy - gmgmk * o.cqx) * rho;
+        const double c42 = -o.xy;
+        const double c43 = gamm1 * o.cpy - gammk * o.cqx;
+        const double c44 = c22;
+        const double c45 = c12;
+        const double c51 = -(two * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * o.xz + gm1sq * gm1sq * o.wy) * rho2;
+        const double c52 = c41;
+        const double c53 = -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * o.xz + gamm1 * gm1sq * o.wy) * rho;
+        const double c54 = c21;
+        const double c55 = c11;
+        const double tt = -two * wvno2;
+        const double c31 = tt * c53;
+        const double c32 = tt * c43;
+        const double c33 = o.a0 + two * (o.cpcq - c11);
+        const double c34 = tt * c23;
+        const double c35 = tt * c13;
+        // ee(i) = sum_j e(j) ca(j, i), accumulated from zero in j order
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, n4 = 0.0;
+        n0 = n0 + e0 * c11; n0 = n0 + e1 * c21; n0 = n0 + e2 * c31; n0 = n0 + e3 * c41; n0 = n0 + e4 * c51;
+        n1 = n1 + e0 * c12; n1 = n1 + e1 * c22; n1 = n1 + e2 * c32; n1 = n1 + e3 * c42; n1 = n1 + e4 * c52;
+        n2 = n2 + e0 * c13; n2 = n2 + e1 * c23; n2 = n2 + e2 * c33; n2 = n2 + e3 * c43; n2 = n2 + e4 * c53;
+        n3 = n3 + e0 * c14; n3 = n3 + e1 * c24; n3 = n3 + e2 * c34; n3 = n3 + e3 * c44; n3 = n3 + e4 * c54;
+        n4 = n4 + e0 * c15; n4 = n4 + e1 * c25; n4 = n4 + e2 * c35; n4 = n4 + e3 * c45; n4 = n4 + e4 * c55;
+        double t1 = 0.0;
+        if (fabs(n0) > t1) t1 = fabs(n0);
+        if (fabs(n1) > t1) t1 = fabs(n1);
+        if (fabs(n2) > t1) t1 = fabs(n2);
+        if (fabs(n3) > t1) t1 = fabs(n3);
+        if (fabs(n4) > t1) t1 = fabs(n4);
+        if (t1 < 1.e-40) t1 = 1.0;
+        e0 = n0 / t1; e1 = n1 / t1; e2 = n2 / t1; e3 = n3 / t1; e4 = n4 / t1;
+    }
+    if (m.llw != 1) {
+        // water layer on top
+        xka = omega / (double)m.A(0);
+        wvnop = wvno + xka;
+        wvnom = fabs(wvno - xka);
+        ra = sqrt(wvnop * wvnom);
+        const double dpth = (double)m.D(0);
+        const double rho1 = (double)m.R(0);
+        const double znul = 1.0e-05;
+        layer_terms(ra * dpth, znul, ra, znul, wvno, xka, znul, dpth, o);
+        const double w0 = -rho1 * o.w;
+        return o.cosp * e0 + w0 * e1;
+    }
+    return e0;
+}
+
+template <int IFUNC>
+DSA_HD double secular(const Layers& m, double wvno, double omega)
+{
+    return IFUNC == 1 ? dltar1(m, wvno, omega) : dltar4(m, wvno, omega);
+}
+
+// hybrid interval halving / Neville iteration, surfdisp96.f:551-668
+template <int IFUNC>
+DSA_HD double nevill(const Layers& m, double t, double c1, double c2, double del1, double del2, double twopi)
+{
+    double x[12], y[12], c3, del3;
+    const double omega = twopi / t;
+    int nev, nctrl = 1, mm = 1;
+    c3 = 0.5 * (c1 + c2);
+    del3 = secular<IFUNC>(m, omega / c3, omega);
+    nev = 1;
+    for (;;) {
+        nctrl = nctrl + 1;
+        if (nctrl >= 100) break;
+        if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) {
+            nev = 0;
+            c3 = 0.5 * (c1 + c2);
+            del3 = secular<IFUNC>(m, omega / c3, omega);
+        }
+        const double s13 = del1 - del3;
+        const double s32 = del3 - del2;
+        if (sign1(del3) * sign1(del1) < 0.0) { c2 = c3; del2 = del3; }
+        else { c1 = c3; del1 = del3; }
+        if (fabs(c1 - c2) <= 1.e-6 * c1) break;
+        if (sign1(s13) != sign1(s32)) nev = 0;
+        const double ss1 = fabs(del1);
+        const double s1 = (double)0.01f * ss1;          // single-precision literal in the reference
+        const double ss2 = fabs(del2);
+        const double s2 = (double)0.01f * ss2;
+        bool halve = (s1 > ss2 || s2 > ss1 || nev == 0);
+        if (!halve) {
+            if (nev == 2) { x[mm + 1] = c3; y[mm + 1] = del3; }
+            else { x[1] = c1; y[1] = del1; x[2] = c2; y[2] = del2; mm = 1; }
+            for (int kk = 1; kk <= mm; ++kk) {
+                const int j = mm - kk + 1;
+                const double denom = y[mm + 1] - y[j];
+                if (fabs(denom) < 1.0e-10 * fabs(y[mm + 1])) { halve = true; break; }
+                x[j] = (-y[j] * x[j + 1] + y[mm + 1] * x[j]) / denom;
+            }
+            if (!halve) {
+                c3 = x[1];
+                del3 = secular<IFUNC>(m, omega / c3, omega);
+                nev = 2;
+                mm = mm + 1;
+                if (mm > 10) mm = 10;
+            }
+        }
+        if (halve) {
+            c3 = 0.5 * (c1 + c2);
+            del3 = secular<IFUNC>(m, omega / c3, omega);
+            nev = 1;
+            mm = 1;
+        }
+    }
+    return c3;
+}
+
+// bracket a sign change in steps of dc, then refine; surfdisp96.f:384-476.  returns iret
+template <int IFUNC>
+DSA_HD int getsol(const Layers& m, double t1, double* c1io, double clow, double dc, double cm, float betmx, int ifirst, double* del1st)
+{
+    const double twopi = 2.0 * 3.141592653589793;
+    double c1 = *c1io, c2, del1, del2;
+    double omega = twopi / t1;
+    double wvno = omega / c1;
+    del1 = secular<IFUNC>(m, wvno, omega);
+    if (ifirst == 1) *del1st = del1;
+    const double plmn = sign1(*del1st) * sign1(del1);
+    int idir = +1;
+    if (ifirst != 1 && plmn < 0.0) idir = -1;
+    for (;;) {
+        if (idir > 0) c2 = c1 + dc; else c2 = c1 - dc;
+        if (c2 <= clow) { idir = +1; c1 = clow; continue; }
+        omega = twopi / t1;
+        wvno = omega / c2;
+        del2 = secular<IFUNC>(m, wvno, omega);
+        if (sign1(del1) != sign1(del2)) break;
+        c1 = c2;
+        del1 = del2;
+        if (c1 < cm) { *c1io = c1; return -1; }
+        if (c1 >= ((double)betmx + dc)) { *c1io = c1; return -1; }
+    }
+    c1 = nevill<IFUNC>(m, t1, c1, c2, del1, del2, twopi);
+    *c1io = c1;
+    if (c1 > (double)betmx) return -1;
+    return 1;
+}
+
+// starting phase velocity from the half-space Rayleigh equation, all REAL*4; surfdisp96.f:361-382
+DSA_HD float gtsolh(float a, float b)
+{
+    float c = 0.95f * b;
+    for (int i = 0; i < 5; ++i) {
+        const float gamma = b / a;
+        const float kappa = c / b;
+        const float k2 = kappa * kappa;
+        const float gk2 = (gamma * kappa) * (gamma * kappa);
+        const float fac1 = sqrtf(1.0f - gk2);
+        const float fac2 = sqrtf(1.0f - k2);
+        const float fr = (2.0f - k2) * (2.0f - k2) - 4.0f * fac1 * fac2;
+        float frp = -(4.0f * (2.0f - k2) * kappa) + 4.0f * fac2 * gamma * gamma * kappa / fac1 + 4.0f * fac1 * kappa / fac2;
+        frp = frp / b;
+        c = c - fr / frp;
+    }
+    return c;
+}
+
+// Brocher relations vs -> vp -> rho as the column drivers apply them (CalSurfG.f90:49-53)
+DSA_HD void brocher_vp_rho(float vs, float* vp, float* rho)
+{
+    const float v2 = vs * vs, v3 = vs * (vs * vs), v4 = ((vs * vs) * vs) * vs;
+    const float p = 0.9409f + 2.0947f * vs - 0.8206f * v2 + 0.2683f * v3 - 0.0251f * v4;
+    const float p2 = p * p, p3 = p * (p * p), p4 = ((p * p) * p) * p, p5 = (((p * p) * p) * p) * p;
+    *vp = p;
+    *rho = 1.6612f * p - 0.4721f * p2 + 0.0671f * p3 - 0.0043f * p4 + 0.000106f * p5;
+}
+
+// Fill a lane's layers from the column's grid values (vs, vp, rho at the nz depths): linear-gradient
+// sublayers (refineGrid2LayerMdl) and earth flattening (sphere) with the host's geometry factors.
+template <int IFUNC>
+DSA_HD void build_layers(const LayerGeom& G, const float* vs, const float* vp, const float* rho, Layers& m)
+{
+    int k = 0;
+    for (int i = 1; i <= G.nz - 1; ++i) {
+        const int nsub = G.nsub[i - 1];
+        for (int j = 1; j <= nsub; ++j) {
+            const float rvp = vp[i - 1] + (float)(2 * j - 1) * (vp[i] - vp[i - 1]) / (float)(2 * nsub);
+            const float rvs = vs[i - 1] + (float)(2 * j - 1) * (vs[i] - vs[i - 1]) / (float)(2 * nsub);
+            const float rrho = rho[i - 1] + (float)(2 * j - 1) * (rho[i] - rho[i - 1]) / (float)(2 * nsub);
+            const size_t o = (size_t)k * m.stride;
+            m.d[o] = G.dflat[k];
+            m.a[o] = (float)((double)rvp * G.tmp[k]);
+            m.b[o] = (float)((double)rvs * G.tmp[k]);
+            m.rho[o] = rrho * (IFUNC == 1 ? G.rhofac_love[k] : G.rhofac_rayl[k]);
+            ++k;
+        }
+    }
+    const size_t o = (size_t)k * m.stride;
+    m.d[o] = 0.0f;
+    m.a[o] = (float)((double)vp[G.nz - 1] * G.tmp[k]);
+    m.b[o] = (float)((double)vs[G.nz - 1] * G.tmp[k]);
+    m.rho[o] = rho[G.nz - 1] * (IFUNC == 1 ? G.rhofac_love[k] : G.rhofac_rayl[k]);
+    m.mmax = k + 1;
+    m.llw = (m.B(0) <= 0.0f) ? 2 : 1;
+}
+
+// One dispersion curve (surfdisp96.f:52-350 with mode = 1): cg[k] for k < kmax, written with `cstride`.
+// igr = 0 phase velocity, 1 group velocity from two roots at T/(1 +- h).
+template <int IFUNC>
+DSA_HD void dispersion_curve(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
+{
+    const int mmax = m.mmax;
+    const float ddc = 0.005f, h = 0.005f;
+    const float sone = 1.500f;
+    const double one = 1.0e-2;
+    int jmn = 1, jsol = 1;
+    float betmx = -1.e20f, betmn = 1.e20f;
+    for (int i = 0; i < mmax; ++i) {
+        const float bi = m.B(i), ai = m.A(i);
+        if (bi > 0.01f && bi < betmn) { betmn = bi; jmn = i + 1; jsol = 1; }
+        else if (bi <= 0.01f && ai < betmn) { betmn = ai; jmn = i + 1; jsol = 0; }
+        if (bi > betmx) betmx = bi;
+    }
+    const double onea = (double)sone;
+    float cc1;
+    if (jsol == 0) cc1 = betmn;
+    else cc1 = gtsolh(m.A(jmn - 1), m.B(jmn - 1));
+    cc1 = .95f * cc1;
+    cc1 = .90f * cc1;
+    const double cc = (double)cc1;
+    const double dc = fabs((double)ddc);
+    const double cm = cc;
+    double c1 = cc, cprev = 0.0, del1st = 0.0;
+    int k;
+    bool failed = false;
+    for (k = 1; k <= kmax; ++k) {
+        double t1 = t[k - 1];
+        float t1a, t1b = 0.0f;
+        if (igr > 0) {
+            t1a = (float)(t1 / (double)(1.f + h));
+            t1b = (float)(t1 / (double)(1.f - h));
+            t1 = (double)t1a;
+        } else {
+            t1a = (float)t1;
+        }
+        double clow;
+        int ifirst;
+        if (k == 1) { c1 = cc; clow = cc; ifirst = 1; }
+        else { ifirst = 0; c1 = cprev - onea * dc; clow = cm; }
+        int iret = getsol<IFUNC>(m, t1, &c1, clow, dc, cm, betmx, ifirst, &del1st);
+        if (iret == -1) { failed = true; break; }
+        const double ck = c1;
+        cprev = ck;
+        if (igr > 0) {
+            t1 = (double)t1b;
+            clow = 0.0 + one * dc;               // cb(k) is still zero here
+            c1 = c1 - onea * dc;
+            iret = getsol<IFUNC>(m, t1, &c1, clow, dc, cm, betmx, 0, &del1st);
+            if (iret == -1) c1 = ck;
+        } else c1 = 0.0;
+        const float cc0 = (float)ck;
+        const float cc1b = (float)c1;
+        if (igr == 0) cg[(size_t)(k - 1) * cstride] = (double)cc0;
+        else {
+            const float gvel = (1 / t1a - 1 / t1b) / (1 / (t1a * cc0) - 1 / (t1b * cc1b));
+            cg[(size_t)(k - 1) * cstride] = (double)gvel;
+        }
+    }
+    if (failed)
+        for (int i = k; i <= kmax; ++i) cg[(size_t)(i - 1) * cstride] = 0.0;   // the reference logs a warning and zero-fills
+}
+
+}  // namespace dsa

@@ -1,35 +1,203 @@
 // Drop-in level of the C ABI: the reference's CalSurfG / synthetic argument lists
 // (reference src/CalSurfG.f90:939-943 and :2412-2415) on top of one process-wide engine.
+//
+// This file only translates the reference's calling convention into engine calls: which maps and
+// depth-kernel slots each wave type gets, the (period slot, source) loop nest flattened into units,
+// and the two-pass handling of group-velocity data.  All numerical work happens on the device.
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "../../include/dsurftomo_amd.h"
 
 namespace {
+
 std::string g_dropin_error = "";
+dsa_engine* g_engine = nullptr;
+
+int engine()
+{
+    if (g_engine) return 0;
+    int dev = 0;
+    if (const char* s = getenv("DSA_DEVICE")) dev = atoi(s);
+    const int rc = dsa_create(&g_engine, dev);
+    if (rc != 0) { g_dropin_error = dsa_error_string(nullptr); g_engine = nullptr; return rc; }
+    if (const char* s = getenv("DSA_MAX_CHUNK")) dsa_set_option(g_engine, "max_chunk", atof(s));
+    if (const char* s = getenv("DSA_WINDOW_CELLS")) dsa_set_option(g_engine, "window_cells", atof(s));
+    return 0;
 }
+
+int fail(int rc)
+{
+    g_dropin_error = dsa_error_string(g_engine);
+    return rc;
+}
+
+// where the four wave types live in the engine's map store and depth-kernel slots
+struct Layout {
+    int kRc, kRg, kLc, kLg, kmax;
+    int oRc, oRg, oLc, oLg, nmaps;     // first map of pvRc / pvRg / pvLc / pvLg
+    int sRc, sRg, sLc, sLg;            // first depth-kernel slot (reference kmax1/kmax2/kmax3 offsets, :1094-1098)
+};
+
+Layout make_layout(int kRc, int kRg, int kLc, int kLg, int kmax, bool clobber)
+{
+    Layout L{};
+    L.kRc = kRc; L.kRg = kRg; L.kLc = kLc; L.kLg = kLg; L.kmax = kmax;
+    // pvRc / pvLc are sized kmax in the reference because the group periods' phase velocities are
+    // written over their head; here they only need max(phase periods, group periods) columns
+    const int nRc = clobber ? std::max(kRc, kRg) : kRc, nLc = clobber ? std::max(kLc, kLg) : kLc;
+    L.oRc = 0; L.oRg = L.oRc + nRc; L.oLc = L.oRg + kRg; L.oLg = L.oLc + nLc; L.nmaps = L.oLg + kLg;
+    L.sRc = 0; L.sRg = kRc; L.sLc = kRc + kRg; L.sLg = kRc + kRg + kLc;
+    return L;
+}
+
+struct Units {
+    std::vector<int> map, nrec, mode, slot, data;
+    std::vector<float> sx, sz, rx, rz;
+    int ndata = 0;
+};
+
+// flatten CalSurfG.f90:1144-1183: returns 0 or DSA_ERR_ARGUMENT
+int make_units(const Layout& L, bool rows, int nsrcsurf, int nrcf, const int* wavetype, const int* igrt, const int* periods,
+               const int* nrc1, const int* nsrcsurf1, const float* scxf, const float* sczf, const float* rcxf, const float* rczf,
+               Units& U)
+{
+    int count1 = 0;
+    for (int knumi = 1; knumi <= L.kmax; ++knumi)
+        for (int srcnum = 1; srcnum <= nsrcsurf1[knumi - 1]; ++srcnum) {
+            const size_t sk = (size_t)(knumi - 1) * nsrcsurf + (srcnum - 1);
+            const int wt = wavetype[sk], gr = igrt[sk], per = periods[sk], nr = nrc1[sk];
+            int mt, mp;      // map of the travel times, map of the rays
+            if (wt == 2 && gr == 0) { mt = L.oRc + per - 1; mp = mt; }
+            else if (wt == 2 && gr == 1) { mt = L.oRg + per - 1; mp = L.oRc + per - 1; }
+            else if (wt == 1 && gr == 0) { mt = L.oLc + per - 1; mp = mt; }
+            else if (wt == 1 && gr == 1) { mt = L.oLg + per - 1; mp = L.oLc + per - 1; }
+            else { g_dropin_error = "wavetype must be 1 (Love) or 2 (Rayleigh) and igrt 0 or 1"; return DSA_ERR_ARGUMENT; }
+            if (per < 1 || mt >= L.nmaps || nr < 0 || nr > nrcf) { g_dropin_error = "period index or receiver count out of range"; return DSA_ERR_ARGUMENT; }
+            const int passes = (rows && gr == 1) ? 2 : 1;
+            for (int ig = 1; ig <= passes; ++ig) {
+                U.map.push_back(ig == 1 ? mt : mp);
+                U.nrec.push_back(nr);
+                U.mode.push_back(!rows ? 1 : (gr == 0 ? 3 : (ig == 1 ? 1 : 2)));
+                U.slot.push_back(knumi - 1);
+                U.data.push_back(count1);
+                U.sx.push_back(scxf[sk]);
+                U.sz.push_back(sczf[sk]);
+                for (int i = 0; i < nr; ++i) {
+                    U.rx.push_back(rcxf[sk * (size_t)nrcf + i]);
+                    U.rz.push_back(rczf[sk * (size_t)nrcf + i]);
+                }
+            }
+            count1 += nr;
+        }
+    U.ndata = count1;
+    return 0;
+}
+
+const char* kBoundaryNote =
+    " Note that at least one two-point ray path\n tracked along the boundary of the model.\n"
+    " This class of path is unlikely to be\n a true path, and it is STRONGLY RECOMMENDED\n"
+    " that you adjust the dimensions of your grid\n to prevent this from occurring.\n";
+
+}  // namespace
 
 extern "C" {
 
 const char* dsa_dropin_error(void) { return g_dropin_error.c_str(); }
 
-int dsa_calsurfg(const int*, const int*, const int*, const int*, const float*, int*, float*, int*, float*,
-                 const float*, const float*, const float*, const float*, const int*, const int*, const int*,
-                 const int*, const double*, const double*, const double*, const double*, const int*, const int*,
-                 const int*, const float*, const float*, const float*, const float*, const float*, const float*,
-                 const int*, const int*, const int*, const int*, const int*, int*)
+int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,
+                 int* iw, float* rw, int* col, float* dsurf,
+                 const float* goxdf, const float* gozdf, const float* dvxdf, const float* dvzdf,
+                 const int* kmaxRc, const int* kmaxRg, const int* kmaxLc, const int* kmaxLg,
+                 const double* tRc, const double* tRg, const double* tLc, const double* tLg,
+                 const int* wavetype, const int* igrt, const int* periods, const float* depz,
+                 const float* minthk, const float* scxf, const float* sczf, const float* rcxf,
+                 const float* rczf, const int* nrc1, const int* nsrcsurf1, const int* kmax,
+                 const int* nsrcsurf, const int* nrcf, int* nar)
 {
-    g_dropin_error = "dsa_calsurfg: ray/Frechet and dispersion stages are not built yet";
-    return DSA_ERR_STATE;
+    (void)nparpi;
+    if (!nx || !ny || !nz || !vels || !iw || !rw || !col || !dsurf || !kmax || !nar) { g_dropin_error = "dsa_calsurfg: null argument"; return DSA_ERR_ARGUMENT; }
+    int rc = engine();
+    if (rc != 0) return rc;
+    dsa_engine* e = g_engine;
+    const Layout L = make_layout(*kmaxRc, *kmaxRg, *kmaxLc, *kmaxLg, *kmax, true);
+    if (L.kRc + L.kRg + L.kLc + L.kLg != L.kmax) { g_dropin_error = "dsa_calsurfg: kmax must equal kmaxRc+kmaxRg+kmaxLc+kmaxLg"; return DSA_ERR_ARGUMENT; }
+    // dispersion: depth kernels per type; the phase velocities at the group periods overwrite the head
+    // of the phase-velocity block (CalSurfG.f90:1100-1140)
+    if ((rc = dsa_dispersion_begin(e, *nx, *ny, *nz, vels, depz, *minthk, L.kmax, L.nmaps)) != 0) return fail(rc);
+    if ((rc = dsa_dispersion_run(e, 2, 0, L.kRc, tRc, 1, L.sRc, L.oRc)) != 0) return fail(rc);
+    if (L.kRg > 0) {
+        if ((rc = dsa_dispersion_run(e, 2, 1, L.kRg, tRg, 1, L.sRg, L.oRg)) != 0) return fail(rc);
+        if ((rc = dsa_dispersion_run(e, 2, 0, L.kRg, tRg, 0, 0, L.oRc)) != 0) return fail(rc);
+    }
+    if ((rc = dsa_dispersion_run(e, 1, 0, L.kLc, tLc, 1, L.sLc, L.oLc)) != 0) return fail(rc);
+    if (L.kLg > 0) {
+        if ((rc = dsa_dispersion_run(e, 1, 1, L.kLg, tLg, 1, L.sLg, L.oLg)) != 0) return fail(rc);
+        if ((rc = dsa_dispersion_run(e, 1, 0, L.kLg, tLg, 0, 0, L.oLc)) != 0) return fail(rc);
+    }
+    if ((rc = dsa_maps_from_dispersion(e, *goxdf, *gozdf, *dvxdf, *dvzdf, 8)) != 0) return fail(rc);
+    if ((rc = dsa_kernels_from_dispersion(e)) != 0) return fail(rc);
+    Units U;
+    if ((rc = make_units(L, true, *nsrcsurf, *nrcf, wavetype, igrt, periods, nrc1, nsrcsurf1, scxf, sczf, rcxf, rczf, U)) != 0) return rc;
+    if ((rc = dsa_plan_units(e, (int)U.map.size(), U.map.data(), U.sx.data(), U.sz.data(), U.nrec.data(), U.rx.data(), U.rz.data(),
+                             U.mode.data(), U.slot.data(), U.data.data())) != 0) return fail(rc);
+    long long cap = LLONG_MAX, n = 0;      // the reference's interface carries no capacity for rw / iw / col
+    if (const char* s = getenv("DSA_MAXNAR")) cap = atoll(s);
+    *nar = 0;
+    if ((rc = dsa_solve_rows(e, dsurf, rw, iw + 1, col, cap, &n)) != 0) return fail(rc);   // the reference fills iw(nar+1)
+    if (n > INT_MAX) { g_dropin_error = "dsa_calsurfg: more than 2^31-1 matrix entries"; return DSA_ERR_ARGUMENT; }
+    *nar = (int)n;
+    double st[DSA_STAT_COUNT + 8];
+    if (dsa_get_stats(e, st) == 0 && st[DSA_STAT_RAYS_CLAMPED] > 0) fputs(kBoundaryNote, stdout);
+    return 0;
 }
 
-int dsa_synthetic(const int*, const int*, const int*, const int*, const float*, float*, const float*, const float*,
-                  const float*, const float*, const int*, const int*, const int*, const int*, const double*,
-                  const double*, const double*, const double*, const int*, const int*, const int*, const float*,
-                  const float*, const float*, const float*, const float*, const float*, const int*, const int*,
-                  const int*, const int*, const int*, const float*)
+int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,
+                  float* obst,
+                  const float* goxdf, const float* gozdf, const float* dvxdf, const float* dvzdf,
+                  const int* kmaxRc, const int* kmaxRg, const int* kmaxLc, const int* kmaxLg,
+                  const double* tRc, const double* tRg, const double* tLc, const double* tLg,
+                  const int* wavetype, const int* igrt, const int* periods, const float* depz,
+                  const float* minthk, const float* scxf, const float* sczf, const float* rcxf,
+                  const float* rczf, const int* nrc1, const int* nsrcsurf1, const int* kmax,
+                  const int* nsrcsurf, const int* nrcf, const float* noiselevel)
 {
-    g_dropin_error = "dsa_synthetic: dispersion stage is not built yet";
-    return DSA_ERR_STATE;
+    (void)nparpi;
+    if (!nx || !ny || !nz || !vels || !obst || !kmax) { g_dropin_error = "dsa_synthetic: null argument"; return DSA_ERR_ARGUMENT; }
+    int rc = engine();
+    if (rc != 0) return rc;
+    dsa_engine* e = g_engine;
+    const Layout L = make_layout(*kmaxRc, *kmaxRg, *kmaxLc, *kmaxLg, *kmax, false);
+    // caldespersion per type, no depth kernels, dicing 5 (CalSurfG.f90:2487-2617)
+    if ((rc = dsa_dispersion_begin(e, *nx, *ny, *nz, vels, depz, *minthk, std::max(L.kmax, 1), std::max(L.nmaps, 1))) != 0) return fail(rc);
+    if ((rc = dsa_dispersion_run(e, 2, 0, L.kRc, tRc, 0, 0, L.oRc)) != 0) return fail(rc);
+    if ((rc = dsa_dispersion_run(e, 2, 1, L.kRg, tRg, 0, 0, L.oRg)) != 0) return fail(rc);
+    if ((rc = dsa_dispersion_run(e, 1, 0, L.kLc, tLc, 0, 0, L.oLc)) != 0) return fail(rc);
+    if ((rc = dsa_dispersion_run(e, 1, 1, L.kLg, tLg, 0, 0, L.oLg)) != 0) return fail(rc);
+    if ((rc = dsa_maps_from_dispersion(e, *goxdf, *gozdf, *dvxdf, *dvzdf, 5)) != 0) return fail(rc);
+    Units U;
+    if ((rc = make_units(L, false, *nsrcsurf, *nrcf, wavetype, igrt, periods, nrc1, nsrcsurf1, scxf, sczf, rcxf, rczf, U)) != 0) return rc;
+    if ((rc = dsa_plan_units(e, (int)U.map.size(), U.map.data(), U.sx.data(), U.sz.data(), U.nrec.data(), U.rx.data(), U.rz.data(),
+                             U.mode.data(), nullptr, U.data.data())) != 0) return fail(rc);
+    if ((rc = dsa_solve(e, obst)) != 0) return fail(rc);
+    // obst = t + t * gaussian() * noiselevel (:2840).  The reference draws from the compiler's unseeded
+    // random_number; the Fortran shim calls this entry with noiselevel 0 and adds the reference's own
+    // gaussian() on its side.  Called directly with a non-zero level, a private generator is used.
+    if (noiselevel && *noiselevel != 0.0f) {
+        unsigned long long s = 0x9E3779B97F4A7C15ull;
+        auto uni = [&s]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((s >> 40) * (1.0 / 16777216.0)); };
+        for (int k = 0; k < U.ndata; ++k) {
+            float x1, x2, w = 2.0f;
+            while (w >= 1.0f) { x1 = 2.0f * uni() - 1.0f; x2 = 2.0f * uni() - 1.0f; w = x1 * x1 + x2 * x2; }
+            w = sqrtf((-2.0f * logf(w)) / w);
+            obst[k] = obst[k] + obst[k] * (x1 * w) * *noiselevel;
+        }
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -17,8 +17,10 @@
 
 #if defined(__HIPCC__)
 #define DSA_HD __host__ __device__ __forceinline__
+#define DSA_HDM __host__ __device__ __forceinline__
 #else
 #define DSA_HD static inline
+#define DSA_HDM inline
 #endif
 
 namespace dsa {

@@ -65,15 +65,46 @@ struct Engine {
     DevBuf<unsigned long long> clocks;
     double phase_ticks[8] = {};
 
-    double stats[16] = {};
+    // Frechet rows: depth-kernel factor S (ray_kernels.hip) and per-launch ray scratch
+    bool have_sens = false;
+    int sens_nz = 0, sens_kmax = 0;
+    DevBuf<double> Srow, sen_vs, sen_vp, sen_rho;
+    DevBuf<float> vels_d;
+    std::vector<int> h_trace;          // ids of the rays to trace (flag kRayPath), ascending
+    size_t ndata = 0;                  // data (travel times / rows) addressed by the planned rays
+    size_t ray_budget = 0;             // bytes for ray slabs per launch (0 = default)
+    DevBuf<int> trace_ids, vlist, nvv, counts, offsets, coo_col, coo_iw;
+    DevBuf<float> slabs, coo_rw;
+    DevBuf<int32_t> rayinfo;
+
+    // dispersion stage (disp_kernels.hip): Vs model -> pv maps + depth kernels, all resident
+    bool disp_ready = false;
+    int disp_nx = 0, disp_ny = 0, disp_nz = 0, disp_kmax_total = 0, disp_nmaps = 0;
+    std::vector<float> h_depz;
+    LayerGeom h_geom{};
+    DevBuf<LayerGeom> geom;
+    DevBuf<double> pvstore, curves, tper;
+    DevBuf<float> disp_ws;
+
+    double stats[32] = {};
 
     ~Engine();
     void fail(int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
     template <class T> int ensure(DevBuf<T>& b, size_t n);
     int init(int device_index);
     int set_maps(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int dicing, int nm, const double* pv);
-    int plan(int nunits, const int* map_index, const float* scx, const float* scz, const int* nrec, const float* rcx, const float* rcz);
-    int solve(float* dsurf);
+    int plan(int nunits, const int* map_index, const float* scx, const float* scz, const int* nrec, const float* rcx, const float* rcz,
+             const int* mode, const int* sen_slot, const int* data_first);
+    int set_sensitivity(int nz, int kmax, const float* vels, const float* depz, const double* svs, const double* svp, const double* srho, bool on_device);
+    int finish_maps(int nm);
+    int dispersion_begin(int nx, int ny, int nz, const float* vels, const float* depz, float minthk, int kmax_total, int nmaps_total);
+    int dispersion_run(int iwave, int igr, int nper, const double* t, int with_kernels, int sen_slot, int map_first);
+    int dispersion_copy_map(int from, int to, int n);
+    int dispersion_fetch(int map_first, int nper, double* pv, int with_kernels, int sen_slot, double* svs, double* svp, double* srho);
+    int maps_from_dispersion(float goxd, float gozd, float dvxd, float dvzd, int dicing);
+    int kernels_from_dispersion();
+    int solve(float* dsurf, float* rw, int* iw, int* col, long long cap, long long* nar);
+    int trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, long long cap, long long* nar);
     BatchPtrs batch() const;
     FimLaunch launch_shape(int nnx, int nnz) const;
     void launch_srtimes_chunk(int r0, int nr, int first_unit);

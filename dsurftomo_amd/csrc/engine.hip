@@ -57,6 +57,9 @@ Engine::~Engine()
     rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
     rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(F_c); rel(seed_c); rel(nseed_c);
     rel(prob_r); rel(prob_c); rel(info); rel(clocks); rel(lists);
+    rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
+    rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo);
+    rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -85,23 +88,32 @@ int Engine::set_maps(int nx, int ny, float goxd, float gozd, float dvxd, float d
     if (nx < 4 || ny < 4 || nm < 1 || !pv || dicing < 1 || dicing > 16) { fail(DSA_ERR_ARGUMENT, "set_maps: bad arguments (nx=%d ny=%d nmaps=%d dicing=%d)", nx, ny, nm, dicing); return DSA_ERR_ARGUMENT; }
     HIP_TRY(this, hipSetDevice(device));
     make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, dicing);
+    const size_t nv = (size_t)nx * ny;
+    std::vector<float> hv(nv * nm);
+    for (size_t k = 0; k < nv * nm; ++k) hv[k] = (float)pv[k];       // velv = real(pv), CalSurfG.f90:1492
+    if (ensure(velv, hv.size())) return status;
+    HIP_TRY(this, hipMemcpyAsync(velv.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, stream));
+    hmin_slow = 1e30f;
+    for (float v : hv) if (v > 0.0f && 1.0f / v < hmin_slow) hmin_slow = 1.0f / v;
+    return finish_maps(nm);
+}
+
+// velv (nm maps of fp32 vertex values) is on the device and g / hmin_slow are set: tables + dicing
+int Engine::finish_maps(int nm)
+{
     if (g.nnx > 32767 || g.nnz > 32767) { fail(DSA_ERR_ARGUMENT, "grid %dx%d exceeds the 32767-node index range", g.nnx, g.nnz); return DSA_ERR_ARGUMENT; }
     nmaps = nm;
     nfield = (size_t)g.nnx * g.nnz;
     nrec_c = (size_t)g.nbx * g.nbz * kTileRecs;
-    const size_t nv = (size_t)nx * ny;
-    std::vector<float> hv(nv * nm);
-    for (size_t k = 0; k < nv * nm; ++k) hv[k] = (float)pv[k];       // velv = real(pv), CalSurfG.f90:1492
-    hmin_slow = 1e30f;
-    for (float v : hv) if (v > 0.0f && 1.0f / v < hmin_slow) hmin_slow = 1.0f / v;
+    const size_t nv = (size_t)g.nx * g.ny;
+    const int dicing = g.gdx;
     std::vector<float> cb(4 * (dicing + 1)), rb(4 * (dicing * kSgdl + 1)), rc(g.nnx);
     basis_table(dicing, cb.data());
     basis_table(dicing * kSgdl, rb.data());
     risti_table(g.gox, g.dnx, g.earth, g.nnx, rc.data());
     dpl = min_cell_km(g);
-    if (ensure(velv, hv.size()) || ensure(veln, nfield * nm) || ensure(slow, nrec_c * nm) || ensure(risti_c, rc.size()) ||
+    if (ensure(veln, nfield * nm) || ensure(slow, nrec_c * nm) || ensure(risti_c, rc.size()) ||
         ensure(cbasis, cb.size()) || ensure(rbasis, rb.size())) return status;
-    HIP_TRY(this, hipMemcpyAsync(velv.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(cbasis.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(rbasis.p, rb.data(), rb.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(risti_c.p, rc.data(), rc.size() * 4, hipMemcpyHostToDevice, stream));
@@ -114,8 +126,120 @@ int Engine::set_maps(int nx, int ny, float goxd, float gozd, float dvxd, float d
     return 0;
 }
 
+// ---- dispersion stage -----------------------------------------------------------------------------
+int Engine::dispersion_begin(int nx, int ny, int nz, const float* vels, const float* depz, float minthk, int kmax_total, int nmaps_total)
+{
+    if (nx < 1 || ny < 1 || nz < 2 || nz > 64 || !vels || !depz || kmax_total < 1 || nmaps_total < 1 || !(minthk > 0.0f)) { fail(DSA_ERR_ARGUMENT, "dispersion: bad arguments (nx=%d ny=%d nz=%d kmax=%d)", nx, ny, nz, kmax_total); return DSA_ERR_ARGUMENT; }
+    HIP_TRY(this, hipSetDevice(device));
+    if (make_layer_geom(nz, depz, minthk, h_geom) != 0) { fail(DSA_ERR_ARGUMENT, "dispersion: the refined column exceeds %d layers", kMaxLayers); return DSA_ERR_ARGUMENT; }
+    const size_t ncol = (size_t)nx * ny;
+    disp_nx = nx; disp_ny = ny; disp_nz = nz; disp_kmax_total = kmax_total; disp_nmaps = nmaps_total;
+    h_depz.assign(depz, depz + nz);
+    const size_t nsen = ncol * kmax_total * nz;
+    if (ensure(geom, 1) || ensure(vels_d, ncol * nz) || ensure(pvstore, ncol * nmaps_total) || ensure(sen_vs, nsen) || ensure(sen_vp, nsen) || ensure(sen_rho, nsen)) return status;
+    HIP_TRY(this, hipMemcpyAsync(geom.p, &h_geom, sizeof(LayerGeom), hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipMemcpyAsync(vels_d.p, vels, ncol * nz * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipMemsetAsync(pvstore.p, 0, ncol * nmaps_total * 8, stream));
+    HIP_TRY(this, hipMemsetAsync(sen_vs.p, 0, nsen * 8, stream));
+    HIP_TRY(this, hipMemsetAsync(sen_vp.p, 0, nsen * 8, stream));
+    HIP_TRY(this, hipMemsetAsync(sen_rho.p, 0, nsen * 8, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    disp_ready = true;
+    have_sens = false;
+    stats[DSA_STAT_MS_DISPERSION] = 0.0;
+    stats[DSA_STAT_CURVES] = 0.0;
+    return 0;
+}
+
+// one wave type: nper periods -> maps [map_first, map_first + nper) and, with kernels, depth-kernel
+// slots [sen_slot, sen_slot + nper)
+int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int with_kernels, int sen_slot, int map_first)
+{
+    if (!disp_ready) { fail(DSA_ERR_STATE, "dispersion: call dsa_dispersion_begin first"); return DSA_ERR_STATE; }
+    if (nper <= 0) return 0;
+    if ((iwave != 1 && iwave != 2) || nper > kMaxPeriods || !t || map_first < 0 || map_first + nper > disp_nmaps ||
+        (with_kernels && (sen_slot < 0 || sen_slot + nper > disp_kmax_total))) { fail(DSA_ERR_ARGUMENT, "dispersion: bad arguments (iwave=%d nper=%d map=%d slot=%d)", iwave, nper, map_first, sen_slot); return DSA_ERR_ARGUMENT; }
+    HIP_TRY(this, hipSetDevice(device));
+    const int ncol = disp_nx * disp_ny;
+    const int npert = with_kernels ? 1 + 6 * disp_nz : 1;
+    const size_t nlanes = (size_t)ncol * npert;
+    if (ensure(curves, nlanes * nper) || ensure(disp_ws, (size_t)4 * h_geom.rmax * nlanes) || ensure(tper, kMaxPeriods)) return status;
+    HIP_TRY(this, hipMemcpyAsync(tper.p, t, (size_t)nper * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipEventRecord(events[1], stream));
+    launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, stream);
+    launch_depth_kernels(vels_d.p, ncol, disp_nz, nper, curves.p, with_kernels, pvstore.p + (size_t)map_first * ncol, sen_vs.p, sen_vp.p, sen_rho.p,
+                         disp_kmax_total, sen_slot, stream);
+    HIP_TRY(this, hipEventRecord(events[2], stream));
+    HIP_TRY(this, hipGetLastError());
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    float ms = 0;
+    HIP_TRY(this, hipEventElapsedTime(&ms, events[1], events[2]));
+    stats[DSA_STAT_MS_DISPERSION] += ms;
+    stats[DSA_STAT_CURVES] += (double)nlanes;
+    return 0;
+}
+
+int Engine::dispersion_copy_map(int from, int to, int n)
+{
+    if (!disp_ready || from < 0 || to < 0 || n < 0 || from + n > disp_nmaps || to + n > disp_nmaps) { fail(DSA_ERR_ARGUMENT, "dispersion: bad map copy"); return DSA_ERR_ARGUMENT; }
+    const size_t ncol = (size_t)disp_nx * disp_ny;
+    HIP_TRY(this, hipSetDevice(device));
+    if (n) HIP_TRY(this, hipMemcpyAsync(pvstore.p + (size_t)to * ncol, pvstore.p + (size_t)from * ncol, (size_t)n * ncol * 8, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    return 0;
+}
+
+// host copies in the reference's per-type layouts: pv(ncol, nper), sen(ncol, nper, nz)
+int Engine::dispersion_fetch(int map_first, int nper, double* pv, int with_kernels, int sen_slot, double* svs, double* svp, double* srho)
+{
+    if (!disp_ready || nper < 0 || map_first < 0 || map_first + nper > disp_nmaps) { fail(DSA_ERR_ARGUMENT, "dispersion: bad fetch"); return DSA_ERR_ARGUMENT; }
+    HIP_TRY(this, hipSetDevice(device));
+    const size_t ncol = (size_t)disp_nx * disp_ny;
+    if (pv && nper) HIP_TRY(this, hipMemcpy(pv, pvstore.p + (size_t)map_first * ncol, (size_t)nper * ncol * 8, hipMemcpyDeviceToHost));
+    if (with_kernels && nper) {
+        if (sen_slot < 0 || sen_slot + nper > disp_kmax_total || !svs || !svp || !srho) { fail(DSA_ERR_ARGUMENT, "dispersion: bad kernel fetch"); return DSA_ERR_ARGUMENT; }
+        double* dst[3] = { svs, svp, srho };
+        const double* srcs[3] = { sen_vs.p, sen_vp.p, sen_rho.p };
+        for (int q = 0; q < 3; ++q)
+            for (int i = 0; i < disp_nz; ++i)
+                HIP_TRY(this, hipMemcpy(dst[q] + (size_t)i * nper * ncol, srcs[q] + ((size_t)i * disp_kmax_total + sen_slot) * ncol, (size_t)nper * ncol * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int Engine::maps_from_dispersion(float goxd, float gozd, float dvxd, float dvzd, int dicing)
+{
+    if (!disp_ready) { fail(DSA_ERR_STATE, "maps: call dsa_dispersion_begin / run first"); return DSA_ERR_STATE; }
+    if (disp_nx < 4 || disp_ny < 4 || dicing < 1 || dicing > 16) { fail(DSA_ERR_ARGUMENT, "maps: bad arguments"); return DSA_ERR_ARGUMENT; }
+    HIP_TRY(this, hipSetDevice(device));
+    make_grid(g, disp_nx, disp_ny, goxd, gozd, dvxd, dvzd, dicing);
+    const size_t n = (size_t)disp_nx * disp_ny * disp_nmaps;
+    if (ensure(velv, n)) return status;
+    launch_to_float(pvstore.p, velv.p, n, stream);
+    std::vector<float> hv(n);
+    HIP_TRY(this, hipMemcpyAsync(hv.data(), velv.p, n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    hmin_slow = 1e30f;
+    for (float v : hv) if (v > 0.0f && 1.0f / v < hmin_slow) hmin_slow = 1.0f / v;
+    if (!(hmin_slow < 1e30f)) { fail(DSA_ERR_INTERNAL, "maps: no positive phase velocity came out of the dispersion stage"); return DSA_ERR_INTERNAL; }
+    return finish_maps(disp_nmaps);
+}
+
+int Engine::kernels_from_dispersion()
+{
+    if (!disp_ready) { fail(DSA_ERR_STATE, "depth kernels: call dsa_dispersion_begin / run first"); return DSA_ERR_STATE; }
+    HIP_TRY(this, hipSetDevice(device));
+    const size_t ncol = (size_t)disp_nx * disp_ny;
+    if (ensure(Srow, ncol * disp_kmax_total * (disp_nz - 1))) return status;
+    launch_sen_combine((int)ncol, disp_kmax_total, disp_nz, vels_d.p, sen_vs.p, sen_vp.p, sen_rho.p, h_depz[disp_nz - 2] < 35.0f ? 1 : 0, Srow.p, stream);
+    HIP_TRY(this, hipGetLastError());
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    sens_nz = disp_nz; sens_kmax = disp_kmax_total; have_sens = true;
+    return 0;
+}
+
 int Engine::plan(int nunits, const int* map_index, const float* scx, const float* scz, const int* nrec,
-                 const float* rcx, const float* rcz)
+                 const float* rcx, const float* rcz, const int* mode, const int* sen_slot, const int* data_first)
 {
     if (!have_maps) { fail(DSA_ERR_STATE, "plan: call dsa_set_maps first"); return DSA_ERR_STATE; }
     if (nunits < 0 || (nunits > 0 && (!map_index || !scx || !scz || !nrec))) { fail(DSA_ERR_ARGUMENT, "plan: bad arguments"); return DSA_ERR_ARGUMENT; }
@@ -133,12 +257,15 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         s.period = map_index[u];
         s.first_ray = (int)nr;
         s.nrec = nrec[u];
+        s.sen_slot = sen_slot ? sen_slot[u] : 0;
         if (nrec[u] < 0) { fail(DSA_ERR_ARGUMENT, "plan: negative receiver count"); return DSA_ERR_ARGUMENT; }
         nr += (size_t)nrec[u];
         risti_table(s.rgox, s.rdnx, g.earth, s.rnx, &h_risti_r[(size_t)u * kRefMax]);
     }
     if (nr > 0 && (!rcx || !rcz)) { fail(DSA_ERR_ARGUMENT, "plan: receivers missing"); return DSA_ERR_ARGUMENT; }
     h_rays.resize(nr);
+    h_trace.clear();
+    ndata = 0;
     for (int u = 0; u < nunits; ++u)
         for (int k = 0; k < h_src[u].nrec; ++k) {
             const size_t r = (size_t)h_src[u].first_ray + k;
@@ -148,7 +275,12 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
                 fail(DSA_ERR_OUTSIDE, "Receiver lies outside model (lat,long)= %g %g", 90.0 - rx * 180.0 / kPi, rz * 180.0 / kPi);
                 return DSA_ERR_OUTSIDE;
             }
-            h_rays[r] = RayDesc{ u, rx, rz, sinf(rx) };
+            const int fl = mode ? (mode[u] & (kRayTime | kRayPath)) : (kRayTime | kRayPath);
+            const int data = (data_first ? data_first[u] : h_src[u].first_ray) + k;
+            if (data < 0 || (k == 0 && u > 0 && h_src[u - 1].nrec > 0 && data < h_rays[h_src[u - 1].first_ray].data)) { fail(DSA_ERR_ARGUMENT, "plan: data indices must be non-negative and non-decreasing (unit %d)", u); return DSA_ERR_ARGUMENT; }
+            h_rays[r] = RayDesc{ u, rx, rz, sinf(rx), data, fl };
+            if (fl & kRayPath) h_trace.push_back((int)r);
+            ndata = std::max(ndata, (size_t)data + 1);
         }
     // chunk size from the memory budget
     size_t free_b = 0, total_b = 0;
@@ -163,13 +295,14 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
     const size_t C = (size_t)chunk;
     { const FimLaunch lc = launch_shape(g.nnx, g.nnz); lists_stride = (size_t)2 * lc.list_cap + lc.ready_cap; }
-    if (ensure(lists, C * lists_stride) || ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(nr, 1)) || ensure(err, 4) ||
+    if (ensure(lists, C * lists_stride) || ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(ndata, 1)) || ensure(trace_ids, std::max<size_t>(h_trace.size(), 1)) || ensure(err, 4) ||
         ensure(slow_r, C * kRefRecs) || ensure(F_r, C * kRefRecs) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(F_c, C * nrec_c) ||
         ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
+    if (!h_trace.empty()) HIP_TRY(this, hipMemcpyAsync(trace_ids.p, h_trace.data(), h_trace.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = true;
     last_chunk_first = -1;
@@ -186,12 +319,21 @@ BatchPtrs Engine::batch() const
     return b;
 }
 
-int Engine::solve(float* dsurf)
+int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, long long* nar)
 {
     if (!planned) { fail(DSA_ERR_STATE, "solve: call dsa_plan first"); return DSA_ERR_STATE; }
+    const bool rows = rw && iw && col && nar;
+    if (rows && !have_sens) { fail(DSA_ERR_STATE, "solve: Frechet rows need the depth kernels (dsa_set_depth_kernels / dsa_depthkernel) first"); return DSA_ERR_STATE; }
+    if (rows) {
+        *nar = 0;
+        for (const SourceDesc& s : h_src)
+            if (s.sen_slot < 0 || s.sen_slot >= sens_kmax) { fail(DSA_ERR_ARGUMENT, "solve: a unit uses depth-kernel slot %d of %d", s.sen_slot, sens_kmax); return DSA_ERR_ARGUMENT; }
+    }
     HIP_TRY(this, hipSetDevice(device));
     const int nunits = (int)h_src.size();
-    std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
+    { const double keep_ms = stats[DSA_STAT_MS_DISPERSION], keep_n = stats[DSA_STAT_CURVES];
+      std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
+      stats[DSA_STAT_MS_DISPERSION] = keep_ms; stats[DSA_STAT_CURVES] = keep_n; }
     std::fill(phase_ticks, phase_ticks + 8, 0.0);
     stats[DSA_STAT_UNITS] = nunits;
     stats[DSA_STAT_CHUNK] = chunk;
@@ -230,8 +372,10 @@ int Engine::solve(float* dsurf)
         h_flags.resize((size_t)n * 4);
         HIP_TRY(this, hipMemcpyAsync(h_info.data(), info.p, (size_t)n * 16 * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipMemcpyAsync(h_flags.data(), flags.p, (size_t)n * 4 * 4, hipMemcpyDeviceToHost, stream));
-        if (dsurf && r1 > r0)
-            HIP_TRY(this, hipMemcpyAsync(dsurf + r0, out.p + r0, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, stream));
+        if (dsurf && r1 > r0) {
+            const int d0 = h_rays[r0].data, d1 = h_rays[r1 - 1].data + 1;
+            HIP_TRY(this, hipMemcpyAsync(dsurf + d0, out.p + d0, (size_t)(d1 - d0) * 4, hipMemcpyDeviceToHost, stream));
+        }
         std::vector<unsigned long long> h_clk((size_t)n * 8);
         HIP_TRY(this, hipMemcpyAsync(h_clk.data(), clocks.p, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipStreamSynchronize(stream));
@@ -263,6 +407,7 @@ int Engine::solve(float* dsurf)
         }
         last_chunk_first = first;
         last_chunk_n = n;
+        if (rows && trace_chunk(first, n, rw, iw, col, cap, nar) != 0) return status;
     }
     HIP_TRY(this, hipEventRecord(events[7], stream));
     HIP_TRY(this, hipEventSynchronize(events[7]));
@@ -287,7 +432,98 @@ FimLaunch Engine::launch_shape(int nnx, int nnz) const
 
 void Engine::launch_srtimes_chunk(int r0, int nr, int first_unit)
 {
-    launch_srtimes(g, batch(), first_unit, rays.p + r0, nr, veln.p, nfield, dpl, out.p + r0, err.p, stream);
+    launch_srtimes(g, batch(), first_unit, rays.p + r0, nr, veln.p, nfield, dpl, out.p, err.p, stream);
+}
+
+// Depth kernels of the Frechet rows: sen_*(nx*ny, kmax, nz) fp64 and the Vs model vels(nx, ny, nz)
+// in the reference's layout (CalSurfG.f90:1005-1016).  on_device: the sen pointers are the engine's
+// own device arrays (filled by the dispersion stage); else host arrays to upload.
+int Engine::set_sensitivity(int nz, int kmax, const float* vels, const float* depz, const double* svs, const double* svp,
+                            const double* srho, bool on_device)
+{
+    if (!have_maps) { fail(DSA_ERR_STATE, "depth kernels: call dsa_set_maps first"); return DSA_ERR_STATE; }
+    if (nz < 2 || kmax < 1 || !vels || !depz) { fail(DSA_ERR_ARGUMENT, "depth kernels: bad arguments"); return DSA_ERR_ARGUMENT; }
+    HIP_TRY(this, hipSetDevice(device));
+    const size_t ncol = (size_t)g.nx * g.ny, n = ncol * kmax * nz;
+    if (ensure(Srow, ncol * kmax * (nz - 1)) || ensure(vels_d, ncol * nz)) return status;
+    HIP_TRY(this, hipMemcpyAsync(vels_d.p, vels, ncol * nz * 4, hipMemcpyHostToDevice, stream));
+    if (!on_device) {
+        if (!svs || !svp || !srho) { fail(DSA_ERR_ARGUMENT, "depth kernels: arrays missing"); return DSA_ERR_ARGUMENT; }
+        if (ensure(sen_vs, n) || ensure(sen_vp, n) || ensure(sen_rho, n)) return status;
+        HIP_TRY(this, hipMemcpyAsync(sen_vs.p, svs, n * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(this, hipMemcpyAsync(sen_vp.p, svp, n * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(this, hipMemcpyAsync(sen_rho.p, srho, n * 8, hipMemcpyHostToDevice, stream));
+    }
+    launch_sen_combine((int)ncol, kmax, nz, vels_d.p, sen_vs.p, sen_vp.p, sen_rho.p, depz[nz - 2] < 35.0f ? 1 : 0, Srow.p, stream);
+    HIP_TRY(this, hipGetLastError());
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    sens_nz = nz; sens_kmax = kmax; have_sens = true;
+    return 0;
+}
+
+// rays and rows of the resident chunk [first_unit, first_unit + n): launches of at most `per`
+// rays (slab memory), each: zero slabs -> trace -> list -> count -> scan -> write -> copy out
+int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, long long cap, long long* nar)
+{
+    const int r0 = h_src[first_unit].first_ray;
+    const int r1 = h_src[first_unit + n - 1].first_ray + h_src[first_unit + n - 1].nrec;
+    const size_t t0 = std::lower_bound(h_trace.begin(), h_trace.end(), r0) - h_trace.begin();
+    const size_t t1 = std::lower_bound(h_trace.begin(), h_trace.end(), r1) - h_trace.begin();
+    if (t1 <= t0) return 0;
+    const size_t slab_stride = (size_t)(g.nvx + 2) * (g.nvz + 2), vlist_stride = (size_t)g.nvx * g.nvz;
+    const size_t per_ray = (slab_stride + vlist_stride) * 4 + 32;
+    size_t budget = ray_budget;
+    if (!budget) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+        budget = std::min<size_t>((size_t)8 << 30, free_b / 4 + slabs.cap * 4 + vlist.cap * 4);
+    }
+    size_t per = std::max<size_t>(budget / per_ray, 64);
+    per = std::min<size_t>(per, (size_t)0x7fffffff / (vlist_stride * (size_t)(sens_nz - 1)));   // int offsets
+    per = std::max<size_t>(std::min(per, t1 - t0), 1);
+    if (ensure(slabs, per * slab_stride) || ensure(vlist, per * vlist_stride) || ensure(nvv, per) || ensure(counts, per) ||
+        ensure(offsets, per + 1) || ensure(rayinfo, per * 2)) return status;
+    std::vector<int32_t> h_info;
+    hipEvent_t ea = events[1], eb = events[2], ec = events[3];
+    for (size_t t = t0; t < t1; t += per) {
+        const int m = (int)std::min(per, t1 - t);
+        HIP_TRY(this, hipEventRecord(ea, stream));
+        HIP_TRY(this, hipMemsetAsync(slabs.p, 0, (size_t)m * slab_stride * 4, stream));
+        launch_rays(g, batch(), first_unit, rays.p, trace_ids.p + t, m, veln.p, nfield, dpl, slabs.p, slab_stride, rayinfo.p, err.p, stream);
+        HIP_TRY(this, hipEventRecord(eb, stream));
+        RowArgs a{};
+        a.rays = rays.p; a.trace_ids = trace_ids.p + t; a.n = m; a.src = src.p; a.unit_base = first_unit;
+        a.slabs = slabs.p; a.slab_stride = slab_stride; a.vlist = vlist.p; a.vlist_stride = vlist_stride; a.nv = nvv.p;
+        a.S = Srow.p; a.kmax = sens_kmax; a.nz = sens_nz; a.counts = counts.p; a.offsets = offsets.p;
+        launch_row_list(g, a, stream);
+        launch_row_emit(g, a, false, stream);
+        launch_scan(counts.p, m, offsets.p, stream);
+        int total = 0;
+        HIP_TRY(this, hipMemcpyAsync(&total, offsets.p + m, 4, hipMemcpyDeviceToHost, stream));
+        h_info.resize((size_t)m * 2);
+        HIP_TRY(this, hipMemcpyAsync(h_info.data(), rayinfo.p, (size_t)m * 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(this, hipStreamSynchronize(stream));
+        if (*nar + total > cap) { fail(DSA_ERR_ARGUMENT, "Frechet rows need more than the %lld entries provided", cap); return DSA_ERR_ARGUMENT; }
+        if (total > 0) {
+            if (ensure(coo_rw, (size_t)total) || ensure(coo_iw, (size_t)total) || ensure(coo_col, (size_t)total)) return status;
+            a.rw = coo_rw.p; a.iw = coo_iw.p; a.col = coo_col.p;
+            launch_row_emit(g, a, true, stream);
+            HIP_TRY(this, hipMemcpyAsync(rw + *nar, coo_rw.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(this, hipMemcpyAsync(iw + *nar, coo_iw.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(this, hipMemcpyAsync(col + *nar, coo_col.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(this, hipEventRecord(ec, stream));
+        HIP_TRY(this, hipStreamSynchronize(stream));
+        HIP_TRY(this, hipGetLastError());
+        *nar += total;
+        float ms = 0;
+        HIP_TRY(this, hipEventElapsedTime(&ms, ea, eb)); stats[DSA_STAT_MS_RAYS] += ms;
+        HIP_TRY(this, hipEventElapsedTime(&ms, eb, ec)); stats[DSA_STAT_MS_ROWS] += ms;
+        stats[DSA_STAT_RAYS] += m;
+        for (int q = 0; q < m; ++q) { stats[DSA_STAT_RAY_STEPS] += h_info[2 * q + 1]; stats[DSA_STAT_RAYS_CLAMPED] += h_info[2 * q] & 1; }
+    }
+    stats[DSA_STAT_NAR] = (double)*nar;
+    return 0;
 }
 
 // download tiled records and untile on the host: which = 0 -> T (raw), 1 -> tau (raw)
@@ -375,6 +611,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "max_chunk" && value >= 0) { en->max_chunk = (int)value; return 0; }
     if (n == "list_cap" && value >= 0) { en->list_cap = (int)value; return 0; }
     if (n == "ready_cap" && value >= 0) { en->ready_cap = (int)value; return 0; }
+    if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
     if (n == "fim_threads" && (value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;
@@ -389,13 +626,68 @@ int dsa_set_maps(dsa_engine* e, int nx, int ny, float goxd, float gozd, float dv
 int dsa_plan(dsa_engine* e, int nunits, const int* map_index, const float* scx, const float* scz, const int* nrec, const float* rcx, const float* rcz)
 {
     if (!e) return DSA_ERR_ARGUMENT;
-    return reinterpret_cast<Engine*>(e)->plan(nunits, map_index, scx, scz, nrec, rcx, rcz);
+    return reinterpret_cast<Engine*>(e)->plan(nunits, map_index, scx, scz, nrec, rcx, rcz, nullptr, nullptr, nullptr);
+}
+
+int dsa_plan_units(dsa_engine* e, int nunits, const int* map_index, const float* scx, const float* scz, const int* nrec, const float* rcx, const float* rcz,
+                   const int* mode, const int* sen_slot, const int* data_first)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->plan(nunits, map_index, scx, scz, nrec, rcx, rcz, mode, sen_slot, data_first);
+}
+
+int dsa_set_depth_kernels(dsa_engine* e, int nz, int kmax, const float* vels, const float* depz, const double* sen_vs, const double* sen_vp, const double* sen_rho)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->set_sensitivity(nz, kmax, vels, depz, sen_vs, sen_vp, sen_rho, false);
+}
+
+int dsa_dispersion_begin(dsa_engine* e, int nx, int ny, int nz, const float* vels, const float* depz, float minthk, int kmax_total, int nmaps_total)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->dispersion_begin(nx, ny, nz, vels, depz, minthk, kmax_total, nmaps_total);
+}
+
+int dsa_dispersion_run(dsa_engine* e, int iwave, int igr, int nper, const double* t, int with_kernels, int sen_slot, int map_first)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->dispersion_run(iwave, igr, nper, t, with_kernels, sen_slot, map_first);
+}
+
+int dsa_dispersion_copy_maps(dsa_engine* e, int from, int to, int n)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->dispersion_copy_map(from, to, n);
+}
+
+int dsa_dispersion_fetch(dsa_engine* e, int map_first, int nper, double* pv, int with_kernels, int sen_slot, double* sen_vs, double* sen_vp, double* sen_rho)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->dispersion_fetch(map_first, nper, pv, with_kernels, sen_slot, sen_vs, sen_vp, sen_rho);
+}
+
+int dsa_maps_from_dispersion(dsa_engine* e, float goxd, float gozd, float dvxd, float dvzd, int dicing)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->maps_from_dispersion(goxd, gozd, dvxd, dvzd, dicing);
+}
+
+int dsa_kernels_from_dispersion(dsa_engine* e)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->kernels_from_dispersion();
 }
 
 int dsa_solve(dsa_engine* e, float* dsurf)
 {
     if (!e) return DSA_ERR_ARGUMENT;
-    return reinterpret_cast<Engine*>(e)->solve(dsurf);
+    return reinterpret_cast<Engine*>(e)->solve(dsurf, nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+int dsa_solve_rows(dsa_engine* e, float* dsurf, float* rw, int* iw, int* col, long long capacity, long long* nar)
+{
+    if (!e || !rw || !iw || !col || !nar) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<Engine*>(e)->solve(dsurf, rw, iw, col, capacity, nar);
 }
 
 int dsa_get_dims(const dsa_engine* e, int* nnx, int* nnz)

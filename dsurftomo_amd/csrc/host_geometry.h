@@ -6,6 +6,7 @@
 
 #include <math.h>
 
+#include "dispersion_core.h"
 #include "source_stage.h"
 
 namespace dsa {
@@ -97,7 +98,45 @@ inline int make_source(const GridDesc& g, float x, float z, SourceDesc& s)
     s.cwnz = ez - s.cwz0;
     s.nbx_r = (s.rnx + 7) / 8;
     s.nbz_r = (s.rnz + 7) / 8;
-    s.period = 0; s.first_ray = 0; s.nrec = 0;
+    s.period = 0; s.first_ray = 0; s.nrec = 0; s.sen_slot = 0;
+    return 0;
+}
+
+// Velocity-independent layer geometry of a call: sublayer counts and thicknesses of
+// refineGrid2LayerMdl (CalSurfG.f90:2352-2411) pushed through the earth-flattening transform of
+// `sphere` (surfdisp96.f:480-547) with libm log / powf.  Returns 0, or -1 when the refined model
+// exceeds the reference's NL = 200 layers.
+inline int make_layer_geom(int nz, const float* depz, float minthk0, LayerGeom& G)
+{
+    G.nz = nz;
+    float thk[kMaxLayers];
+    int k = 0;
+    for (int i = 1; i <= nz - 1; ++i) {
+        const float t = depz[i] - depz[i - 1];
+        const float minthk = t / minthk0;
+        const int nsub = (int)((t + 1.0e-4f) / minthk) + 1;
+        if (nsub < 1 || k + nsub + 1 > kMaxLayers) return -1;
+        G.nsub[i - 1] = nsub;
+        const float newthk = t / (float)nsub;
+        for (int j = 0; j < nsub; ++j) thk[k++] = newthk;
+    }
+    thk[k++] = 1.0f;              // sphere() gives the half space unit thickness before flattening
+    G.rmax = k;
+    const double ar = 6370.0;
+    double dr = 0.0, r0 = ar;
+    for (int i = 0; i < k; ++i) {
+        dr = dr + (double)thk[i];
+        const double r1 = ar - dr;
+        const double z0 = ar * log(ar / r0);
+        const double z1 = ar * log(ar / r1);
+        G.dflat[i] = (float)(z1 - z0);
+        const double tmp = (ar + ar) / (r0 + r1);
+        G.tmp[i] = tmp;
+        const float x = (float)tmp, x2 = x * x;
+        G.rhofac_love[i] = 1.0f / (x * (x2 * x2));        // btp**(-5): binary powering, then the reciprocal
+        G.rhofac_rayl[i] = powf(x, -2.275f);
+        r0 = r1;
+    }
     return 0;
 }
 

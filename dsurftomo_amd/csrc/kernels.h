@@ -75,10 +75,49 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           hipStream_t stream);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
-struct RayDesc { int src; float rx, rz; float sin_rx; };   // sin_rx = libm sinf(rx), made on the host
+// data = 0-based index of the datum (travel time / Frechet row) this ray belongs to;
+// flags: kRayTime = write the receiver time, kRayPath = trace the ray and emit its row
+struct RayDesc { int src; float rx, rz; float sin_rx; int data; int flags; };   // sin_rx = libm sinf(rx), made on the host
+constexpr int kRayTime = 1, kRayPath = 2;
 // RayDesc::src is a global unit index; unit_base is the first unit held by the batch arrays
 void launch_srtimes(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, int nrays,
                     const float* d_veln_all, size_t field_stride, float dpl, float* d_out, int32_t* d_err,
                     hipStream_t stream);
+
+// rays and Frechet rows (ray_kernels.hip) ------------------------------------------------------------
+// trace_ids: indices into d_rays of the rays to trace (flag kRayPath), `n` of them; ray t of the
+// launch owns slab t (slab_stride floats, zeroed by the caller) and rayinfo[2t..2t+1] = (flags, steps)
+void launch_rays(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, const int* d_trace_ids, int n,
+                 const float* d_veln_all, size_t field_stride, float dpl, float* d_slabs, size_t slab_stride,
+                 int32_t* d_rayinfo, int32_t* d_err, hipStream_t stream);
+
+// S[(k * kmax + slot) * ncol + c] = (sen_vp * coe_a + sen_rho * coe_rho) + sen_vs, the depth-kernel
+// factor of a Frechet row entry (reference CalSurfG.f90:1395-1423); vels: (nz, ny*nx) fp32
+void launch_sen_combine(int ncol, int kmax, int nz, const float* d_vels, const double* d_sen_vs, const double* d_sen_vp,
+                        const double* d_sen_rho, int shallow, double* d_S, hipStream_t stream);
+
+struct RowArgs {
+    const RayDesc* rays; const int* trace_ids; int n;      // the rays of this launch
+    const SourceDesc* src; int unit_base;
+    const float* slabs; size_t slab_stride;
+    int* vlist; size_t vlist_stride; int* nv;              // kept vertices per ray (scan order jj outer, kk inner)
+    const double* S; int kmax, nz;
+    int* counts;                                           // entries per ray
+    const int* offsets;                                    // exclusive scan of counts
+    float* rw; int* iw; int* col;                          // COO out: value, 1-based row, 1-based column
+};
+void launch_row_list(const GridDesc& g, const RowArgs& a, hipStream_t stream);
+void launch_row_emit(const GridDesc& g, const RowArgs& a, bool write, hipStream_t stream);
+// offsets[0..n] = exclusive prefix sums of counts[0..n-1]
+void launch_scan(const int* d_counts, int n, int* d_offsets, hipStream_t stream);
+
+// dispersion (disp_kernels.hip) ---------------------------------------------------------------------
+struct LayerGeom;
+// curves: (npert, kmax, ncol) fp64; ws: 4 * rmax * nlanes floats of layer workspace; iwave 1 Love, 2 Rayleigh
+void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
+                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, hipStream_t stream);
+void launch_depth_kernels(const float* d_vels, int ncol, int nz, int kmax, const double* d_curves, int with_kernels, double* d_pv,
+                          double* d_sen_vs, double* d_sen_vp, double* d_sen_rho, int kmax_total, int slot0, hipStream_t stream);
+void launch_to_float(const double* d_in, float* d_out, size_t n, hipStream_t stream);
 
 }  // namespace dsa

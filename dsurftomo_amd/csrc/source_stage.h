@@ -50,6 +50,7 @@ struct SourceDesc {
     int cwz0, cwx0, cwnz, cwnx;   // coarse march window
     int nbx_r, nbz_r;             // 8x8 tiles of the refined grid
     int first_ray, nrec;          // receivers of this source: rays [first_ray, first_ray+nrec)
+    int sen_slot;                 // period slot of the depth kernels used by this unit's Frechet rows
 };
 
 // per-source scratch in device memory (all sources of a batch laid out back to back)

@@ -310,6 +310,7 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrays) return;
     const RayDesc rd = rays[r];
+    if (!(rd.flags & kRayTime)) return;
     const int slot = rd.src - unit_base;
     const SourceDesc sd = b.src[slot];
     const Rec* F = b.F_c + (size_t)slot * g.nbx * g.nbz * kTileRecs;
@@ -318,7 +319,7 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
     const float rcx1 = rd.rx, rcz1 = rd.rz, scx = sd.scx, scz = sd.scz;
     int irx = (int)((rcx1 - gox) / dnx) + 1;
     int irz = (int)((rcz1 - goz) / dnz) + 1;
-    if (irx < 1 || irx > g.nnx || irz < 1 || irz > g.nnz) { atomicExch(err, r + 1); out[r] = 0.0f; return; }
+    if (irx < 1 || irx > g.nnx || irz < 1 || irz > g.nnz) { atomicExch(err, r + 1); out[rd.data] = 0.0f; return; }
     if (irx == g.nnx) irx -= 1;
     if (irz == g.nnz) irz -= 1;
     const int isx = (int)((scx - gox) / dnx) + 1;
@@ -359,7 +360,7 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
                 trr = trr + t_value(F[rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1)].T) * produ;
             }
     }
-    out[r] = trr;
+    out[rd.data] = trr;
 }
 
 void launch_srtimes(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, int nrays,

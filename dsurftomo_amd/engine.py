@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsurftomo_amd.so")
 
 STAT_NAMES = ("ms_total", "ms_fim_coarse", "ms_fim_refined", "ms_stages", "launches_fim_coarse", "units",
-              "rounds_max", "evals_total", "chunk", "rescans", "freezes")
+              "rounds_max", "evals_total", "chunk", "rescans", "freezes", "rays", "ray_steps", "rays_clamped",
+              "ms_rays", "ms_rows", "nar", "ms_dispersion", "curves")
 
 _f32, _i32, _vp = C.c_float, C.c_int, C.c_void_p
 _lib = None
@@ -43,6 +44,15 @@ def load_library():
     L.dsa_set_maps.argtypes = [_vp, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _i32, _vp]
     L.dsa_plan.argtypes = [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
     L.dsa_solve.argtypes = [_vp, _vp]
+    L.dsa_plan_units.argtypes = [_vp, _i32] + [_vp] * 9
+    L.dsa_set_depth_kernels.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
+    L.dsa_solve_rows.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.dsa_dispersion_begin.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp, _f32, _i32, _i32]
+    L.dsa_dispersion_run.argtypes = [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32]
+    L.dsa_dispersion_copy_maps.argtypes = [_vp, _i32, _i32, _i32]
+    L.dsa_dispersion_fetch.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]
+    L.dsa_maps_from_dispersion.argtypes = [_vp, _f32, _f32, _f32, _f32, _i32]
+    L.dsa_kernels_from_dispersion.argtypes = [_vp]
     L.dsa_get_dims.argtypes = [_vp, C.POINTER(_i32), C.POINTER(_i32)]
     L.dsa_keep_fields.argtypes = [_vp, _i32]
     L.dsa_get_field.argtypes = [_vp, _i32, _vp]
@@ -69,6 +79,8 @@ class Engine:
         self._h = h
         self.nnx = self.nnz = 0
         self._nrays = 0
+        self._ndata = 0
+        self._disp = (0, 0, 0)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -95,7 +107,8 @@ class Engine:
         self._check(self._L.dsa_get_dims(self._h, C.byref(a), C.byref(b)))
         self.nnx, self.nnz = a.value, b.value
 
-    def plan(self, map_index, scx, scz, nrec, rcx, rcz):
+    def plan(self, map_index, scx, scz, nrec, rcx, rcz, mode=None, sen_slot=None, data_first=None):
+        """mode / sen_slot / data_first: optional per-unit arrays (see dsa_plan_units)"""
         map_index = np.ascontiguousarray(map_index, np.int32)
         scx = np.ascontiguousarray(scx, np.float32)
         scz = np.ascontiguousarray(scz, np.float32)
@@ -108,12 +121,66 @@ class Engine:
         self._nrays = int(nrec.sum())
         if rcx.size != self._nrays or rcz.size != self._nrays:
             raise ValueError("receiver arrays must hold sum(nrec) entries")
-        self._check(self._L.dsa_plan(self._h, n, _p(map_index), _p(scx), _p(scz), _p(nrec), _p(rcx), _p(rcz)))
+        opt = [None if a is None else np.ascontiguousarray(a, np.int32) for a in (mode, sen_slot, data_first)]
+        if any(a is not None and a.size != n for a in opt):
+            raise ValueError("per-unit arrays differ in length")
+        self._ndata = self._nrays if opt[2] is None else (int((opt[2] + nrec).max()) if n else 0)
+        self._check(self._L.dsa_plan_units(self._h, n, _p(map_index), _p(scx), _p(scz), _p(nrec), _p(rcx), _p(rcz),
+                                           *[None if a is None else _p(a) for a in opt]))
 
     def solve(self, want_times=True):
-        out = np.zeros(self._nrays, np.float32) if want_times else None
+        out = np.zeros(self._ndata, np.float32) if want_times else None
         self._check(self._L.dsa_solve(self._h, _p(out) if want_times else None))
         return out
+
+    def set_depth_kernels(self, vels, depz, sen_vs, sen_vp, sen_rho):
+        """vels: (nz, ny, nx) fp32 [Fortran vels(nx,ny,nz)]; sen_*: (nz, kmax, ny*nx) fp64 [Fortran (nx*ny, kmax, nz)]"""
+        vels = np.ascontiguousarray(vels, np.float32)
+        depz = np.ascontiguousarray(depz, np.float32)
+        sen = [np.ascontiguousarray(a, np.float64) for a in (sen_vs, sen_vp, sen_rho)]
+        nz, kmax = sen[0].shape[0], sen[0].shape[1]
+        self._check(self._L.dsa_set_depth_kernels(self._h, nz, kmax, _p(vels), _p(depz), *[_p(a) for a in sen]))
+
+    def solve_rows(self, capacity):
+        """receiver times plus Frechet rows as COO (rw, row, col), rows / columns 1-based"""
+        out = np.zeros(self._ndata, np.float32)
+        rw = np.zeros(capacity, np.float32)
+        iw = np.zeros(capacity, np.int32)
+        col = np.zeros(capacity, np.int32)
+        nar = C.c_longlong(0)
+        self._check(self._L.dsa_solve_rows(self._h, _p(out), _p(rw), _p(iw), _p(col), capacity, C.byref(nar)))
+        n = nar.value
+        return out, rw[:n].copy(), iw[:n].copy(), col[:n].copy()
+
+    # ---- dispersion stage ------------------------------------------------------------------------
+    def dispersion_begin(self, vels, depz, minthk, kmax_total, nmaps_total):
+        """vels: (nz, ny, nx) fp32"""
+        vels = np.ascontiguousarray(vels, np.float32)
+        nz, ny, nx = vels.shape
+        self._disp = (nx, ny, nz)
+        self._check(self._L.dsa_dispersion_begin(self._h, nx, ny, nz, _p(vels), _p(np.ascontiguousarray(depz, np.float32)),
+                                                 float(minthk), int(kmax_total), int(nmaps_total)))
+
+    def dispersion_run(self, iwave, igr, t, kernels, sen_slot=0, map_first=0):
+        t = np.ascontiguousarray(t, np.float64)
+        self._check(self._L.dsa_dispersion_run(self._h, iwave, igr, t.size, _p(t), int(bool(kernels)), sen_slot, map_first))
+
+    def dispersion_fetch(self, map_first, nper, kernels=False, sen_slot=0):
+        nx, ny, nz = self._disp
+        pv = np.zeros((nper, nx * ny))
+        sen = [np.zeros((nz, nper, nx * ny)) for _ in range(3)] if kernels else [None] * 3
+        self._check(self._L.dsa_dispersion_fetch(self._h, map_first, nper, _p(pv), int(bool(kernels)), sen_slot,
+                                                 *[None if a is None else _p(a) for a in sen]))
+        return (pv, *sen) if kernels else pv
+
+    def maps_from_dispersion(self, goxd, gozd, dvxd, dvzd, dicing=8):
+        self._check(self._L.dsa_maps_from_dispersion(self._h, goxd, gozd, dvxd, dvzd, dicing))
+        a, b = _i32(), _i32()
+        self._check(self._L.dsa_get_dims(self._h, C.byref(a), C.byref(b)))
+        self.nnx, self.nnz = a.value, b.value
+
+    def kernels_from_dispersion(self):
+        self._check(self._L.dsa_kernels_from_dispersion(self._h))
 
     def traveltimes(self, map_index, scx, scz, nrec, rcx, rcz):
         self.plan(map_index, scx, scz, nrec, rcx, rcz)

@@ -51,7 +51,8 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 /* tuning knobs: "window_cells" (causal window of the fixed-point solve, in cell travel times,
  * default 3), "max_chunk" (cap on sources resident per chunk, 0 = memory budget only),
  * "list_cap" / "ready_cap" (active-list sizes of the solve kernel, 0 = derived from the grid),
- * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024) */
+ * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024), "ray_budget" (bytes of
+ * per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up to 8 GB) */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
 
 /* ---- engine level --------------------------------------------------------------------------- */
@@ -68,9 +69,52 @@ int dsa_set_maps(dsa_engine* e, int nx, int ny, float goxd, float gozd, float dv
 int dsa_plan(dsa_engine* e, int nunits, const int* map_index, const float* scx, const float* scz,
              const int* nrec, const float* rcx, const float* rcz);
 
+/* Same with per-unit extras (any may be NULL): mode[u] bit 0 = produce receiver times, bit 1 = trace
+ * rays / emit Frechet rows (default both); sen_slot[u] = period slot of the depth kernels used
+ * by unit u's rows; data_first[u] = 0-based index of the datum of unit u's first receiver
+ * (default: running receiver count).  Group-velocity data take two units with the same
+ * data_first: times on the group-velocity map, rays on the phase-velocity map
+ * (reference CalSurfG.f90:1166-1183, :1360-1376). */
+int dsa_plan_units(dsa_engine* e, int nunits, const int* map_index, const float* scx, const float* scz,
+                   const int* nrec, const float* rcx, const float* rcz, const int* mode,
+                   const int* sen_slot, const int* data_first);
+
+/* Depth kernels for the Frechet rows, in the reference's layout: vels(nx,ny,nz) fp32,
+ * depz(nz), sen_*(nx*ny, kmax, nz) fp64 (CalSurfG.f90:1005-1016).  Uploaded and folded with the
+ * Brocher chain-rule factors (:1385-1423) once. */
+int dsa_set_depth_kernels(dsa_engine* e, int nz, int kmax, const float* vels, const float* depz,
+                          const double* sen_vs, const double* sen_vp, const double* sen_rho);
+
+/* Dispersion stage on the device (reference depthkernel CalSurfG.f90:1-169 / caldespersion
+ * :2866-2927 over surfdisp96.f): spherical earth, fundamental mode.
+ *   begin: the Vs model vels(nx,ny,nz), depths depz(nz), sublayering minthk; room for
+ *          `nmaps_total` phase/group-velocity maps and `kmax_total` depth-kernel slots.
+ *   run:   one wave type (iwave 1 Love / 2 Rayleigh, igr 0 phase / 1 group) at periods t[nper]:
+ *          maps [map_first, map_first+nper) and, if with_kernels, slots [sen_slot, sen_slot+nper).
+ *   copy_maps: duplicate maps inside the store (the reference overwrites the head of pvRc / pvLc
+ *          with the phase velocities at the group periods, CalSurfG.f90:1110, :1128).
+ *   fetch: host copies in the reference's layouts pv(nx*ny, nper), sen_*(nx*ny, nper, nz).
+ *   maps_from_dispersion / kernels_from_dispersion: hand the resident results to the solve
+ *          (same effect as dsa_set_maps / dsa_set_depth_kernels, no host round trip). */
+int dsa_dispersion_begin(dsa_engine* e, int nx, int ny, int nz, const float* vels, const float* depz,
+                         float minthk, int kmax_total, int nmaps_total);
+int dsa_dispersion_run(dsa_engine* e, int iwave, int igr, int nper, const double* t, int with_kernels,
+                       int sen_slot, int map_first);
+int dsa_dispersion_copy_maps(dsa_engine* e, int from, int to, int n);
+int dsa_dispersion_fetch(dsa_engine* e, int map_first, int nper, double* pv, int with_kernels,
+                         int sen_slot, double* sen_vs, double* sen_vp, double* sen_rho);
+int dsa_maps_from_dispersion(dsa_engine* e, float goxd, float gozd, float dvxd, float dvzd, int dicing);
+int dsa_kernels_from_dispersion(dsa_engine* e);
+
 /* Solve every planned unit: eikonal field per unit, then receiver times into dsurf (host,
- * sum(nrec) floats, unit-major order == the reference's (knumi, srcnum, istep) order). */
+ * one float per datum, unit-major order == the reference's (knumi, srcnum, istep) order). */
 int dsa_solve(dsa_engine* e, float* dsurf);
+
+/* dsa_solve plus rays and Frechet rows (reference rpaths + row loop, CalSurfG.f90:1377-1432):
+ * COO triplets in the reference's order -- rw[k] value, iw[k] 1-based row (datum), col[k]
+ * 1-based column (k-1)*nvx*nvz + (jj-1)*nvx + kk -- *nar entries, at most `capacity`. */
+int dsa_solve_rows(dsa_engine* e, float* dsurf, float* rw, int* iw, int* col, long long capacity,
+                   long long* nar);
 
 /* copy one unit's coarse travel-time field (nnz, nnx column-major) back; valid after dsa_solve
  * for units of the last chunk only unless keep_fields was requested */
@@ -88,8 +132,10 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out);
 /* counters of the last dsa_solve: see DSA_STAT_* */
 enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, DSA_STAT_MS_STAGES,
        DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_EVALS_TOTAL,
-       DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_FREEZES, DSA_STAT_COUNT };
-int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 6: counters, then 6 phase-clock sums */);
+       DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_FREEZES, DSA_STAT_RAYS, DSA_STAT_RAY_STEPS,
+       DSA_STAT_RAYS_CLAMPED, DSA_STAT_MS_RAYS, DSA_STAT_MS_ROWS, DSA_STAT_NAR, DSA_STAT_MS_DISPERSION,
+       DSA_STAT_CURVES, DSA_STAT_COUNT };
+int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 7: counters, then 7 phase-clock sums */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */
 int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,

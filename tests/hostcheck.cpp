@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../dsurftomo_amd/csrc/host_geometry.h"
+#include "../dsurftomo_amd/csrc/ray_core.h"
 
 using namespace dsa;
 
@@ -247,6 +248,87 @@ int hc_solve_source(int nx, int ny, float goxd, float gozd, float dvxd, float dv
     for (size_t k = 0; k < (size_t)g.nnx * g.nnz; ++k) ttn[k] = t_value(ttn[k]);
     stats[0] = P.ended; stats[1] = P.err; stats[2] = P.evals_r;
     if (box_out) { box_out[0] = s.vnl; box_out[1] = s.vnr; box_out[2] = s.vnt; box_out[3] = s.vnb; box_out[4] = s.rnx; box_out[5] = s.rnz; }
+    return 0;
+}
+
+// trace_ray (ray_core.h) on oracle-format fields: ttn / veln x-major (nnz fastest), refined
+// snapshot ttnr / nstsr x-major with leading dimension rnz.  fdm comes back in the oracle's layout
+// fdm[vx * (nvz+2) + vz].
+int hc_trace_ray(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const float* veln,
+                 const float* ttn, const float* ttnr, const int* nstsr, float sx, float sz, float rx, float rz,
+                 float* fdm, int* flags, int* nsteps)
+{
+    GridDesc g; make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
+    SourceDesc s;
+    if (make_source(g, sx, sz, s) != 0) return -2;
+    std::vector<Rec> F((size_t)g.nbx * g.nbz * kTileRecs, Rec{ kInf, kInf });
+    for (int ix = 0; ix < g.nnx; ++ix)
+        for (int iz = 0; iz < g.nnz; ++iz) F[rec_index(g.nbz, iz, ix)].T = ttn[(size_t)ix * g.nnz + iz];
+    std::vector<int8_t> S((size_t)s.rnx * s.rnz);
+    for (size_t k = 0; k < S.size(); ++k) S[k] = (int8_t)(nstsr[k] > 0 ? 1 : (nstsr[k] < 0 ? -1 : 0));
+    std::vector<float> slab((size_t)(g.nvx + 2) * (g.nvz + 2), 0.0f);
+    RayFields f{ F.data(), veln, ttnr, S.data() };
+    *flags = 0;
+    const int rc = trace_ray(g, s, f, rx, rz, min_cell_km(g), slab.data(), flags, nsteps);
+    for (int vx = 0; vx < g.nvx + 2; ++vx)
+        for (int vz = 0; vz < g.nvz + 2; ++vz) fdm[(size_t)vx * (g.nvz + 2) + vz] = slab[(size_t)vz * (g.nvx + 2) + vx];
+    return rc;
+}
+
+float hc_sinf(float x) { return sinf_libm(x); }
+
+// count of fp32 values in [lo, hi] where sinf_libm differs from this machine's libm sinf
+long hc_sinf_sweep(float lo, float hi)
+{
+    long bad = 0;
+    for (float v = lo; v <= hi; v = nextafterf(v, 1e30f)) {
+        const float a = sinf(v), b = sinf_libm(v);
+        if (std::memcmp(&a, &b, 4) != 0) ++bad;
+    }
+    return bad;
+}
+
+void hc_brocher_chain(float v, int shallow, float* a, float* r) { brocher_chain(v, shallow != 0, a, r); }
+
+// dispersion_core.h on the host: pv(c, k) and, with kernels, sen_q(c, k, i) for a (nz, ncol) Vs
+// model -- the arithmetic of disp_kernels.hip run serially with this machine's libm
+int hc_depthkernel(int ncol, int nz, const float* vels, const float* depz, float minthk, int iwave, int igr, int kmax,
+                   const double* t, int with_kernels, double* pv, double* sen_vs, double* sen_vp, double* sen_rho)
+{
+    LayerGeom G;
+    if (make_layer_geom(nz, depz, minthk, G) != 0) return -1;
+    std::vector<float> ws((size_t)4 * G.rmax);
+    const int npert = with_kernels ? 1 + 6 * nz : 1;
+    std::vector<double> curves((size_t)npert * kmax);
+    double* out[3] = { sen_vs, sen_vp, sen_rho };
+    for (int c = 0; c < ncol; ++c) {
+        for (int p = 0; p < npert; ++p) {
+            float vs[64], vp[64], rho[64];
+            for (int k = 0; k < nz; ++k) { vs[k] = vels[(size_t)k * ncol + c]; brocher_vp_rho(vs[k], &vp[k], &rho[k]); }
+            if (p > 0) {
+                const int idx = p - 1, i = idx / 6, q = (idx % 6) >> 1, s = idx & 1;
+                float* arr = q == 0 ? vs : (q == 1 ? vp : rho);
+                const float base = arr[i], dln = 0.01f;
+                arr[i] = s ? base + 0.5f * dln * base : base - 0.5f * dln * base;
+            }
+            Layers m;
+            m.d = ws.data(); m.a = m.d + G.rmax; m.b = m.a + G.rmax; m.rho = m.b + G.rmax; m.stride = 1;
+            if (iwave == 1) { build_layers<1>(G, vs, vp, rho, m); dispersion_curve<1>(m, igr, kmax, t, &curves[(size_t)p * kmax], 1); }
+            else { build_layers<2>(G, vs, vp, rho, m); dispersion_curve<2>(m, igr, kmax, t, &curves[(size_t)p * kmax], 1); }
+        }
+        for (int k = 0; k < kmax; ++k) pv[(size_t)k * ncol + c] = curves[k];
+        if (!with_kernels) continue;
+        for (int i = 0; i < nz; ++i) {
+            float base[3];
+            base[0] = vels[(size_t)i * ncol + c];
+            brocher_vp_rho(base[0], &base[1], &base[2]);
+            for (int q = 0; q < 3; ++q)
+                for (int k = 0; k < kmax; ++k) {
+                    const double cg1 = curves[(size_t)(1 + 6 * i + 2 * q) * kmax + k], cg2 = curves[(size_t)(2 + 6 * i + 2 * q) * kmax + k];
+                    out[q][((size_t)i * kmax + k) * ncol + c] = (cg2 - cg1) / (double)(0.01f * base[q]);
+                }
+        }
+    }
     return 0;
 }
 
