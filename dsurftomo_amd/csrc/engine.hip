@@ -287,14 +287,17 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
     size_t budget = mem_budget ? mem_budget : (size_t)(0.6 * (double)free_b);
     const size_t rr = (size_t)kRefMax * kRefMax;
-    per_unit_bytes = nrec_c * 8 + (size_t)(40 * (g.nnx + g.nnz) + 10240) * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
+    {   // the refined and the coarse solve of a unit share one list region: size it for the larger shape
+        const FimLaunch lc = launch_shape(g.nnx, g.nnz), lr = launch_shape(kRefMax, kRefMax);
+        lists_stride = std::max((size_t)2 * lc.list_cap + lc.ready_cap, (size_t)2 * lr.list_cap + lr.ready_cap);
+    }
+    per_unit_bytes = nrec_c * 8 + lists_stride * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
                      (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(SourceDesc);
     size_t c = budget / per_unit_bytes;
     if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B)", budget, per_unit_bytes); return DSA_ERR_DEVICE; }
     chunk = (int)std::min<size_t>(c, (size_t)std::max(nunits, 1));
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
     const size_t C = (size_t)chunk;
-    { const FimLaunch lc = launch_shape(g.nnx, g.nnz); lists_stride = (size_t)2 * lc.list_cap + lc.ready_cap; }
     if (ensure(lists, C * lists_stride) || ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(ndata, 1)) || ensure(trace_ids, std::max<size_t>(h_trace.size(), 1)) || ensure(err, 4) ||
         ensure(slow_r, C * kRefRecs) || ensure(F_r, C * kRefRecs) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||

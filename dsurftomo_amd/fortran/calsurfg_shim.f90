@@ -1,0 +1,111 @@
+! Drop-in replacement for the reference's CalSurfG.o: exports the link symbols `calsurfg_` and
+! `synthetic_` with the reference's argument lists (reference src/CalSurfG.f90:939-943 and
+! :2412-2415; called from main.f90:338-342 and :355-359) and forwards them over ISO_C_BINDING to
+! dsa_calsurfg / dsa_synthetic in libdsurftomo_amd.so (include/dsurftomo_amd.h).
+!
+! Link it instead of CalSurfG.o (surfdisp96.o is then unused as well):
+!   flang ... main.o calsurfg_shim.o <other reference objects> -L<repo>/dsurftomo_amd -ldsurftomo_amd
+!
+! Where the reference prints a message and STOPs (a source or receiver outside the model), the
+! engine returns an error; this shim prints the engine's text -- the same words -- and stops too.
+module dsa_bindings
+  use iso_c_binding
+  implicit none
+  interface
+    integer(c_int) function dsa_calsurfg(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf, &
+        goxdf,gozdf,dvxdf,dvzdf,kmaxRc,kmaxRg,kmaxLc,kmaxLg,tRc,tRg,tLc,tLg, &
+        wavetype,igrt,periods,depz,minthk,scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1, &
+        kmax,nsrcsurf,nrcf,nar) bind(C, name='dsa_calsurfg')
+      import :: c_int, c_float, c_double
+      integer(c_int) :: nx,ny,nz,nparpi,kmaxRc,kmaxRg,kmaxLc,kmaxLg,kmax,nsrcsurf,nrcf,nar
+      real(c_float) :: vels(*),rw(*),dsurf(*),goxdf,gozdf,dvxdf,dvzdf,depz(*),minthk
+      real(c_float) :: scxf(*),sczf(*),rcxf(*),rczf(*)
+      integer(c_int) :: iw(*),col(*),wavetype(*),igrt(*),periods(*),nrc1(*),nsrcsurf1(*)
+      real(c_double) :: tRc(*),tRg(*),tLc(*),tLg(*)
+    end function
+    integer(c_int) function dsa_synthetic(nx,ny,nz,nparpi,vels,obst, &
+        goxdf,gozdf,dvxdf,dvzdf,kmaxRc,kmaxRg,kmaxLc,kmaxLg,tRc,tRg,tLc,tLg, &
+        wavetype,igrt,periods,depz,minthk,scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1, &
+        kmax,nsrcsurf,nrcf,noiselevel) bind(C, name='dsa_synthetic')
+      import :: c_int, c_float, c_double
+      integer(c_int) :: nx,ny,nz,nparpi,kmaxRc,kmaxRg,kmaxLc,kmaxLg,kmax,nsrcsurf,nrcf
+      real(c_float) :: vels(*),obst(*),goxdf,gozdf,dvxdf,dvzdf,depz(*),minthk,noiselevel
+      real(c_float) :: scxf(*),sczf(*),rcxf(*),rczf(*)
+      integer(c_int) :: wavetype(*),igrt(*),periods(*),nrc1(*),nsrcsurf1(*)
+      real(c_double) :: tRc(*),tRg(*),tLc(*),tLg(*)
+    end function
+    function dsa_dropin_error() bind(C, name='dsa_dropin_error') result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function
+    integer(c_size_t) function c_strlen(s) bind(C, name='strlen')
+      import :: c_ptr, c_size_t
+      type(c_ptr), value :: s
+    end function
+  end interface
+contains
+  subroutine dsa_stop(where)
+    character(len=*), intent(in) :: where
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: msg(:)
+    integer :: n, i
+    p = dsa_dropin_error()
+    n = int(c_strlen(p))
+    call c_f_pointer(p, msg, [n])
+    write(6,*) (msg(i), i = 1, n)
+    write(6,*) 'TERMINATING PROGRAM!!!! (', where, ')'
+    stop 1
+  end subroutine
+end module
+
+subroutine CalSurfG(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf, &
+    goxdf,gozdf,dvxdf,dvzdf,kmaxRc,kmaxRg,kmaxLc,kmaxLg, &
+    tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk, &
+    scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,nar)
+  use dsa_bindings
+  implicit none
+  integer nx,ny,nz,nparpi,kmax,nsrcsurf,nrcf,nar
+  real vels(nx,ny,nz),rw(*),dsurf(*),goxdf,gozdf,dvxdf,dvzdf,depz(nz),minthk
+  integer iw(*),col(*),kmaxRc,kmaxRg,kmaxLc,kmaxLg
+  real*8 tRc(*),tRg(*),tLc(*),tLg(*)
+  integer wavetype(nsrcsurf,kmax),periods(nsrcsurf,kmax),nrc1(nsrcsurf,kmax),nsrcsurf1(kmax),igrt(nsrcsurf,kmax)
+  real scxf(nsrcsurf,kmax),sczf(nsrcsurf,kmax),rcxf(nrcf,nsrcsurf,kmax),rczf(nrcf,nsrcsurf,kmax)
+  integer rc
+  rc = dsa_calsurfg(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf,goxdf,gozdf,dvxdf,dvzdf, &
+       kmaxRc,kmaxRg,kmaxLc,kmaxLg,tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk, &
+       scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,nar)
+  if (rc /= 0) call dsa_stop('CalSurfG')
+end subroutine
+
+subroutine synthetic(nx,ny,nz,nparpi,vels,obst, &
+    goxdf,gozdf,dvxdf,dvzdf,kmaxRc,kmaxRg,kmaxLc,kmaxLg, &
+    tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk, &
+    scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,noiselevel)
+  use dsa_bindings
+  implicit none
+  integer nx,ny,nz,nparpi,kmax,nsrcsurf,nrcf
+  real vels(nx,ny,nz),obst(*),goxdf,gozdf,dvxdf,dvzdf,depz(nz),minthk,noiselevel
+  integer kmaxRc,kmaxRg,kmaxLc,kmaxLg
+  real*8 tRc(*),tRg(*),tLc(*),tLg(*)
+  integer wavetype(nsrcsurf,kmax),periods(nsrcsurf,kmax),nrc1(nsrcsurf,kmax),nsrcsurf1(kmax),igrt(nsrcsurf,kmax)
+  real scxf(nsrcsurf,kmax),sczf(nsrcsurf,kmax),rcxf(nrcf,nsrcsurf,kmax),rczf(nrcf,nsrcsurf,kmax)
+  real gaussian, zero
+  external gaussian
+  integer rc, knumi, srcnum, istep, count1
+  ! noise-free times from the device, then the reference's own noise statement in the reference's
+  ! loop order (CalSurfG.f90:2840), drawing from the host program's gaussian() like the original
+  zero = 0.0
+  rc = dsa_synthetic(nx,ny,nz,nparpi,vels,obst,goxdf,gozdf,dvxdf,dvzdf, &
+       kmaxRc,kmaxRg,kmaxLc,kmaxLg,tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk, &
+       scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,zero)
+  if (rc /= 0) call dsa_stop('synthetic')
+  count1 = 0
+  do knumi = 1, kmax
+    do srcnum = 1, nsrcsurf1(knumi)
+      do istep = 1, nrc1(srcnum,knumi)
+        count1 = count1 + 1
+        obst(count1) = obst(count1) + obst(count1)*gaussian()*noiselevel
+      enddo
+    enddo
+  enddo
+end subroutine

@@ -213,9 +213,14 @@ def call_boundary(fn, c, synthetic=False, noise=0.0):
             ptr(c["tRc"]), ptr(c["tRg"]), ptr(c["tLc"]), ptr(c["tLg"]), ptr(c["wavetype"]), ptr(c["igrt"]), ptr(c["periods"]),
             ptr(c["depz"]), f32(c["minthk"]), ptr(c["scxf"]), ptr(c["sczf"]), ptr(c["rcxf"]), ptr(c["rczf"]), ptr(c["nrc1"]),
             ptr(c["nsrcsurf1"]), i32(c["kmax"]), i32(c["nsrcsurf"]), i32(c["nrcf"])]
+    own = getattr(fn, "__name__", "").startswith(("dsa_", "dso_"))     # the reference's subroutines return nothing
+
+    def check(rc):
+        if own and rc != 0:
+            raise RuntimeError("%s returned %d" % (fn.__name__, rc))
     if synthetic:
         obst = np.zeros(nd, np.float32)
-        fn(*head, ptr(obst), *tail, f32(noise))
+        check(fn(*head, ptr(obst), *tail, f32(noise)))
         return obst
     cap = nd * npar + 1
     iw = np.zeros(cap + 1, np.int32)
@@ -223,7 +228,7 @@ def call_boundary(fn, c, synthetic=False, noise=0.0):
     col = np.zeros(cap, np.int32)
     dsurf = np.zeros(nd, np.float32)
     nar = C.c_int(0)
-    fn(*head, ptr(iw), ptr(rw), ptr(col), ptr(dsurf), *tail, C.byref(nar))
+    check(fn(*head, ptr(iw), ptr(rw), ptr(col), ptr(dsurf), *tail, C.byref(nar)))
     n = nar.value
     return dict(dsurf=dsurf, nar=n, rw=rw[:n].copy(), iw=iw[1:n + 1].copy(), col=col[:n].copy())
 

@@ -1,0 +1,51 @@
+! Test driver for dsurftomo_amd/fortran/calsurfg_shim.f90: reads one CalSurfG argument set from a
+! flat binary file (written by tests/test_gpu_boundary.py), calls CalSurfG and synthetic through the
+! shim's link symbols exactly as the reference's host program does (main.f90:338-359), and writes
+! the outputs back.  Own code; no reference source involved.
+program shim_driver
+  implicit none
+  integer :: nx,ny,nz,nparpi,kmaxRc,kmaxRg,kmaxLc,kmaxLg,kmax,nsrcsurf,nrcf,ndata,maxnar,nar,i
+  real :: goxd,gozd,dvxd,dvzd,minthk,noiselevel
+  real, allocatable :: vels(:,:,:),depz(:),scxf(:,:),sczf(:,:),rcxf(:,:,:),rczf(:,:,:),rw(:),dsurf(:),obst(:)
+  real*8, allocatable :: tRc(:),tRg(:),tLc(:),tLg(:)
+  integer, allocatable :: wavetype(:,:),igrt(:,:),periods(:,:),nrc1(:,:),nsrcsurf1(:),iw(:),col(:)
+  character(len=512) :: fin, fout
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  open(21,file=trim(fin),access='stream',form='unformatted',status='old')
+  read(21) nx,ny,nz,kmaxRc,kmaxRg,kmaxLc,kmaxLg,kmax,nsrcsurf,nrcf,ndata,maxnar
+  read(21) goxd,gozd,dvxd,dvzd,minthk
+  nparpi = (nx-2)*(ny-2)*(nz-1)
+  allocate(vels(nx,ny,nz),depz(nz),tRc(max(kmaxRc,1)),tRg(max(kmaxRg,1)),tLc(max(kmaxLc,1)),tLg(max(kmaxLg,1)))
+  allocate(wavetype(nsrcsurf,kmax),igrt(nsrcsurf,kmax),periods(nsrcsurf,kmax),nrc1(nsrcsurf,kmax),nsrcsurf1(kmax))
+  allocate(scxf(nsrcsurf,kmax),sczf(nsrcsurf,kmax),rcxf(nrcf,nsrcsurf,kmax),rczf(nrcf,nsrcsurf,kmax))
+  allocate(rw(maxnar),iw(2*maxnar+1),col(maxnar),dsurf(ndata),obst(ndata))
+  read(21) vels, depz
+  if (kmaxRc > 0) read(21) tRc(1:kmaxRc)
+  if (kmaxRg > 0) read(21) tRg(1:kmaxRg)
+  if (kmaxLc > 0) read(21) tLc(1:kmaxLc)
+  if (kmaxLg > 0) read(21) tLg(1:kmaxLg)
+  read(21) wavetype, igrt, periods, nrc1, nsrcsurf1, scxf, sczf, rcxf, rczf
+  close(21)
+  write(6,*) 'inputs', nx,ny,nz,kmax,nsrcsurf,nrcf,ndata,maxnar,sum(nrc1),sum(nsrcsurf1),sum(scxf),sum(rcxf),minthk,depz
+  iw = 0
+  rw = 0.0
+  col = 0
+  noiselevel = 0.0
+  call synthetic(nx,ny,nz,nparpi,vels,obst,goxd,gozd,dvxd,dvzd,kmaxRc,kmaxRg,kmaxLc,kmaxLg, &
+       tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk,scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax, &
+       nsrcsurf,nrcf,noiselevel)
+  call CalSurfG(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf,goxd,gozd,dvxd,dvzd,kmaxRc,kmaxRg,kmaxLc,kmaxLg, &
+       tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk,scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax, &
+       nsrcsurf,nrcf,nar)
+  open(22,file=trim(fout),access='stream',form='unformatted',status='replace')
+  write(22) nar
+  write(22) dsurf, obst
+  write(22) rw(1:nar), (iw(1+i), i=1,nar), col(1:nar)
+  close(22)
+end program
+
+! the reference's host program provides gaussian() (gaussian.f90); the shim's synthetic calls it
+real function gaussian()
+  gaussian = 0.0
+end function

@@ -92,6 +92,22 @@ def main_dispersion():
     print("b_boundary ->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def main_taipei():
+    """b_taipei.npz: the reference's CalSurfG on its own Taipei example (inputs under taipei/): travel
+    times and the matrix reduced to row sums / column absolute sums / entry count (the full COO
+    list is 565 k entries)"""
+    import taipei
+    c = taipei.load()
+    a = L.call_boundary(L.ref().calsurfg_, c)
+    G = np.zeros((c["ndata"], c["nparpi"]), np.float32)
+    G[a["iw"] - 1, a["col"] - 1] = a["rw"]
+    path = os.path.join(HERE, "b_taipei.npz")
+    np.savez_compressed(path, dsurf=a["dsurf"], nar=np.int32(a["nar"]), row_sums=G.sum(axis=1, dtype=np.float64),
+                        col_abs_sums=np.abs(G).sum(axis=0, dtype=np.float64), row_counts=(G != 0).sum(axis=1).astype(np.int32))
+    print("b_taipei ->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
 if __name__ == "__main__":
     main()
     main_dispersion()
+    main_taipei()

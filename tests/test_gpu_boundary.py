@@ -1,0 +1,156 @@
+"""Whole-boundary parity on the GPU: the drop-in entries dsa_calsurfg / dsa_synthetic (C ABI), the
+Fortran shim, and the dispersion stage, against the oracle and the committed golden vectors.
+
+Tolerances.  Travel times: 1e-4 s (north_star).  The eikonal solve can differ from Fast Marching
+only where two arrivals tie to the last bit, so rays, rows and dispersion -- which run
+the reference's arithmetic operation for operation -- are expected to be bit-identical almost
+everywhere; the assertions leave room for a tie changing a ray: at most 0.5 % of the matrix
+entries may differ, none by more than 2e-3 (entries are O(0.1)).  Dispersion runs in fp64 with the
+device's sin / cos / exp instead of libm's; a last-bit difference there can move an fp32-rounded
+phase velocity by one ulp (2.4e-7), i.e. a depth kernel by 2.4e-7 / (0.01 v) ~ 1e-5.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _libs as L
+import synth
+import taipei
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "default": dict(),
+    "deep": dict(deep=True, nz=7, nx=10, ny=13, seed=5),
+    "groups": dict(kRc=0, kRg=2, kLc=0, kLg=1),
+    "big": dict(nx=20, ny=18, nz=6, nsrc=8, nrcf=7, kRc=3, kRg=1, kLc=1, kLg=1),
+}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dsurftomo_amd import engine
+    return engine.load_library()
+
+
+def dense(r, ndata, npar):
+    G = np.zeros((ndata, npar), np.float32)
+    G[r["iw"] - 1, r["col"] - 1] = r["rw"]
+    return G
+
+
+def check_rows(o, d, c):
+    assert np.abs(o["dsurf"] - d["dsurf"]).max() <= 1e-4
+    Go, Gd = dense(o, c["ndata"], c["nparpi"]), dense(d, c["ndata"], c["nparpi"])
+    differ = Go.view(np.uint32) != Gd.view(np.uint32)
+    assert differ.sum() <= 0.005 * max(o["nar"], 1), "%d of %d matrix entries differ" % (differ.sum(), o["nar"])
+    assert np.abs(Go - Gd).max() <= 2e-3
+    assert abs(o["nar"] - d["nar"]) <= 0.005 * o["nar"]
+    # the reference's order: rows ascending, columns ascending inside a row
+    key = d["iw"].astype(np.int64) * (c["nparpi"] + 1) + d["col"]
+    assert (np.diff(key) > 0).all()
+    return int(differ.sum())
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_dropin_calsurfg_and_synthetic(lib, name):
+    c = synth.boundary_case(**CASES[name])
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    d = L.call_boundary(lib.dsa_calsurfg, c)
+    assert lib.dsa_dropin_error() == b"" or d["nar"] > 0, lib.dsa_dropin_error()
+    check_rows(o, d, c)
+    so = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
+    sd = L.call_boundary(lib.dsa_synthetic, c, synthetic=True)
+    assert np.abs(so - sd).max() <= 1e-4
+
+
+def test_taipei_example(lib):
+    """BASELINE.json configs[0]: first forward call of the Taipei inversion (18x18x9 model, 26
+    Rayleigh phase periods, 2061 data) against the reference's own output (golden) and the oracle"""
+    c = taipei.load()
+    d = L.call_boundary(lib.dsa_calsurfg, c)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "b_taipei.npz"))
+    assert np.abs(d["dsurf"] - z["dsurf"]).max() <= 1e-4
+    assert abs(d["nar"] - int(z["nar"])) <= 0.005 * int(z["nar"])
+    G = dense(d, c["ndata"], c["nparpi"])
+    assert np.abs(G.sum(axis=1, dtype=np.float64) - z["row_sums"]).max() <= 5e-3
+    assert np.abs(np.abs(G).sum(axis=0, dtype=np.float64) - z["col_abs_sums"]).max() <= 2e-2
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    check_rows(o, d, c)
+
+
+@pytest.mark.parametrize("iwave,igr", [(2, 0), (2, 1), (1, 0), (1, 1)])
+def test_dispersion_stage(iwave, igr):
+    from dsurftomo_amd.engine import Engine
+    c = synth.boundary_case(nx=12, ny=10, nz=7)
+    vel = np.ascontiguousarray(c["vels"].T)
+    t = np.array([1.0, 2.0, 4.0, 7.0, 11.0, 16.0, 22.0])
+    ref = L.depthkernel("oracle", vel, c["depz"], float(c["minthk"]), iwave, igr, t)
+    e = Engine(0)
+    try:
+        e.dispersion_begin(vel, c["depz"], float(c["minthk"]), len(t), len(t))
+        e.dispersion_run(iwave, igr, t, True, 0, 0)
+        dev = e.dispersion_fetch(0, len(t), True, 0)
+    finally:
+        e.close()
+    assert np.abs(dev[0] - ref[0]).max() <= 5e-7
+    assert (dev[0] == ref[0]).mean() >= 0.99
+    for a, b in zip(dev[1:], ref[1:]):
+        assert np.abs(a - b).max() <= 5e-5
+        assert (a == b).mean() >= 0.98
+
+
+def test_engine_rows_from_host_kernels():
+    """engine level: maps and depth kernels handed over from the host (dsa_set_maps +
+    dsa_set_depth_kernels + dsa_plan_units + dsa_solve_rows) instead of the device dispersion stage"""
+    from dsurftomo_amd.engine import Engine
+    c = synth.boundary_case(kRc=3, kRg=0, kLc=0, kLg=0)
+    vel = np.ascontiguousarray(c["vels"].T)
+    pv, svs, svp, srho = L.depthkernel("oracle", vel, c["depz"], float(c["minthk"]), 2, 0, c["tRc"])
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    maps, sx, sz, nrec, rx, rz, slot = [], [], [], [], [], [], []
+    for k in range(c["kmax"]):
+        for s in range(c["nsrcsurf1"][k]):
+            maps.append(c["periods"][s, k] - 1); sx.append(c["scxf"][s, k]); sz.append(c["sczf"][s, k]); slot.append(k)
+            nrec.append(c["nrc1"][s, k])
+            rx += list(c["rcxf"][:nrec[-1], s, k]); rz += list(c["rczf"][:nrec[-1], s, k])
+    e = Engine(0)
+    try:
+        e.set_maps(c["nx"], c["ny"], c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], pv)
+        e.set_depth_kernels(vel, c["depz"], svs, svp, srho)
+        e.plan(maps, sx, sz, nrec, rx, rz, sen_slot=slot)
+        t, rw, iw, col = e.solve_rows(c["ndata"] * c["nparpi"])
+        st = e.stats()
+    finally:
+        e.close()
+    check_rows(o, dict(dsurf=t, rw=rw, iw=iw, col=col, nar=rw.size), c)
+    assert st["rays"] == c["ndata"] and st["nar"] == rw.size
+
+
+def test_fortran_shim(tmp_path):
+    """calsurfg_ / synthetic_ through the flang-built shim and a Fortran caller"""
+    exe = os.path.join(L.ROOT, "tests", "build", "shim_driver")
+    if not os.path.exists(exe):
+        pytest.skip("tests/build/shim_driver was not built (flang missing)")
+    c = synth.boundary_case()
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    so = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
+    maxnar = c["ndata"] * c["nparpi"]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([c["nx"], c["ny"], c["nz"], c["kRc"], c["kRg"], c["kLc"], c["kLg"], c["kmax"], c["nsrcsurf"], c["nrcf"], c["ndata"], maxnar], np.int32).tofile(f)
+        np.array([c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], c["minthk"]], np.float32).tofile(f)
+        for a in (c["vels"], c["depz"], c["tRc"], c["tRg"], c["tLc"], c["tLg"], c["wavetype"], c["igrt"], c["periods"], c["nrc1"], c["nsrcsurf1"],
+                  c["scxf"], c["sczf"], c["rcxf"], c["rczf"]):
+            f.write(np.asarray(a).tobytes(order="F"))
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and os.path.exists(fout), r.stdout + r.stderr
+    with open(fout, "rb") as f:
+        nar = int(np.fromfile(f, np.int32, 1)[0])
+        dsurf = np.fromfile(f, np.float32, c["ndata"]); obst = np.fromfile(f, np.float32, c["ndata"])
+        rw = np.fromfile(f, np.float32, nar); iw = np.fromfile(f, np.int32, nar); col = np.fromfile(f, np.int32, nar)
+    check_rows(o, dict(dsurf=dsurf, rw=rw, iw=iw, col=col, nar=nar), c)
+    assert np.abs(obst - so).max() <= 1e-4

@@ -73,3 +73,19 @@ def test_boundary_golden():
     vel = np.ascontiguousarray(c["vels"].T)
     for a, k in zip(L.depthkernel("oracle", vel, c["depz"], float(c["minthk"]), 2, 1, c["tRg"]), ("pvRg", "sen_vsRg", "sen_vpRg", "sen_rhoRg")):
         assert (bits64(a) != bits64(z[k])).sum() == 0
+
+
+def test_taipei_golden():
+    """the oracle on the reference's Taipei example against the reference's own output"""
+    import taipei
+    z = np.load(os.path.join(GDIR, "b_taipei.npz"))
+    c = taipei.load()
+    assert c["ndata"] == z["dsurf"].size == 2061 and c["kmax"] == 26
+    b = L.call_boundary(L.oracle().dso_calsurfg, c)
+    assert b["nar"] == int(z["nar"])
+    assert (bits(b["dsurf"]) != bits(z["dsurf"])).sum() == 0
+    G = np.zeros((c["ndata"], c["nparpi"]), np.float32)
+    G[b["iw"] - 1, b["col"] - 1] = b["rw"]
+    assert (G.sum(axis=1, dtype=np.float64) == z["row_sums"]).all()
+    assert (np.abs(G).sum(axis=0, dtype=np.float64) == z["col_abs_sums"]).all()
+    assert ((G != 0).sum(axis=1) == z["row_counts"]).all()
