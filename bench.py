@@ -125,8 +125,10 @@ def main():
     eng = Engine(local_rank)
     if os.environ.get("DSA_MAX_CHUNK"):
         eng.set_option("max_chunk", int(os.environ["DSA_MAX_CHUNK"]))
+    t_setup = time.perf_counter()
     eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     eng.plan(units["map_index"][sl], units["scx"][sl], units["scz"][sl], units["nrec"][sl], units["rcx"][rsl], units["rcz"][rsl])
+    setup_ms = 1000.0 * (time.perf_counter() - t_setup)      # host buffers -> HBM: maps, dicing, descriptors
     n = eng.nnx
 
     dev = torch.device("cuda", local_rank)
@@ -187,10 +189,12 @@ def main():
                          "launches": int(acc["launches_fim_coarse"]),
                          "avg_launch_ms": round(acc["ms_fim_coarse"] / max(acc["launches_fim_coarse"], 1), 3),
                          "solves_per_launch": round(my_units / max(acc["launches_fim_coarse"], 1), 1),
-                         "note": "dependency/latency-bound kernel: ~5 evaluations x ~600 fp32 instructions per node; see DESIGN.md"},
+                         "note": "dependency/latency-bound kernel: ~2.2 evaluations x ~600 fp32 instructions per node along an O(N)-deep front; see DESIGN.md 7"},
             "kernel_ms_per_step": {"fim_coarse": round(acc["ms_fim_coarse"] / args.steps, 2), "fim_refined": round(acc["ms_fim_refined"] / args.steps, 2),
                                    "stages": round(acc["ms_stages"] / args.steps, 2)},
             "evals_per_node": round(acc["evals_total"] / max(my_units, 1) / (n * n), 3),
+            "setup_ms": round(setup_ms, 1),
+            "value_incl_setup": round(solves / (dt + setup_ms / 1000.0), 2),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
