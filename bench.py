@@ -125,6 +125,8 @@ def main():
     eng = Engine(local_rank)
     if os.environ.get("DSA_MAX_CHUNK"):
         eng.set_option("max_chunk", int(os.environ["DSA_MAX_CHUNK"]))
+    if os.environ.get("DSA_FIM_SORTED"):
+        eng.set_option("fim_sorted", int(os.environ["DSA_FIM_SORTED"]))
     t_setup = time.perf_counter()
     eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     eng.plan(units["map_index"][sl], units["scx"][sl], units["scz"][sl], units["nrec"][sl], units["rcx"][rsl], units["rcz"][rsl])

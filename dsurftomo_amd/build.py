@@ -42,7 +42,8 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = ["-D" + d for d in os.environ.get("DSA_DEFINES", "").split() if d]     # experiments only
+        cmd = [hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -291,7 +291,9 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     const size_t rr = (size_t)kRefMax * kRefMax;
     {   // the refined and the coarse solve of a unit share one list region: size it for the larger shape
         const FimLaunch lc = launch_shape(g.nnx, g.nnz), lr = launch_shape(kRefMax, kRefMax);
-        lists_stride = std::max((size_t)2 * lc.list_cap + lc.ready_cap, (size_t)2 * lr.list_cap + lr.ready_cap);
+        lists_stride = std::max((size_t)4 * lc.list_cap + lc.ready_cap, (size_t)4 * lr.list_cap + lr.ready_cap);
+        lists_stride = std::max(lists_stride, (size_t)2 * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile masks + one list
+        lists_stride = (lists_stride + 1) & ~(size_t)1;      // the masks are 8-byte words
     }
     per_unit_bytes = nrec_c * 8 + lists_stride * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
                      (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(SourceDesc);
@@ -432,6 +434,10 @@ FimLaunch Engine::launch_shape(int nnx, int nnz) const
     l.list_cap = list_cap > 0 ? list_cap : 16 * (nnx + nnz) + 4096;
     l.ready_cap = ready_cap > 0 ? ready_cap : 8 * (nnx + nnz) + 2048;
     l.threads = fim_threads;
+    // the ordered variant keeps a tile bitmap in LDS: up to 32 KB per workgroup (N <= 4097)
+    const int ntile = tiles_of(nnx) * tiles_of(nnz);
+    l.tile_words = (ntile + 31) / 32;
+    l.sorted = (fim_sorted && l.tile_words * 4 <= 36 * 1024) ? 1 : 0;
     return l;
 }
 
@@ -617,6 +623,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "list_cap" && value >= 0) { en->list_cap = (int)value; return 0; }
     if (n == "ready_cap" && value >= 0) { en->ready_cap = (int)value; return 0; }
     if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
+    if (n == "fim_sorted" && (value == 0 || value == 1)) { en->fim_sorted = (int)value; return 0; }
     if (n == "fim_threads" && (value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;

@@ -60,11 +60,14 @@ __device__ __forceinline__ int wave_alloc(int* counter, bool want)
     return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
 }
 
-__device__ __forceinline__ void push_next(const Lists& L, int id, bool want)
+// A list entry is (node, key): key is an upper bound of the node's lower bound at the time it was
+// queued (the acceptance time of the neighbour that queued it), so `key < theta` routes the node
+// without touching its neighbourhood; +inf means "unknown, compute it".
+__device__ __forceinline__ void push_next(const Lists& L, int id, float key, bool want)
 {
     const int pos = wave_alloc(&L.sc[SC_NEXT], want);
     if (want) {
-        if (pos < L.cap) L.next[pos] = id;
+        if (pos < L.cap) { L.next[2 * pos] = id; L.next[2 * pos + 1] = (int)f2u(key); }
         else L.sc[SC_OVERFLOW] = 1;    // the node keeps its queued bit; a rescan picks it up
     }
 }
@@ -82,16 +85,19 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 
 }  // namespace
 
+#ifndef DSA_FIM_WAVES
+#define DSA_FIM_WAVES 4
+#endif
 // One workgroup of NT threads per problem.  The solver wants ~124 VGPRs, i.e. 4 waves per SIMD: tell the
 // compiler so, otherwise it targets 8 waves/SIMD (64 VGPRs) and spills the solver.
 template <int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fim(const FimProblem* __restrict__ problems, int cap, int rcap)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVES, DSA_FIM_WAVES))) void k_fim(const FimProblem* __restrict__ problems, int cap, int rcap)
 {
     __shared__ int smem[SC_COUNT];
     const FimProblem p = problems[blockIdx.x];
     const int tid = threadIdx.x;
     Lists L;
-    L.cur = (GI32*)p.lists; L.next = L.cur + cap; L.ready = L.cur + 2 * cap; L.sc = smem;
+    L.cur = (GI32*)p.lists; L.next = L.cur + 2 * cap; L.ready = L.cur + 4 * cap; L.sc = smem;
     L.cap = cap; L.rcap = rcap;
     int* sc = L.sc;
     // The pointers come out of a struct in memory, so the compiler would use FLAT instructions (which
@@ -110,12 +116,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     const int nseed = *p.seed_count;
     if (tid == 0) {
-        sc[SC_CUR] = nseed < cap ? nseed : cap; sc[SC_NEXT] = 0; sc[SC_READY] = 0; sc[SC_READY_ODD] = 0;
-        sc[SC_TMIN] = 0x7f800000; sc[SC_OVERFLOW] = nseed > cap ? 1 : 0; sc[SC_THETA] = 0x7f800000;
+        sc[SC_CUR] = nseed <= cap && nseed <= p.seed_cap ? nseed : 0; sc[SC_NEXT] = 0; sc[SC_READY] = 0; sc[SC_READY_ODD] = 0;
+        sc[SC_TMIN] = 0x7f800000; sc[SC_OVERFLOW] = (nseed > cap || nseed > p.seed_cap) ? 1 : 0; sc[SC_THETA] = 0x7f800000;
         sc[SC_FREEZE] = (int)0xff800000u;      // -inf: nothing frozen
         sc[SC_HASH] = 0;
     }
-    for (int i = tid; i < nseed && i < cap; i += NT) L.cur[i] = p.seed[i];
+    if (nseed <= cap && nseed <= p.seed_cap)
+        for (int i = tid; i < nseed; i += NT) { L.cur[2 * i] = p.seed[i]; L.cur[2 * i + 1] = 0x7f800000; }
     __syncthreads();
 
     int rounds = 0, rescans = 0, stall = 0, freezes = 0;   // cycle bookkeeping is used by thread 0 only
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if ((__hip_atomic_load(tau_word(id), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & kQueuedBit) &&
                     !t_pinned(F[id].T)) {
                     const int pos = atomicAdd(&sc[SC_NEXT], 1);
-                    if (pos < cap) L.cur[pos] = id; else sc[SC_OVERFLOW] = 1;
+                    if (pos < cap) { L.cur[2 * pos] = id; L.cur[2 * pos + 1] = 0x7f800000; } else sc[SC_OVERFLOW] = 1;
                 }
             __syncthreads();
             cnt = sc[SC_NEXT] < cap ? sc[SC_NEXT] : cap;
@@ -160,20 +167,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
                 const int i = base + u * NT + tid;
-                ids[u] = i < cnt ? L.cur[i] : -1;
+                ids[u] = i < cnt ? L.cur[2 * i] : -1;
+                lbs[u] = i < cnt ? u2f((unsigned)L.cur[2 * i + 1]) : kInf;     // the entry's key
             }
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
-                lbs[u] = kInf; own[u] = kInf;
+                own[u] = kInf;
                 if (ids[u] < 0) continue;
                 const int id = ids[u];
+                if (frozen_any) own[u] = F[id].tau;
+                if (open || lbs[u] < theta) continue;               // routed by its key: no neighbour loads
                 int iz, ix;                                         // 0-based
                 rec_coords(nbz, id, &iz, &ix);
                 const float a = ix > 0 ? F[rec_index(nbz, iz, ix - 1)].tau : kInf;
                 const float b = ix + 1 < nnx ? F[rec_index(nbz, iz, ix + 1)].tau : kInf;
                 const float c = iz > 0 ? F[rec_index(nbz, iz - 1, ix)].tau : kInf;
                 const float d = iz + 1 < nnz ? F[rec_index(nbz, iz + 1, ix)].tau : kInf;
-                if (frozen_any) own[u] = F[id].tau;
                 lbs[u] = fminf(fminf(tau_value(a), tau_value(b)), fminf(tau_value(c), tau_value(d)));
             }
             float tmin_lane = kInf;
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (got) L.ready[want_o ? rhalf + po : pe] = id;
                 if (got || frozen) atomicAnd(tau_word(id), ~kQueuedBit);             // before the barrier: see header
                 const bool defer = cand && !got;
-                push_next(L, id, defer);
+                push_next(L, id, lb, defer);
                 if (defer) tmin_lane = fminf(tmin_lane, lb);
             }
             tmin_lane = wave_min(tmin_lane);
@@ -279,8 +288,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    push_next(L, nid[q], !(olds[q] & kQueuedBit));
-                    push_next(L, nid[4 + q], !(olds[4 + q] & kQueuedBit));
+                    push_next(L, nid[q], k, !(olds[q] & kQueuedBit));                                    // lb(Y) <= tau(X)
+                    push_next(L, nid[4 + q], tau_value(h.near_tau[q]), !(olds[4 + q] & kQueuedBit));    // lb(Z) <= tau(Y)
                 }
                 const unsigned hv = wave_sum(changed ? (((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u)) : 0u);
                 const float kmin = wave_min(changed ? k : kInf);
@@ -331,11 +340,295 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
-size_t fim_lds_bytes(const FimLaunch&) { return SC_COUNT * sizeof(int); }
+
+// ---------------------------------------------------------------------------------------------
+// Variant with a spatially ordered active set.
+//
+// Measured on the list kernel above (profiles/r01_pmc_k_fim_tiled_pruned.txt): at full occupancy the
+// SIMDs are 26 % busy and waves sit in s_waitcnt 70 % of the time; adding waves does not help.  What
+// saturates is the per-CU vector memory path: lists grow in activation order, so the 64 lanes of a
+// load touch 64 different 128-B lines (43.6 M L1 line accesses and 15 M L2 requests per solve for
+// 2.35 M evaluations).  Here the active set is a 64-bit node mask per 8x8 tile (global scratch) plus
+// a tile bitmap in LDS; every round the node list is rebuilt from them in record order (a block
+// scan), so neighbouring lanes work on neighbouring nodes of the front and share lines.  Activation
+// is an atomicOr on the tile's mask (dedupe = the old value), deferred nodes simply keep their bit,
+// and the lists cannot overflow.  The round structure, the local solver, the pruning rules, the
+// window and the cycle freeze are those of k_fim; results are bit-identical (same fixed point).
+typedef __attribute__((address_space(1))) unsigned long long GU64;
+
+template <int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVES, DSA_FIM_WAVES))) void k_fim_sorted(const FimProblem* __restrict__ problems, int cap, int rcap)
+{
+    extern __shared__ unsigned dyn_lds[];
+    __shared__ int smem[SC_COUNT];
+    constexpr int kWaveBuf = 256;                            // nodes a wave expands at a time
+    __shared__ int wbuf[(NT / 64) * kWaveBuf];
+    constexpr int kTileBuf = 256;                            // tiles a wave gathers at a time
+    __shared__ int wtile[(NT / 64) * kTileBuf];
+    const FimProblem p = problems[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* sc = smem;
+    typedef __attribute__((address_space(1))) Rec GRec;
+    typedef __attribute__((address_space(1))) const float GCF32;
+    GRec* const F = (GRec*)p.F;
+    GCF32* const slow = (GCF32*)p.slow;
+    GCF32* const risti = (GCF32*)p.risti;
+    const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
+    const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
+    GU64* const mask = (GU64*)p.lists;                       // ntile node masks
+    GI32* const ready = (GI32*)p.lists + 2 * ntile;          // rcap
+    unsigned* const tb = dyn_lds;                            // tile bitmap, nwords
+    auto ld = [&](int id) { Rec r; r.T = F[id].T; r.tau = F[id].tau; return r; };
+    const int rhalf = rcap / 2;
+
+    for (int i = tid; i < ntile; i += NT) mask[i] = 0ull;
+    for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
+    if (tid == 0) {
+        sc[SC_READY] = 0; sc[SC_READY_ODD] = 0; sc[SC_TMIN] = 0x7f800000; sc[SC_THETA] = 0x7f800000;
+        sc[SC_FREEZE] = (int)0xff800000u; sc[SC_HASH] = 0; sc[SC_OVERFLOW] = 0; sc[SC_CUR] = 0;
+    }
+    __syncthreads();
+    const int nseed = *p.seed_count;
+    if (nseed <= p.seed_cap) {
+        for (int i = tid; i < nseed; i += NT) {
+            const int id = p.seed[i];
+            atomicAnd((unsigned*)&F[id].tau, ~kQueuedBit);
+            atomicOr((unsigned long long*)&mask[id >> 6], 1ull << (id & 63));
+            atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31));
+        }
+    } else {
+        // more seeds than the prologue's list holds: they are flagged on the field (queued bit of tau)
+        for (int id = tid; id < ntile * kTileRecs; id += NT) {
+            const unsigned w = __hip_atomic_load((unsigned*)&F[id].tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!(w & kQueuedBit)) continue;
+            atomicAnd((unsigned*)&F[id].tau, ~kQueuedBit);
+            if (t_pinned(F[id].T)) continue;
+            atomicOr((unsigned long long*)&mask[id >> 6], 1ull << (id & 63));
+            atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31));
+        }
+    }
+    __syncthreads();
+
+    int rounds = 0, stall = 0, freezes = 0, max_cnt = 0;
+    unsigned hist[4] = { 1u, 2u, 3u, 4u };
+    unsigned long long tA = 0, tB0 = 0, tB1 = 0, tE = 0, t0 = wall_clock64(), sum_cnt = 0, sum_ready = 0;
+    float best_tmin = -kInf;
+    unsigned long long evals = 0;
+    for (;;) {
+        const float theta = u2f((unsigned)sc[SC_THETA]);
+        const bool open = !(theta < kInf);
+        const float freeze = u2f((unsigned)sc[SC_FREEZE]);
+        const bool frozen_any = freeze > -kInf;
+
+        // ---- pass A: every wave sweeps its share of the tile bitmap in chunks of 64 tiles (no
+        // workgroup barrier inside): lanes = tiles to fetch the node masks, then the set bits are
+        // expanded into a wave-local buffer in record order and lanes = nodes compute the lower
+        // bounds and route (neighbouring lanes read neighbouring nodes).
+        int seen = 0;
+        float tmin_lane = kInf;
+        int* const nbuf = wbuf + wave * kWaveBuf;
+        int* const tbuf = wtile + wave * kTileBuf;
+        constexpr int NW = NT / 64;
+        for (int wb = 0; (wb * 4 * NW + wave) * 16 < nwords; ++wb) {
+            // 64 bitmap words of this wave: 16-word groups dealt round-robin to the waves, ascending
+            const int w = ((wb * 4 + (lane >> 4)) * NW + wave) * 16 + (lane & 15);
+            const unsigned bits = w < nwords ? tb[w] : 0u;
+            const int nt_lane = __popc(bits);
+            int tincl = nt_lane;
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(tincl, o); if (lane >= o) tincl += v; }
+            const int ttotal = __shfl(tincl, 63);
+            if (ttotal == 0) continue;                                     // wave-uniform
+            const int toff = tincl - nt_lane;
+            for (int tbase = 0; tbase < ttotal; tbase += kTileBuf) {
+                {   // active tiles with rank in [tbase, tbase + kTileBuf), in tile order
+                    unsigned bb = bits;
+                    int idx = toff;
+                    while (bb) {
+                        const int b2 = __ffs((int)bb) - 1;
+                        bb &= bb - 1u;
+                        if (idx >= tbase && idx < tbase + kTileBuf) tbuf[idx - tbase] = (w << 5) + b2;
+                        ++idx;
+                    }
+                }
+                const int ntiles = min(ttotal - tbase, kTileBuf);
+                for (int t0 = 0; t0 < ntiles; t0 += 64) {
+                    // lanes = tiles: one fetch of 64 node masks
+                    const int tile = t0 + lane < ntiles ? tbuf[t0 + lane] : -1;
+                    unsigned long long m = 0ull;
+                    if (tile >= 0) {
+                        m = mask[tile];
+                        if (m == 0ull) atomicAnd(&tb[tile >> 5], ~(1u << (tile & 31)));      // the tile has drained
+                    }
+                    const int n = __popcll(m);
+                    int incl = n;
+                    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                    const int total = __shfl(incl, 63);
+                    const int off = incl - n;
+                    seen += total;
+                    for (int base = 0; base < total; base += kWaveBuf) {
+                        {
+                            unsigned long long mm = m;
+                            int idx = off;
+                            while (mm) {
+                                const int nb = __ffsll((long long)mm) - 1;
+                                mm &= mm - 1ull;
+                                if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = (tile << 6) + nb;
+                                ++idx;
+                            }
+                        }
+                        const int nn = min(total - base, kWaveBuf);
+                        // lanes = nodes, in record order
+                        for (int j0 = 0; j0 < nn; j0 += 64) {
+                            const int j = j0 + lane;
+                            const bool have = j < nn;
+                            const int id = have ? nbuf[j] : 0;
+                            int iz, ix;
+                            rec_coords(nbz, id, &iz, &ix);
+                            float lb = kInf, own = kInf;
+                            if (have) {
+                                const float a = ix > 0 ? F[rec_index(nbz, iz, ix - 1)].tau : kInf;
+                                const float b2 = ix + 1 < nnx ? F[rec_index(nbz, iz, ix + 1)].tau : kInf;
+                                const float c2 = iz > 0 ? F[rec_index(nbz, iz - 1, ix)].tau : kInf;
+                                const float d2 = iz + 1 < nnz ? F[rec_index(nbz, iz + 1, ix)].tau : kInf;
+                                if (frozen_any) own = F[id].tau;
+                                lb = fminf(fminf(a, b2), fminf(c2, d2));
+                            }
+                            const bool frozen = have && frozen_any && own < freeze;
+                            const bool cand = have && !frozen;
+                            const bool odd = ((ix + iz) & 1) != 0;
+                            const bool want_e = cand && (open || lb < theta) && !odd;
+                            const bool want_o = cand && (open || lb < theta) && odd;
+                            const int pe = wave_alloc(&sc[SC_READY], want_e);
+                            const int po = wave_alloc(&sc[SC_READY_ODD], want_o);
+                            const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
+                            if (got) ready[want_o ? rhalf + po : pe] = id;
+                            // leaving the active set happens before the barrier, so a change that lands while
+                            // the node is being evaluated sets the bit again
+                            if (got || frozen) atomicAnd((unsigned long long*)&mask[id >> 6], ~(1ull << (id & 63)));
+                            if (cand && !got) tmin_lane = fminf(tmin_lane, lb);
+                        }
+                    }
+                }
+            }
+        }
+        tmin_lane = wave_min(tmin_lane);
+        if (lane == 0) {
+            if (tmin_lane < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(tmin_lane));
+            if (seen) atomicAdd(&sc[SC_CUR], seen);
+        }
+        __syncthreads();
+        const int cnt = sc[SC_CUR];
+        if (cnt == 0) break;
+        { const unsigned long long t1 = wall_clock64(); tA += t1 - t0; t0 = t1; sum_cnt += cnt; if (cnt > max_cnt) max_cnt = cnt; }
+
+        // ---- pass B: evaluate, even nodes first
+        const int nready_even = sc[SC_READY] < rhalf ? sc[SC_READY] : rhalf;
+        const int nready_odd = sc[SC_READY_ODD] < rhalf ? sc[SC_READY_ODD] : rhalf;
+        for (int half = 0; half < 2; ++half) {
+            const int nready = half ? nready_odd : nready_even;
+            for (int j0 = 0; j0 < nready; j0 += NT) {
+                const int j = j0 + tid;
+                const bool act = j < nready;
+                const int id = act ? ready[half ? rhalf + j : j] : 0;
+                int iz, ix;
+                rec_coords(nbz, id, &iz, &ix);
+                Hood h;
+                h.in[0] = act && ix > 0;          h.in_outer[0] = act && ix > 1;
+                h.in[1] = act && ix + 1 < nnx;    h.in_outer[1] = act && ix + 2 < nnx;
+                h.in[2] = act && iz > 0;          h.in_outer[2] = act && iz > 1;
+                h.in[3] = act && iz + 1 < nnz;    h.in_outer[3] = act && iz + 2 < nnz;
+                int nid[8];
+                nid[0] = rec_index(nbz, iz, ix - 1); nid[4] = rec_index(nbz, iz, ix - 2);
+                nid[1] = rec_index(nbz, iz, ix + 1); nid[5] = rec_index(nbz, iz, ix + 2);
+                nid[2] = rec_index(nbz, iz - 1, ix); nid[6] = rec_index(nbz, iz - 2, ix);
+                nid[3] = rec_index(nbz, iz + 1, ix); nid[7] = rec_index(nbz, iz + 2, ix);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const Rec a = h.in[q] ? ld(nid[q]) : Rec{ kInf, kInf };
+                    const Rec b = h.in_outer[q] ? ld(nid[4 + q]) : Rec{ kInf, kInf };
+                    h.near_[q] = a.T; h.near_tau[q] = a.tau;
+                    h.outer[q] = b.T; h.outer_tau[q] = b.tau;
+                }
+                const Rec own = act ? ld(id) : Rec{ -1.0f, 0.0f };
+                const float t_old = own.T;
+                const float k_old = own.tau;
+                bool changed = false;
+                float c = 0.0f, k = kInf;
+                if (!t_pinned(t_old)) {
+                    const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
+                    c = solve_node(h, slow[id], geom, &k);
+                    ++evals;
+                    changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
+                }
+                if (changed) { F[id].T = c; F[id].tau = k; }
+                // dependents: same pruning as k_fim; the tile mask's old value tells whether the node was
+                // already active and whether its tile has to enter the bitmap
+                const float t_lo = fminf(t_value(t_old), c), k_lo = fminf(k_old, k);
+                bool want[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float ky = h.near_tau[q];
+                    want[q] = changed && h.in[q] && !t_pinned(h.near_[q]) && k_lo <= ky;
+                    want[4 + q] = changed && h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) &&
+                                  t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q];
+                }
+                unsigned long long olds[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    olds[q] = want[q] ? atomicOr((unsigned long long*)&mask[nid[q] >> 6], 1ull << (nid[q] & 63)) : ~0ull;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (olds[q] == 0ull) atomicOr(&tb[(nid[q] >> 6) >> 5], 1u << ((nid[q] >> 6) & 31));
+                const unsigned hv = wave_sum(changed ? (((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u)) : 0u);
+                const float kmin = wave_min(changed ? k : kInf);
+                if (lane == 0) {
+                    if (hv) atomicAdd(reinterpret_cast<unsigned*>(&sc[SC_HASH]), hv);
+                    if (kmin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(kmin));
+                }
+            }
+            __syncthreads();
+            { const unsigned long long t1 = wall_clock64(); (half ? tB1 : tB0) += t1 - t0; t0 = t1; }
+        }
+        sum_ready += nready_even + nready_odd;
+        if (tid == 0) {
+            sc[SC_READY] = 0; sc[SC_READY_ODD] = 0; sc[SC_CUR] = 0;
+            const float tmin = u2f((unsigned)sc[SC_TMIN]);
+            sc[SC_THETA] = (int)f2u(tmin + p.window);
+            sc[SC_TMIN] = 0x7f800000;
+            const unsigned hsh = (unsigned)sc[SC_HASH];
+            sc[SC_HASH] = 0;
+            if (tmin > best_tmin) best_tmin = tmin;
+            const bool repeat = hsh != 0u && (hsh == hist[1] || hsh == hist[2] || hsh == hist[3] || hsh == hist[0]);
+            hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = hsh;
+            if (repeat) { if (++stall >= kCycleRounds) { sc[SC_FREEZE] = (int)f2u(best_tmin + p.window); stall = 0; ++freezes; } }
+            else stall = 0;
+        }
+        ++rounds;
+        __syncthreads();
+        { const unsigned long long t1 = wall_clock64(); tE += t1 - t0; t0 = t1; }
+        if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
+    }
+    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals);
+    if (tid == 0) {
+        p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
+        if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }
+    }
+}
+
+size_t fim_lds_bytes(const FimLaunch& l) { return l.sorted ? (size_t)l.tile_words * 4 : 0; }
+
 
 void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream)
 {
     if (nproblems <= 0) return;
+    if (l.sorted) {
+        const size_t lds = fim_lds_bytes(l);
+        if (l.threads == 256) hipLaunchKernelGGL(k_fim_sorted<256>, dim3(nproblems), dim3(256), lds, stream, d_problems, l.list_cap, l.ready_cap);
+        else if (l.threads == 512) hipLaunchKernelGGL(k_fim_sorted<512>, dim3(nproblems), dim3(512), lds, stream, d_problems, l.list_cap, l.ready_cap);
+        else hipLaunchKernelGGL(k_fim_sorted<1024>, dim3(nproblems), dim3(1024), lds, stream, d_problems, l.list_cap, l.ready_cap);
+        return;
+    }
     if (l.threads == 256) hipLaunchKernelGGL(k_fim<256>, dim3(nproblems), dim3(256), 0, stream, d_problems, l.list_cap, l.ready_cap);
     else if (l.threads == 512) hipLaunchKernelGGL(k_fim<512>, dim3(nproblems), dim3(512), 0, stream, d_problems, l.list_cap, l.ready_cap);
     else hipLaunchKernelGGL(k_fim<1024>, dim3(nproblems), dim3(1024), 0, stream, d_problems, l.list_cap, l.ready_cap);

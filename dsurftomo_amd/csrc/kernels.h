@@ -18,7 +18,8 @@ struct FimProblem {
     const float* risti;
     const int* seed;
     const int* seed_count;
-    int* lists;            // scratch for the active lists: 2 * list_cap + ready_cap ints
+    int seed_cap;          // entries of `seed`; a larger count means: collect the queued nodes from the field
+    int* lists;            // scratch for the active lists: 2 lists of list_cap (node, key) pairs + ready_cap ints
     int nnx, nnz, nbx, nbz;
     float ri, dnx, dnz;
     float window;          // causal window (seconds of travel time) evaluated per round
@@ -31,6 +32,8 @@ struct FimLaunch {
     int list_cap;          // entries per active list
     int ready_cap;         // entries of the dense ready list
     int threads;           // workgroup size: 256, 512 or 1024
+    int sorted;            // 1: k_fim_sorted (tile masks + LDS tile bitmap), 0: k_fim (lists in activation order)
+    int tile_words;        // words of the LDS tile bitmap (sorted variant)
 };
 
 size_t fim_lds_bytes(const FimLaunch& l);

@@ -271,7 +271,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     const SourceDesc sd = b.src[s];
     FimProblem r;
     r.F = b.F_r + (size_t)s * kRefRecs; r.slow = b.slow_r + (size_t)s * kRefRecs; r.risti = b.risti_r + (size_t)s * kRefMax;
-    r.seed = b.seed_r + (size_t)s * kSeedR; r.seed_count = b.nseed_r + s; r.lists = b.lists + (size_t)s * b.lists_stride;
+    r.seed = b.seed_r + (size_t)s * kSeedR; r.seed_count = b.nseed_r + s; r.seed_cap = kSeedR; r.lists = b.lists + (size_t)s * b.lists_stride;
     r.nnx = sd.rnx; r.nnz = sd.rnz; r.nbx = sd.nbx_r; r.nbz = sd.nbz_r;
     r.ri = g.earth; r.dnx = sd.rdnx; r.dnz = sd.rdnz; r.window = window_r;
     r.max_rounds = 64 * (sd.rnx + sd.rnz) + 4096;
@@ -281,7 +281,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     FimProblem c;
     c.F = b.F_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
     c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
-    c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.lists = b.lists + (size_t)s * b.lists_stride;
+    c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.seed_cap = kSeedC; c.lists = b.lists + (size_t)s * b.lists_stride;
     c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
     c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = window_c;
     c.max_rounds = 64 * (g.nnx + g.nnz) + 4096;

@@ -51,7 +51,9 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 /* tuning knobs: "window_cells" (causal window of the fixed-point solve, in cell travel times,
  * default 3), "max_chunk" (cap on sources resident per chunk, 0 = memory budget only),
  * "list_cap" / "ready_cap" (active-list sizes of the solve kernel, 0 = derived from the grid),
- * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024), "ray_budget" (bytes of
+ * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024), "fim_sorted" (1 = the
+ * variant of the solve kernel that keeps its active set in tile masks and walks it in record order;
+ * identical results), "ray_budget" (bytes of
  * per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up to 8 GB) */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
 

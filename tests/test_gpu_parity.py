@@ -85,3 +85,18 @@ def test_fields_match_oracle(engine, nx, kind, gd):
     # "ties"); those are bounded but can exceed 1e-4 s at isolated nodes.  Receivers (above) hold 1e-4.
     assert nbad_nodes <= 0.005 * total
     assert worst <= 2e-3
+
+
+def test_sorted_variant_identical(engine):
+    """the tile-mask / ordered-sweep variant of the solve kernel reaches the same fixed point, bit for bit"""
+    nx = 35
+    pv = np.stack([synth.medium(nx, "checker4"), synth.medium(nx, "smooth")])
+    u = synth.units(nx, 12, 2, 6)
+    out = []
+    for v in (0, 1):
+        engine.set_option("fim_sorted", v)
+        engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        out.append((engine.traveltimes(**u), engine.field(23)))
+    engine.set_option("fim_sorted", 0)
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
