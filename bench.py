@@ -175,8 +175,11 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
+            # PMC passes are separate runs (rocprofv3 --pmc); the committed per-solve figure is scaled to this launch
             with open(tfile) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                per_solve = json.load(f).get("hbm_bytes_per_solve")
+            if per_solve:
+                traffic = round(per_solve * my_units / max(acc["launches_fim_coarse"], 1))
         line = {
             "metric": "source-period FMM solves/sec on NxN grid; travel-time max-abs-err vs ref",
             "value": round(solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
