@@ -58,6 +58,7 @@ struct Engine {
     DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists;
     size_t lists_stride = 0;
     int fim_threads = 256;
+    int fim_lds_pad = 0;               // dynamic LDS bytes per workgroup of the solve kernel (occupancy limiter)
     int fim_sorted = 0;                // 1: k_fim_sorted (same results, same speed, half the HBM fetch)
     DevBuf<int8_t> S_r, cinit;
     DevBuf<int16_t> rst, cst;

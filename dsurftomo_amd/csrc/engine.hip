@@ -434,6 +434,7 @@ FimLaunch Engine::launch_shape(int nnx, int nnz) const
     l.list_cap = list_cap > 0 ? list_cap : 16 * (nnx + nnz) + 4096;
     l.ready_cap = ready_cap > 0 ? ready_cap : 8 * (nnx + nnz) + 2048;
     l.threads = fim_threads;
+    l.lds_pad = fim_lds_pad;
     // the ordered variant keeps a tile bitmap in LDS: up to 32 KB per workgroup (N <= 4097)
     const int ntile = tiles_of(nnx) * tiles_of(nnz);
     l.tile_words = (ntile + 31) / 32;
@@ -623,6 +624,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "list_cap" && value >= 0) { en->list_cap = (int)value; return 0; }
     if (n == "ready_cap" && value >= 0) { en->ready_cap = (int)value; return 0; }
     if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
+    if (n == "fim_lds_pad" && value >= 0 && value <= 64 * 1024) { en->fim_lds_pad = (int)value; return 0; }
     if (n == "fim_sorted" && (value == 0 || value == 1)) { en->fim_sorted = (int)value; return 0; }
     if (n == "fim_threads" && (value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);

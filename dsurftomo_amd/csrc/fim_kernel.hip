@@ -629,9 +629,10 @@ void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l,
         else hipLaunchKernelGGL(k_fim_sorted<1024>, dim3(nproblems), dim3(1024), lds, stream, d_problems, l.list_cap, l.ready_cap);
         return;
     }
-    if (l.threads == 256) hipLaunchKernelGGL(k_fim<256>, dim3(nproblems), dim3(256), 0, stream, d_problems, l.list_cap, l.ready_cap);
-    else if (l.threads == 512) hipLaunchKernelGGL(k_fim<512>, dim3(nproblems), dim3(512), 0, stream, d_problems, l.list_cap, l.ready_cap);
-    else hipLaunchKernelGGL(k_fim<1024>, dim3(nproblems), dim3(1024), 0, stream, d_problems, l.list_cap, l.ready_cap);
+    const size_t pad = (size_t)l.lds_pad;
+    if (l.threads == 256) hipLaunchKernelGGL(k_fim<256>, dim3(nproblems), dim3(256), pad, stream, d_problems, l.list_cap, l.ready_cap);
+    else if (l.threads == 512) hipLaunchKernelGGL(k_fim<512>, dim3(nproblems), dim3(512), pad, stream, d_problems, l.list_cap, l.ready_cap);
+    else hipLaunchKernelGGL(k_fim<1024>, dim3(nproblems), dim3(1024), pad, stream, d_problems, l.list_cap, l.ready_cap);
 }
 
 }  // namespace dsa

@@ -34,6 +34,7 @@ struct FimLaunch {
     int threads;           // workgroup size: 256, 512 or 1024
     int sorted;            // 1: k_fim_sorted (tile masks + LDS tile bitmap), 0: k_fim (lists in activation order)
     int tile_words;        // words of the LDS tile bitmap (sorted variant)
+    int lds_pad;           // extra dynamic LDS per workgroup (bytes): limits the workgroups resident per CU
 };
 
 size_t fim_lds_bytes(const FimLaunch& l);

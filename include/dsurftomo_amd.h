@@ -53,7 +53,8 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  * "list_cap" / "ready_cap" (active-list sizes of the solve kernel, 0 = derived from the grid),
  * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024), "fim_sorted" (1 = the
  * variant of the solve kernel that keeps its active set in tile masks and walks it in record order;
- * identical results), "ray_budget" (bytes of
+ * identical results), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits
+ * the workgroups resident per CU), "ray_budget" (bytes of
  * per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up to 8 GB) */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""The whole CalSurfG boundary at the headline size (no oracle: timing and sanity only):
+nx = ny = 131 (1025^2 grid), nz = 9, 16 Rayleigh phase periods, 1000 sources per period, R receivers each."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _libs as L      # noqa: E402
+import synth           # noqa: E402
+from dsurftomo_amd import engine as E   # noqa: E402
+
+
+def main():
+    nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    nsrc = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    lib = E.load_library()
+    t0 = time.perf_counter()
+    c = synth.boundary_case(nx=131, ny=131, nz=9, kRc=16, kRg=0, kLc=0, kLg=0, nsrc=nsrc, nrcf=nrec, dvd=0.01, ragged=False)
+    c["tRc"] = np.linspace(2.0, 17.0, 16)
+    print("case built in %.1f s: ndata %d, nparpi %d" % (time.perf_counter() - t0, c["ndata"], c["nparpi"]), flush=True)
+    nd, npar = c["ndata"], c["nparpi"]
+    cap = int(nd * 2200)
+    i32 = lambda v: C.byref(C.c_int(int(v)))
+    f32 = lambda v: C.byref(C.c_float(float(v)))
+    iw = np.zeros(cap + 1, np.int32); rw = np.zeros(cap, np.float32); col = np.zeros(cap, np.int32); dsurf = np.zeros(nd, np.float32)
+    os.environ["DSA_MAXNAR"] = str(cap)
+    nar = C.c_int(0)
+    for k in range(2):
+        t0 = time.perf_counter()
+        rc = lib.dsa_calsurfg(i32(c["nx"]), i32(c["ny"]), i32(c["nz"]), i32(npar), L.ptr(c["vels"]), L.ptr(iw), L.ptr(rw), L.ptr(col), L.ptr(dsurf),
+                              f32(c["goxd"]), f32(c["gozd"]), f32(c["dvxd"]), f32(c["dvzd"]), i32(c["kRc"]), i32(0), i32(0), i32(0),
+                              L.ptr(c["tRc"]), L.ptr(c["tRg"]), L.ptr(c["tLc"]), L.ptr(c["tLg"]), L.ptr(c["wavetype"]), L.ptr(c["igrt"]), L.ptr(c["periods"]),
+                              L.ptr(c["depz"]), f32(c["minthk"]), L.ptr(c["scxf"]), L.ptr(c["sczf"]), L.ptr(c["rcxf"]), L.ptr(c["rczf"]), L.ptr(c["nrc1"]),
+                              L.ptr(c["nsrcsurf1"]), i32(c["kmax"]), i32(c["nsrcsurf"]), i32(c["nrcf"]), C.byref(nar))
+        dt = time.perf_counter() - t0
+        print("dsa_calsurfg pass %d: rc %d (%s), %.2f s wall; %d solves, %d rays, nar %d (%.0f per row, %.2f GB of COO)" %
+              (k, rc, lib.dsa_dropin_error().decode(), dt, 16 * nsrc, nd, nar.value, nar.value / max(nd, 1), nar.value * 12 / 1e9), flush=True)
+    print("dsurf range %.3f .. %.3f s, rw range %.3g .. %.3g" % (dsurf.min(), dsurf.max(), rw[:nar.value].min(), rw[:nar.value].max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@ windows = [float(w) for w in sys.argv[3].split(',')] if len(sys.argv) > 3 else [
 kind = sys.argv[4] if len(sys.argv) > 4 else 'smooth'
 threads = [int(t) for t in sys.argv[5].split(',')] if len(sys.argv) > 5 else [512]
 e = Engine(0)
+if os.environ.get('DSA_LDS_PAD'): e.set_option('fim_lds_pad', int(os.environ['DSA_LDS_PAD']))
 nper = 2
 pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)])
 e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)

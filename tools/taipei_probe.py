@@ -25,6 +25,33 @@ def main():
         d = L.call_boundary(lib.dsa_calsurfg, c)
         dt = time.perf_counter() - t0
         print("device call %d: %.3f s wall, nar %d" % (k, dt, d["nar"]))
+        st = np.zeros(40)
+        lib.dsa_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+    # stage times of the last call (the drop-in's process-wide engine is not exposed; time the stages through an own engine)
+    e = E.Engine(0)
+    vel = np.ascontiguousarray(c["vels"].T)
+    for k in range(2):
+        t0 = time.perf_counter()
+        e.dispersion_begin(vel, c["depz"], float(c["minthk"]), c["kmax"], c["kmax"])
+        e.dispersion_run(2, 0, c["tRc"], True, 0, 0)
+        t1 = time.perf_counter()
+        e.maps_from_dispersion(c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], 8)
+        e.kernels_from_dispersion()
+        t2 = time.perf_counter()
+        maps, sx, sz, nrec, rx, rz, slot = [], [], [], [], [], [], []
+        for kk in range(c["kmax"]):
+            for s in range(c["nsrcsurf1"][kk]):
+                maps.append(c["periods"][s, kk] - 1); sx.append(c["scxf"][s, kk]); sz.append(c["sczf"][s, kk]); slot.append(kk)
+                nrec.append(c["nrc1"][s, kk]); rx += list(c["rcxf"][:nrec[-1], s, kk]); rz += list(c["rczf"][:nrec[-1], s, kk])
+        e.plan(maps, sx, sz, nrec, rx, rz, sen_slot=slot)
+        t3 = time.perf_counter()
+        out = e.solve_rows(c["ndata"] * c["nparpi"])
+        t4 = time.perf_counter()
+        st = e.stats()
+        print("stages (own engine) pass %d: dispersion %.1f ms (kernel %.1f, %d curves), maps+kernels %.1f ms, plan %.1f ms (%d units), solve_rows %.1f ms "
+              "[fim coarse %.1f refined %.1f stages %.1f rays %.1f rows %.1f]" % (k, 1e3 * (t1 - t0), st["ms_dispersion"], st["curves"], 1e3 * (t2 - t1), 1e3 * (t3 - t2), len(maps),
+              1e3 * (t4 - t3), st["ms_fim_coarse"], st["ms_fim_refined"], st["ms_stages"], st["ms_rays"], st["ms_rows"]))
+    e.close()
     ref = L.ref()
     if ref is not None and "--no-ref" not in sys.argv:
         for threads in (os.cpu_count(), 1):
