@@ -8,25 +8,47 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dsurftomo_amd.h"
+#include "engine.h"
 
 namespace {
 
 std::string g_dropin_error = "";
 dsa_engine* g_engine = nullptr;
 
+std::vector<dsa_engine*> g_pool;      // one engine per GPU of this process (DSA_DEVICES), g_engine = g_pool[0]
+
+// DSA_DEVICES = "4" (the first four GPUs) or "0,2,3" (a list); default: the single GPU DSA_DEVICE (0).
+// An index may repeat (two engines on one GPU), which is how the sharded path is tested on one GPU.
 int engine()
 {
     if (g_engine) return 0;
-    int dev = 0;
-    if (const char* s = getenv("DSA_DEVICE")) dev = atoi(s);
-    const int rc = dsa_create(&g_engine, dev);
-    if (rc != 0) { g_dropin_error = dsa_error_string(nullptr); g_engine = nullptr; return rc; }
-    if (const char* s = getenv("DSA_MAX_CHUNK")) dsa_set_option(g_engine, "max_chunk", atof(s));
-    if (const char* s = getenv("DSA_WINDOW_CELLS")) dsa_set_option(g_engine, "window_cells", atof(s));
+    std::vector<int> devs;
+    if (const char* s = getenv("DSA_DEVICES")) {
+        const std::string str(s);
+        if (str.find(',') == std::string::npos) { for (int k = 0; k < atoi(s); ++k) devs.push_back(k); }
+        else { size_t p = 0; while (p < str.size()) { devs.push_back(atoi(str.c_str() + p)); p = str.find(',', p); if (p == std::string::npos) break; ++p; } }
+    }
+    if (devs.empty()) devs.push_back(getenv("DSA_DEVICE") ? atoi(getenv("DSA_DEVICE")) : 0);
+    for (int dev : devs) {
+        dsa_engine* e = nullptr;
+        const int rc = dsa_create(&e, dev);
+        if (rc != 0) {
+            g_dropin_error = dsa_error_string(nullptr);
+            for (dsa_engine* q : g_pool) dsa_destroy(q);
+            g_pool.clear();
+            return rc;
+        }
+        if (const char* s = getenv("DSA_MAX_CHUNK")) dsa_set_option(e, "max_chunk", atof(s));
+        if (const char* s = getenv("DSA_WINDOW_CELLS")) dsa_set_option(e, "window_cells", atof(s));
+        g_pool.push_back(e);
+    }
+    g_engine = g_pool[0];
     return 0;
 }
 
@@ -123,38 +145,88 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     if (!nx || !ny || !nz || !vels || !iw || !rw || !col || !dsurf || !kmax || !nar) { g_dropin_error = "dsa_calsurfg: null argument"; return DSA_ERR_ARGUMENT; }
     int rc = engine();
     if (rc != 0) return rc;
-    dsa_engine* e = g_engine;
     const Layout L = make_layout(*kmaxRc, *kmaxRg, *kmaxLc, *kmaxLg, *kmax, true);
     if (L.kRc + L.kRg + L.kLc + L.kLg != L.kmax) { g_dropin_error = "dsa_calsurfg: kmax must equal kmaxRc+kmaxRg+kmaxLc+kmaxLg"; return DSA_ERR_ARGUMENT; }
-    // dispersion: depth kernels per type; the phase velocities at the group periods overwrite the head
-    // of the phase-velocity block (CalSurfG.f90:1100-1140)
-    if ((rc = dsa_dispersion_begin(e, *nx, *ny, *nz, vels, depz, *minthk, L.kmax, L.nmaps)) != 0) return fail(rc);
-    if ((rc = dsa_dispersion_run(e, 2, 0, L.kRc, tRc, 1, L.sRc, L.oRc)) != 0) return fail(rc);
-    if (L.kRg > 0) {
-        if ((rc = dsa_dispersion_run(e, 2, 1, L.kRg, tRg, 1, L.sRg, L.oRg)) != 0) return fail(rc);
-        if ((rc = dsa_dispersion_run(e, 2, 0, L.kRg, tRg, 0, 0, L.oRc)) != 0) return fail(rc);
-    }
-    if ((rc = dsa_dispersion_run(e, 1, 0, L.kLc, tLc, 1, L.sLc, L.oLc)) != 0) return fail(rc);
-    if (L.kLg > 0) {
-        if ((rc = dsa_dispersion_run(e, 1, 1, L.kLg, tLg, 1, L.sLg, L.oLg)) != 0) return fail(rc);
-        if ((rc = dsa_dispersion_run(e, 1, 0, L.kLg, tLg, 0, 0, L.oLc)) != 0) return fail(rc);
-    }
-    if ((rc = dsa_maps_from_dispersion(e, *goxdf, *gozdf, *dvxdf, *dvzdf, 8)) != 0) return fail(rc);
-    if ((rc = dsa_kernels_from_dispersion(e)) != 0) return fail(rc);
     Units U;
     if ((rc = make_units(L, true, *nsrcsurf, *nrcf, wavetype, igrt, periods, nrc1, nsrcsurf1, scxf, sczf, rcxf, rczf, U)) != 0) return rc;
-    if ((rc = dsa_plan_units(e, (int)U.map.size(), U.map.data(), U.sx.data(), U.sz.data(), U.nrec.data(), U.rx.data(), U.rz.data(),
-                             U.mode.data(), U.slot.data(), U.data.data())) != 0) return fail(rc);
-    long long cap = LLONG_MAX, n = 0;      // the reference's interface carries no capacity for rw / iw / col
+    long long cap = LLONG_MAX;             // the reference's interface carries no capacity for rw / iw / col
     if (const char* s = getenv("DSA_MAXNAR")) cap = atoll(s);
     *nar = 0;
-    if ((rc = dsa_solve_rows(e, dsurf, rw, iw + 1, col, cap, &n)) != 0) return fail(rc);   // the reference fills iw(nar+1)
+
+    // Every engine runs the dispersion stage for the whole model (it is small next to the solves) and then
+    // its contiguous slice of the unit list; the two units of a group-velocity datum stay together.
+    const int ne = (int)g_pool.size(), nu = (int)U.map.size();
+    std::vector<int> cut(ne + 1, nu);
+    cut[0] = 0;
+    for (int k = 1; k < ne; ++k) {
+        int c = (int)((long long)nu * k / ne);
+        while (c > 0 && c < nu && U.data[c] == U.data[c - 1] && U.mode[c] == 2) ++c;      // do not split a (times, rays) pair
+        cut[k] = std::max(c, cut[k - 1]);
+    }
+    std::vector<size_t> ray0(nu + 1, 0);
+    for (int u = 0; u < nu; ++u) ray0[u + 1] = ray0[u] + (size_t)U.nrec[u];
+    struct Part { std::vector<float> rw; std::vector<int> iw, col; long long n = 0; int rc = 0; std::string err; double clamped = 0; };
+    std::vector<Part> part(ne);
+    auto work = [&](int k) {
+        dsa_engine* e = g_pool[k];
+        dsa::Engine* en = reinterpret_cast<dsa::Engine*>(e);
+        Part& P = part[k];
+        auto bad = [&](int r) { P.rc = r; P.err = dsa_error_string(e); };
+        int r;
+        // dispersion: depth kernels per type; the phase velocities at the group periods overwrite the head
+        // of the phase-velocity block (CalSurfG.f90:1100-1140)
+        if ((r = dsa_dispersion_begin(e, *nx, *ny, *nz, vels, depz, *minthk, L.kmax, L.nmaps)) != 0) return bad(r);
+        if ((r = dsa_dispersion_run(e, 2, 0, L.kRc, tRc, 1, L.sRc, L.oRc)) != 0) return bad(r);
+        if (L.kRg > 0) {
+            if ((r = dsa_dispersion_run(e, 2, 1, L.kRg, tRg, 1, L.sRg, L.oRg)) != 0) return bad(r);
+            if ((r = dsa_dispersion_run(e, 2, 0, L.kRg, tRg, 0, 0, L.oRc)) != 0) return bad(r);
+        }
+        if ((r = dsa_dispersion_run(e, 1, 0, L.kLc, tLc, 1, L.sLc, L.oLc)) != 0) return bad(r);
+        if (L.kLg > 0) {
+            if ((r = dsa_dispersion_run(e, 1, 1, L.kLg, tLg, 1, L.sLg, L.oLg)) != 0) return bad(r);
+            if ((r = dsa_dispersion_run(e, 1, 0, L.kLg, tLg, 0, 0, L.oLc)) != 0) return bad(r);
+        }
+        if ((r = dsa_maps_from_dispersion(e, *goxdf, *gozdf, *dvxdf, *dvzdf, 8)) != 0) return bad(r);
+        if ((r = dsa_kernels_from_dispersion(e)) != 0) return bad(r);
+        const int a = cut[k], b = cut[k + 1];
+        if ((r = dsa_plan_units(e, b - a, U.map.data() + a, U.sx.data() + a, U.sz.data() + a, U.nrec.data() + a, U.rx.data() + ray0[a],
+                                U.rz.data() + ray0[a], U.mode.data() + a, U.slot.data() + a, U.data.data() + a)) != 0) return bad(r);
+        if (ne == 1) {
+            r = dsa_solve_rows(e, dsurf, rw, iw + 1, col, cap, &P.n);          // the reference fills iw(nar+1)
+        } else {
+            en->grow_rw = &P.rw; en->grow_iw = &P.iw; en->grow_col = &P.col;
+            r = en->solve(dsurf, nullptr, nullptr, nullptr, cap, &P.n);
+            en->grow_rw = nullptr; en->grow_iw = nullptr; en->grow_col = nullptr;
+        }
+        if (r != 0) return bad(r);
+        double st[DSA_STAT_COUNT + 8];
+        if (dsa_get_stats(e, st) == 0) P.clamped = st[DSA_STAT_RAYS_CLAMPED];
+    };
+    if (ne == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < ne; ++k) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
+    }
+    long long n = 0;
+    double clamped = 0;
+    for (int k = 0; k < ne; ++k) {
+        if (part[k].rc != 0) { g_dropin_error = part[k].err; return part[k].rc; }
+        if (ne > 1) {
+            if (n + part[k].n > cap) { g_dropin_error = "dsa_calsurfg: more matrix entries than DSA_MAXNAR"; return DSA_ERR_ARGUMENT; }
+            std::memcpy(rw + n, part[k].rw.data(), (size_t)part[k].n * 4);
+            std::memcpy(iw + 1 + n, part[k].iw.data(), (size_t)part[k].n * 4);
+            std::memcpy(col + n, part[k].col.data(), (size_t)part[k].n * 4);
+        }
+        n += part[k].n;
+        clamped += part[k].clamped;
+    }
     if (n > INT_MAX) { g_dropin_error = "dsa_calsurfg: more than 2^31-1 matrix entries"; return DSA_ERR_ARGUMENT; }
     *nar = (int)n;
-    double st[DSA_STAT_COUNT + 8];
-    if (dsa_get_stats(e, st) == 0 && st[DSA_STAT_RAYS_CLAMPED] > 0) fputs(kBoundaryNote, stdout);
+    if (clamped > 0) fputs(kBoundaryNote, stdout);
     return 0;
 }
+
 
 int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,
                   float* obst,

@@ -88,6 +88,11 @@ struct Engine {
     DevBuf<double> pvstore, curves, tper;
     DevBuf<float> disp_ws;
 
+    // optional growing host destination of the COO rows (used when several engines share one call)
+    std::vector<float>* grow_rw = nullptr;
+    std::vector<int>* grow_iw = nullptr;
+    std::vector<int>* grow_col = nullptr;
+
     double stats[32] = {};
 
     ~Engine();

@@ -329,7 +329,8 @@ BatchPtrs Engine::batch() const
 int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, long long* nar)
 {
     if (!planned) { fail(DSA_ERR_STATE, "solve: call dsa_plan first"); return DSA_ERR_STATE; }
-    const bool rows = rw && iw && col && nar;
+    const bool grow = grow_rw && grow_iw && grow_col;
+    const bool rows = ((rw && iw && col) || grow) && nar;
     if (rows && !have_sens) { fail(DSA_ERR_STATE, "solve: Frechet rows need the depth kernels (dsa_set_depth_kernels / dsa_depthkernel) first"); return DSA_ERR_STATE; }
     if (rows) {
         *nar = 0;
@@ -516,6 +517,10 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
         HIP_TRY(this, hipMemcpyAsync(h_info.data(), rayinfo.p, (size_t)m * 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipStreamSynchronize(stream));
         if (*nar + total > cap) { fail(DSA_ERR_ARGUMENT, "Frechet rows need more than the %lld entries provided", cap); return DSA_ERR_ARGUMENT; }
+        if (total > 0 && grow_rw && grow_iw && grow_col) {
+            grow_rw->resize((size_t)(*nar + total)); grow_iw->resize((size_t)(*nar + total)); grow_col->resize((size_t)(*nar + total));
+            rw = grow_rw->data(); iw = grow_iw->data(); col = grow_col->data();
+        }
         if (total > 0) {
             if (ensure(coo_rw, (size_t)total) || ensure(coo_iw, (size_t)total) || ensure(coo_col, (size_t)total)) return status;
             a.rw = coo_rw.p; a.iw = coo_iw.p; a.col = coo_col.p;

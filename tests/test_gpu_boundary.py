@@ -12,6 +12,7 @@ phase velocity by one ulp (2.4e-7), i.e. a depth kernel by 2.4e-7 / (0.01 v) ~ 1
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -154,3 +155,28 @@ def test_fortran_shim(tmp_path):
         rw = np.fromfile(f, np.float32, nar); iw = np.fromfile(f, np.int32, nar); col = np.fromfile(f, np.int32, nar)
     check_rows(o, dict(dsurf=dsurf, rw=rw, iw=iw, col=col, nar=nar), c)
     assert np.abs(obst - so).max() <= 1e-4
+
+
+def test_dropin_sharded_over_engines():
+    """DSA_DEVICES: the drop-in call splits its units over several engines (one per GPU; here two engines
+    on GPU 0, in a fresh process because the engine pool is made once per process) and stitches dsurf and
+    the COO rows back in the reference's order"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _libs as L, synth
+from dsurftomo_amd import engine
+lib = engine.load_library()
+for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, nsrc=8, nrcf=7, kRc=3, kRg=1, kLc=1, kLg=1)):
+    c = synth.boundary_case(**kw)
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    d = L.call_boundary(lib.dsa_calsurfg, c)
+    assert o["nar"] == d["nar"], (o["nar"], d["nar"])
+    assert np.abs(o["dsurf"] - d["dsurf"]).max() <= 1e-4
+    assert (o["iw"] == d["iw"]).all() and (o["col"] == d["col"]).all()
+    assert np.abs(o["rw"] - d["rw"]).max() <= 2e-3
+print("sharded ok")
+''' % (L.ROOT, os.path.join(L.ROOT, "tests"))
+    env = dict(os.environ, DSA_DEVICES="0,0,0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
