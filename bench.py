@@ -190,11 +190,11 @@ def main():
                        "parallelism": "units sharded over %d GPU(s), RCCL all-gather of receiver times" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "k_fim (coarse fixed-point solve)", "bytes_per_solve": bps,
+                         "kernel": "k_fim_sorted<256> (coarse fixed-point solve)", "bytes_per_solve": bps,
                          "launches": int(acc["launches_fim_coarse"]),
                          "avg_launch_ms": round(acc["ms_fim_coarse"] / max(acc["launches_fim_coarse"], 1), 3),
                          "solves_per_launch": round(my_units / max(acc["launches_fim_coarse"], 1), 1),
-                         "note": "dependency/latency-bound kernel: ~2.2 evaluations x ~600 fp32 instructions per node along an O(N)-deep front; see DESIGN.md 7"},
+                         "note": "achieved = algorithmic bytes / kernel time; the kernel moves ~100x more (traffic) because thousands of fronts in flight do not fit the caches; see DESIGN.md 7"},
             "kernel_ms_per_step": {"fim_coarse": round(acc["ms_fim_coarse"] / args.steps, 2), "fim_refined": round(acc["ms_fim_refined"] / args.steps, 2),
                                    "stages": round(acc["ms_stages"] / args.steps, 2)},
             "evals_per_node": round(acc["evals_total"] / max(my_units, 1) / (n * n), 3),

@@ -348,7 +348,8 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     // causal window: a few cells' worth of travel time (narrowest cell, fastest velocity of the model)
     const float cell_c = dpl * hmin_slow;
     const float window_c = window_cells * cell_c;
-    const float window_r = window_cells * cell_c / (float)kSgdl;
+    // the refined boxes are small (129^2): a wider window there costs nothing and saves rounds
+    const float window_r = std::max(window_cells, 1.5f) * cell_c / (float)kSgdl;
     HIP_TRY(this, hipMemsetAsync(err.p, 0, 4 * sizeof(int32_t), stream));
     HIP_TRY(this, hipEventRecord(events[0], stream));
     std::vector<int32_t> h_info, h_flags;
@@ -408,6 +409,8 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             unsigned long long ev;
             std::memcpy(&ev, fi + 12, 8);
             stats[DSA_STAT_EVALS_TOTAL] += (double)ev;
+            std::memcpy(&ev, fi + 14, 8);
+            stats[DSA_STAT_CHANGES_TOTAL] += (double)ev;
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
             if (fi[2] < 0 || fi[10] < 0) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }

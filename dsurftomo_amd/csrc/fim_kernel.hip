@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     unsigned hist[4] = { 1u, 2u, 3u, 4u };
     unsigned long long tA = 0, tB0 = 0, tB1 = 0, tE = 0, t0 = wall_clock64(), sum_cnt = 0, sum_ready = 0;   // phase clocks (thread 0)
     float best_tmin = -kInf;
-    unsigned long long evals = 0;
+    unsigned long long evals = 0, nchanged = 0;
     for (;;) {
         int cnt = sc[SC_CUR];
         if (cnt == 0) {
@@ -177,6 +177,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 const int id = ids[u];
                 if (frozen_any) own[u] = F[id].tau;
                 if (open || lbs[u] < theta) continue;               // routed by its key: no neighbour loads
+#ifdef DSA_KEY_ROUTING
+                // wait for the neighbour that queued this node to become final (its acceptance time inside the
+                // window) instead of evaluating against its provisional value; seeds (+inf) use the bound
+                if (lbs[u] < kInf && !frozen_any) continue;
+#endif
                 int iz, ix;                                         // 0-based
                 rec_coords(nbz, id, &iz, &ix);
                 const float a = ix > 0 ? F[rec_index(nbz, iz, ix - 1)].tau : kInf;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     ++evals;
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
-                if (changed) { F[id].T = c; F[id].tau = k; }           // adjacent stores (8 bytes); queued bit clear
+                if (changed) { F[id].T = c; F[id].tau = k; ++nchanged; }   // adjacent stores (8 bytes); queued bit clear
                 // Dependents.  A change of this node X can only matter to
                 //   * a near node Y if X can enter Y's walk: min(tau_X old, new) <= tau_Y.  (If X is and
                 //     was accepted later than Y, Y's walk stopped at or before X with a value <= tau_Y,
@@ -332,8 +337,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
     }
     // counters: evaluations summed over threads
-    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
-    if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals);
+    for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); nchanged += __shfl_xor(nchanged, o); }
+    if ((tid & 63) == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), nchanged); }
     if (tid == 0) {
         p.info[0] = rounds; p.info[1] = rescans; p.info[3] = freezes;
         if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     unsigned hist[4] = { 1u, 2u, 3u, 4u };
     unsigned long long tA = 0, tB0 = 0, tB1 = 0, tE = 0, t0 = wall_clock64(), sum_cnt = 0, sum_ready = 0;
     float best_tmin = -kInf;
-    unsigned long long evals = 0;
+    unsigned long long evals = 0, nchanged = 0;
     for (;;) {
         const float theta = u2f((unsigned)sc[SC_THETA]);
         const bool open = !(theta < kInf);
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     ++evals;
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
-                if (changed) { F[id].T = c; F[id].tau = k; }
+                if (changed) { F[id].T = c; F[id].tau = k; ++nchanged; }
                 // dependents: same pruning as k_fim; the tile mask's old value tells whether the node was
                 // already active and whether its tile has to enter the bitmap
                 const float t_lo = fminf(t_value(t_old), c), k_lo = fminf(k_old, k);
@@ -608,8 +613,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         { const unsigned long long t1 = wall_clock64(); tE += t1 - t0; t0 = t1; }
         if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
     }
-    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals);
+    for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); nchanged += __shfl_xor(nchanged, o); }
+    if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), nchanged); }
     if (tid == 0) {
         p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
         if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }

@@ -49,11 +49,11 @@ const char* dsa_error_string(const dsa_engine* e);   /* e may be NULL: last crea
 int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 
 /* tuning knobs: "window_cells" (causal window of the fixed-point solve, in cell travel times,
- * default 3), "max_chunk" (cap on sources resident per chunk, 0 = memory budget only),
+ * default 0.4), "max_chunk" (cap on sources resident per chunk, 0 = memory budget only),
  * "list_cap" / "ready_cap" (active-list sizes of the solve kernel, 0 = derived from the grid),
- * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024), "fim_sorted" (1 = the
- * variant of the solve kernel that keeps its active set in tile masks and walks it in record order;
- * identical results), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits
+ * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024), "fim_sorted" (1, default = the
+ * solve kernel that keeps its active set in tile masks and walks it in record order; 0 = the variant
+ * with lists in activation order; same fixed point), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits
  * the workgroups resident per CU), "ray_budget" (bytes of
  * per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up to 8 GB) */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
@@ -137,7 +137,7 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_EVALS_TOTAL,
        DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_FREEZES, DSA_STAT_RAYS, DSA_STAT_RAY_STEPS,
        DSA_STAT_RAYS_CLAMPED, DSA_STAT_MS_RAYS, DSA_STAT_MS_ROWS, DSA_STAT_NAR, DSA_STAT_MS_DISPERSION,
-       DSA_STAT_CURVES, DSA_STAT_COUNT };
+       DSA_STAT_CURVES, DSA_STAT_CHANGES_TOTAL, DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 7: counters, then 7 phase-clock sums */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */

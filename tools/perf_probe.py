@@ -25,7 +25,7 @@ for wc, nt in [(w, t) for t in threads for w in windows]:
     same = 'first' if ref is None else f'identical={np.array_equal(ref.view(np.uint32), t.view(np.uint32))} maxdiff={np.abs(ref - t).max():.2g}'
     if ref is None: ref = t
     print(f'N={e.nnx} {kind} units {n:5d} wg {nt:4d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
-          f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} freezes {st["freezes"]:.0f} | {same}', flush=True)
+          f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} changes/node {st["changes_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} freezes {st["freezes"]:.0f} | {same}', flush=True)
     pt = np.array(st["phase_ticks"]); tot = pt[:4].sum()
     if tot > 0:
         print(f'      phase share: passA {pt[0]/tot:.2f} evalEven {pt[1]/tot:.2f} evalOdd {pt[2]/tot:.2f} roundEnd {pt[3]/tot:.2f} | us/unit {tot/n/100:.0f} | avg list {pt[4]/n/max(st["rounds_max"],1):.0f} avg ready/round {pt[5]/n/max(st["rounds_max"],1):.0f} max list {pt[6]:.0f}', flush=True)
