@@ -629,7 +629,8 @@ void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l,
     if (nproblems <= 0) return;
     if (l.sorted) {
         const size_t lds = fim_lds_bytes(l);
-        if (l.threads == 256) hipLaunchKernelGGL(k_fim_sorted<256>, dim3(nproblems), dim3(256), lds, stream, d_problems, l.list_cap, l.ready_cap);
+        if (l.threads == 128) hipLaunchKernelGGL(k_fim_sorted<128>, dim3(nproblems), dim3(128), lds, stream, d_problems, l.list_cap, l.ready_cap);
+        else if (l.threads == 256) hipLaunchKernelGGL(k_fim_sorted<256>, dim3(nproblems), dim3(256), lds, stream, d_problems, l.list_cap, l.ready_cap);
         else if (l.threads == 512) hipLaunchKernelGGL(k_fim_sorted<512>, dim3(nproblems), dim3(512), lds, stream, d_problems, l.list_cap, l.ready_cap);
         else hipLaunchKernelGGL(k_fim_sorted<1024>, dim3(nproblems), dim3(1024), lds, stream, d_problems, l.list_cap, l.ready_cap);
         return;
