@@ -125,6 +125,8 @@ def main():
     eng = Engine(local_rank)
     if os.environ.get("DSA_MAX_CHUNK"):
         eng.set_option("max_chunk", int(os.environ["DSA_MAX_CHUNK"]))
+    if os.environ.get("DSA_MEM_BUDGET_GB"):
+        eng.set_memory_budget(int(float(os.environ["DSA_MEM_BUDGET_GB"]) * 1e9))
     if os.environ.get("DSA_FIM_SORTED"):
         eng.set_option("fim_sorted", int(os.environ["DSA_FIM_SORTED"]))
     t_setup = time.perf_counter()

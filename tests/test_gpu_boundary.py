@@ -104,9 +104,12 @@ def test_dispersion_stage(iwave, igr):
         assert (a == b).mean() >= 0.98
 
 
-def test_engine_rows_from_host_kernels():
+@pytest.mark.parametrize("max_chunk,ray_budget", [(0, 0), (2, 40000)])
+def test_engine_rows_from_host_kernels(max_chunk, ray_budget):
     """engine level: maps and depth kernels handed over from the host (dsa_set_maps +
-    dsa_set_depth_kernels + dsa_plan_units + dsa_solve_rows) instead of the device dispersion stage"""
+    dsa_set_depth_kernels + dsa_plan_units + dsa_solve_rows) instead of the device dispersion stage;
+    second variant: two units per chunk and a ray budget of a few rays per launch, so that the unit
+    chunks and the ray launches are stitched many times"""
     from dsurftomo_amd.engine import Engine
     c = synth.boundary_case(kRc=3, kRg=0, kLc=0, kLg=0)
     vel = np.ascontiguousarray(c["vels"].T)
@@ -120,6 +123,8 @@ def test_engine_rows_from_host_kernels():
             rx += list(c["rcxf"][:nrec[-1], s, k]); rz += list(c["rczf"][:nrec[-1], s, k])
     e = Engine(0)
     try:
+        e.set_option("max_chunk", max_chunk)
+        e.set_option("ray_budget", ray_budget)
         e.set_maps(c["nx"], c["ny"], c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], pv)
         e.set_depth_kernels(vel, c["depz"], svs, svp, srho)
         e.plan(maps, sx, sz, nrec, rx, rz, sen_slot=slot)
