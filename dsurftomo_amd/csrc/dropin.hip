@@ -21,6 +21,7 @@ namespace {
 std::string g_dropin_error = "";
 dsa_engine* g_engine = nullptr;
 
+int g_last_first[4] = { -1, -1, -1, -1 }, g_last_count[4] = { 0, 0, 0, 0 }, g_last_ncol = 0;   // maps of the last call: Rc, Rg, Lc, Lg
 std::vector<dsa_engine*> g_pool;      // one engine per GPU of this process (DSA_DEVICES), g_engine = g_pool[0]
 
 // DSA_DEVICES = "4" (the first four GPUs) or "0,2,3" (a list); default: the single GPU DSA_DEVICE (0).
@@ -118,6 +119,15 @@ int make_units(const Layout& L, bool rows, int nsrcsurf, int nrcf, const int* wa
         }
     U.ndata = count1;
     return 0;
+}
+
+void remember(const Layout& L, int ncol, bool clobbered)
+{
+    // after a CalSurfG call the head of the phase-velocity blocks holds the group periods' phase velocities
+    (void)clobbered;
+    g_last_first[0] = L.oRc; g_last_first[1] = L.oRg; g_last_first[2] = L.oLc; g_last_first[3] = L.oLg;
+    g_last_count[0] = L.kRc; g_last_count[1] = L.kRg; g_last_count[2] = L.kLc; g_last_count[3] = L.kLg;
+    g_last_ncol = ncol;
 }
 
 const char* kBoundaryNote =
@@ -223,8 +233,19 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     }
     if (n > INT_MAX) { g_dropin_error = "dsa_calsurfg: more than 2^31-1 matrix entries"; return DSA_ERR_ARGUMENT; }
     *nar = (int)n;
+    remember(L, *nx * *ny, true);
     if (clamped > 0) fputs(kBoundaryNote, stdout);
     return 0;
+}
+
+// phase / group velocity maps of the last drop-in call, pv(nx*ny, count) fp64 in the reference's layout;
+// which = 0 Rayleigh phase, 1 Rayleigh group, 2 Love phase, 3 Love group.  (The reference's `synthetic`
+// writes them to velmap2d*.dat, CalSurfG.f90:2559-2617; the Fortran shim does that with this call.)
+int dsa_dropin_velocity_maps(const int* which, double* pv)
+{
+    if (!which || !pv || *which < 0 || *which > 3 || !g_engine || g_last_first[*which] < 0) { g_dropin_error = "dsa_dropin_velocity_maps: no maps (call dsa_synthetic / dsa_calsurfg first)"; return DSA_ERR_STATE; }
+    const int rc = dsa_dispersion_fetch(g_engine, g_last_first[*which], g_last_count[*which], pv, 0, 0, nullptr, nullptr, nullptr);
+    return rc != 0 ? fail(rc) : 0;
 }
 
 
@@ -251,6 +272,7 @@ int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi
     if ((rc = dsa_dispersion_run(e, 1, 0, L.kLc, tLc, 0, 0, L.oLc)) != 0) return fail(rc);
     if ((rc = dsa_dispersion_run(e, 1, 1, L.kLg, tLg, 0, 0, L.oLg)) != 0) return fail(rc);
     if ((rc = dsa_maps_from_dispersion(e, *goxdf, *gozdf, *dvxdf, *dvzdf, 5)) != 0) return fail(rc);
+    remember(L, *nx * *ny, false);
     Units U;
     if ((rc = make_units(L, false, *nsrcsurf, *nrcf, wavetype, igrt, periods, nrc1, nsrcsurf1, scxf, sczf, rcxf, rczf, U)) != 0) return rc;
     if ((rc = dsa_plan_units(e, (int)U.map.size(), U.map.data(), U.sx.data(), U.sz.data(), U.nrec.data(), U.rx.data(), U.rz.data(),

@@ -34,6 +34,11 @@ module dsa_bindings
       integer(c_int) :: wavetype(*),igrt(*),periods(*),nrc1(*),nsrcsurf1(*)
       real(c_double) :: tRc(*),tRg(*),tLc(*),tLg(*)
     end function
+    integer(c_int) function dsa_dropin_velocity_maps(which, pv) bind(C, name='dsa_dropin_velocity_maps')
+      import :: c_int, c_double
+      integer(c_int) :: which
+      real(c_double) :: pv(*)
+    end function
     function dsa_dropin_error() bind(C, name='dsa_dropin_error') result(p)
       import :: c_ptr
       type(c_ptr) :: p
@@ -91,7 +96,11 @@ subroutine synthetic(nx,ny,nz,nparpi,vels,obst, &
   real scxf(nsrcsurf,kmax),sczf(nsrcsurf,kmax),rcxf(nrcf,nsrcsurf,kmax),rczf(nrcf,nsrcsurf,kmax)
   real gaussian, zero
   external gaussian
-  integer rc, knumi, srcnum, istep, count1
+  integer rc, knumi, srcnum, istep, count1, which, kk, i, j, k
+  integer kper(4)
+  real*8, allocatable :: pv(:,:)
+  real*8 tper
+  character(len=16) :: fname(4)
   ! noise-free times from the device, then the reference's own noise statement in the reference's
   ! loop order (CalSurfG.f90:2840), drawing from the host program's gaussian() like the original
   zero = 0.0
@@ -99,6 +108,30 @@ subroutine synthetic(nx,ny,nz,nparpi,vels,obst, &
        kmaxRc,kmaxRg,kmaxLc,kmaxLg,tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk, &
        scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,zero)
   if (rc /= 0) call dsa_stop('synthetic')
+  ! the 2-D velocity maps the reference writes for plotting (CalSurfG.f90:2559-2617), same statements
+  kper = (/ kmaxRc, kmaxRg, kmaxLc, kmaxLg /)
+  fname = (/ 'velmap2dRc.dat  ', 'velmap2dRg.dat  ', 'velmap2dLc.dat  ', 'velmap2dLg.dat  ' /)
+  do kk = 1, 4
+    if (kper(kk) <= 0) cycle
+    allocate(pv(nx*ny, kper(kk)))
+    which = kk - 1
+    rc = dsa_dropin_velocity_maps(which, pv)
+    if (rc /= 0) call dsa_stop('synthetic')
+    open(62, file=trim(fname(kk)))
+    do k = 1, kper(kk)
+      if (kk == 1) tper = tRc(k)
+      if (kk == 2) tper = tRg(k)
+      if (kk == 3) tper = tLc(k)
+      if (kk == 4) tper = tLg(k)
+      do j = 1, ny-2
+        do i = 1, nx-2
+          write(62,'(5f8.4)') gozdf+(j-1)*dvzdf, goxdf-(i-1)*dvxdf, tper, pv((j+1)*nx+i+1,k)
+        enddo
+      enddo
+    enddo
+    close(62)
+    deallocate(pv)
+  enddo
   count1 = 0
   do knumi = 1, kmax
     do srcnum = 1, nsrcsurf1(knumi)

@@ -161,6 +161,10 @@ int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi
                   const float* rczf, const int* nrc1, const int* nsrcsurf1, const int* kmax,
                   const int* nsrcsurf, const int* nrcf, const float* noiselevel);
 
+/* pv(nx*ny, kmaxXX) of the last drop-in call: which = 0 Rc, 1 Rg, 2 Lc, 3 Lg (what the reference's synthetic
+ * writes to velmap2d*.dat, CalSurfG.f90:2559-2617) */
+int dsa_dropin_velocity_maps(const int* which, double* pv);
+
 /* text of the last error of the process-wide engine used by the drop-in level */
 const char* dsa_dropin_error(void);
 

@@ -152,7 +152,7 @@ def test_fortran_shim(tmp_path):
         for a in (c["vels"], c["depz"], c["tRc"], c["tRg"], c["tLc"], c["tLg"], c["wavetype"], c["igrt"], c["periods"], c["nrc1"], c["nsrcsurf1"],
                   c["scxf"], c["sczf"], c["rcxf"], c["rczf"]):
             f.write(np.asarray(a).tobytes(order="F"))
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0 and os.path.exists(fout), r.stdout + r.stderr
     with open(fout, "rb") as f:
         nar = int(np.fromfile(f, np.int32, 1)[0])
@@ -160,6 +160,21 @@ def test_fortran_shim(tmp_path):
         rw = np.fromfile(f, np.float32, nar); iw = np.fromfile(f, np.int32, nar); col = np.fromfile(f, np.int32, nar)
     check_rows(o, dict(dsurf=dsurf, rw=rw, iw=iw, col=col, nar=nar), c)
     assert np.abs(obst - so).max() <= 1e-4
+    # the velocity-map files of `synthetic` (CalSurfG.f90:2559-2617) against the reference's own, byte for byte
+    names = [n for n, k in (("velmap2dRc.dat", c["kRc"]), ("velmap2dRg.dat", c["kRg"]), ("velmap2dLc.dat", c["kLc"]), ("velmap2dLg.dat", c["kLg"])) if k > 0]
+    for n in names:
+        assert os.path.getsize(str(tmp_path / n)) > 0
+    if L.ref() is not None:
+        refdir = tmp_path / "ref"
+        refdir.mkdir()
+        cwd = os.getcwd()
+        try:
+            os.chdir(str(refdir))
+            L.call_boundary(L.ref().synthetic_, c, synthetic=True)
+        finally:
+            os.chdir(cwd)
+        for n in names:
+            assert (tmp_path / n).read_bytes() == (refdir / n).read_bytes(), n
 
 
 def test_dropin_sharded_over_engines():
