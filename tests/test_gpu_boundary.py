@@ -200,3 +200,14 @@ print("sharded ok")
     env = dict(os.environ, DSA_DEVICES="0,0,0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_synthetic_noise_statistics(lib):
+    """dsa_synthetic called directly with a noise level (the Fortran shim passes 0 and adds the host program's
+    gaussian() itself): obst = t (1 + level * g), g ~ N(0, 1) from the engine's own generator"""
+    c = synth.boundary_case(nx=20, ny=18, nz=5, nsrc=8, nrcf=7, kRc=3, kRg=1, kLc=1, kLg=1)
+    clean = L.call_boundary(lib.dsa_synthetic, c, synthetic=True)
+    noisy = L.call_boundary(lib.dsa_synthetic, c, synthetic=True, noise=0.02)
+    g = (noisy / clean - 1.0) / 0.02
+    assert clean.size >= 250 and np.isfinite(g).all()
+    assert abs(g.mean()) < 0.25 and 0.8 < g.std() < 1.2 and np.abs(g).max() < 6.0
