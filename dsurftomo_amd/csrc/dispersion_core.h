@@ -323,7 +323,9 @@ DSA_HD int getsol(const Layers& m, double t1, double* c1io, double clow, double 
     const double plmn = sign1(*del1st) * sign1(del1);
     int idir = +1;
     if (ifirst != 1 && plmn < 0.0) idir = -1;
-    for (;;) {
+    // (bounded: with NaN in the model no comparison ever ends the reference's loop; a device lane must not spin)
+    for (int guard = 0; ; ++guard) {
+        if (guard > 100000) { *c1io = c1; return -1; }
         if (idir > 0) c2 = c1 + dc; else c2 = c1 - dc;
         if (c2 <= clow) { idir = +1; c1 = clow; continue; }
         omega = twopi / t1;
