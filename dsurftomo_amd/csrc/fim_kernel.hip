@@ -621,7 +621,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     }
 }
 
-size_t fim_lds_bytes(const FimLaunch& l) { return l.sorted ? (size_t)l.tile_words * 4 : 0; }
+size_t fim_lds_bytes(const FimLaunch& l) { return (l.sorted ? (size_t)l.tile_words * 4 : 0) + (size_t)l.lds_pad; }
 
 
 void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream)

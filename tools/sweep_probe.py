@@ -8,6 +8,7 @@ nsrc = int(sys.argv[1]); combos = [tuple(float(v) for v in c.split(',')) for c i
 kind = sys.argv[3] if len(sys.argv) > 3 else 'smooth'
 nx = 131
 e = Engine(0)
+if os.environ.get('DSA_LDS_PAD'): e.set_option('fim_lds_pad', int(os.environ['DSA_LDS_PAD']))
 pv = np.stack([synth.medium(nx, kind, p) for p in range(2)])
 e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
 u = synth.units(nx, nsrc, 2, 32)
