@@ -211,3 +211,18 @@ def test_synthetic_noise_statistics(lib):
     g = (noisy / clean - 1.0) / 0.02
     assert clean.size >= 250 and np.isfinite(g).all()
     assert abs(g.mean()) < 0.25 and 0.8 < g.std() < 1.2 and np.abs(g).max() < 6.0
+
+
+def test_forward_cli_on_the_taipei_directory(tmp_path):
+    """python -m dsurftomo_amd.forward: the reference's input files in, residual table and matrix out"""
+    out = str(tmp_path / "fw")
+    r = subprocess.run([sys.executable, "-m", "dsurftomo_amd.forward", taipei.HERE, "--out", out], capture_output=True, text=True,
+                       timeout=600, cwd=L.ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tab = np.loadtxt(out + ".residual.dat")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "b_taipei.npz"))
+    assert tab.shape == (2061, 3)
+    assert np.abs(tab[:, 1] - z["dsurf"]).max() <= 1e-4 + 1e-6          # the text file keeps 6 decimals
+    G = np.load(out + ".G.npz")
+    assert abs(int(G["rw"].size) - int(z["nar"])) <= 0.005 * int(z["nar"]) and tuple(G["shape"]) == (2061, 2048)
+    assert (np.diff(G["row"]) >= 0).all()
