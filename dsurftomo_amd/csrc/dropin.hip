@@ -238,6 +238,32 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     return 0;
 }
 
+// aprod with the reference's argument list (aprod.f90:7; LSMR calls it with the same matrix hundreds of times per
+// inversion step, lsmrModule.f90:390-497).  The matrix goes to the device the first time it is seen; it is
+// recognised again by its address, its size and a sample of its entries.
+int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, const int* leniw, const int* lenrw,
+              const int* iw, const float* rw)
+{
+    (void)leniw; (void)lenrw;
+    if (!mode || !m || !n || !x || !y || !iw || !rw) { g_dropin_error = "dsa_aprod: null argument"; return DSA_ERR_ARGUMENT; }
+    int rc = engine();
+    if (rc != 0) return rc;
+    static const void *s_iw = nullptr, *s_rw = nullptr;
+    static long long s_nar = -1;
+    static int s_m = 0, s_n = 0;
+    static double s_sum = 0.0;
+    const long long nar = iw[0];
+    double sum = 0.0;
+    const long long step = std::max<long long>(1, nar / 997);
+    for (long long k = 0; k < nar; k += step) sum += (double)rw[k] * (double)(1 + (k & 7)) + (double)iw[1 + k] + 3.0 * (double)iw[1 + nar + k];
+    if (iw != s_iw || rw != s_rw || nar != s_nar || *m != s_m || *n != s_n || sum != s_sum) {
+        if ((rc = dsa_spmv_load(g_engine, *m, *n, nar, rw, iw + 1, iw + 1 + nar)) != 0) return fail(rc);
+        s_iw = iw; s_rw = rw; s_nar = nar; s_m = *m; s_n = *n; s_sum = sum;
+    }
+    if ((rc = dsa_spmv(g_engine, *mode, x, y)) != 0) return fail(rc);
+    return 0;
+}
+
 // phase / group velocity maps of the last drop-in call, pv(nx*ny, count) fp64 in the reference's layout;
 // which = 0 Rayleigh phase, 1 Rayleigh group, 2 Love phase, 3 Love group.  (The reference's `synthetic`
 // writes them to velmap2d*.dat, CalSurfG.f90:2559-2617; the Fortran shim does that with this call.)

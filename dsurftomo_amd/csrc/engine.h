@@ -17,6 +17,8 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+struct SpmvState;
+
 struct Engine {
     int device = 0;
     std::string arch;
@@ -92,6 +94,8 @@ struct Engine {
     std::vector<float>* grow_rw = nullptr;
     std::vector<int>* grow_iw = nullptr;
     std::vector<int>* grow_col = nullptr;
+
+    SpmvState* spmv = nullptr;         // device copy of a COO matrix for dsa_spmv (spmv.hip)
 
     double stats[32] = {};
 

@@ -49,8 +49,15 @@ int Engine::ensure(DevBuf<T>& b, size_t n)
     return 0;
 }
 
+void release_spmv(SpmvState* s);
+
+template int Engine::ensure<long long>(DevBuf<long long>&, size_t);
+template int Engine::ensure<float>(DevBuf<float>&, size_t);
+template int Engine::ensure<int>(DevBuf<int>&, size_t);
+
 Engine::~Engine()
 {
+    release_spmv(spmv);
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     rel(velv); rel(veln); rel(slow); rel(risti_c); rel(cbasis); rel(rbasis);
     rel(src); rel(rays); rel(out); rel(err);

@@ -59,6 +59,8 @@ def load_library():
     L.dsa_get_velocity.argtypes = [_vp, _i32, _vp]
     L.dsa_get_refined.argtypes = [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]
     L.dsa_get_stats.argtypes = [_vp, _vp]
+    L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]
+    L.dsa_spmv.argtypes = [_vp, _i32, _vp, _vp]
     L.dsa_debug_field.argtypes = [_vp, _i32, _i32, _vp]
     L.dsa_dropin_error.restype = C.c_char_p
     _lib = L
@@ -181,6 +183,23 @@ class Engine:
 
     def kernels_from_dispersion(self):
         self._check(self._L.dsa_kernels_from_dispersion(self._h))
+
+    # ---- matrix-vector products of the inversion step (reference aprod) ---------------------------
+    def spmv_load(self, m, n, rw, row, col):
+        """COO matrix with 1-based row / col indices"""
+        rw = np.ascontiguousarray(rw, np.float32)
+        row = np.ascontiguousarray(row, np.int32)
+        col = np.ascontiguousarray(col, np.int32)
+        self._mn = (int(m), int(n))
+        self._check(self._L.dsa_spmv_load(self._h, int(m), int(n), rw.size, _p(rw), _p(row), _p(col)))
+
+    def spmv(self, mode, x, y):
+        """mode 1: returns y + A x; mode 2: returns x + A^T y (fp32, the reference's accumulation order)"""
+        x = np.array(x, np.float32, copy=True)
+        y = np.array(y, np.float32, copy=True)
+        assert x.size == self._mn[1] and y.size == self._mn[0]
+        self._check(self._L.dsa_spmv(self._h, int(mode), _p(x), _p(y)))
+        return y if mode == 1 else x
 
     def traveltimes(self, map_index, scx, scz, nrec, rcx, rcz):
         self.plan(map_index, scx, scz, nrec, rcx, rcz)

@@ -119,6 +119,13 @@ int dsa_solve(dsa_engine* e, float* dsurf);
 int dsa_solve_rows(dsa_engine* e, float* dsurf, float* rw, int* iw, int* col, long long capacity,
                    long long* nar);
 
+/* ---- next to the path: the matrix-vector products of the inversion step (reference aprod.f90:7-60) ----
+ * load: COO matrix (rw[k], 1-based row[k] <= m, col[k] <= n), kept on the device in row-major and
+ * column-major order; spmv mode 1: y += A x, mode 2: x += A^T y on host vectors x[n], y[m].
+ * Every output element adds its entries in storage order in fp32, like the reference's loop. */
+int dsa_spmv_load(dsa_engine* e, int m, int n, long long nar, const float* rw, const int* row, const int* col);
+int dsa_spmv(dsa_engine* e, int mode, float* x, float* y);
+
 /* copy one unit's coarse travel-time field (nnz, nnx column-major) back; valid after dsa_solve
  * for units of the last chunk only unless keep_fields was requested */
 int dsa_get_dims(const dsa_engine* e, int* nnx, int* nnz);
@@ -160,6 +167,11 @@ int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi
                   const float* minthk, const float* scxf, const float* sczf, const float* rcxf,
                   const float* rczf, const int* nrc1, const int* nsrcsurf1, const int* kmax,
                   const int* nsrcsurf, const int* nrcf, const float* noiselevel);
+
+/* the reference's aprod (aprod.f90:7-60: mode 1 y += A x, mode 2 x += A^T y; iw = [nar, rows, cols]) on the
+ * device; the matrix is uploaded when first seen (dsurftomo_amd/fortran/aprod_shim.f90 exports `aprod_`) */
+int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, const int* leniw,
+              const int* lenrw, const int* iw, const float* rw);
 
 /* pv(nx*ny, kmaxXX) of the last drop-in call: which = 0 Rc, 1 Rg, 2 Lc, 3 Lg (what the reference's synthetic
  * writes to velmap2d*.dat, CalSurfG.f90:2559-2617) */

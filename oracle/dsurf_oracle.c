@@ -1027,3 +1027,16 @@ int dso_synthetic(const int *pnx, const int *pny, const int *pnz, const int *pnp
     free(veln); free(ttn);
     return rc;
 }
+
+/* aprod.f90:7-60 */
+void dso_aprod(const int *mode, const int *m, const int *n, float *x, float *y, const int *leniw, const int *lenrw,
+               const int *iw, const float *rw)
+{
+    (void)m; (void)n; (void)leniw; (void)lenrw;
+    const int kk = iw[0];
+    const int *row = iw + 1, *col = iw + 1 + kk;
+    for (int k = 0; k < kk; ++k) {
+        if (*mode == 1) y[row[k] - 1] = y[row[k] - 1] + rw[k] * x[col[k] - 1];
+        else x[col[k] - 1] = x[col[k] - 1] + rw[k] * y[row[k] - 1];
+    }
+}

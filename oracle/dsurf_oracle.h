@@ -99,6 +99,10 @@ void dso_depthkernel(int nx, int ny, int nz, const float *vel, double *pv, doubl
 /* Whole-boundary restatements with the reference's argument lists (CalSurfG.f90:939-943, :2412-2415).
  * All arguments by pointer exactly like the Fortran symbols calsurfg_ / synthetic_.
  * Return 0, or a negative code where the reference would STOP. */
+/* aprod, aprod.f90:7-60: mode 1 y += A x, mode 2 x += A^T y; iw = [nar, rows(1..nar), cols(1..nar)] 1-based */
+void dso_aprod(const int *mode, const int *m, const int *n, float *x, float *y, const int *leniw, const int *lenrw,
+               const int *iw, const float *rw);
+
 int dso_calsurfg(const int *nx, const int *ny, const int *nz, const int *nparpi, const float *vels,
                  int *iw, float *rw, int *col, float *dsurf,
                  const float *goxdf, const float *gozdf, const float *dvxdf, const float *dvzdf,

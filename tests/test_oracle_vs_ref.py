@@ -93,3 +93,22 @@ def test_boundary_bitwise(kw):
     sa = L.call_boundary(L.ref().synthetic_, c, synthetic=True)
     sb = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
     assert (bits(sa) != bits(sb)).sum() == 0
+
+
+def test_aprod_bitwise():
+    import ctypes as C
+    r = synth.LCG(2)
+    m, n, nar = 50, 40, 900
+    row = (1 + (r.uniform(nar) * m).astype(np.int32)).clip(1, m).astype(np.int32)
+    col = (1 + (r.uniform(nar) * n).astype(np.int32)).clip(1, n).astype(np.int32)
+    rw = (r.uniform(nar) - 0.5).astype(np.float32)
+    iw = np.concatenate([[nar], row, col]).astype(np.int32)
+    ib = lambda v: C.byref(C.c_int(int(v)))
+    for mode in (1, 2):
+        out = []
+        for fn in (L.oracle().dso_aprod, L.ref().aprod_):
+            x = (r.uniform(n) if False else np.linspace(-1, 1, n)).astype(np.float32)
+            y = np.linspace(2, -2, m).astype(np.float32)
+            fn(ib(mode), ib(m), ib(n), L.ptr(x), L.ptr(y), ib(iw.size), ib(nar), L.ptr(iw), L.ptr(rw))
+            out.append((x.copy(), y.copy()))
+        assert (bits(out[0][0]) != bits(out[1][0])).sum() == 0 and (bits(out[0][1]) != bits(out[1][1])).sum() == 0

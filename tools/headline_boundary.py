@@ -42,6 +42,28 @@ def main():
         print("dsa_calsurfg pass %d: rc %d (%s), %.2f s wall; %d solves, %d rays, nar %d (%.0f per row, %.2f GB of COO)" %
               (k, rc, lib.dsa_dropin_error().decode(), dt, 16 * nsrc, nd, nar.value, nar.value / max(nd, 1), nar.value * 12 / 1e9), flush=True)
     print("dsurf range %.3f .. %.3f s, rw range %.3g .. %.3g" % (dsurf.min(), dsurf.max(), rw[:nar.value].min(), rw[:nar.value].max()))
+    if "--spmv" in sys.argv:
+        n = nar.value
+        e = E.Engine(0)
+        t0 = time.perf_counter()
+        e.spmv_load(nd, npar, rw[:n], iw[1:n + 1], col[:n])
+        t1 = time.perf_counter()
+        x = np.linspace(-1, 1, npar).astype(np.float32); y = np.linspace(1, -1, nd).astype(np.float32)
+        for mode in (1, 2, 1, 2):
+            t2 = time.perf_counter(); out = e.spmv(mode, x, y); t3 = time.perf_counter()
+            print("device aprod mode %d: %.1f ms (%.0f GB/s on 8 B per entry)" % (mode, 1e3 * (t3 - t2), n * 8 / (t3 - t2) / 1e9), flush=True)
+        print("matrix load (host stable sorts + upload of %d entries): %.2f s" % (n, t1 - t0))
+        iwf = np.concatenate([[n], iw[1:n + 1], col[:n]]).astype(np.int32)
+        ib = lambda v: C.byref(C.c_int(int(v)))
+        for mode in (1, 2):
+            xx, yy = x.copy(), y.copy()
+            t2 = time.perf_counter()
+            L.oracle().dso_aprod(ib(mode), ib(nd), ib(npar), L.ptr(xx), L.ptr(yy), ib(iwf.size), ib(n), L.ptr(iwf), L.ptr(rw))
+            t3 = time.perf_counter()
+            got = e.spmv(mode, x, y)
+            want = yy if mode == 1 else xx
+            print("CPU aprod (C restatement, one core) mode %d: %.1f ms; device result identical: %s" % (mode, 1e3 * (t3 - t2), bool((got.view(np.uint32) == want.view(np.uint32)).all())), flush=True)
+        e.close()
 
 
 if __name__ == "__main__":
