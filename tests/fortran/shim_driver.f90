@@ -4,7 +4,8 @@
 ! the outputs back.  Own code; no reference source involved.
 program shim_driver
   implicit none
-  integer :: nx,ny,nz,nparpi,kmaxRc,kmaxRg,kmaxLc,kmaxLg,kmax,nsrcsurf,nrcf,ndata,maxnar,nar,i
+  integer :: nx,ny,nz,nparpi,kmaxRc,kmaxRg,kmaxLc,kmaxLg,kmax,nsrcsurf,nrcf,ndata,maxnar,nar,i,leniw
+  real, allocatable :: xv(:), yv(:)
   real :: goxd,gozd,dvxd,dvzd,minthk,noiselevel
   real, allocatable :: vels(:,:,:),depz(:),scxf(:,:),sczf(:,:),rcxf(:,:,:),rczf(:,:,:),rw(:),dsurf(:),obst(:)
   real*8, allocatable :: tRc(:),tRg(:),tLc(:),tLg(:)
@@ -42,6 +43,22 @@ program shim_driver
   write(22) nar
   write(22) dsurf, obst
   write(22) rw(1:nar), (iw(1+i), i=1,nar), col(1:nar)
+  ! the matrix-vector products the way the host program sets them up (main.f90:457-461, lsmrModule.f90:390-497)
+  iw(1) = nar
+  do i = 1, nar
+    iw(1+nar+i) = col(i)
+  enddo
+  leniw = 2*nar + 1
+  allocate(xv(nparpi), yv(ndata))
+  do i = 1, nparpi
+    xv(i) = real(mod(i*7, 13) - 6) * 0.125
+  enddo
+  do i = 1, ndata
+    yv(i) = real(mod(i*5, 11) - 5) * 0.25
+  enddo
+  call aprod(1, ndata, nparpi, xv, yv, leniw, nar, iw, rw)
+  call aprod(2, ndata, nparpi, xv, yv, leniw, nar, iw, rw)
+  write(22) xv, yv
   close(22)
 end program
 

@@ -158,6 +158,15 @@ def test_fortran_shim(tmp_path):
         nar = int(np.fromfile(f, np.int32, 1)[0])
         dsurf = np.fromfile(f, np.float32, c["ndata"]); obst = np.fromfile(f, np.float32, c["ndata"])
         rw = np.fromfile(f, np.float32, nar); iw = np.fromfile(f, np.int32, nar); col = np.fromfile(f, np.int32, nar)
+        xv = np.fromfile(f, np.float32, c["nparpi"]); yv = np.fromfile(f, np.float32, c["ndata"])
+    # aprod_ through aprod_shim.f90: y += A x then x += A^T y, against the oracle's aprod on the same matrix
+    x0 = (((np.arange(1, c["nparpi"] + 1) * 7) % 13 - 6) * 0.125).astype(np.float32)
+    y0 = (((np.arange(1, c["ndata"] + 1) * 5) % 11 - 5) * 0.25).astype(np.float32)
+    iwf = np.concatenate([[nar], iw, col]).astype(np.int32)
+    ib = lambda v: C.byref(C.c_int(int(v)))
+    for mode in (1, 2):
+        L.oracle().dso_aprod(ib(mode), ib(c["ndata"]), ib(c["nparpi"]), L.ptr(x0), L.ptr(y0), ib(iwf.size), ib(nar), L.ptr(iwf), L.ptr(rw))
+    assert (x0.view(np.uint32) != xv.view(np.uint32)).sum() == 0 and (y0.view(np.uint32) != yv.view(np.uint32)).sum() == 0
     check_rows(o, dict(dsurf=dsurf, rw=rw, iw=iw, col=col, nar=nar), c)
     assert np.abs(obst - so).max() <= 1e-4
     # the velocity-map files of `synthetic` (CalSurfG.f90:2559-2617) against the reference's own, byte for byte
