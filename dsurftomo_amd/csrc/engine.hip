@@ -54,6 +54,7 @@ void release_spmv(SpmvState* s);
 template int Engine::ensure<long long>(DevBuf<long long>&, size_t);
 template int Engine::ensure<float>(DevBuf<float>&, size_t);
 template int Engine::ensure<int>(DevBuf<int>&, size_t);
+template int Engine::ensure<unsigned char>(DevBuf<unsigned char>&, size_t);
 
 Engine::~Engine()
 {

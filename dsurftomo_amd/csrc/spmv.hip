@@ -7,6 +7,7 @@
 // (for A x) and by column (for A^T y) is made once per matrix on the host, the permuted value / index
 // arrays live in HBM, and a product is one pass over them.  HBM-bound: 8 bytes per entry and product.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -57,6 +58,53 @@ struct SpmvState {
 using dsa::Engine;
 using dsa::SpmvState;
 
+namespace dsa {
+
+__global__ void k_iota(long long n, int* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)i;
+}
+// counts[key - 1] += 1 (1-based keys); the totals do not depend on the order of the atomics
+__global__ void k_histogram(long long n, const int* __restrict__ key, unsigned long long* __restrict__ counts)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[key[i] - 1], 1ull);
+}
+// exclusive scan of nseg counts in place into ptr[0..nseg] (one workgroup; nseg is a row or column count)
+__global__ __launch_bounds__(1024) void k_scan64(int nseg, long long* __restrict__ ptr)
+{
+    __shared__ long long s_sum[1024];
+    const int tid = threadIdx.x;
+    const int per = (nseg + 1023) / 1024;
+    const int lo = min(tid * per, nseg), hi = min(lo + per, nseg);
+    long long s = 0;
+    for (int i = lo; i < hi; ++i) s += ptr[i];
+    s_sum[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long v = tid >= d ? s_sum[tid - d] : 0;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    long long run = s_sum[tid] - s;
+    for (int i = lo; i < hi; ++i) { const long long c = ptr[i]; ptr[i] = run; run += c; }
+    if (tid == 1023) ptr[nseg] = s_sum[1023];
+}
+// permuted copies: val_out[i] = rw[perm[i]], idx_out[i] = other[perm[i]] - 1
+__global__ void k_gather(long long n, const int* __restrict__ perm, const float* __restrict__ rw, const int* __restrict__ other,
+                         float* __restrict__ val_out, int* __restrict__ idx_out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = perm[i];
+    val_out[i] = rw[k];
+    idx_out[i] = other[k] - 1;
+}
+
+}  // namespace dsa
+
 namespace {
 
 #define SP_TRY(e, call)                                                                        \
@@ -65,15 +113,30 @@ namespace {
         if (_r != hipSuccess) { (e)->fail(DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(_r)); return DSA_ERR_DEVICE; } \
     } while (0)
 
-// stable counting sort of entry indices by key (1-based keys in [1, nkeys])
-void stable_order(long long nar, const int* key, int nkeys, std::vector<long long>& ptr, std::vector<long long>& order)
+// One ordering of the matrix (by row or by column) built on the device: a STABLE radix sort of the entry
+// numbers by key keeps the storage order inside every segment, which is what the accumulation order needs.
+int build_order(Engine* e, long long nar, int nkeys, const int* d_key, const int* d_other, const float* d_rw,
+                dsa::DevBuf<long long>& dptr, dsa::DevBuf<float>& dval, dsa::DevBuf<int>& didx,
+                dsa::DevBuf<int>& keys_out, dsa::DevBuf<int>& perm_in, dsa::DevBuf<int>& perm_out, dsa::DevBuf<unsigned char>& tmp)
 {
-    ptr.assign((size_t)nkeys + 1, 0);
-    for (long long k = 0; k < nar; ++k) ptr[(size_t)key[k]] += 1;          // key is 1-based: counts land at [key]
-    for (int r = 0; r < nkeys; ++r) ptr[(size_t)r + 1] += ptr[(size_t)r];   // ptr[r] = first entry of 0-based segment r
-    order.resize((size_t)nar);
-    std::vector<long long> next(ptr.begin(), ptr.end() - 1);
-    for (long long k = 0; k < nar; ++k) order[(size_t)next[(size_t)key[k] - 1]++] = k;
+    if (e->ensure(dptr, (size_t)nkeys + 1) || e->ensure(dval, std::max<size_t>((size_t)nar, 1)) || e->ensure(didx, std::max<size_t>((size_t)nar, 1)) ||
+        e->ensure(keys_out, std::max<size_t>((size_t)nar, 1)) || e->ensure(perm_in, std::max<size_t>((size_t)nar, 1)) || e->ensure(perm_out, std::max<size_t>((size_t)nar, 1))) return e->status;
+    SP_TRY(e, hipMemsetAsync(dptr.p, 0, ((size_t)nkeys + 1) * 8, e->stream));
+    if (nar > 0) {
+        const unsigned blocks = (unsigned)((nar + 255) / 256);
+        hipLaunchKernelGGL(dsa::k_iota, dim3(blocks), dim3(256), 0, e->stream, nar, perm_in.p);
+        hipLaunchKernelGGL(dsa::k_histogram, dim3(blocks), dim3(256), 0, e->stream, nar, d_key, reinterpret_cast<unsigned long long*>(dptr.p));
+        int bits = 1;
+        while ((1ll << bits) <= nkeys) ++bits;
+        size_t tmp_bytes = 0;
+        SP_TRY(e, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, keys_out.p, perm_in.p, perm_out.p, (int)nar, 0, bits, e->stream));
+        if (e->ensure(tmp, tmp_bytes)) return e->status;
+        SP_TRY(e, hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, d_key, keys_out.p, perm_in.p, perm_out.p, (int)nar, 0, bits, e->stream));
+        hipLaunchKernelGGL(dsa::k_gather, dim3(blocks), dim3(256), 0, e->stream, nar, perm_out.p, d_rw, d_other, dval.p, didx.p);
+    }
+    hipLaunchKernelGGL(dsa::k_scan64, dim3(1), dim3(1024), 0, e->stream, nkeys, dptr.p);
+    SP_TRY(e, hipGetLastError());
+    return 0;
 }
 
 }  // namespace
@@ -84,32 +147,30 @@ int dsa_spmv_load(dsa_engine* h, int m, int n, long long nar, const float* rw, c
 {
     if (!h) return DSA_ERR_ARGUMENT;
     Engine* e = reinterpret_cast<Engine*>(h);
-    if (m < 1 || n < 1 || nar < 0 || (nar > 0 && (!rw || !row || !col))) { e->fail(DSA_ERR_ARGUMENT, "spmv_load: bad arguments"); return DSA_ERR_ARGUMENT; }
+    if (m < 1 || n < 1 || nar < 0 || nar > 0x7fffffffll || (nar > 0 && (!rw || !row || !col))) { e->fail(DSA_ERR_ARGUMENT, "spmv_load: bad arguments"); return DSA_ERR_ARGUMENT; }
     for (long long k = 0; k < nar; ++k)
         if (row[k] < 1 || row[k] > m || col[k] < 1 || col[k] > n) { e->fail(DSA_ERR_ARGUMENT, "spmv_load: entry %lld has index (%d, %d) outside %d x %d", k, row[k], col[k], m, n); return DSA_ERR_ARGUMENT; }
     SP_TRY(e, hipSetDevice(e->device));
     if (!e->spmv) e->spmv = new SpmvState();
     SpmvState& S = *e->spmv;
     S.m = m; S.n = n; S.nar = nar;
-    std::vector<long long> ptr, order;
-    std::vector<float> v((size_t)nar);
-    std::vector<int> ix((size_t)nar);
-    auto upload = [&](const int* key, int nkeys, const int* other, dsa::DevBuf<long long>& dptr, dsa::DevBuf<float>& dval, dsa::DevBuf<int>& didx) -> int {
-        stable_order(nar, key, nkeys, ptr, order);
-        for (long long k = 0; k < nar; ++k) { v[(size_t)k] = rw[order[(size_t)k]]; ix[(size_t)k] = other[order[(size_t)k]] - 1; }
-        if (e->ensure(dptr, (size_t)nkeys + 1) || e->ensure(dval, std::max<size_t>((size_t)nar, 1)) || e->ensure(didx, std::max<size_t>((size_t)nar, 1))) return e->status;
-        SP_TRY(e, hipMemcpy(dptr.p, ptr.data(), ((size_t)nkeys + 1) * 8, hipMemcpyHostToDevice));
-        if (nar) {
-            SP_TRY(e, hipMemcpy(dval.p, v.data(), (size_t)nar * 4, hipMemcpyHostToDevice));
-            SP_TRY(e, hipMemcpy(didx.p, ix.data(), (size_t)nar * 4, hipMemcpyHostToDevice));
-        }
-        return 0;
-    };
-    int rc;
-    if ((rc = upload(row, m, col, S.rowptr, S.val_r, S.col_r)) != 0) return rc;
-    if ((rc = upload(col, n, row, S.colptr, S.val_c, S.row_c)) != 0) return rc;
-    if (e->ensure(S.x, (size_t)n) || e->ensure(S.y, (size_t)m)) return e->status;
-    return 0;
+    dsa::DevBuf<float> d_rw;
+    dsa::DevBuf<int> d_row, d_col, keys_out, perm_in, perm_out;
+    dsa::DevBuf<unsigned char> tmp;
+    auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
+    int rc = 0;
+    const size_t nn = std::max<size_t>((size_t)nar, 1);
+    if (e->ensure(d_rw, nn) || e->ensure(d_row, nn) || e->ensure(d_col, nn) || e->ensure(S.x, (size_t)n) || e->ensure(S.y, (size_t)m)) rc = e->status;
+    if (rc == 0 && nar > 0) {
+        if (hipMemcpyAsync(d_rw.p, rw, (size_t)nar * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemcpyAsync(d_row.p, row, (size_t)nar * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemcpyAsync(d_col.p, col, (size_t)nar * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess) { e->fail(DSA_ERR_DEVICE, "spmv_load: upload failed"); rc = DSA_ERR_DEVICE; }
+    }
+    if (rc == 0) rc = build_order(e, nar, m, d_row.p, d_col.p, d_rw.p, S.rowptr, S.val_r, S.col_r, keys_out, perm_in, perm_out, tmp);
+    if (rc == 0) rc = build_order(e, nar, n, d_col.p, d_row.p, d_rw.p, S.colptr, S.val_c, S.row_c, keys_out, perm_in, perm_out, tmp);
+    if (rc == 0 && hipStreamSynchronize(e->stream) != hipSuccess) { e->fail(DSA_ERR_DEVICE, "spmv_load: device ordering failed"); rc = DSA_ERR_DEVICE; }
+    rel(d_rw); rel(d_row); rel(d_col); rel(keys_out); rel(perm_in); rel(perm_out); rel(tmp);
+    return rc;
 }
 
 // mode 1: y += A x (x: n in, y: m in/out); mode 2: x += A^T y (y: m in, x: n in/out); host vectors

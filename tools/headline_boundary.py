@@ -52,7 +52,7 @@ def main():
         for mode in (1, 2, 1, 2):
             t2 = time.perf_counter(); out = e.spmv(mode, x, y); t3 = time.perf_counter()
             print("device aprod mode %d: %.1f ms (%.0f GB/s on 8 B per entry)" % (mode, 1e3 * (t3 - t2), n * 8 / (t3 - t2) / 1e9), flush=True)
-        print("matrix load (host stable sorts + upload of %d entries): %.2f s" % (n, t1 - t0))
+        print("matrix load (upload + stable radix sorts on the device, %d entries): %.2f s" % (n, t1 - t0))
         iwf = np.concatenate([[n], iw[1:n + 1], col[:n]]).astype(np.int32)
         ib = lambda v: C.byref(C.c_int(int(v)))
         for mode in (1, 2):
