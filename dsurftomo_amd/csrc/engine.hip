@@ -293,9 +293,9 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     // chunk size from the memory budget
     size_t free_b = 0, total_b = 0;
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
-    // default: 60 % of free HBM, at most 80 GB per chunk of sources (larger chunks gain nothing: the solve
-    // kernel already has thousands of workgroups in flight)
-    size_t budget = mem_budget ? mem_budget : std::min<size_t>((size_t)(0.6 * (double)free_b), (size_t)80 << 30);
+    // default: 60 % of free HBM, at most 150 GB per chunk of sources (one launch for the 16 000 units of the
+    // headline configuration: +3 % over two launches, whose tails leave CUs idle)
+    size_t budget = mem_budget ? mem_budget : std::min<size_t>((size_t)(0.6 * (double)free_b), (size_t)150 << 30);
     const size_t rr = (size_t)kRefMax * kRefMax;
     {   // the refined and the coarse solve of a unit share one list region: size it for the larger shape
         const FimLaunch lc = launch_shape(g.nnx, g.nnz), lr = launch_shape(kRefMax, kRefMax);

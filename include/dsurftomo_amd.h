@@ -45,7 +45,7 @@ enum dsa_status {
 int dsa_create(dsa_engine** out, int device_index);
 void dsa_destroy(dsa_engine* e);
 const char* dsa_error_string(const dsa_engine* e);   /* e may be NULL: last creation error */
-/* memory the engine may use for per-source fields (bytes, 0 = default: 60 % of free HBM, at most 80 GB) */
+/* memory the engine may use for per-source fields (bytes, 0 = default: 60 % of free HBM, at most 150 GB) */
 int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 
 /* tuning knobs: "window_cells" (causal window of the fixed-point solve, in cell travel times,
