@@ -192,11 +192,17 @@ DSA_HD uint64_t accept_rank(float t_raw, float tau_raw)
     return ((uint64_t)a.u << 32) | sec;
 }
 
-// rstar: rank of the open-edge node that ended the refined stage (~0 if none)
-DSA_HD bool ref_alive(const SourceDesc& s, const SourceScratch& w, uint64_t rstar, int iz, int ix)
+// rstar: rank of the open-edge node that ended the refined stage (~0 if none); eid: its scan index
+// (ix-1)*rnz + (iz-1), or -1.  A node whose rank TIES with that node's was accepted before it iff it comes
+// earlier in scan order: the reference's march inserts the x-, x+, z-, z+ neighbours in that order, so of two
+// mirror-image nodes with bit-equal times the one with the lower index sits higher in its tree and is popped
+// first (seen at the symmetric partner of the terminating node in homogeneous media).
+DSA_HD bool ref_alive(const SourceDesc& s, const SourceScratch& w, uint64_t rstar, int eid, int iz, int ix)
 {
     const Rec r = w.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)];
-    return t_pinned(r.T) || accept_rank(r.T, r.tau) < rstar;
+    if (t_pinned(r.T)) return true;
+    const uint64_t rk = accept_rank(r.T, r.tau);
+    return rk < rstar || (rk == rstar && (ix - 1) * s.rnz + (iz - 1) < eid);
 }
 
 // classify node (iz, ix): returns status (-1, 0, 1) and the value to keep in *tout
@@ -209,7 +215,8 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
         if (t_value(raw) < kInf) { *tout = raw; return 1; }
         *tout = kInf; return -1;
     }
-    if (ref_alive(s, w, rstar, iz, ix)) { *tout = t_value(raw); return 0; }
+    const int eid = ex > 0 ? (ex - 1) * s.rnz + (ez - 1) : -1;
+    if (ref_alive(s, w, rstar, eid, iz, ix)) { *tout = t_value(raw); return 0; }
     // not alive: close iff it touches an alive node; its value is the trial value from the alive
     // set (the edge node that ended the stage is alive but was never propagated)
     Stencil st;
@@ -218,15 +225,15 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
     bool touch = false;
     for (int d = 0; d < 2; ++d) {
         st.ej[d] = jx[d] >= 1 && jx[d] <= s.rnx;
-        st.aj[d] = st.ej[d] && ref_alive(s, w, rstar, iz, jx[d]);
+        st.aj[d] = st.ej[d] && ref_alive(s, w, rstar, eid, iz, jx[d]);
         st.tj[d] = st.aj[d] ? t_value(w.F_r[rec_index(s.nbz_r, iz - 1, jx[d] - 1)].T) : kInf;
-        const bool o = jx2[d] >= 1 && jx2[d] <= s.rnx && ref_alive(s, w, rstar, iz, jx2[d]);
+        const bool o = jx2[d] >= 1 && jx2[d] <= s.rnx && ref_alive(s, w, rstar, eid, iz, jx2[d]);
         st.oj[d] = o;
         st.tj2[d] = o ? t_value(w.F_r[rec_index(s.nbz_r, iz - 1, jx2[d] - 1)].T) : kInf;
         st.ek[d] = kz[d] >= 1 && kz[d] <= s.rnz;
-        st.ak[d] = st.ek[d] && ref_alive(s, w, rstar, kz[d], ix);
+        st.ak[d] = st.ek[d] && ref_alive(s, w, rstar, eid, kz[d], ix);
         st.tk[d] = st.ak[d] ? t_value(w.F_r[rec_index(s.nbz_r, kz[d] - 1, ix - 1)].T) : kInf;
-        const bool p = kz2[d] >= 1 && kz2[d] <= s.rnz && ref_alive(s, w, rstar, kz2[d], ix);
+        const bool p = kz2[d] >= 1 && kz2[d] <= s.rnz && ref_alive(s, w, rstar, eid, kz2[d], ix);
         st.ok[d] = p;
         st.tk2[d] = p ? t_value(w.F_r[rec_index(s.nbz_r, kz2[d] - 1, ix - 1)].T) : kInf;
         touch = touch || st.aj[d] || st.ak[d];
