@@ -227,13 +227,14 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
     float tn[4], key[4];
     int idx[4] = { 0, 1, 2, 3 };
     unsigned alive = 0u;            // bit q: near neighbour q is alive
+    float tnow = -kInf;             // clock of the most recent neighbour acceptance taken into account
     for (int q = 0; q < 4; ++q) {
         const bool in = h.in[q];
         const float raw = in ? h.near_[q] : kInf;
         tn[q] = t_value(raw);
         const bool pin = in && t_pinned(raw);
-        if (pin) alive |= 1u << q;
         const float k = in ? tau_value(h.near_tau[q]) : kInf;
+        if (pin) { alive |= 1u << q; tnow = k > tnow ? k : tnow; }
         key[q] = (in && !pin) ? k : kInf;          // +inf: not a candidate of the walk
     }
     // sort the candidates by (acceptance time, index): 5-comparator network, same order as a stable sort
@@ -247,7 +248,6 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
     DSA_CE(0, 1); DSA_CE(2, 3); DSA_CE(0, 2); DSA_CE(1, 3); DSA_CE(1, 2);
 #undef DSA_CE
 
-    float tnow = -kInf;
     auto eval = [&](void) -> float {
         Stencil s;
         for (int d = 0; d < 2; ++d) {
@@ -258,8 +258,9 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
             const float oxr = h.in_outer[d] ? h.outer[d] : kInf;
             const float ozr = h.in_outer[2 + d] ? h.outer[2 + d] : kInf;
             s.tj2[d] = t_value(oxr);   s.tk2[d] = t_value(ozr);
-            s.oj[d] = h.in_outer[d] && (t_pinned(oxr) || tau_value(h.outer_tau[d]) < tnow);
-            s.ok[d] = h.in_outer[2 + d] && (t_pinned(ozr) || tau_value(h.outer_tau[2 + d]) < tnow);
+            const float kox = tau_value(h.outer_tau[d]), koz = tau_value(h.outer_tau[2 + d]);
+            s.oj[d] = h.in_outer[d] && (kox < tnow || kox == 0.0f);       // 0: alive before any march
+            s.ok[d] = h.in_outer[2 + d] && (koz < tnow || koz == 0.0f);
         }
         return fouds2(s, slown, g);
     };
@@ -296,6 +297,7 @@ struct MarchView {
     int cap;
     int ntr;
     int error;            // 1: window overflow, 2: tree overflow
+    float clock;          // number of accepts so far (see mv_accept_root)
 };
 
 DSA_HD float& mv_T(MarchView& m, int iz, int ix) { return m.F[rec_index(m.nbz, iz - 1, ix - 1)].T; }
@@ -392,9 +394,20 @@ DSA_HD float mv_trial(MarchView& m, int iz, int ix)
 }
 
 // accept the root and update its four neighbours; returns false on error
+// The tree of the reference is not always a valid heap here (start values in the source cell, injected
+// refined values, keys raised by an update that only sifts up), so nodes can be accepted out of order: a node
+// with a SMALLER time after one with a larger time.  What matters downstream is the order, not the value:
+// a node two steps away only enters a second-order stencil if it was accepted before the in-between node was
+// (the reference never re-evaluates a node when a node two steps away is accepted).  So every accept of a
+// serial march records its sequence number in tau, as a value far below any travel time (all marched nodes
+// are accepted before every node of the fixed-point solve); 0 = alive before the march started.
+constexpr float kSeqClock = 1.0e-30f;
+
 DSA_HD bool mv_accept_root(MarchView& m)
 {
     const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
+    m.clock += 1.0f;
+    m.F[rec_index(m.nbz, iz - 1, ix - 1)].tau = m.clock * kSeqClock;
     mv_set(m, iz, ix, 0);
     mv_pop_root(m);
     for (int i = ix - 1; i <= ix + 1; i += 2) {

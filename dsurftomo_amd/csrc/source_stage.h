@@ -123,7 +123,7 @@ DSA_HD int refined_startup(const GridDesc& g, const SourceDesc& s, SourceScratch
     m.F = w.F_r; m.slow = w.slow_r; m.nbz = s.nbz_r; m.risti = w.risti_r;
     m.status = w.rst; m.wz0 = s.rwz0; m.wx0 = s.rwx0; m.wnz = kRWin; m.wnx = kRWin;
     m.nnz = s.rnz; m.nnx = s.rnx; m.ri = g.earth; m.dnx = s.rdnx; m.dnz = s.rdnz;
-    m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0;
+    m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0; m.clock = 0.0f;
     for (int q = 0; q < kRWin * kRWin; ++q) w.rst[q] = -1;
     const int isx = s.isx_r, isz = s.isz_r;
     float vss[2][2];
@@ -165,7 +165,7 @@ DSA_HD void refined_encode(const SourceDesc& s, SourceScratch& w, int ended)
             if (ix < 1 || ix > s.rnx || iz < 1 || iz > s.rnz) continue;
             const int st = w.rst[lx * kRWin + lz];
             Rec& r = w.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)];
-            if (st == 0) { r.tau = r.T; r.T = -r.T; }              // -0.0f for an exact zero keeps the sign bit
+            if (st == 0) { r.T = -r.T; }                           // tau = accept number of the march; -0.0f keeps the sign bit
             else if (st > 0 && ended) r.tau = r.T;                 // keep the trial value
             else { r.T = kInf; r.tau = kInf; }
         }
@@ -257,13 +257,15 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
     m.F = F_c; m.slow = slow_c; m.nbz = g.nbz; m.risti = risti_c;
     m.status = w.cst; m.wz0 = s.cwz0; m.wx0 = s.cwx0; m.wnz = s.cwnz; m.wnx = s.cwnx;
     m.nnz = g.nnz; m.nnx = g.nnx; m.ri = g.earth; m.dnx = g.dnx; m.dnz = g.dnz;
-    m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0;
+    m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0; m.clock = 0.0f;
     int ninit = 0;
     // tree start order of the reference: ix outer, iz inner (:341-347)
     for (int lx = 0; lx < s.cwnx; ++lx)
         for (int lz = 0; lz < s.cwnz; ++lz) {
             const int q = lx * s.cwnz + lz;
             w.cinit[q] = 0;
+            if (w.cst[q] == 0) F_c[rec_index(g.nbz, s.cwz0 + lz, s.cwx0 + lx)].tau = 0.0f;      // alive before the march
+
             if (w.cst[q] > 0) { w.cinit[q] = 1; ++ninit; mv_add(m, s.cwz0 + lz + 1, s.cwx0 + lx + 1); }
         }
     while (m.ntr > 0 && ninit > 0 && m.error == 0) {
@@ -278,7 +280,7 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
             const int ix = s.cwx0 + lx + 1, iz = s.cwz0 + lz + 1;
             Rec& r = F_c[rec_index(g.nbz, iz - 1, ix - 1)];
             const int st = w.cst[lx * s.cwnz + lz];
-            if (st == 0) { r.tau = t_value(r.T); r.T = -t_value(r.T); }
+            if (st == 0) { r.T = -t_value(r.T); }          // tau: accept number of the march, 0 for the hand-off's alive nodes
             else { r.T = kInf; r.tau = kInf; }
         }
 }

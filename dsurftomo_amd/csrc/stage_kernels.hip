@@ -360,6 +360,10 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
                 trr = trr + t_value(F[rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1)].T) * produ;
             }
     }
+    // A source inside the last cell next to a high model edge ends the reference's refined stage at once and
+    // leaves its whole field at the initial 0 (the literal open-edge test, CalSurfG.f90:396-407); here such a
+    // field is +inf (never reached).  Report the reference's 0 rather than a non-finite time.
+    if (!(trr < kInf)) trr = 0.0f;
     out[rd.data] = trr;
 }
 

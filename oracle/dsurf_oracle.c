@@ -8,6 +8,7 @@
 #include "dsurf_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -351,8 +352,45 @@ static void addtree(fmm *f, int iz, int ix)
     sift_up(f, iz, ix, f->ntr);
 }
 
+/* Diagnostic only (never used for parity): DSO_VALID_HEAP=1 in the environment makes updtree restore the heap
+ * property when a key was RAISED as well.  The reference does not (below), so its march can pop nodes out of
+ * order; comparing the two tells which differences of the product come from that. */
+static int valid_heap_mode(void)
+{
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("DSO_VALID_HEAP"); mode = (e && e[0] == '1') ? 1 : 0; }
+    return mode;
+}
+
+static void sift_down_from(fmm *f, int tpp)
+{
+    for (;;) {
+        int tpc = 2 * tpp;
+        if (tpc > f->ntr) break;
+        if (tpc < f->ntr && hkey(f, tpc) > hkey(f, tpc + 1)) tpc += 1;
+        if (!(hkey(f, tpc) < hkey(f, tpp))) break;
+        ST(f, f->hz[tpp], f->hx[tpp]) = tpc;
+        ST(f, f->hz[tpc], f->hx[tpc]) = tpp;
+        hswap(f, tpc, tpp);
+        tpp = tpc;
+    }
+}
+
 /* only ever moves an entry towards the root, also when its key was raised (:894-921) */
-static void updtree(fmm *f, int iz, int ix) { sift_up(f, iz, ix, ST(f, iz, ix)); }
+static long g_heap_violations = 0;     /* diagnostic counter: updates that left a parent above a smaller child */
+long dso_heap_violations(int reset) { const long v = g_heap_violations; if (reset) g_heap_violations = 0; return v; }
+
+static void updtree(fmm *f, int iz, int ix)
+{
+    sift_up(f, iz, ix, ST(f, iz, ix));
+    if (valid_heap_mode()) { sift_down_from(f, ST(f, iz, ix)); return; }
+    const int p = ST(f, iz, ix), c = 2 * p;
+    if ((c <= f->ntr && hkey(f, c) < hkey(f, p)) || (c + 1 <= f->ntr && hkey(f, c + 1) < hkey(f, p))) {
+        g_heap_violations += 1;
+        if (getenv("DSO_TRACE_HEAP") && g_heap_violations <= 12)
+            fprintf(stderr, "heap violation %ld: node ix %d iz %d key %.7f raised above a child (heap size %d, position %d)\n", g_heap_violations, ix - 1, iz - 1, TT(f, iz, ix), f->ntr, p);
+    }
+}
 
 static void downtree(fmm *f)
 {
@@ -436,6 +474,10 @@ static int travel(fmm *f, float scx, float scz, int urg)
             if (swrg) { ST(f, iz, ix) = 0; break; }
         }
         ix = f->hx[1]; iz = f->hz[1];
+        if (urg == 2 && getenv("DSO_TRACE_POPS")) {      /* diagnostic: the first accepts of the coarse stage */
+            static int shown = 0;
+            if (shown < atoi(getenv("DSO_TRACE_POPS"))) { ++shown; fprintf(stderr, "pop %d: ix %d iz %d T %.7f (heap %d)\n", shown, ix - 1, iz - 1, TT(f, iz, ix), f->ntr); }
+        }
         ST(f, iz, ix) = 0;
         downtree(f);
         for (int i = ix - 1; i <= ix + 1; i += 2) {
