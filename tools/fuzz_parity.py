@@ -9,7 +9,10 @@ nsrc = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 e = Engine(0)
 worst = 0.0
-for nx, kind, gd in ((18, "homog", 8), (18, "smooth", 8), (35, "checker4", 8), (35, "rough", 8), (27, "smooth", 5), (35, "checker", 8), (22, "rough", 8)):
+GRIDS = ((18, "homog", 8), (18, "smooth", 8), (35, "checker4", 8), (35, "rough", 8), (27, "smooth", 5), (35, "checker", 8), (22, "rough", 8))
+if len(sys.argv) > 3:
+    GRIDS = tuple((int(a.split(":")[0]), a.split(":")[1], int(a.split(":")[2])) for a in sys.argv[3:])
+for nx, kind, gd in GRIDS:
     g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
     pv = synth.medium(nx, kind); veln = L.o_gridder(g, pv); N = g.nnx
     r = synth.LCG(seed * 1000 + nx)
