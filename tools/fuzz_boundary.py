@@ -8,10 +8,11 @@ from dsurftomo_amd import engine as E
 lib = E.load_library()
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 r = synth.LCG(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+big = len(sys.argv) > 3 and sys.argv[3] == 'big'       # 28..40 vertices per side: rays cross the refined box and long coarse paths
 bad = 0
 for k in range(ncases):
     u = r.uniform(12)
-    kw = dict(nx=6 + int(u[0] * 16), ny=6 + int(u[1] * 16), nz=3 + int(u[2] * 6), kRc=int(u[3] * 4), kRg=int(u[4] * 3), kLc=int(u[5] * 3), kLg=int(u[6] * 2),
+    kw = dict(nx=(28 if big else 6) + int(u[0] * (12 if big else 16)), ny=(28 if big else 6) + int(u[1] * (12 if big else 16)), nz=3 + int(u[2] * 6), kRc=int(u[3] * 4), kRg=int(u[4] * 3), kLc=int(u[5] * 3), kLg=int(u[6] * 2),
               nsrc=2 + int(u[7] * 6), nrcf=2 + int(u[8] * 6), dvd=0.02 + 0.08 * u[9], seed=int(u[10] * 1e6), deep=bool(u[11] > 0.7))
     if kw["kRc"] + kw["kRg"] + kw["kLc"] + kw["kLg"] == 0: kw["kRc"] = 1
     c = synth.boundary_case(**kw)
