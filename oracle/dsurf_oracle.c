@@ -329,6 +329,13 @@ static inline void hswap(fmm *f, int p, int q)
     f->hx[q] = tx; f->hz[q] = tz;
 }
 
+/* Diagnostic only (DSO_TIE_STATS=1): what decides which of two neighbouring tree entries with bit-equal keys the
+ * reference pops first?  Counted per exact tie between the popped node and a neighbour still in the tree. */
+static long g_tie[8];          /* [0] ties, [1] popped one was inserted earlier, [2..5] popped one lies at x-, x+, z-, z+ of the other */
+static int *g_ins = NULL;      /* insertion number per node */
+static long g_ins_n = 0, g_ins_cap = 0;
+void dso_tie_stats(long *out, int reset) { for (int i = 0; i < 8; ++i) { out[i] = g_tie[i]; if (reset) g_tie[i] = 0; } }
+
 static void sift_up(fmm *f, int iz, int ix, int tpc)
 {
     int tpp = tpc / 2;
@@ -345,6 +352,7 @@ static void sift_up(fmm *f, int iz, int ix, int tpc)
 
 static void addtree(fmm *f, int iz, int ix)
 {
+    if (g_ins) g_ins[(size_t)(ix - 1) * f->ld + (iz - 1)] = (int)(++g_ins_n);
     f->ntr += 1;
     ST(f, iz, ix) = f->ntr;
     f->hx[f->ntr] = ix;
@@ -434,6 +442,10 @@ static float bilinear(const float nv[2][2], float dnx, float dnz, float dsx, flo
 /* travel, CalSurfG.f90:288-487. urg: 0 plain, 1 refined stage (early exit), 2 continue from nsts>0 */
 static int travel(fmm *f, float scx, float scz, int urg)
 {
+    if (getenv("DSO_TIE_STATS")) {
+        const long need = (long)f->ld * f->nnx;
+        if (need > g_ins_cap) { free(g_ins); g_ins = (int *)calloc((size_t)need, sizeof(int)); g_ins_cap = need; }
+    }
     int isx = (int)((scx - f->gox) / f->dnx) + 1;
     int isz = (int)((scz - f->goz) / f->dnz) + 1;
     if (isx < 1 || isx > f->nnx || isz < 1 || isz > f->nnz) return -1;
@@ -477,6 +489,17 @@ static int travel(fmm *f, float scx, float scz, int urg)
         if (urg == 2 && getenv("DSO_TRACE_POPS")) {      /* diagnostic: the first accepts of the coarse stage */
             static int shown = 0;
             if (shown < atoi(getenv("DSO_TRACE_POPS"))) { ++shown; fprintf(stderr, "pop %d: ix %d iz %d T %.7f (heap %d)\n", shown, ix - 1, iz - 1, TT(f, iz, ix), f->ntr); }
+        }
+        if (g_ins && urg != 1) {
+            const float key = TT(f, iz, ix);
+            const int nx4[4] = { ix - 1, ix + 1, ix, ix }, nz4[4] = { iz, iz, iz - 1, iz + 1 };
+            for (int q = 0; q < 4; ++q) {
+                if (nx4[q] < 1 || nx4[q] > f->nnx || nz4[q] < 1 || nz4[q] > f->nnz) continue;
+                if (ST(f, nz4[q], nx4[q]) <= 0 || TT(f, nz4[q], nx4[q]) != key) continue;
+                g_tie[0] += 1;
+                if (g_ins[(size_t)(ix - 1) * f->ld + (iz - 1)] < g_ins[(size_t)(nx4[q] - 1) * f->ld + (nz4[q] - 1)]) g_tie[1] += 1;
+                g_tie[2 + (q ^ 1)] += 1;       /* the popped node seen from the neighbour */
+            }
         }
         ST(f, iz, ix) = 0;
         downtree(f);
