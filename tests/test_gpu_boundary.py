@@ -235,3 +235,19 @@ def test_forward_cli_on_the_taipei_directory(tmp_path):
     G = np.load(out + ".G.npz")
     assert abs(int(G["rw"].size) - int(z["nar"])) <= 0.005 * int(z["nar"]) and tuple(G["shape"]) == (2061, 2048)
     assert (np.diff(G["row"]) >= 0).all()
+
+
+def test_dropin_empty_slots_and_sources_without_receivers(lib):
+    """a period slot without sources and a source without receivers (the reference's loops simply skip them)"""
+    c = synth.boundary_case(kRc=3, kRg=1, kLc=1, kLg=0, nsrc=3, nrcf=4, ragged=False)
+    c["nsrcsurf1"][1] = 0                         # second Rayleigh phase period: no sources
+    c["nrc1"][0, 0] = 0                           # first source of the first period: no receivers
+    c["nrc1"][2, 3] = 0                           # a group-velocity source without receivers
+    c["ndata"] = int(sum(c["nrc1"][s, k] for k in range(c["kmax"]) for s in range(c["nsrcsurf1"][k])))
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    d = L.call_boundary(lib.dsa_calsurfg, c)
+    check_rows(o, d, c)
+    assert (o["dsurf"].view(np.uint32) != d["dsurf"].view(np.uint32)).sum() == 0
+    so = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
+    sd = L.call_boundary(lib.dsa_synthetic, c, synthetic=True)
+    assert np.abs(so - sd).max() <= 1e-4
