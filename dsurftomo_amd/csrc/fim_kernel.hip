@@ -72,15 +72,36 @@ __device__ __forceinline__ void push_next(const Lists& L, int id, float key, boo
     }
 }
 
-__device__ __forceinline__ float wave_min(float v)
+// Wave-wide scans and reductions on the VALU's data-parallel primitives (row shifts inside the four rows of 16
+// lanes, then the two row broadcasts): six dependent VALU operations instead of six LDS permutes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_scan_incl(int v)
 {
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    v += dpp_or_zero<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);      // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ unsigned wave_sum(unsigned v)
+__device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ unsigned wave_sum(unsigned v) { return (unsigned)wave_last(wave_scan_incl((int)v)); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_inf(float v)
 {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0x7f800000, (int)__float_as_uint(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+    v = fminf(v, dpp_or_inf<0x111, 0xf>(v));
+    v = fminf(v, dpp_or_inf<0x112, 0xf>(v));
+    v = fminf(v, dpp_or_inf<0x114, 0xf>(v));
+    v = fminf(v, dpp_or_inf<0x118, 0xf>(v));
+    v = fminf(v, dpp_or_inf<0x142, 0xa>(v));
+    v = fminf(v, dpp_or_inf<0x143, 0xc>(v));
+    return __uint_as_float((unsigned)wave_last((int)__float_as_uint(v)));
 }
 
 }  // namespace
@@ -381,10 +402,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
     const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
     GU64* const mask = (GU64*)p.lists;                       // ntile node masks
-    GI32* const ready = (GI32*)p.lists + 2 * ntile;          // rcap
+    constexpr int rhalf = 1024;                              // ready nodes of one colour a round can take
+    __shared__ int ready[2 * rhalf];                         // (the rest stay in their masks for the next round)
     unsigned* const tb = dyn_lds;                            // tile bitmap, nwords
     auto ld = [&](int id) { Rec r; r.T = F[id].T; r.tau = F[id].tau; return r; };
-    const int rhalf = rcap / 2;
+    // tile -> (bx, bz) without an integer division: floor(t / nbz) = hi32(t * ceil(2^32 / nbz)) while t * nbz < 2^32
+    const bool by_mul = nbz > 1 && (unsigned long long)ntile * (unsigned long long)nbz < (1ull << 32);
+    const unsigned nbz_inv = by_mul ? 0xffffffffu / (unsigned)nbz + 1u : 0u;
+    auto coords = [&](int id, int* iz0, int* ix0) {
+        const unsigned tile = (unsigned)id >> 6;
+        const unsigned bx = by_mul ? __umulhi(tile, nbz_inv) : tile / (unsigned)nbz;
+        const unsigned bz = tile - bx * (unsigned)nbz;
+        *ix0 = (int)(bx << kTileShift) + ((id >> 3) & 7);
+        *iz0 = (int)(bz << kTileShift) + (id & 7);
+    };
 
     for (int i = tid; i < ntile; i += NT) mask[i] = 0ull;
     for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
@@ -419,103 +450,132 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     unsigned long long tA = 0, tB0 = 0, tB1 = 0, tE = 0, t0 = wall_clock64(), sum_cnt = 0, sum_ready = 0;
     float best_tmin = -kInf;
     unsigned long long evals = 0, nchanged = 0;
+#ifdef DSA_PASSA_CLOCKS
+    unsigned long long sub[5] = { 0, 0, 0, 0, 0 }, tsub = wall_clock64();
+#define DSA_TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = wall_clock64(); sub[k] += t1_ - tsub; tsub = t1_; } while (0)
+#else
+#define DSA_TICK(k) do { } while (0)
+#endif
     for (;;) {
         const float theta = u2f((unsigned)sc[SC_THETA]);
         const bool open = !(theta < kInf);
         const float freeze = u2f((unsigned)sc[SC_FREEZE]);
         const bool frozen_any = freeze > -kInf;
 
-        // ---- pass A: every wave sweeps its share of the tile bitmap in chunks of 64 tiles (no
-        // workgroup barrier inside): lanes = tiles to fetch the node masks, then the set bits are
-        // expanded into a wave-local buffer in record order and lanes = nodes compute the lower
-        // bounds and route (neighbouring lanes read neighbouring nodes).
+#ifdef DSA_PASSA_CLOCKS
+        tsub = wall_clock64();
+#endif
+        // ---- pass A: every wave sweeps its share of the tile bitmap (no workgroup barrier inside).  The active
+        // tiles of the share are first collected in LDS, in tile order; then their node masks are fetched
+        // with up to four loads in flight per lane, the set bits are expanded into a wave-local buffer in record
+        // order, and lanes = nodes (four per lane, so sixteen loads in flight) compute the lower bounds and
+        // route.  The pass costs two dependent memory round trips however the front is spread over the bitmap.
         int seen = 0;
         float tmin_lane = kInf;
         int* const nbuf = wbuf + wave * kWaveBuf;
         int* const tbuf = wtile + wave * kTileBuf;
         constexpr int NW = NT / 64;
+        constexpr int kQ = kTileBuf / 64, kI = kWaveBuf / 64;
+        auto sweep_tiles = [&](int ntiles) {
+            DSA_TICK(0);
+            int tl[kQ];
+            unsigned long long m[kQ];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                tl[q] = q * 64 + lane < ntiles ? tbuf[q * 64 + lane] : -1;
+                m[q] = tl[q] >= 0 ? mask[tl[q]] : 0ull;
+            }
+            DSA_TICK(1);
+            int off[kQ], total = 0;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                if (tl[q] >= 0 && m[q] == 0ull) atomicAnd(&tb[tl[q] >> 5], ~(1u << (tl[q] & 31)));      // the tile has drained
+                const int n = __popcll(m[q]);
+                const int incl = wave_scan_incl(n);
+                off[q] = total + incl - n;
+                total += wave_last(incl);
+            }
+            seen += total;
+            for (int base = 0; base < total; base += kWaveBuf) {
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) {
+                    unsigned long long mm = m[q];
+                    int idx = off[q];
+                    while (mm) {
+                        const int nb = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1ull;
+                        if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = (tl[q] << 6) + nb;
+                        ++idx;
+                    }
+                }
+                const int nn = min(total - base, kWaveBuf);
+                DSA_TICK(2);
+                int id[kI], par[kI];
+                float lb[kI], own[kI];
+#pragma unroll
+                for (int i = 0; i < kI; ++i) {
+                    const bool have = i * 64 + lane < nn;
+                    id[i] = have ? nbuf[i * 64 + lane] : -1;
+                    int iz, ix;
+                    coords(have ? id[i] : 0, &iz, &ix);
+                    par[i] = (ix + iz) & 1;
+                    lb[i] = kInf; own[i] = kInf;
+                    if (have) {
+                        const float a = ix > 0 ? F[rec_index(nbz, iz, ix - 1)].tau : kInf;
+                        const float b2 = ix + 1 < nnx ? F[rec_index(nbz, iz, ix + 1)].tau : kInf;
+                        const float c2 = iz > 0 ? F[rec_index(nbz, iz - 1, ix)].tau : kInf;
+                        const float d2 = iz + 1 < nnz ? F[rec_index(nbz, iz + 1, ix)].tau : kInf;
+                        if (frozen_any) own[i] = F[id[i]].tau;
+                        lb[i] = fminf(fminf(a, b2), fminf(c2, d2));
+                    }
+                }
+                DSA_TICK(3);
+#pragma unroll
+                for (int i = 0; i < kI; ++i) {
+                    if (i * 64 >= nn) break;                                     // wave-uniform
+                    const bool have = id[i] >= 0;
+                    const bool frozen = have && frozen_any && own[i] < freeze;
+                    const bool cand = have && !frozen;
+                    const bool odd = par[i] != 0;
+                    const bool want_e = cand && (open || lb[i] < theta) && !odd;
+                    const bool want_o = cand && (open || lb[i] < theta) && odd;
+                    const int pe = wave_alloc(&sc[SC_READY], want_e);
+                    const int po = wave_alloc(&sc[SC_READY_ODD], want_o);
+                    const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
+                    if (got) ready[want_o ? rhalf + po : pe] = id[i];
+                    // leaving the active set happens before the barrier, so a change that lands while
+                    // the node is being evaluated sets the bit again
+                    if (got || frozen) atomicAnd((unsigned long long*)&mask[id[i] >> 6], ~(1ull << (id[i] & 63)));
+                    if (cand && !got) tmin_lane = fminf(tmin_lane, lb[i]);
+                }
+                DSA_TICK(4);
+            }
+        };
+        int ntw = 0;                                                               // tiles collected, wave-uniform
         for (int wb = 0; (wb * 4 * NW + wave) * 16 < nwords; ++wb) {
             // 64 bitmap words of this wave: 16-word groups dealt round-robin to the waves, ascending
             const int w = ((wb * 4 + (lane >> 4)) * NW + wave) * 16 + (lane & 15);
             const unsigned bits = w < nwords ? tb[w] : 0u;
             const int nt_lane = __popc(bits);
-            int tincl = nt_lane;
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(tincl, o); if (lane >= o) tincl += v; }
-            const int ttotal = __shfl(tincl, 63);
-            if (ttotal == 0) continue;                                     // wave-uniform
+            const int tincl = wave_scan_incl(nt_lane);
+            const int ttotal = wave_last(tincl);
             const int toff = tincl - nt_lane;
-            for (int tbase = 0; tbase < ttotal; tbase += kTileBuf) {
-                {   // active tiles with rank in [tbase, tbase + kTileBuf), in tile order
-                    unsigned bb = bits;
-                    int idx = toff;
-                    while (bb) {
-                        const int b2 = __ffs((int)bb) - 1;
-                        bb &= bb - 1u;
-                        if (idx >= tbase && idx < tbase + kTileBuf) tbuf[idx - tbase] = (w << 5) + b2;
-                        ++idx;
-                    }
+            for (int tbase = 0; tbase < ttotal;) {                                 // wave-uniform
+                const int take = min(kTileBuf - ntw, ttotal - tbase);
+                unsigned bb = bits;
+                int idx = toff;
+                while (bb) {
+                    const int b2 = __ffs((int)bb) - 1;
+                    bb &= bb - 1u;
+                    if (idx >= tbase && idx < tbase + take) tbuf[ntw + idx - tbase] = (w << 5) + b2;
+                    ++idx;
                 }
-                const int ntiles = min(ttotal - tbase, kTileBuf);
-                for (int t0 = 0; t0 < ntiles; t0 += 64) {
-                    // lanes = tiles: one fetch of 64 node masks
-                    const int tile = t0 + lane < ntiles ? tbuf[t0 + lane] : -1;
-                    unsigned long long m = 0ull;
-                    if (tile >= 0) {
-                        m = mask[tile];
-                        if (m == 0ull) atomicAnd(&tb[tile >> 5], ~(1u << (tile & 31)));      // the tile has drained
-                    }
-                    const int n = __popcll(m);
-                    int incl = n;
-                    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                    const int total = __shfl(incl, 63);
-                    const int off = incl - n;
-                    seen += total;
-                    for (int base = 0; base < total; base += kWaveBuf) {
-                        {
-                            unsigned long long mm = m;
-                            int idx = off;
-                            while (mm) {
-                                const int nb = __ffsll((long long)mm) - 1;
-                                mm &= mm - 1ull;
-                                if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = (tile << 6) + nb;
-                                ++idx;
-                            }
-                        }
-                        const int nn = min(total - base, kWaveBuf);
-                        // lanes = nodes, in record order
-                        for (int j0 = 0; j0 < nn; j0 += 64) {
-                            const int j = j0 + lane;
-                            const bool have = j < nn;
-                            const int id = have ? nbuf[j] : 0;
-                            int iz, ix;
-                            rec_coords(nbz, id, &iz, &ix);
-                            float lb = kInf, own = kInf;
-                            if (have) {
-                                const float a = ix > 0 ? F[rec_index(nbz, iz, ix - 1)].tau : kInf;
-                                const float b2 = ix + 1 < nnx ? F[rec_index(nbz, iz, ix + 1)].tau : kInf;
-                                const float c2 = iz > 0 ? F[rec_index(nbz, iz - 1, ix)].tau : kInf;
-                                const float d2 = iz + 1 < nnz ? F[rec_index(nbz, iz + 1, ix)].tau : kInf;
-                                if (frozen_any) own = F[id].tau;
-                                lb = fminf(fminf(a, b2), fminf(c2, d2));
-                            }
-                            const bool frozen = have && frozen_any && own < freeze;
-                            const bool cand = have && !frozen;
-                            const bool odd = ((ix + iz) & 1) != 0;
-                            const bool want_e = cand && (open || lb < theta) && !odd;
-                            const bool want_o = cand && (open || lb < theta) && odd;
-                            const int pe = wave_alloc(&sc[SC_READY], want_e);
-                            const int po = wave_alloc(&sc[SC_READY_ODD], want_o);
-                            const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
-                            if (got) ready[want_o ? rhalf + po : pe] = id;
-                            // leaving the active set happens before the barrier, so a change that lands while
-                            // the node is being evaluated sets the bit again
-                            if (got || frozen) atomicAnd((unsigned long long*)&mask[id >> 6], ~(1ull << (id & 63)));
-                            if (cand && !got) tmin_lane = fminf(tmin_lane, lb);
-                        }
-                    }
-                }
+                ntw += take; tbase += take;
+                if (ntw == kTileBuf) { sweep_tiles(ntw); ntw = 0; }
             }
         }
+        if (ntw) sweep_tiles(ntw);
+        DSA_TICK(0);
         tmin_lane = wave_min(tmin_lane);
         if (lane == 0) {
             if (tmin_lane < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(tmin_lane));
@@ -536,7 +596,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 const bool act = j < nready;
                 const int id = act ? ready[half ? rhalf + j : j] : 0;
                 int iz, ix;
-                rec_coords(nbz, id, &iz, &ix);
+                coords(id, &iz, &ix);
                 Hood h;
                 h.in[0] = act && ix > 0;          h.in_outer[0] = act && ix > 1;
                 h.in[1] = act && ix + 1 < nnx;    h.in_outer[1] = act && ix + 2 < nnx;
@@ -577,13 +637,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     want[4 + q] = changed && h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) &&
                                   t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q];
                 }
-                unsigned long long olds[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    olds[q] = want[q] ? atomicOr((unsigned long long*)&mask[nid[q] >> 6], 1ull << (nid[q] & 63)) : ~0ull;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (olds[q] == 0ull) atomicOr(&tb[(nid[q] >> 6) >> 5], 1u << ((nid[q] >> 6) & 31));
+                    if (want[q]) {
+                        atomicOr((unsigned long long*)&mask[nid[q] >> 6], 1ull << (nid[q] & 63));
+                        atomicOr(&tb[(nid[q] >> 6) >> 5], 1u << ((nid[q] >> 6) & 31));
+                    }
                 const unsigned hv = wave_sum(changed ? (((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u)) : 0u);
                 const float kmin = wave_min(changed ? k : kInf);
                 if (lane == 0) {
@@ -618,6 +677,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     if (tid == 0) {
         p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
         if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }
+#ifdef DSA_PASSA_CLOCKS
+        if (p.clocks) for (int k = 0; k < 5; ++k) p.clocks[k] = sub[k];
+#endif
     }
 }
 
