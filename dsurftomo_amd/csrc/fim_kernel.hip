@@ -391,6 +391,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     __shared__ int wbuf[(NT / 64) * kWaveBuf];
     constexpr int kTileBuf = 256;                            // tiles a wave gathers at a time
     __shared__ int wtile[(NT / 64) * kTileBuf];
+    __shared__ unsigned wclr[(NT / 64) * kTileBuf * 2];      // per gathered tile: the node bits that leave the active set
     const FimProblem p = problems[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* sc = smem;
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         float tmin_lane = kInf;
         int* const nbuf = wbuf + wave * kWaveBuf;
         int* const tbuf = wtile + wave * kTileBuf;
+        unsigned* const clr = wclr + wave * kTileBuf * 2;
         constexpr int NW = NT / 64;
         constexpr int kQ = kTileBuf / 64, kI = kWaveBuf / 64;
         auto sweep_tiles = [&](int ntiles) {
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
             for (int q = 0; q < kQ; ++q) {
                 tl[q] = q * 64 + lane < ntiles ? tbuf[q * 64 + lane] : -1;
                 m[q] = tl[q] >= 0 ? mask[tl[q]] : 0ull;
+                if (q * 64 < ntiles) { clr[2 * (q * 64 + lane)] = 0u; clr[2 * (q * 64 + lane) + 1] = 0u; }
             }
             DSA_TICK(1);
             int off[kQ], total = 0;
@@ -504,18 +507,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     while (mm) {
                         const int nb = __ffsll((long long)mm) - 1;
                         mm &= mm - 1ull;
-                        if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = (tl[q] << 6) + nb;
+                        if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = ((q * 64 + lane) << 6) + nb;     // (tile slot, node)
                         ++idx;
                     }
                 }
                 const int nn = min(total - base, kWaveBuf);
                 DSA_TICK(2);
-                int id[kI], par[kI];
+                int id[kI], par[kI], slot[kI];
                 float lb[kI], own[kI];
 #pragma unroll
                 for (int i = 0; i < kI; ++i) {
                     const bool have = i * 64 + lane < nn;
-                    id[i] = have ? nbuf[i * 64 + lane] : -1;
+                    const int e = have ? nbuf[i * 64 + lane] : 0;
+                    slot[i] = e >> 6;
+                    id[i] = have ? (tbuf[slot[i]] << 6) + (e & 63) : -1;
                     int iz, ix;
                     coords(have ? id[i] : 0, &iz, &ix);
                     par[i] = (ix + iz) & 1;
@@ -543,13 +548,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     const int po = wave_alloc(&sc[SC_READY_ODD], want_o);
                     const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
                     if (got) ready[want_o ? rhalf + po : pe] = id[i];
-                    // leaving the active set happens before the barrier, so a change that lands while
-                    // the node is being evaluated sets the bit again
-                    if (got || frozen) atomicAnd((unsigned long long*)&mask[id[i] >> 6], ~(1ull << (id[i] & 63)));
+                    if (got || frozen) atomicOr(&clr[2 * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
                     if (cand && !got) tmin_lane = fminf(tmin_lane, lb[i]);
                 }
                 DSA_TICK(4);
             }
+            // leaving the active set, one atomic per tile; it happens before the barrier, so a change that lands
+            // while a node is being evaluated sets its bit again
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+                if (tl[q] >= 0) {
+                    const unsigned long long c = (unsigned long long)clr[2 * (q * 64 + lane)] | ((unsigned long long)clr[2 * (q * 64 + lane) + 1] << 32);
+                    if (c) atomicAnd((unsigned long long*)&mask[tl[q]], ~c);
+                }
         };
         int ntw = 0;                                                               // tiles collected, wave-uniform
         for (int wb = 0; (wb * 4 * NW + wave) * 16 < nwords; ++wb) {
@@ -637,12 +648,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     want[4 + q] = changed && h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) &&
                                   t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q];
                 }
+                // the eight dependents lie in the node's own tile and in at most one other tile per direction (when
+                // the near one has left the tile, the outer one is in the same neighbour tile): five atomics at most
+                const int own_tile = id >> 6;
+                unsigned long long own_bits = 0ull;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (want[q]) {
-                        atomicOr((unsigned long long*)&mask[nid[q] >> 6], 1ull << (nid[q] & 63));
-                        atomicOr(&tb[(nid[q] >> 6) >> 5], 1u << ((nid[q] >> 6) & 31));
+                for (int d = 0; d < 4; ++d) {
+                    const int near_tile = nid[d] >> 6;
+                    const int far_tile = near_tile != own_tile ? near_tile : nid[4 + d] >> 6;      // (the outer one may lie outside the grid)
+                    unsigned long long far_bits = 0ull;
+                    if (want[d]) { const unsigned long long b = 1ull << (nid[d] & 63); if (near_tile == own_tile) own_bits |= b; else far_bits |= b; }
+                    if (want[4 + d]) { const unsigned long long b = 1ull << (nid[4 + d] & 63); if ((nid[4 + d] >> 6) == own_tile) own_bits |= b; else far_bits |= b; }
+                    if (far_bits) {
+                        atomicOr((unsigned long long*)&mask[far_tile], far_bits);
+                        atomicOr(&tb[far_tile >> 5], 1u << (far_tile & 31));
                     }
+                }
+                if (own_bits) {
+                    atomicOr((unsigned long long*)&mask[own_tile], own_bits);
+                    atomicOr(&tb[own_tile >> 5], 1u << (own_tile & 31));
+                }
                 const unsigned hv = wave_sum(changed ? (((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u)) : 0u);
                 const float kmin = wave_min(changed ? k : kInf);
                 if (lane == 0) {
