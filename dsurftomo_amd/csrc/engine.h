@@ -47,7 +47,7 @@ struct Engine {
     size_t per_unit_bytes = 0;
     int chunk = 0;
     int max_chunk = 0;
-    float window_cells = 0.4f;         // causal window of the coarse solve in cell travel times (measured optimum 0.35-0.5)
+    float window_cells = 1.25f;        // causal window of the coarse solve in cell travel times (measured optimum 1.0-1.5)
     int list_cap = 0, ready_cap = 0;   // 0 = derive from the grid
     int last_chunk_first = -1, last_chunk_n = 0;
 

@@ -86,14 +86,7 @@ int Engine::init(int device_index)
     hipDeviceProp_t prop;
     HIP_TRY(this, hipGetDeviceProperties(&prop, device));
     arch = prop.gcnArchName;
-    // DSA_CU_MASK=<hex words, comma separated>: confine the engine's stream to a subset of the compute units (an
-    // experiment knob: tells per-CU limits from chip-wide ones)
-    if (const char* cm = getenv("DSA_CU_MASK")) {
-        std::vector<uint32_t> words;
-        for (const char* q = cm; *q;) { char* end; words.push_back((uint32_t)strtoul(q, &end, 16)); q = *end ? end + 1 : end; }
-        HIP_TRY(this, hipExtStreamCreateWithCUMask(&stream, (uint32_t)words.size(), words.data()));
-    } else
-        HIP_TRY(this, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(this, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& ev : events) HIP_TRY(this, hipEventCreate(&ev));
     return 0;
 }

@@ -25,6 +25,7 @@ for nx, kind, gd in GRIDS:
     sx = np.clip(sx, g.gox, np.float32(g.gox + np.float32(N - 1) * g.dnx)); sz = np.clip(sz, g.goz, np.float32(g.goz + np.float32(N - 1) * g.dnz))
     e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv, dicing=gd)
     e.set_option("max_chunk", nsrc)
+    if os.environ.get("DSA_WINDOW_CELLS"): e.set_option("window_cells", float(os.environ["DSA_WINDOW_CELLS"]))
     e.traveltimes(np.zeros(nsrc, np.int32), sx, sz, np.zeros(nsrc, np.int32), np.zeros(0, np.float32), np.zeros(0, np.float32))
     nbad = 0; mx = 0.0; ndiff = 0; ndeg = 0; nexact = 0; nover = 0
     for k in range(nsrc):
