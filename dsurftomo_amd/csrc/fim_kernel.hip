@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     float best_tmin = -kInf;
     unsigned long long evals = 0, nchanged = 0;
 #ifdef DSA_PASSA_CLOCKS
-    unsigned long long sub[5] = { 0, 0, 0, 0, 0 }, tsub = wall_clock64();
+    unsigned long long sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tsub = wall_clock64();
 #define DSA_TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = wall_clock64(); sub[k] += t1_ - tsub; tsub = t1_; } while (0)
 #else
 #define DSA_TICK(k) do { } while (0)
@@ -535,21 +535,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     }
                 }
                 DSA_TICK(3);
+                // routing: one slot allocation per colour for the whole window
+                unsigned long long be[kI], bo[kI];
+                bool frozen[kI];
+                int ne = 0, no = 0;
 #pragma unroll
                 for (int i = 0; i < kI; ++i) {
-                    if (i * 64 >= nn) break;                                     // wave-uniform
                     const bool have = id[i] >= 0;
-                    const bool frozen = have && frozen_any && own[i] < freeze;
-                    const bool cand = have && !frozen;
-                    const bool odd = par[i] != 0;
-                    const bool want_e = cand && (open || lb[i] < theta) && !odd;
-                    const bool want_o = cand && (open || lb[i] < theta) && odd;
-                    const int pe = wave_alloc(&sc[SC_READY], want_e);
-                    const int po = wave_alloc(&sc[SC_READY_ODD], want_o);
+                    frozen[i] = have && frozen_any && own[i] < freeze;
+                    const bool want = have && !frozen[i] && (open || lb[i] < theta);
+                    be[i] = __ballot(want && par[i] == 0);
+                    bo[i] = __ballot(want && par[i] != 0);
+                    ne += __popcll(be[i]); no += __popcll(bo[i]);
+                }
+                int base_e = 0, base_o = 0;
+                if (lane == 0) {
+                    if (ne) base_e = atomicAdd(&sc[SC_READY], ne);
+                    if (no) base_o = atomicAdd(&sc[SC_READY_ODD], no);
+                }
+                base_e = __builtin_amdgcn_readfirstlane(base_e);
+                base_o = __builtin_amdgcn_readfirstlane(base_o);
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int i = 0; i < kI; ++i) {
+                    const bool have = id[i] >= 0;
+                    const bool want_e = (be[i] >> lane) & 1ull, want_o = (bo[i] >> lane) & 1ull;
+                    const int pe = base_e + __popcll(be[i] & below), po = base_o + __popcll(bo[i] & below);
+                    base_e += __popcll(be[i]); base_o += __popcll(bo[i]);
                     const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
                     if (got) ready[want_o ? rhalf + po : pe] = id[i];
-                    if (got || frozen) atomicOr(&clr[2 * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
-                    if (cand && !got) tmin_lane = fminf(tmin_lane, lb[i]);
+                    if (got || frozen[i]) atomicOr(&clr[2 * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
+                    if (have && !frozen[i] && !got) tmin_lane = fminf(tmin_lane, lb[i]);
                 }
                 DSA_TICK(4);
             }
@@ -603,6 +619,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         for (int half = 0; half < 2; ++half) {
             const int nready = half ? nready_odd : nready_even;
             for (int j0 = 0; j0 < nready; j0 += NT) {
+#ifdef DSA_PASSA_CLOCKS
+                tsub = wall_clock64();
+#endif
                 const int j = j0 + tid;
                 const bool act = j < nready;
                 const int id = act ? ready[half ? rhalf + j : j] : 0;
@@ -626,6 +645,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     h.outer[q] = b.T; h.outer_tau[q] = b.tau;
                 }
                 const Rec own = act ? ld(id) : Rec{ -1.0f, 0.0f };
+                DSA_TICK(5);
                 const float t_old = own.T;
                 const float k_old = own.tau;
                 bool changed = false;
@@ -636,6 +656,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     ++evals;
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
+                DSA_TICK(6);
                 if (changed) { F[id].T = c; F[id].tau = k; ++nchanged; }
                 // dependents: same pruning as k_fim; the tile mask's old value tells whether the node was
                 // already active and whether its tile has to enter the bitmap
@@ -674,6 +695,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     if (hv) atomicAdd(reinterpret_cast<unsigned*>(&sc[SC_HASH]), hv);
                     if (kmin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(kmin));
                 }
+                DSA_TICK(7);
             }
             __syncthreads();
             { const unsigned long long t1 = wall_clock64(); (half ? tB1 : tB0) += t1 - t0; t0 = t1; }
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
         if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }
 #ifdef DSA_PASSA_CLOCKS
-        if (p.clocks) for (int k = 0; k < 5; ++k) p.clocks[k] = sub[k];
+        if (p.clocks) { p.clocks[0] = sub[0] + sub[1]; p.clocks[1] = sub[2] + sub[3]; p.clocks[2] = sub[4]; p.clocks[3] = sub[5]; p.clocks[4] = sub[6]; p.clocks[5] = sub[7]; }
 #endif
     }
 }

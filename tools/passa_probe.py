@@ -8,10 +8,10 @@ e = Engine(0)
 pv = np.stack([synth.medium(nx, 'smooth', p) for p in range(2)])
 e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
 u = synth.units(nx, nsrc, 2, 32)
-e.set_option('window_cells', 0.4); e.set_option('fim_threads', nt)
+e.set_option('window_cells', float(sys.argv[3]) if len(sys.argv) > 3 else 1.25); e.set_option('fim_threads', nt)
 e.plan(**u); t0 = time.time(); e.solve(); dt = time.time() - t0
 st = e.stats(); n = 2 * nsrc
 pt = np.array(st["phase_ticks"], dtype=float)
 r = st['rounds_max']
-print('units %d wg %d: %.1f solves/s fim %.1f ms; pass A per round (us, thread 0, avg over units): collect %.2f maskload %.2f scan+expand %.2f tauload %.2f route %.2f' %
-      (n, nt, n / dt, st['ms_fim_coarse'], *(pt[:5] / n / r / 100)))
+print('units %d wg %d: %.1f solves/s fim %.1f ms; per round (us, thread 0, avg over units): pass A collect+masks %.2f expand+tau loads %.2f route %.2f | eval passes: loads %.2f solve %.2f store+activate %.2f | rounds %d' %
+      (n, nt, n / dt, st['ms_fim_coarse'], *(pt[:6] / n / r / 100), r))
