@@ -44,15 +44,19 @@ struct Rec { float T, tau; };
 constexpr int kTileShift = 3, kTile = 8, kTileRecs = 64;
 DSA_HD int tiles_of(int n) { return (n + kTile - 1) >> kTileShift; }
 // record index of node (iz0, ix0), 0-based; nbz = tiles_of(nnz)
+// inside a tile: eight rows (ix) of eight records (iz), one row = 64 B
+DSA_HD int rec_in_tile(int iz0, int ix0) { return ((ix0 & 7) << 3) + (iz0 & 7); }
+DSA_HD int rec_ix_in_tile(int r) { return (r >> 3) & 7; }
+DSA_HD int rec_iz_in_tile(int r) { return r & 7; }
 DSA_HD int rec_index(int nbz, int iz0, int ix0)
 {
-    return (((ix0 >> kTileShift) * nbz + (iz0 >> kTileShift)) << 6) + ((ix0 & 7) << 3) + (iz0 & 7);
+    return (((ix0 >> kTileShift) * nbz + (iz0 >> kTileShift)) << 6) + rec_in_tile(iz0, ix0);
 }
 DSA_HD void rec_coords(int nbz, int id, int* iz0, int* ix0)
 {
     const int tile = id >> 6, bx = tile / nbz, bz = tile - bx * nbz;
-    *ix0 = (bx << kTileShift) + ((id >> 3) & 7);
-    *iz0 = (bz << kTileShift) + (id & 7);
+    *ix0 = (bx << kTileShift) + rec_ix_in_tile(id);
+    *iz0 = (bz << kTileShift) + rec_iz_in_tile(id);
 }
 
 // Geometry of one node column (depends on ix only); reference CalSurfG.f90:613-615.

@@ -109,6 +109,9 @@ __device__ __forceinline__ float wave_min(float v)
 #ifndef DSA_FIM_WAVES
 #define DSA_FIM_WAVES 4
 #endif
+#ifndef DSA_FIM_GROUP
+#define DSA_FIM_GROUP 1
+#endif
 // One workgroup of NT threads per problem.  The solver wants ~124 VGPRs, i.e. 4 waves per SIMD: tell the
 // compiler so, otherwise it targets 8 waves/SIMD (64 VGPRs) and spills the solver.
 template <int NT>
@@ -414,8 +417,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         const unsigned tile = (unsigned)id >> 6;
         const unsigned bx = by_mul ? __umulhi(tile, nbz_inv) : tile / (unsigned)nbz;
         const unsigned bz = tile - bx * (unsigned)nbz;
-        *ix0 = (int)(bx << kTileShift) + ((id >> 3) & 7);
-        *iz0 = (int)(bz << kTileShift) + (id & 7);
+        *ix0 = (int)(bx << kTileShift) + rec_ix_in_tile(id);
+        *iz0 = (int)(bz << kTileShift) + rec_iz_in_tile(id);
     };
 
     for (int i = tid; i < ntile; i += NT) mask[i] = 0ull;
@@ -579,9 +582,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 }
         };
         int ntw = 0;                                                               // tiles collected, wave-uniform
-        for (int wb = 0; (wb * 4 * NW + wave) * 16 < nwords; ++wb) {
+        constexpr int kG = DSA_FIM_GROUP;                                          // bitmap words per group
+        for (int wb = 0; (wb * (64 / kG) * NW + wave) * kG < nwords; ++wb) {
             // 64 bitmap words of this wave: 16-word groups dealt round-robin to the waves, ascending
-            const int w = ((wb * 4 + (lane >> 4)) * NW + wave) * 16 + (lane & 15);
+            const int w = ((wb * (64 / kG) + lane / kG) * NW + wave) * kG + lane % kG;
             const unsigned bits = w < nwords ? tb[w] : 0u;
             const int nt_lane = __popc(bits);
             const int tincl = wave_scan_incl(nt_lane);

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsurftomo_amd.so")
+LIB_PATH = os.environ.get("DSA_LIB_PATH") or os.path.join(_HERE, "libdsurftomo_amd.so")   # (override: A/B builds)
 
 STAT_NAMES = ("ms_total", "ms_fim_coarse", "ms_fim_refined", "ms_stages", "launches_fim_coarse", "units",
               "rounds_max", "evals_total", "chunk", "rescans", "freezes", "rays", "ray_steps", "rays_clamped",
