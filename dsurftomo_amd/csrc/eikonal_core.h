@@ -59,6 +59,20 @@ DSA_HD void rec_coords(int nbz, int id, int* iz0, int* ix0)
     *iz0 = (bz << kTileShift) + rec_iz_in_tile(id);
 }
 
+// Record indices of the eight stencil nodes of record `id` (x-, x+, z-, z+; near ones in [0..3], outer ones in
+// [4..7]) without going through coordinates: inside a tile a step in x is 8 records and a step in z is 1; leaving the
+// tile adds the distance to the neighbouring tile (nbz tiles further in x, one tile further in z).  Indices of
+// nodes outside the grid are meaningless (callers test the coordinates before using them).
+DSA_HD void rec_stencil(int nbz, int id, int* nid)
+{
+    const int rx = rec_ix_in_tile(id), rz = rec_iz_in_tile(id);
+    const int dx = (nbz << 6) - 64, dz = 56;
+    nid[0] = id - 8 - (rx == 0 ? dx : 0);  nid[4] = id - 16 - (rx < 2 ? dx : 0);
+    nid[1] = id + 8 + (rx == 7 ? dx : 0);  nid[5] = id + 16 + (rx > 5 ? dx : 0);
+    nid[2] = id - 1 - (rz == 0 ? dz : 0);  nid[6] = id - 2 - (rz < 2 ? dz : 0);
+    nid[3] = id + 1 + (rz == 7 ? dz : 0);  nid[7] = id + 2 + (rz > 5 ? dz : 0);
+}
+
 // Geometry of one node column (depends on ix only); reference CalSurfG.f90:613-615.
 struct NodeGeom {
     float ri;     // earth radius

@@ -400,16 +400,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     int* sc = smem;
     typedef __attribute__((address_space(1))) Rec GRec;
     typedef __attribute__((address_space(1))) const float GCF32;
-    GRec* const F = (GRec*)p.F;
-    GCF32* const slow = (GCF32*)p.slow;
+    // All per-problem arrays are addressed as (uniform base, 32-bit byte offset): the loads and atomics then take the
+    // base from scalar registers and one VGPR of offset instead of a 64-bit address pair computed on the VALU
+    // (the largest field, 513^2 tiles of 512 B, is 135 MB).
+    typedef __attribute__((address_space(1))) char GChar;
+    GChar* const Fb = (GChar*)p.F;
+    GChar* const slowb = (GChar*)p.slow;
     GCF32* const risti = (GCF32*)p.risti;
     const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
     const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
-    GU64* const mask = (GU64*)p.lists;                       // ntile node masks
+    GChar* const maskb = (GChar*)p.lists;                    // ntile node masks
+    auto rec = [&](int id) -> GRec* { return (GRec*)(Fb + ((unsigned)id << 3)); };
+    auto slow_at = [&](int id) -> float { return *(GCF32*)(slowb + ((unsigned)id << 2)); };
+    auto mask_at = [&](int tile) -> GU64* { return (GU64*)(maskb + ((unsigned)tile << 3)); };
     constexpr int rhalf = 1024;                              // ready nodes of one colour a round can take
     __shared__ int ready[2 * rhalf];                         // (the rest stay in their masks for the next round)
     unsigned* const tb = dyn_lds;                            // tile bitmap, nwords
-    auto ld = [&](int id) { Rec r; r.T = F[id].T; r.tau = F[id].tau; return r; };
+    auto ld = [&](int id) { Rec r; r.T = rec(id)->T; r.tau = rec(id)->tau; return r; };
     // tile -> (bx, bz) without an integer division: floor(t / nbz) = hi32(t * ceil(2^32 / nbz)) while t * nbz < 2^32
     const bool by_mul = nbz > 1 && (unsigned long long)ntile * (unsigned long long)nbz < (1ull << 32);
     const unsigned nbz_inv = by_mul ? 0xffffffffu / (unsigned)nbz + 1u : 0u;
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         *iz0 = (int)(bz << kTileShift) + rec_iz_in_tile(id);
     };
 
-    for (int i = tid; i < ntile; i += NT) mask[i] = 0ull;
+    for (int i = tid; i < ntile; i += NT) *mask_at(i) = 0ull;
     for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
     if (tid == 0) {
         sc[SC_READY] = 0; sc[SC_READY_ODD] = 0; sc[SC_TMIN] = 0x7f800000; sc[SC_THETA] = 0x7f800000;
@@ -432,18 +439,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     if (nseed <= p.seed_cap) {
         for (int i = tid; i < nseed; i += NT) {
             const int id = p.seed[i];
-            atomicAnd((unsigned*)&F[id].tau, ~kQueuedBit);
-            atomicOr((unsigned long long*)&mask[id >> 6], 1ull << (id & 63));
+            atomicAnd((unsigned*)&rec(id)->tau, ~kQueuedBit);
+            atomicOr((unsigned long long*)mask_at(id >> 6), 1ull << (id & 63));
             atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31));
         }
     } else {
         // more seeds than the prologue's list holds: they are flagged on the field (queued bit of tau)
         for (int id = tid; id < ntile * kTileRecs; id += NT) {
-            const unsigned w = __hip_atomic_load((unsigned*)&F[id].tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned w = __hip_atomic_load((unsigned*)&rec(id)->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!(w & kQueuedBit)) continue;
-            atomicAnd((unsigned*)&F[id].tau, ~kQueuedBit);
-            if (t_pinned(F[id].T)) continue;
-            atomicOr((unsigned long long*)&mask[id >> 6], 1ull << (id & 63));
+            atomicAnd((unsigned*)&rec(id)->tau, ~kQueuedBit);
+            if (t_pinned(rec(id)->T)) continue;
+            atomicOr((unsigned long long*)mask_at(id >> 6), 1ull << (id & 63));
             atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31));
         }
     }
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     unsigned hist[4] = { 1u, 2u, 3u, 4u };
     unsigned long long tA = 0, tB0 = 0, tB1 = 0, tE = 0, t0 = wall_clock64(), sum_cnt = 0, sum_ready = 0;
     float best_tmin = -kInf;
-    unsigned long long evals = 0, nchanged = 0;
+    unsigned evals = 0, nchanged = 0;                        // per lane (a lane evaluates < 2^32 nodes)
 #ifdef DSA_PASSA_CLOCKS
     unsigned long long sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tsub = wall_clock64();
 #define DSA_TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = wall_clock64(); sub[k] += t1_ - tsub; tsub = t1_; } while (0)
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 tl[q] = q * 64 + lane < ntiles ? tbuf[q * 64 + lane] : -1;
-                m[q] = tl[q] >= 0 ? mask[tl[q]] : 0ull;
+                m[q] = tl[q] >= 0 ? *mask_at(tl[q]) : 0ull;
                 if (q * 64 < ntiles) { clr[2 * (q * 64 + lane)] = 0u; clr[2 * (q * 64 + lane) + 1] = 0u; }
             }
             DSA_TICK(1);
@@ -529,11 +536,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     par[i] = (ix + iz) & 1;
                     lb[i] = kInf; own[i] = kInf;
                     if (have) {
-                        const float a = ix > 0 ? F[rec_index(nbz, iz, ix - 1)].tau : kInf;
-                        const float b2 = ix + 1 < nnx ? F[rec_index(nbz, iz, ix + 1)].tau : kInf;
-                        const float c2 = iz > 0 ? F[rec_index(nbz, iz - 1, ix)].tau : kInf;
-                        const float d2 = iz + 1 < nnz ? F[rec_index(nbz, iz + 1, ix)].tau : kInf;
-                        if (frozen_any) own[i] = F[id[i]].tau;
+                        int nid[8];
+                        rec_stencil(nbz, id[i], nid);
+                        const float a = ix > 0 ? rec(nid[0])->tau : kInf;
+                        const float b2 = ix + 1 < nnx ? rec(nid[1])->tau : kInf;
+                        const float c2 = iz > 0 ? rec(nid[2])->tau : kInf;
+                        const float d2 = iz + 1 < nnz ? rec(nid[3])->tau : kInf;
+                        if (frozen_any) own[i] = rec(id[i])->tau;
                         lb[i] = fminf(fminf(a, b2), fminf(c2, d2));
                     }
                 }
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
             for (int q = 0; q < kQ; ++q)
                 if (tl[q] >= 0) {
                     const unsigned long long c = (unsigned long long)clr[2 * (q * 64 + lane)] | ((unsigned long long)clr[2 * (q * 64 + lane) + 1] << 32);
-                    if (c) atomicAnd((unsigned long long*)&mask[tl[q]], ~c);
+                    if (c) atomicAnd((unsigned long long*)mask_at(tl[q]), ~c);
                 }
         };
         int ntw = 0;                                                               // tiles collected, wave-uniform
@@ -620,6 +629,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         // ---- pass B: evaluate, even nodes first
         const int nready_even = sc[SC_READY] < rhalf ? sc[SC_READY] : rhalf;
         const int nready_odd = sc[SC_READY_ODD] < rhalf ? sc[SC_READY_ODD] : rhalf;
+        unsigned hv_lane = 0u;
+        float kmin_lane = kInf;
         for (int half = 0; half < 2; ++half) {
             const int nready = half ? nready_odd : nready_even;
             for (int j0 = 0; j0 < nready; j0 += NT) {
@@ -637,10 +648,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 h.in[2] = act && iz > 0;          h.in_outer[2] = act && iz > 1;
                 h.in[3] = act && iz + 1 < nnz;    h.in_outer[3] = act && iz + 2 < nnz;
                 int nid[8];
-                nid[0] = rec_index(nbz, iz, ix - 1); nid[4] = rec_index(nbz, iz, ix - 2);
-                nid[1] = rec_index(nbz, iz, ix + 1); nid[5] = rec_index(nbz, iz, ix + 2);
-                nid[2] = rec_index(nbz, iz - 1, ix); nid[6] = rec_index(nbz, iz - 2, ix);
-                nid[3] = rec_index(nbz, iz + 1, ix); nid[7] = rec_index(nbz, iz + 2, ix);
+                rec_stencil(nbz, id, nid);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const Rec a = h.in[q] ? ld(nid[q]) : Rec{ kInf, kInf };
@@ -656,12 +664,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 float c = 0.0f, k = kInf;
                 if (!t_pinned(t_old)) {
                     const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
-                    c = solve_node(h, slow[id], geom, &k);
+                    c = solve_node(h, slow_at(id), geom, &k);
+#ifdef DSA_DOUBLE_SOLVE
+                    {   // experiment: marginal cost of the local solver (same result twice, opaque to the compiler)
+                        Hood h2 = h; unsigned zi = 0u; asm volatile("" : "+v"(zi));
+                        h2.near_[0] = u2f(f2u(h.near_[0]) ^ zi);
+                        float k2; const float c2 = solve_node(h2, slow_at(id), geom, &k2);
+                        c = fminf(c, c2); k = fminf(k, k2);
+                    }
+#endif
                     ++evals;
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
                 DSA_TICK(6);
-                if (changed) { F[id].T = c; F[id].tau = k; ++nchanged; }
+                if (changed) { rec(id)->T = c; rec(id)->tau = k; ++nchanged; }
                 // dependents: same pruning as k_fim; the tile mask's old value tells whether the node was
                 // already active and whether its tile has to enter the bitmap
                 const float t_lo = fminf(t_value(t_old), c), k_lo = fminf(k_old, k);
@@ -685,21 +701,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     if (want[d]) { const unsigned long long b = 1ull << (nid[d] & 63); if (near_tile == own_tile) own_bits |= b; else far_bits |= b; }
                     if (want[4 + d]) { const unsigned long long b = 1ull << (nid[4 + d] & 63); if ((nid[4 + d] >> 6) == own_tile) own_bits |= b; else far_bits |= b; }
                     if (far_bits) {
-                        atomicOr((unsigned long long*)&mask[far_tile], far_bits);
+                        atomicOr((unsigned long long*)mask_at(far_tile), far_bits);
                         atomicOr(&tb[far_tile >> 5], 1u << (far_tile & 31));
                     }
                 }
                 if (own_bits) {
-                    atomicOr((unsigned long long*)&mask[own_tile], own_bits);
+                    atomicOr((unsigned long long*)mask_at(own_tile), own_bits);
                     atomicOr(&tb[own_tile >> 5], 1u << (own_tile & 31));
                 }
-                const unsigned hv = wave_sum(changed ? (((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u)) : 0u);
-                const float kmin = wave_min(changed ? k : kInf);
+                // change hash and earliest change: accumulated per lane, reduced once per round (below)
+                if (changed) { hv_lane += ((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u); kmin_lane = fminf(kmin_lane, k); }
+                DSA_TICK(7);
+            }
+            if (half == 1) {
+                const unsigned hv = wave_sum(hv_lane);
+                const float kmin = wave_min(kmin_lane);
                 if (lane == 0) {
                     if (hv) atomicAdd(reinterpret_cast<unsigned*>(&sc[SC_HASH]), hv);
                     if (kmin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(kmin));
                 }
-                DSA_TICK(7);
             }
             __syncthreads();
             { const unsigned long long t1 = wall_clock64(); (half ? tB1 : tB0) += t1 - t0; t0 = t1; }
@@ -723,8 +743,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         { const unsigned long long t1 = wall_clock64(); tE += t1 - t0; t0 = t1; }
         if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
     }
-    for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); nchanged += __shfl_xor(nchanged, o); }
-    if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), evals); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), nchanged); }
+    {
+        unsigned long long e64 = evals, c64 = nchanged;
+        for (int o = 32; o > 0; o >>= 1) { e64 += __shfl_xor(e64, o); c64 += __shfl_xor(c64, o); }
+        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), e64); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), c64); }
+    }
     if (tid == 0) {
         p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
         if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }

@@ -6,8 +6,8 @@ cd "$(dirname "$0")/.."
 mkdir -p dsurftomo_amd/build/ab
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
-  DSA_DEFINES="$defs" python -m dsurftomo_amd.build > /dev/null
+  DSA_DEFINES="$defs" python -m dsurftomo_amd.build --force > /dev/null
   cp dsurftomo_amd/libdsurftomo_amd.so dsurftomo_amd/build/ab/lib_$name.so
   echo "built $name ($defs)"
 done
-python -m dsurftomo_amd.build > /dev/null
+python -m dsurftomo_amd.build --force > /dev/null
