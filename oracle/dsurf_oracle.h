@@ -131,6 +131,24 @@ int dso_traveltimes(int nx, int ny, float goxd, float gozd, float dvxd, float dv
                     const int *nrc1, const float *scxf, const float *sczf, const float *rcxf,
                     const float *rczf, float *dsurf, int nthreads);
 
+/* ---- inversion step next to the path (lsmr_oracle.c) ---- */
+/* lsmrblas.f90:247-277 and :317-359, unit stride */
+float dso_dnrm2(int n, const float *x);
+void dso_dscal(int n, float sa, float *x);
+/* LSMR as shipped with the reference (lsmrModule.f90:36; single precision, arguments by pointer like the Fortran
+ * module procedure, without nout) */
+void dso_lsmr(const int *m, const int *n, const int *leniw, const int *lenrw, const int *iw, const float *rw,
+              const float *b, const float *damp, const float *atol, const float *btol, const float *conlim,
+              const int *itnlim, const int *localSize, float *x, int *istop, int *itn, float *normA,
+              float *condA, float *normr, float *normAr, float *normx);
+/* getpercentile.f90:1-51 */
+void dso_getpercentile(int n, const float *array, float *q25, float *q75);
+/* main.f90:361-466 (residual, weights, DWS, regularisation rows) and :520-535 (model update) */
+void dso_iteration_system(int nx, int ny, int nz, int dall, int nar_in, float *rw, int *iw, int *col,
+                          const float *obst, const float *dsyn, float threshold0, float weight0,
+                          float *cbst, float *datweight, float *norm, int *m_out, int *nar_out, float *dws);
+void dso_model_update(int nx, int ny, int nz, float *dv, float *vsf, float minvel, float maxvel);
+
 #ifdef __cplusplus
 }
 #endif

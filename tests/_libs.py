@@ -44,7 +44,7 @@ def _stale(target, sources):
 
 
 def build_oracle():
-    srcs = [os.path.join(ORACLE_DIR, n) for n in ("dsurf_oracle.c", "surfdisp_oracle.c", "dsurf_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, n) for n in ("dsurf_oracle.c", "surfdisp_oracle.c", "lsmr_oracle.c", "dsurf_oracle.h")]
     if _stale(ORACLE_SO, srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
@@ -53,7 +53,7 @@ def build_oracle():
 def build_ref():
     """Build oracle/_ref from the reference sources when they are present; else use a prebuilt copy."""
     if os.path.isdir(REFERENCE_SRC):
-        if _stale(REF_SO, [os.path.join(ORACLE_DIR, "ref_whitebox.f90")]):
+        if _stale(REF_SO, [os.path.join(ORACLE_DIR, n) for n in ("ref_whitebox.f90", "ref_whitebox_lsmr.f90", "Makefile")]):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
     return REF_SO if os.path.exists(REF_SO) else None
 

@@ -107,7 +107,29 @@ def main_taipei():
     print("b_taipei ->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def main_lsmr():
+    """b_lsmr.npz: the reference's LSMR (lsmrModule.f90:36, through oracle/ref_whitebox_lsmr.f90) on the regularised
+    system of the boundary case.  The matrix comes from the reference's calsurfg_; the system around it (main.f90:361-466
+    is part of the reference's main program, which does not build here) is assembled by the oracle's restatement and is
+    stored with the vectors."""
+    import inversion as inv
+    c = synth.boundary_case()
+    fwd = L.call_boundary(L.ref().calsurfg_, c)
+    r = synth.LCG(77)
+    obst = (fwd["dsurf"] * (1.0 + 0.04 * (r.uniform(c["ndata"]) - 0.5))).astype(np.float32)
+    S = inv.build_system(c, fwd, obst, 3.0, 2.0)
+    a = inv.call_lsmr(L.ref().ref_wb_lsmr, S, 1.0)
+    path = os.path.join(HERE, "b_lsmr.npz")
+    np.savez_compressed(path, iw=S["iw"], rw=S["rw"], b=S["b"], m=np.int32(S["m"]), n=np.int32(S["n"]), **a)
+    print("b_lsmr ->", path, "%.1f KB" % (os.path.getsize(path) / 1024.0), "itn", a["itn"], "istop", a["istop"])
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "lsmr":
+        main_lsmr()
+        sys.exit(0)
     main()
     main_dispersion()
     main_taipei()
+    main_lsmr()
