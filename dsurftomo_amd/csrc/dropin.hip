@@ -240,14 +240,9 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
 
 // aprod with the reference's argument list (aprod.f90:7; LSMR calls it with the same matrix hundreds of times per
 // inversion step, lsmrModule.f90:390-497).  The matrix goes to the device the first time it is seen; it is
-// recognised again by its address, its size and a sample of its entries.
-int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, const int* leniw, const int* lenrw,
-              const int* iw, const float* rw)
+// recognised again by its address, its size and a sample of its entries (`force`: load regardless).
+static int load_matrix_cached(int m, int n, const int* iw, const float* rw, bool force)
 {
-    (void)leniw; (void)lenrw;
-    if (!mode || !m || !n || !x || !y || !iw || !rw) { g_dropin_error = "dsa_aprod: null argument"; return DSA_ERR_ARGUMENT; }
-    int rc = engine();
-    if (rc != 0) return rc;
     static const void *s_iw = nullptr, *s_rw = nullptr;
     static long long s_nar = -1;
     static int s_m = 0, s_n = 0;
@@ -256,11 +251,40 @@ int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, c
     double sum = 0.0;
     const long long step = std::max<long long>(1, nar / 997);
     for (long long k = 0; k < nar; k += step) sum += (double)rw[k] * (double)(1 + (k & 7)) + (double)iw[1 + k] + 3.0 * (double)iw[1 + nar + k];
-    if (iw != s_iw || rw != s_rw || nar != s_nar || *m != s_m || *n != s_n || sum != s_sum) {
-        if ((rc = dsa_spmv_load(g_engine, *m, *n, nar, rw, iw + 1, iw + 1 + nar)) != 0) return fail(rc);
-        s_iw = iw; s_rw = rw; s_nar = nar; s_m = *m; s_n = *n; s_sum = sum;
+    if (force || iw != s_iw || rw != s_rw || nar != s_nar || m != s_m || n != s_n || sum != s_sum) {
+        const int rc = dsa_spmv_load(g_engine, m, n, nar, rw, iw + 1, iw + 1 + nar);
+        if (rc != 0) return rc;
+        s_iw = iw; s_rw = rw; s_nar = nar; s_m = m; s_n = n; s_sum = sum;
     }
+    return 0;
+}
+
+int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, const int* leniw, const int* lenrw,
+              const int* iw, const float* rw)
+{
+    (void)leniw; (void)lenrw;
+    if (!mode || !m || !n || !x || !y || !iw || !rw) { g_dropin_error = "dsa_aprod: null argument"; return DSA_ERR_ARGUMENT; }
+    int rc = engine();
+    if (rc != 0) return rc;
+    if ((rc = load_matrix_cached(*m, *n, iw, rw, false)) != 0) return fail(rc);
     if ((rc = dsa_spmv(g_engine, *mode, x, y)) != 0) return fail(rc);
+    return 0;
+}
+
+// LSMR with the reference's argument list (lsmrModule.f90:36-39, called at main.f90:487); nout is ignored (the
+// reference's main program never opens that unit, main.f90:47,107).  dsurftomo_amd/fortran/lsmr_shim.f90 exports
+// the module procedure.
+int dsa_lsmr_dropin(const int* m, const int* n, const int* leniw, const int* lenrw, const int* iw, const float* rw,
+                    const float* b, const float* damp, const float* atol, const float* btol, const float* conlim,
+                    const int* itnlim, const int* localSize, const int* nout, float* x, int* istop, int* itn,
+                    float* normA, float* condA, float* normr, float* normAr, float* normx)
+{
+    (void)leniw; (void)lenrw; (void)nout;
+    if (!m || !n || !iw || !rw || !b || !damp || !atol || !btol || !conlim || !itnlim || !localSize || !x) { g_dropin_error = "dsa_lsmr_dropin: null argument"; return DSA_ERR_ARGUMENT; }
+    int rc = engine();
+    if (rc != 0) return rc;
+    if ((rc = load_matrix_cached(*m, *n, iw, rw, true)) != 0) return fail(rc);      // one solve per matrix: always current
+    if ((rc = dsa_lsmr(g_engine, b, *damp, *atol, *btol, *conlim, *itnlim, *localSize, x, istop, itn, normA, condA, normr, normAr, normx)) != 0) return fail(rc);
     return 0;
 }
 

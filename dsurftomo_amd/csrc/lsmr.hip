@@ -1,0 +1,303 @@
+// LSMR of the inversion step with all vectors resident on the device (reference lsmrModule.f90:36-750 as
+// shipped with DSurfTomo: single precision, local reorthogonalisation over the last `localSize` v's; called once
+// per outer iteration at main.f90:487).  SURVEY.md 8f rank 1.
+//
+// The reference's results depend on the order of its fp32 sums, so the order is kept:
+//   * the two matrix products add every output element's entries in storage order (spmv.hip);
+//   * dnrm2 (lsmrblas.f90:247-277) is a running (scale, ssq) recurrence and dot_product an in-order sum: one
+//     wavefront forms the per-element terms in parallel -- the divisions and squares of dnrm2, the products of
+//     the dot -- and only the final additions run as a serial chain fed by readlane (one dependent v_add per
+//     element; ~0.45 ms per 137 k elements).  dnrm2's scale only changes at a new running maximum; a batch of 64
+//     that contains one takes a scalar path, all others use the scale they start with;
+//   * everything else is element-wise.
+// The scalar recurrences (plane rotations, norm estimates, stopping rules) run on the host in fp32 exactly as
+// written in the reference; three scalars come back per iteration (beta, alpha, normx).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/dsurftomo_amd.h"
+#include "engine.h"
+#include "spmv_state.h"
+
+namespace dsa {
+
+namespace {
+
+__device__ __forceinline__ float lane_value(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
+
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+constexpr int kBatch = 4;       // 64-element batches in flight per step (their loads overlap the previous step's chain)
+
+// out[0] = dnrm2(n, x, 1), lsmrblas.f90:247-277.  One wavefront.
+__global__ __launch_bounds__(64) void k_nrm2(int n, const float* __restrict__ x, float* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    if (n < 1) { if (lane == 0) out[0] = 0.0f; return; }
+    if (n == 1) { if (lane == 0) out[0] = fabsf(x[0]); return; }
+    float scale = 0.0f, ssq = 1.0f;                    // wave-uniform
+    float cur[kBatch], nxt[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) { const int i = u * 64 + lane; cur[u] = i < n ? fabsf(x[i]) : 0.0f; }
+    for (int base = 0; base < n; base += 64 * kBatch) {
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) { const int i = base + 64 * kBatch + u * 64 + lane; nxt[u] = i < n ? fabsf(x[i]) : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const float a = cur[u];                    // |x(i)|; zero for skipped (zero) elements and beyond n
+            const float bmax = wave_max(a);
+            if (bmax == 0.0f) continue;                // nothing but zeros: the reference skips them
+            if (bmax <= scale) {
+                // no new maximum in this batch (ties take the reference's else branch too): ssq += (|x|/scale)**2,
+                // and a zero element adds +0 to ssq >= 1, which changes nothing
+                const float q = a / scale;
+                const float t = q * q;
+#pragma unroll
+                for (int i = 0; i < 64; ++i) ssq = ssq + lane_value(t, i);
+            } else {
+                for (int i = 0; i < 64; ++i) {
+                    const float xi = lane_value(a, i);
+                    if (xi != 0.0f) {
+                        if (scale < xi) { const float q = scale / xi; ssq = 1.0f + ssq * (q * q); scale = xi; }
+                        else { const float q = xi / scale; ssq = ssq + q * q; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) cur[u] = nxt[u];
+    }
+    if (lane == 0) out[0] = scale * sqrtf(ssq);
+}
+
+// out[0] = sum over i of a(i) * b(i), added in order from 0 (the reference's inlined dot_product, lsmrModule.f90:744)
+__global__ __launch_bounds__(64) void k_dot(int n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    float acc = 0.0f;
+    float cur[kBatch], nxt[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) { const int i = u * 64 + lane; cur[u] = i < n ? a[i] * b[i] : 0.0f; }
+    for (int base = 0; base < n; base += 64 * kBatch) {
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) { const int i = base + 64 * kBatch + u * 64 + lane; nxt[u] = i < n ? a[i] * b[i] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int left = n - (base + u * 64);
+            if (left >= 64) {
+#pragma unroll
+                for (int i = 0; i < 64; ++i) acc = acc + lane_value(cur[u], i);
+            } else {
+                for (int i = 0; i < left; ++i) acc = acc + __shfl(cur[u], i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) cur[u] = nxt[u];
+    }
+    if (lane == 0) out[0] = acc;
+}
+
+__global__ void k_scal(int n, float sa, float* __restrict__ x)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = sa * x[i];
+}
+// v = v - d * lv, d from device memory (localVOrtho, lsmrModule.f90:745)
+__global__ void k_axmy(int n, const float* __restrict__ d, const float* __restrict__ lv, float* __restrict__ v)
+{
+    const float dd = d[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = v[i] - dd * lv[i];
+}
+// lsmrModule.f90:545-547: hbar = h - c1*hbar; x = x + c2*hbar; h = v - c3*h
+__global__ void k_update(int n, float c1, float c2, float c3, const float* __restrict__ v, float* __restrict__ h,
+                         float* __restrict__ hbar, float* __restrict__ x)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float hb = h[i] - c1 * hbar[i];
+        hbar[i] = hb;
+        x[i] = x[i] + c2 * hb;
+        h[i] = v[i] - c3 * h[i];
+    }
+}
+
+// lsmrModule.f90:686-711
+float d2norm(float a, float b)
+{
+    const float scale = fabsf(a) + fabsf(b);
+    if (scale == 0.0f) return 0.0f;
+    const float p = a / scale, q = b / scale;
+    return scale * sqrtf(p * p + q * q);
+}
+
+#define LS_TRY(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _r = (call);                                                                \
+        if (_r != hipSuccess) { (e)->fail(DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(_r)); return DSA_ERR_DEVICE; } \
+    } while (0)
+
+}  // namespace
+
+}  // namespace dsa
+
+using dsa::Engine;
+using dsa::SpmvState;
+
+extern "C" {
+
+// LSMR on the matrix of the last dsa_spmv_load.  Arguments and results as lsmrModule.f90:36-50 (without the matrix,
+// which is resident, and without nout).  b: m values (host, not modified), x: n values (host, out).
+int dsa_lsmr(dsa_engine* h_, const float* b, float damp, float atol, float btol, float conlim, int itnlim, int localSize,
+             float* x, int* istop, int* itn, float* normA, float* condA, float* normr, float* normAr, float* normx)
+{
+    if (!h_) return DSA_ERR_ARGUMENT;
+    Engine* e = reinterpret_cast<Engine*>(h_);
+    if (!e->spmv) { e->fail(DSA_ERR_STATE, "lsmr: call dsa_spmv_load first"); return DSA_ERR_STATE; }
+    if (!b || !x || !istop || !itn || !normA || !condA || !normr || !normAr || !normx) { e->fail(DSA_ERR_ARGUMENT, "lsmr: null argument"); return DSA_ERR_ARGUMENT; }
+    SpmvState& S = *e->spmv;
+    const int m = S.m, n = S.n;
+    const int localVecs = std::max(0, std::min(localSize, std::min(m, n)));                 // :365
+    LS_TRY(e, hipSetDevice(e->device));
+    if (e->ensure(S.u, (size_t)m) || e->ensure(S.v, (size_t)n) || e->ensure(S.h, (size_t)n) || e->ensure(S.hbar, (size_t)n) ||
+        e->ensure(S.xs, (size_t)n) || e->ensure(S.localV, std::max<size_t>((size_t)n * (size_t)localVecs, 1)) || e->ensure(S.scal, 16)) return e->status;
+    hipStream_t st = e->stream;
+    float *u = S.u.p, *v = S.v.p, *hh = S.h.p, *hbar = S.hbar.p, *xs = S.xs.p, *sc = S.scal.p;
+    auto grid = [](int len) { return dim3((unsigned)std::min(4096, std::max(1, (len + 255) / 256))); };
+    auto scal = [&](int len, float sa, float* p) { hipLaunchKernelGGL(dsa::k_scal, grid(len), dim3(256), 0, st, len, sa, p); };
+    float host_scalar = 0.0f;
+    auto nrm2 = [&](int len, const float* p, float* out) -> int {
+        hipLaunchKernelGGL(dsa::k_nrm2, dim3(1), dim3(64), 0, st, len, p, sc);
+        if (hipMemcpyAsync(&host_scalar, sc, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            e->fail(DSA_ERR_DEVICE, "lsmr: norm failed: %s", hipGetErrorString(hipGetLastError())); return DSA_ERR_DEVICE; }
+        *out = host_scalar;
+        return 0;
+    };
+    int rc = 0;
+
+    LS_TRY(e, hipMemcpyAsync(u, b, (size_t)m * 4, hipMemcpyHostToDevice, st));               // u = b, v = 0, x = 0 (:383-385)
+    LS_TRY(e, hipMemsetAsync(v, 0, (size_t)n * 4, st));
+    LS_TRY(e, hipMemsetAsync(xs, 0, (size_t)n * 4, st));
+    LS_TRY(e, hipMemsetAsync(hbar, 0, (size_t)n * 4, st));
+    float alpha = 0.0f, beta = 0.0f;
+    if ((rc = nrm2(m, u, &beta)) != 0) return rc;
+    if (beta > 0.0f) {
+        scal(m, 1.0f / beta, u);
+        dsa::spmv_device(e, 2, v, u);                                                        // v = A'u
+        if ((rc = nrm2(n, v, &alpha)) != 0) return rc;
+    }
+    if (alpha > 0.0f) scal(n, 1.0f / alpha, v);
+    *itn = 0; *istop = 0; *normA = 0.0f; *condA = 0.0f; *normx = 0.0f;
+    *normr = beta;
+    *normAr = alpha * beta;
+    const bool damped = damp > 0.0f;
+    if (*normAr != 0.0f) {
+        bool localOrtho = false, localVQueueFull = false;
+        int localPointer = 0;
+        if (localVecs > 0) {                                                                 // :408-413
+            localPointer = 1; localOrtho = true;
+            LS_TRY(e, hipMemcpyAsync(S.localV.p, v, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        }
+        float zetabar = alpha * beta, alphabar = alpha, rho = 1.0f, rhobar = 1.0f, cbar = 1.0f, sbar = 0.0f;
+        LS_TRY(e, hipMemcpyAsync(hh, v, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        float betadd = beta, betad = 0.0f, rhodold = 1.0f, tautildeold = 0.0f, thetatilde = 0.0f, zeta = 0.0f, d = 0.0f;
+        float normA2 = alpha * alpha, maxrbar = 0.0f, minrbar = 1e+30f;
+        const float normb = beta;
+        float ctol = 0.0f;
+        if (conlim > 0.0f) ctol = 1.0f / conlim;
+        for (;;) {                                                                           // :480
+            *itn += 1;
+            scal(m, -alpha, u);
+            dsa::spmv_device(e, 1, v, u);                                                    // u = A v - alpha u
+            if ((rc = nrm2(m, u, &beta)) != 0) return rc;
+            if (beta > 0.0f) {
+                scal(m, 1.0f / beta, u);
+                if (localOrtho) {                                                            // localVEnqueue, :715-727
+                    if (localPointer < localVecs) localPointer += 1;
+                    else { localPointer = 1; localVQueueFull = true; }
+                    LS_TRY(e, hipMemcpyAsync(S.localV.p + (size_t)(localPointer - 1) * (size_t)n, v, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+                }
+                scal(n, -beta, v);
+                dsa::spmv_device(e, 2, v, u);                                                // v = A'u - beta v
+                if (localOrtho) {                                                            // localVOrtho, :731-748
+                    const int lim = localVQueueFull ? localVecs : localPointer;
+                    for (int k = 0; k < lim; ++k) {
+                        const float* lv = S.localV.p + (size_t)k * (size_t)n;
+                        hipLaunchKernelGGL(dsa::k_dot, dim3(1), dim3(64), 0, st, n, (const float*)v, lv, sc + 1);
+                        hipLaunchKernelGGL(dsa::k_axmy, grid(n), dim3(256), 0, st, n, (const float*)(sc + 1), lv, v);
+                    }
+                }
+                if ((rc = nrm2(n, v, &alpha)) != 0) return rc;
+                if (alpha > 0.0f) scal(n, 1.0f / alpha, v);
+            }
+            // plane rotations and estimates, :516-600, on the host in the reference's order
+            const float alphahat = dsa::d2norm(alphabar, damp);
+            const float chat = alphabar / alphahat, shat = damp / alphahat;
+            const float rhoold = rho;
+            rho = dsa::d2norm(alphahat, beta);
+            const float c = alphahat / rho, s = beta / rho;
+            const float thetanew = s * alpha;
+            alphabar = c * alpha;
+            const float rhobarold = rhobar, zetaold = zeta;
+            const float thetabar = sbar * rho, rhotemp = cbar * rho;
+            rhobar = dsa::d2norm(cbar * rho, thetanew);
+            cbar = cbar * rho / rhobar;
+            sbar = thetanew / rhobar;
+            zeta = cbar * zetabar;
+            zetabar = -sbar * zetabar;
+            {
+                const float c1 = thetabar * rho / (rhoold * rhobarold);
+                const float c2 = zeta / (rho * rhobar);
+                const float c3 = thetanew / rho;
+                hipLaunchKernelGGL(dsa::k_update, grid(n), dim3(256), 0, st, n, c1, c2, c3, (const float*)v, hh, hbar, xs);
+            }
+            const float betaacute = chat * betadd, betacheck = -shat * betadd;
+            const float betahat = c * betaacute;
+            betadd = -s * betaacute;
+            const float thetatildeold = thetatilde;
+            const float rhotildeold = dsa::d2norm(rhodold, thetabar);
+            const float ctildeold = rhodold / rhotildeold, stildeold = thetabar / rhotildeold;
+            thetatilde = stildeold * rhobar;
+            rhodold = ctildeold * rhobar;
+            betad = -stildeold * betad + ctildeold * betahat;
+            tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
+            const float taud = (zeta - thetatilde * tautildeold) / rhodold;
+            d = d + betacheck * betacheck;
+            {
+                const float e1 = betad - taud;
+                *normr = sqrtf(d + e1 * e1 + betadd * betadd);
+            }
+            normA2 = normA2 + beta * beta;
+            *normA = sqrtf(normA2);
+            normA2 = normA2 + alpha * alpha;
+            maxrbar = maxrbar > rhobarold ? maxrbar : rhobarold;
+            if (*itn > 1) minrbar = minrbar < rhobarold ? minrbar : rhobarold;
+            *condA = (maxrbar > rhotemp ? maxrbar : rhotemp) / (minrbar < rhotemp ? minrbar : rhotemp);
+            *normAr = fabsf(zetabar);
+            if ((rc = nrm2(n, xs, normx)) != 0) return rc;
+            const float test1 = *normr / normb;
+            const float test2 = *normAr / (*normA * *normr);
+            const float test3 = 1.0f / *condA;
+            const float t1 = test1 / (1.0f + *normA * *normx / normb);
+            const float rtol = btol + atol * *normA * *normx / normb;
+            if (*itn >= itnlim) *istop = 7;                                                  // :607-613
+            if (1.0f + test3 <= 1.0f) *istop = 6;
+            if (1.0f + test2 <= 1.0f) *istop = 5;
+            if (1.0f + t1 <= 1.0f) *istop = 4;
+            if (test3 <= ctol) *istop = 3;
+            if (test2 <= atol) *istop = 2;
+            if (test1 <= rtol) *istop = 1;
+            if (*istop != 0) break;
+        }
+    }
+    if (damped && *istop == 2) *istop = 3;                                                   // :651
+    LS_TRY(e, hipMemcpyAsync(x, xs, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    LS_TRY(e, hipGetLastError());
+    LS_TRY(e, hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"

@@ -16,6 +16,7 @@
 
 #include "../../include/dsurftomo_amd.h"
 #include "engine.h"
+#include "spmv_state.h"
 
 namespace dsa {
 
@@ -44,14 +45,6 @@ __global__ __launch_bounds__(256) void k_spmv_segments(int nseg, const long long
     }
     if (lane == 0) out[r] = acc;
 }
-
-struct SpmvState {
-    int m = 0, n = 0;
-    long long nar = 0;
-    DevBuf<long long> rowptr, colptr;
-    DevBuf<float> val_r, val_c, x, y;
-    DevBuf<int> col_r, row_c;
-};
 
 }  // namespace dsa
 
@@ -199,11 +192,19 @@ int dsa_spmv(dsa_engine* h, int mode, float* x, float* y)
 }  // extern "C"
 
 namespace dsa {
+void spmv_device(Engine* e, int mode, float* d_x, float* d_y)
+{
+    SpmvState& S = *e->spmv;
+    if (mode == 1) hipLaunchKernelGGL(k_spmv_segments, dim3((S.m + 3) / 4), dim3(256), 0, e->stream, S.m, S.rowptr.p, S.val_r.p, S.col_r.p, d_x, d_y);
+    else hipLaunchKernelGGL(k_spmv_segments, dim3((S.n + 3) / 4), dim3(256), 0, e->stream, S.n, S.colptr.p, S.val_c.p, S.row_c.p, d_y, d_x);
+}
+
 void release_spmv(SpmvState* s)
 {
     if (!s) return;
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     rel(s->rowptr); rel(s->colptr); rel(s->val_r); rel(s->val_c); rel(s->x); rel(s->y); rel(s->col_r); rel(s->row_c);
+    rel(s->u); rel(s->v); rel(s->h); rel(s->hbar); rel(s->xs); rel(s->localV); rel(s->scal);
     delete s;
 }
 }  // namespace dsa

@@ -61,6 +61,7 @@ def load_library():
     L.dsa_get_stats.argtypes = [_vp, _vp]
     L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]
     L.dsa_spmv.argtypes = [_vp, _i32, _vp, _vp]
+    L.dsa_lsmr.argtypes = [_vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp] + [_vp] * 7
     L.dsa_debug_field.argtypes = [_vp, _i32, _i32, _vp]
     L.dsa_dropin_error.restype = C.c_char_p
     _lib = L
@@ -200,6 +201,19 @@ class Engine:
         assert x.size == self._mn[1] and y.size == self._mn[0]
         self._check(self._L.dsa_spmv(self._h, int(mode), _p(x), _p(y)))
         return y if mode == 1 else x
+
+    def lsmr(self, b, damp, atol=1e-6, btol=1e-6, conlim=100.0, itnlim=400, local_size=10):
+        """LSMR (reference lsmrModule.f90:36, arguments of main.f90:470-489) on the matrix of the last spmv_load;
+        returns dict(x, istop, itn, normA, condA, normr, normAr, normx)"""
+        b = np.ascontiguousarray(b, np.float32)
+        assert b.size == self._mn[0]
+        x = np.zeros(self._mn[1], np.float32)
+        ii = [C.c_int(-1), C.c_int(-1)]
+        ff = [C.c_float(0.0) for _ in range(5)]
+        self._check(self._L.dsa_lsmr(self._h, _p(b), damp, atol, btol, conlim, int(itnlim), int(local_size), _p(x),
+                                     *[C.byref(v) for v in ii], *[C.byref(v) for v in ff]))
+        names = ("normA", "condA", "normr", "normAr", "normx")
+        return dict(x=x, istop=ii[0].value, itn=ii[1].value, **{k: np.float32(v.value) for k, v in zip(names, ff)})
 
     def traveltimes(self, map_index, scx, scz, nrec, rcx, rcz):
         self.plan(map_index, scx, scz, nrec, rcx, rcz)

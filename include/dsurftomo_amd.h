@@ -126,6 +126,15 @@ int dsa_solve_rows(dsa_engine* e, float* dsurf, float* rw, int* iw, int* col, lo
 int dsa_spmv_load(dsa_engine* e, int m, int n, long long nar, const float* rw, const int* row, const int* col);
 int dsa_spmv(dsa_engine* e, int mode, float* x, float* y);
 
+/* LSMR of the inversion step (reference lsmrModule.f90:36-750, single precision as shipped, called at main.f90:487) on
+ * the matrix of the last dsa_spmv_load, all vectors resident on the device.  b[m] right-hand side (host, not
+ * modified), x[n] solution (host, out); the other arguments and results are the reference's (damp, atol, btol,
+ * conlim, itnlim, localSize -> istop, itn, normA, condA, normr, normAr, normx).  Sums run in the reference's order:
+ * results are bit-identical to the reference's LSMR. */
+int dsa_lsmr(dsa_engine* e, const float* b, float damp, float atol, float btol, float conlim, int itnlim,
+             int localSize, float* x, int* istop, int* itn, float* normA, float* condA, float* normr,
+             float* normAr, float* normx);
+
 /* copy one unit's coarse travel-time field (nnz, nnx column-major) back; valid after dsa_solve
  * for units of the last chunk only unless keep_fields was requested */
 int dsa_get_dims(const dsa_engine* e, int* nnx, int* nnz);
@@ -172,6 +181,13 @@ int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi
  * device; the matrix is uploaded when first seen (dsurftomo_amd/fortran/aprod_shim.f90 exports `aprod_`) */
 int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, const int* leniw,
               const int* lenrw, const int* iw, const float* rw);
+
+/* the reference's LSMR with its own argument list (lsmrModule.f90:36-39: every argument by reference; iw = [nar,
+ * rows, cols], nout ignored) on the device; dsurftomo_amd/fortran/lsmr_shim.f90 exports module lsmrModule with it */
+int dsa_lsmr_dropin(const int* m, const int* n, const int* leniw, const int* lenrw, const int* iw, const float* rw,
+                    const float* b, const float* damp, const float* atol, const float* btol, const float* conlim,
+                    const int* itnlim, const int* localSize, const int* nout, float* x, int* istop, int* itn,
+                    float* normA, float* condA, float* normr, float* normAr, float* normx);
 
 /* pv(nx*ny, kmaxXX) of the last drop-in call: which = 0 Rc, 1 Rg, 2 Lc, 3 Lg (what the reference's synthetic
  * writes to velmap2d*.dat, CalSurfG.f90:2559-2617) */

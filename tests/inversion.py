@@ -34,8 +34,8 @@ def build_system(c, fwd, obst, threshold0, weight0):
                 datweight=datweight, norm=norm, dws=dws)
 
 
-def call_lsmr(fn, S, damp, atol=1e-6, btol=1e-6, conlim=100.0, itnlim=400, local_size=10, head=()):
-    """main.f90:470-489's call.  Returns dict(x, istop, itn, normA, condA, normr, normAr, normx)."""
+def call_lsmr(fn, S, damp, atol=1e-6, btol=1e-6, conlim=100.0, itnlim=400, local_size=10, head=(), nout=None):
+    """main.f90:470-489's call (nout: pass a unit number for entries that keep the reference's full list).  Returns dict(x, istop, itn, normA, condA, normr, normAr, normx)."""
     i32 = lambda v: C.byref(C.c_int(int(v)))
     f32 = lambda v: C.byref(C.c_float(float(v)))
     x = np.zeros(S["n"], np.float32)
@@ -43,7 +43,7 @@ def call_lsmr(fn, S, damp, atol=1e-6, btol=1e-6, conlim=100.0, itnlim=400, local
     sc = [C.c_float(0.0) for _ in range(5)]
     iw = np.ascontiguousarray(S["iw"], np.int32); rw = np.ascontiguousarray(S["rw"], np.float32); b = np.ascontiguousarray(S["b"], np.float32)
     rc = fn(*head, i32(S["m"]), i32(S["n"]), i32(iw.size), i32(rw.size), L.ptr(iw), L.ptr(rw), L.ptr(b), f32(damp), f32(atol), f32(btol),
-            f32(conlim), i32(itnlim), i32(local_size), L.ptr(x), C.byref(istop), C.byref(itn), *[C.byref(v) for v in sc])
+            f32(conlim), i32(itnlim), i32(local_size), *([] if nout is None else [i32(nout)]), L.ptr(x), C.byref(istop), C.byref(itn), *[C.byref(v) for v in sc])
     if getattr(fn, "__name__", "").startswith("dsa_") and rc != 0:
         raise RuntimeError("%s returned %d" % (fn.__name__, rc))
     return dict(x=x, istop=istop.value, itn=itn.value, normA=np.float32(sc[0].value), condA=np.float32(sc[1].value),

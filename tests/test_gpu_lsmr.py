@@ -1,0 +1,91 @@
+"""Device LSMR (csrc/lsmr.hip) against the oracle's restatement of the reference's LSMR (pinned bit-exactly to the
+reference's own objects in tests/test_oracle_lsmr.py): bit-identical solution, iteration count and estimates."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import _libs as L
+import inversion as inv
+import synth
+import taipei
+from dsurftomo_amd.engine import Engine, load_library
+
+pytestmark = pytest.mark.gpu
+
+
+def system(c, seed=0, threshold0=3.0, weight0=2.0, fwd=None):
+    fwd = fwd or L.call_boundary(L.oracle().dso_calsurfg, c)
+    r = synth.LCG(77 + seed)
+    obst = (fwd["dsurf"] * (1.0 + 0.04 * (r.uniform(c["ndata"]) - 0.5))).astype(np.float32)
+    return inv.build_system(c, fwd, obst, threshold0, weight0)
+
+
+def device_lsmr(S, damp, **kw):
+    e = Engine(0)
+    try:
+        nar = S["nar"]
+        e.spmv_load(S["m"], S["n"], S["rw"], S["iw"][1:nar + 1], S["iw"][nar + 1:])
+        return e.lsmr(S["b"], damp, **kw)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("damp,local_size,itnlim", [(1.0, 10, 400), (0.0, 10, 60), (0.5, 0, 100), (1.0, 3, 7)])
+def test_lsmr_boundary_case(damp, local_size, itnlim):
+    S = system(synth.boundary_case())
+    want = inv.call_lsmr(L.oracle().dso_lsmr, S, damp, itnlim=itnlim, local_size=local_size)
+    got = device_lsmr(S, damp, itnlim=itnlim, local_size=local_size)
+    assert want["itn"] > 3
+    assert inv.same(got, want) == []
+
+
+def test_lsmr_dropin_entry_and_golden():
+    """dsa_lsmr_dropin (the reference's argument list, what fortran/lsmr_shim.f90 forwards to) against the vectors the
+    reference's LSMR produced (tests/golden/b_lsmr.npz)"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "b_lsmr.npz"))
+    S = dict(m=int(z["m"]), n=int(z["n"]), iw=z["iw"], rw=z["rw"], b=z["b"])
+    lib = load_library()
+    got = inv.call_lsmr(lib.dsa_lsmr_dropin, S, 1.0, nout=0)
+    assert got["itn"] == int(z["itn"]) and got["istop"] == int(z["istop"])
+    assert (got["x"].view(np.uint32) == z["x"].view(np.uint32)).all()
+    for k in ("normA", "condA", "normr", "normAr", "normx"):
+        assert np.float32(got[k]).view(np.uint32) == np.float32(z[k]).view(np.uint32)
+
+
+def test_lsmr_degenerate_inputs():
+    """b = 0 (the reference leaves at once, x = 0) and a matrix with empty rows / columns"""
+    S = system(synth.boundary_case())
+    S0 = dict(S); S0["b"] = np.zeros_like(S["b"])
+    got = device_lsmr(S0, 1.0)
+    assert got["itn"] == 0 and got["istop"] == 0 and not got["x"].any()
+    keep = (np.arange(S["nar"]) % 3) != 0
+    rows, cols = S["iw"][1:S["nar"] + 1][keep], S["iw"][S["nar"] + 1:][keep]
+    S1 = dict(S); S1["rw"] = S["rw"][keep]; S1["nar"] = int(keep.sum())
+    S1["iw"] = np.concatenate([[S1["nar"]], rows, cols]).astype(np.int32)
+    want = inv.call_lsmr(L.oracle().dso_lsmr, S1, 0.3)
+    assert inv.same(device_lsmr(S1, 0.3), want) == []
+
+
+def test_lsmr_taipei_iteration():
+    """first outer iteration of the reference's Taipei example (main.f90:355-489 with the example's weight / damp /
+    threshold): forward call on the device, the system of main.f90:361-466, LSMR on the device == the oracle"""
+    c = taipei.load()
+    fwd = L.call_boundary(load_library().dsa_calsurfg, c)
+    obst = c["obst"]
+    S = inv.build_system(c, fwd, obst, 3.0, 4.0)
+    t0 = time.time(); want = inv.call_lsmr(L.oracle().dso_lsmr, S, 1.0); t_cpu = time.time() - t0
+    e = Engine(0)
+    try:
+        nar = S["nar"]
+        e.spmv_load(S["m"], S["n"], S["rw"], S["iw"][1:nar + 1], S["iw"][nar + 1:])
+        e.lsmr(S["b"], 1.0, itnlim=2)                                  # warm-up (allocation, code load)
+        t0 = time.time(); got = e.lsmr(S["b"], 1.0); t_gpu = time.time() - t0
+    finally:
+        e.close()
+    print("taipei LSMR: m %d n %d nar %d, %d iterations, istop %d | device %.1f ms, C restatement on one core %.1f ms" %
+          (S["m"], S["n"], S["nar"], got["itn"], got["istop"], 1e3 * t_gpu, 1e3 * t_cpu))
+    assert want["itn"] > 10 and np.abs(want["x"]).max() > 0.01
+    assert inv.same(got, want) == []
