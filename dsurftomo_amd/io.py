@@ -41,9 +41,10 @@ def load(directory=HERE, model="MOD"):
     goxd, gozd = (f(v) for v in _vals(next(it))[:2])
     dvxd, dvzd = (f(v) for v in _vals(next(it))[:2])
     nsrc = int(_vals(next(it))[0])
-    next(it)                                   # weight, damp
+    weight0, damp = (f(v) for v in _vals(next(it))[:2])
     minthk = f(_vals(next(it))[0])             # "sablayers"
-    next(it); next(it)                         # velocity bounds, max iteration
+    minvel, maxvel = (f(v) for v in _vals(next(it))[:2])
+    maxiter = int(_vals(next(it))[0])
     spfra = float(_vals(next(it))[0])
     per = []
     for _ in range(4):
@@ -51,6 +52,8 @@ def load(directory=HERE, model="MOD"):
         per.append(np.array([float(v) for v in next(it).split()[:k]], np.float64) if k > 0 else np.zeros(0))
     ifsyn = int(_vals(next(it))[0])
     noiselevel = f(_vals(next(it))[0])
+    nxt = next(it, None)
+    threshold0 = f(_vals(nxt)[0]) if nxt is not None and _vals(nxt) else f(0.0)      # main.f90:210
     kRc, kRg, kLc, kLg = (len(p) for p in per)
     kmax = kRc + kRg + kLc + kLg
     nrc = nsrc
@@ -112,6 +115,7 @@ def load(directory=HERE, model="MOD"):
                 kRc=kRc, kRg=kRg, kLc=kLc, kLg=kLg, tRc=per[0], tRg=per[1], tLc=per[2], tLg=per[3], wavetype=wavetype, igrt=igrt,
                 periods=periods, depz=depz, minthk=minthk, scxf=scxf, sczf=sczf, rcxf=rcxf, rczf=rczf, nrc1=nrc1, nsrcsurf1=nsrc1,
                 kmax=kmax, nsrcsurf=nsrc, nrcf=nrc, ndata=int(nrc1.sum()), spfra=spfra, ifsyn=ifsyn, noiselevel=noiselevel,
+                weight0=weight0, damp=damp, minvel=minvel, maxvel=maxvel, maxiter=maxiter, threshold0=threshold0,
                 vel_obs=np.array(vel_obs, f), dist=np.array(dist, f), obst=(np.array(dist, f) / np.array(vel_obs, f)).astype(f))
 
 

@@ -38,7 +38,8 @@ enum dsa_status {
     DSA_ERR_ARGUMENT = -2,
     DSA_ERR_OUTSIDE = -3,    /* a source or receiver lies outside the model */
     DSA_ERR_INTERNAL = -4,   /* a device-side guard fired (window / tree overflow, no convergence) */
-    DSA_ERR_STATE = -5       /* call order (e.g. solve before plan) */
+    DSA_ERR_STATE = -5,      /* call order (e.g. solve before plan) */
+    DSA_ERR_CAPACITY = -6    /* an output array is too small (the reference: stop 'increase sparsity fraction') */
 };
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -134,6 +135,17 @@ int dsa_spmv(dsa_engine* e, int mode, float* x, float* y);
 int dsa_lsmr(dsa_engine* e, const float* b, float damp, float atol, float btol, float conlim, int itnlim,
              int localSize, float* x, int* istop, int* itn, float* normA, float* condA, float* normr,
              float* normAr, float* normx);
+
+/* One outer iteration's host glue (reference main.f90:361-466 and :520-535; plain host code, no device):
+ * iteration_system: residual cbst = obst - dsyn, percentile weights (getpercentile.f90), rows scaled by their weights,
+ *   DWS norm[maxvp] with dws = {max, mean}, regularisation rows appended.  In/out rw, col (capacity entries) and iw
+ *   (2*capacity + 1: iw[0] = final nar, then rows, then columns -- the layout aprod / LSMR take); cbst has dall + maxvp
+ *   values, *m_out = dall + maxvp rows.
+ * model_update: dv clipped to +-0.5, vsf(nx, ny, nz) += dv on the interior, clipped to [minvel, maxvel]. */
+int dsa_iteration_system(int nx, int ny, int nz, int dall, long long nar_in, long long capacity, float* rw, int* iw,
+                         int* col, const float* obst, const float* dsyn, float threshold0, float weight0, float* cbst,
+                         float* datweight, float* norm, int* m_out, long long* nar_out, float* dws);
+int dsa_model_update(int nx, int ny, int nz, float* dv, float* vsf, float minvel, float maxvel);
 
 /* copy one unit's coarse travel-time field (nnz, nnx column-major) back; valid after dsa_solve
  * for units of the last chunk only unless keep_fields was requested */

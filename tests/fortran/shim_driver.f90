@@ -3,9 +3,12 @@
 ! shim's link symbols exactly as the reference's host program does (main.f90:338-359), and writes
 ! the outputs back.  Own code; no reference source involved.
 program shim_driver
+  use lsmrModule, only: lsmr          ! dsurftomo_amd/fortran/lsmr_shim.f90, like main.f90:21
   implicit none
   integer :: nx,ny,nz,nparpi,kmaxRc,kmaxRg,kmaxLc,kmaxLg,kmax,nsrcsurf,nrcf,ndata,maxnar,nar,i,leniw
-  real, allocatable :: xv(:), yv(:)
+  real, allocatable :: xv(:), yv(:), bv(:), dv(:)
+  integer :: istop, itn, nout
+  real :: damp, atol, btol, conlim, anorm, acond, rnorm, arnorm, xnorm
   real :: goxd,gozd,dvxd,dvzd,minthk,noiselevel
   real, allocatable :: vels(:,:,:),depz(:),scxf(:,:),sczf(:,:),rcxf(:,:,:),rczf(:,:,:),rw(:),dsurf(:),obst(:)
   real*8, allocatable :: tRc(:),tRg(:),tLc(:),tLg(:)
@@ -59,6 +62,17 @@ program shim_driver
   call aprod(1, ndata, nparpi, xv, yv, leniw, nar, iw, rw)
   call aprod(2, ndata, nparpi, xv, yv, leniw, nar, iw, rw)
   write(22) xv, yv
+  ! LSMR the way main.f90:470-489 calls it (module procedure of lsmrModule), on the same matrix
+  allocate(bv(ndata), dv(nparpi))
+  do i = 1, ndata
+    bv(i) = real(mod(i*3, 17) - 8) * 0.01
+  enddo
+  damp = 1.0; atol = 1e-6; btol = 1e-6; conlim = 100; nout = 0
+  dv = 0
+  call LSMR(ndata, nparpi, leniw, nar, iw, rw, bv, damp, atol, btol, conlim, 400, 10, nout, &
+            dv, istop, itn, anorm, acond, rnorm, arnorm, xnorm)
+  write(22) istop, itn
+  write(22) dv, anorm, acond, rnorm, arnorm, xnorm
   close(22)
 end program
 

@@ -159,6 +159,8 @@ def test_fortran_shim(tmp_path):
         dsurf = np.fromfile(f, np.float32, c["ndata"]); obst = np.fromfile(f, np.float32, c["ndata"])
         rw = np.fromfile(f, np.float32, nar); iw = np.fromfile(f, np.int32, nar); col = np.fromfile(f, np.int32, nar)
         xv = np.fromfile(f, np.float32, c["nparpi"]); yv = np.fromfile(f, np.float32, c["ndata"])
+        istop, itn = np.fromfile(f, np.int32, 2)
+        dv = np.fromfile(f, np.float32, c["nparpi"]); est = np.fromfile(f, np.float32, 5)
     # aprod_ through aprod_shim.f90: y += A x then x += A^T y, against the oracle's aprod on the same matrix
     x0 = (((np.arange(1, c["nparpi"] + 1) * 7) % 13 - 6) * 0.125).astype(np.float32)
     y0 = (((np.arange(1, c["ndata"] + 1) * 5) % 11 - 5) * 0.25).astype(np.float32)
@@ -167,6 +169,12 @@ def test_fortran_shim(tmp_path):
     for mode in (1, 2):
         L.oracle().dso_aprod(ib(mode), ib(c["ndata"]), ib(c["nparpi"]), L.ptr(x0), L.ptr(y0), ib(iwf.size), ib(nar), L.ptr(iwf), L.ptr(rw))
     assert (x0.view(np.uint32) != xv.view(np.uint32)).sum() == 0 and (y0.view(np.uint32) != yv.view(np.uint32)).sum() == 0
+    # LSMR through lsmr_shim.f90 (module lsmrModule) against the oracle's LSMR on the same matrix
+    import inversion as inv
+    bv = (((np.arange(1, c["ndata"] + 1) * 3) % 17 - 8) * np.float32(0.01)).astype(np.float32)
+    want = inv.call_lsmr(L.oracle().dso_lsmr, dict(m=c["ndata"], n=c["nparpi"], iw=iwf, rw=rw, b=bv), 1.0)
+    got = dict(x=dv, istop=int(istop), itn=int(itn), normA=est[0], condA=est[1], normr=est[2], normAr=est[3], normx=est[4])
+    assert want["itn"] > 3 and inv.same(got, want) == []
     check_rows(o, dict(dsurf=dsurf, rw=rw, iw=iw, col=col, nar=nar), c)
     assert np.abs(obst - so).max() <= 1e-4
     # the velocity-map files of `synthetic` (CalSurfG.f90:2559-2617) against the reference's own, byte for byte

@@ -89,3 +89,37 @@ def test_lsmr_taipei_iteration():
           (S["m"], S["n"], S["nar"], got["itn"], got["istop"], 1e3 * t_gpu, 1e3 * t_cpu))
     assert want["itn"] > 10 and np.abs(want["x"]).max() > 0.01
     assert inv.same(got, want) == []
+
+
+def test_taipei_inversion_driver_known_answer(tmp_path):
+    """two outer iterations of the reference's Taipei example through dsurftomo_amd.invert.  Known answer of the
+    reference's executable for the first iteration (measured on the reference built with patched
+    argument handling): 'mean,std_devs and rms of residual after weighting: -442.8ms 1224.32ms 1.302' and
+    'min and max velocity variation -0.1868 0.4053'."""
+    import ctypes as C
+    from dsurftomo_amd import invert
+    lines = []
+    vsf, hist = invert.run(taipei.HERE, maxiter=2, out_dir=str(tmp_path), log=lines.append)
+    h = hist[0]
+    print("\n".join(lines))
+    assert abs(h["mean_ms"] - (-442.8)) < 0.06 and abs(h["std_ms"] - 1224.32) < 0.02 and abs(h["rms"] - 1.302) < 6e-4
+    assert abs(h["dv_min"] - (-0.1868)) < 6e-5 and abs(h["dv_max"] - 0.4053) < 6e-5
+    assert hist[1]["rms"] < 0.8 * h["rms"]                              # the update reduces the misfit
+    # the same first iteration assembled from the oracle's pieces gives the same model, bit for bit
+    c = taipei.load()
+    fwd = L.call_boundary(load_library().dsa_calsurfg, c)
+    S = inv.build_system(c, fwd, c["obst"], float(c["threshold0"]), float(c["weight0"]))
+    want = inv.call_lsmr(L.oracle().dso_lsmr, S, float(c["damp"]))
+    assert want["itn"] == h["itn"] and want["istop"] == h["istop"]
+    vs = np.asfortranarray(c["vels"].copy()); dv = want["x"].copy()
+    O = L.oracle()
+    O.dso_model_update.argtypes = [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_float] * 2
+    O.dso_model_update(c["nx"], c["ny"], c["nz"], L.ptr(dv), L.ptr(vs), float(c["minvel"]), float(c["maxvel"]))
+    first = np.loadtxt(str(tmp_path / "DSurfTomo.inMeasure.dat.iter001"))
+    assert first.shape == (16 * 16 * 8, 4)
+    got = first[:, 3].reshape(8, 16, 16).transpose(2, 1, 0)             # [i, j, k]
+    assert np.abs(got - vs[1:-1, 1:-1, :-1]).max() < 6e-6                 # f10.5
+    assert np.allclose(first[0, :3], [121.35, 25.2, c["depz"][0]], atol=1e-5)
+    for name in ("residualFirst.dat", "residualLast.dat", "DSurfTomo.inMeasure.dat", "DSurfTomo.inMeasure.dat.iter002"):
+        assert (tmp_path / name).exists()
+    assert np.loadtxt(str(tmp_path / "residualFirst.dat")).shape == (c["ndata"], 6)
