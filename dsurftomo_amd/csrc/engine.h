@@ -96,6 +96,7 @@ struct Engine {
     std::vector<int>* grow_col = nullptr;
 
     SpmvState* spmv = nullptr;         // device copy of a COO matrix for dsa_spmv (spmv.hip)
+    int lsmr_device_vectors = 0;       // dsa_lsmr: 1 = vectors and ordered reductions on the device, 0 = on the host (lsmr.hip)
 
     double stats[32] = {};
 

@@ -642,6 +642,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
     if (n == "fim_lds_pad" && value >= 0 && value <= 64 * 1024) { en->fim_lds_pad = (int)value; return 0; }
     if (n == "fim_sorted" && (value == 0 || value == 1)) { en->fim_sorted = (int)value; return 0; }
+    if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "fim_threads" && (value == 128 || value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;

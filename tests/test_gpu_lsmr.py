@@ -22,9 +22,10 @@ def system(c, seed=0, threshold0=3.0, weight0=2.0, fwd=None):
     return inv.build_system(c, fwd, obst, threshold0, weight0)
 
 
-def device_lsmr(S, damp, **kw):
+def device_lsmr(S, damp, device_vectors=0, **kw):
     e = Engine(0)
     try:
+        e.set_option("lsmr_device_vectors", device_vectors)
         nar = S["nar"]
         e.spmv_load(S["m"], S["n"], S["rw"], S["iw"][1:nar + 1], S["iw"][nar + 1:])
         return e.lsmr(S["b"], damp, **kw)
@@ -32,11 +33,13 @@ def device_lsmr(S, damp, **kw):
         e.close()
 
 
+@pytest.mark.parametrize("device_vectors", [0, 1])
 @pytest.mark.parametrize("damp,local_size,itnlim", [(1.0, 10, 400), (0.0, 10, 60), (0.5, 0, 100), (1.0, 3, 7)])
-def test_lsmr_boundary_case(damp, local_size, itnlim):
+def test_lsmr_boundary_case(damp, local_size, itnlim, device_vectors):
+    """both placements of the vectors (ordered reductions on the host / on the device) give the reference's bits"""
     S = system(synth.boundary_case())
     want = inv.call_lsmr(L.oracle().dso_lsmr, S, damp, itnlim=itnlim, local_size=local_size)
-    got = device_lsmr(S, damp, itnlim=itnlim, local_size=local_size)
+    got = device_lsmr(S, damp, device_vectors, itnlim=itnlim, local_size=local_size)
     assert want["itn"] > 3
     assert inv.same(got, want) == []
 
@@ -59,14 +62,15 @@ def test_lsmr_degenerate_inputs():
     """b = 0 (the reference leaves at once, x = 0) and a matrix with empty rows / columns"""
     S = system(synth.boundary_case())
     S0 = dict(S); S0["b"] = np.zeros_like(S["b"])
-    got = device_lsmr(S0, 1.0)
-    assert got["itn"] == 0 and got["istop"] == 0 and not got["x"].any()
+    for dvec in (0, 1):
+        got = device_lsmr(S0, 1.0, dvec)
+        assert got["itn"] == 0 and got["istop"] == 0 and not got["x"].any()
     keep = (np.arange(S["nar"]) % 3) != 0
     rows, cols = S["iw"][1:S["nar"] + 1][keep], S["iw"][S["nar"] + 1:][keep]
     S1 = dict(S); S1["rw"] = S["rw"][keep]; S1["nar"] = int(keep.sum())
     S1["iw"] = np.concatenate([[S1["nar"]], rows, cols]).astype(np.int32)
     want = inv.call_lsmr(L.oracle().dso_lsmr, S1, 0.3)
-    assert inv.same(device_lsmr(S1, 0.3), want) == []
+    assert inv.same(device_lsmr(S1, 0.3), want) == [] and inv.same(device_lsmr(S1, 0.3, 1), want) == []
 
 
 def test_lsmr_taipei_iteration():
@@ -83,10 +87,15 @@ def test_lsmr_taipei_iteration():
         e.spmv_load(S["m"], S["n"], S["rw"], S["iw"][1:nar + 1], S["iw"][nar + 1:])
         e.lsmr(S["b"], 1.0, itnlim=2)                                  # warm-up (allocation, code load)
         t0 = time.time(); got = e.lsmr(S["b"], 1.0); t_gpu = time.time() - t0
+        e.set_option("lsmr_device_vectors", 1)
+        e.lsmr(S["b"], 1.0, itnlim=2)
+        t0 = time.time(); got_d = e.lsmr(S["b"], 1.0); t_dev = time.time() - t0
     finally:
         e.close()
-    print("taipei LSMR: m %d n %d nar %d, %d iterations, istop %d | device %.1f ms, C restatement on one core %.1f ms" %
-          (S["m"], S["n"], S["nar"], got["itn"], got["istop"], 1e3 * t_gpu, 1e3 * t_cpu))
+    print("taipei LSMR: m %d n %d nar %d, %d iterations, istop %d | products on the device + ordered sums on the host %.1f ms, "
+          "everything on the device %.1f ms, C restatement on one core %.1f ms" %
+          (S["m"], S["n"], S["nar"], got["itn"], got["istop"], 1e3 * t_gpu, 1e3 * t_dev, 1e3 * t_cpu))
+    assert inv.same(got_d, want) == []
     assert want["itn"] > 10 and np.abs(want["x"]).max() > 0.01
     assert inv.same(got, want) == []
 

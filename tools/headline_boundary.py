@@ -64,6 +64,44 @@ def main():
             want = yy if mode == 1 else xx
             print("CPU aprod (C restatement, one core) mode %d: %.1f ms; device result identical: %s" % (mode, 1e3 * (t3 - t2), bool((got.view(np.uint32) == want.view(np.uint32)).all())), flush=True)
         e.close()
+    if "--lsmr" in sys.argv:
+        # one outer iteration's inversion step at the headline size: system of main.f90:361-466 on the host, LSMR on the device
+        n0 = nar.value
+        maxvp = npar
+        cap2 = n0 + 7 * maxvp
+        rw2 = np.zeros(cap2, np.float32); rw2[:n0] = rw[:n0]
+        col2 = np.zeros(cap2, np.int32); col2[:n0] = col[:n0]
+        iw2 = np.zeros(2 * cap2 + 1, np.int32); iw2[1:n0 + 1] = iw[1:n0 + 1]
+        r = synth.LCG(9)
+        obst = (dsurf * (1.0 + 0.02 * (r.uniform(nd) - 0.5))).astype(np.float32)
+        cbst = np.zeros(nd + maxvp, np.float32); dw = np.zeros(nd, np.float32); norm = np.zeros(maxvp, np.float32); dws = np.zeros(2, np.float32)
+        m, n2 = C.c_int(0), C.c_longlong(0)
+        lib.dsa_iteration_system.argtypes = [C.c_int] * 4 + [C.c_longlong] * 2 + [C.c_void_p] * 5 + [C.c_float] * 2 + [C.c_void_p] * 6
+        t0 = time.perf_counter()
+        rc = lib.dsa_iteration_system(c["nx"], c["ny"], c["nz"], nd, n0, cap2, L.ptr(rw2), L.ptr(iw2), L.ptr(col2), L.ptr(obst), L.ptr(dsurf), 3.0, 4.0,
+                                      L.ptr(cbst), L.ptr(dw), L.ptr(norm), C.byref(m), C.byref(n2), L.ptr(dws))
+        print("dsa_iteration_system (host): rc %d, %.2f s; m %d n %d nar %d" % (rc, time.perf_counter() - t0, m.value, maxvp, n2.value), flush=True)
+        n = n2.value
+        e = E.Engine(0)
+        t0 = time.perf_counter()
+        e.spmv_load(m.value, maxvp, rw2[:n], iw2[1:n + 1], iw2[n + 1:2 * n + 1])
+        print("matrix load: %.2f s" % (time.perf_counter() - t0), flush=True)
+        for dvec in (0, 1):
+            e.set_option("lsmr_device_vectors", dvec)
+            name = "vectors on the device" if dvec else "products on the device, ordered sums on the host"
+            e.lsmr(cbst, 1.0, itnlim=2)
+            t0 = time.perf_counter(); got = e.lsmr(cbst, 1.0, itnlim=30); dt = time.perf_counter() - t0
+            print("LSMR (%s): %d iterations in %.3f s (%.2f ms per iteration)" % (name, got["itn"], dt, 1e3 * dt / max(got["itn"], 1)), flush=True)
+            t0 = time.perf_counter(); full = e.lsmr(cbst, 1.0); dt = time.perf_counter() - t0
+            print("LSMR (%s) to convergence: %d iterations, istop %d, %.3f s; |dv| max %.4f" % (name, full["itn"], full["istop"], dt, np.abs(full["x"]).max()), flush=True)
+        e.set_option("lsmr_device_vectors", 0)
+        import inversion as inv
+        S = dict(m=m.value, n=maxvp, iw=iw2[:2 * n + 1], rw=rw2[:n], b=cbst)
+        t0 = time.perf_counter(); want = inv.call_lsmr(L.oracle().dso_lsmr, S, 1.0, itnlim=3); dt = time.perf_counter() - t0
+        got = e.lsmr(cbst, 1.0, itnlim=3)
+        print("CPU LSMR (C restatement, one core): 3 iterations in %.2f s (%.0f ms per iteration); device result identical: %s" %
+              (dt, 1e3 * dt / 3, inv.same(got, want) == []), flush=True)
+        e.close()
 
 
 if __name__ == "__main__":
