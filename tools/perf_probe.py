@@ -17,14 +17,16 @@ e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
 nb = ((e.nnx + 7) // 8) ** 2
 u = synth.units(nx, nsrc, nper, 32)
 ref = None
-for wc, nt in [(w, t) for t in threads for w in windows]:
+variants = [int(v) for v in os.environ.get('DSA_FIM_VARIANTS', '-1').split(',')]      # fim_sorted values to run (-1: the default)
+for wc, nt, var in [(w, t, v) for v in variants for t in threads for w in windows]:
     e.set_option('window_cells', wc); e.set_option('fim_threads', nt)
+    if var >= 0: e.set_option('fim_sorted', var)
     e.plan(**u)
     t0 = time.time(); t = e.solve(); dt = time.time() - t0
     st = e.stats(); n = nsrc * nper
     same = 'first' if ref is None else f'identical={np.array_equal(ref.view(np.uint32), t.view(np.uint32))} maxdiff={np.abs(ref - t).max():.2g}'
     if ref is None: ref = t
-    print(f'N={e.nnx} {kind} units {n:5d} wg {nt:4d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
+    print(f'N={e.nnx} {kind} variant {var:2d} units {n:5d} wg {nt:4d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
           f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} changes/node {st["changes_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} freezes {st["freezes"]:.0f} | {same}', flush=True)
     pt = np.array(st["phase_ticks"]); tot = pt[:4].sum()
     if tot > 0:
