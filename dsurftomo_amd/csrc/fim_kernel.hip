@@ -109,8 +109,8 @@ __device__ __forceinline__ float wave_min(float v)
 #ifndef DSA_FIM_WAVES
 #define DSA_FIM_WAVES 4
 #endif
-#ifndef DSA_FIM_GROUP
-#define DSA_FIM_GROUP 1
+#ifndef DSA_FIM_GROUP_SHIFT
+#define DSA_FIM_GROUP_SHIFT 4      // log2 of the bitmap words per group handed to a wave (pass A of k_fim_sorted)
 #endif
 // One workgroup of NT threads per problem.  The solver wants ~124 VGPRs, i.e. 4 waves per SIMD: tell the
 // compiler so, otherwise it targets 8 waves/SIMD (64 VGPRs) and spills the solver.
@@ -591,10 +591,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 }
         };
         int ntw = 0;                                                               // tiles collected, wave-uniform
-        constexpr int kG = DSA_FIM_GROUP;                                          // bitmap words per group
-        for (int wb = 0; (wb * (64 / kG) * NW + wave) * kG < nwords; ++wb) {
-            // 64 bitmap words of this wave: 16-word groups dealt round-robin to the waves, ascending
-            const int w = ((wb * (64 / kG) + lane / kG) * NW + wave) * kG + lane % kG;
+        // 64 bitmap words of this wave per trip: groups of 2^gs consecutive words dealt round-robin to the waves,
+        // ascending (16-word groups on large grids: -2.5 % against single words at 1025^2; single words on the small
+        // refined grids, whose whole bitmap is a dozen words)
+        const int gs = nwords >= 64 * NW ? DSA_FIM_GROUP_SHIFT : 0;
+        for (int wb = 0; ((wb * (64 >> gs) * NW + wave) << gs) < nwords; ++wb) {
+            const int w = (((wb * (64 >> gs) + (lane >> gs)) * NW + wave) << gs) + (lane & ((1 << gs) - 1));
             const unsigned bits = w < nwords ? tb[w] : 0u;
             const int nt_lane = __popc(bits);
             const int tincl = wave_scan_incl(nt_lane);
