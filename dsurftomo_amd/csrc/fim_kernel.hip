@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 {
     extern __shared__ unsigned dyn_lds[];
     __shared__ int smem[SC_COUNT];
-    constexpr int kWaveBuf = 256;                            // nodes a wave expands at a time
+    constexpr int kWaveBuf = 256;                            // nodes a wave expands at a time (128: -4 %, 512: -6 %)
     __shared__ int wbuf[(NT / 64) * kWaveBuf];
     constexpr int kTileBuf = 256;                            // tiles a wave gathers at a time
     __shared__ int wtile[(NT / 64) * kTileBuf];
