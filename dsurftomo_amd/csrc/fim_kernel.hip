@@ -667,14 +667,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 if (!t_pinned(t_old)) {
                     const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
                     c = solve_node(h, slow_at(id), geom, &k);
-#ifdef DSA_DOUBLE_SOLVE
-                    {   // experiment: marginal cost of the local solver (same result twice, opaque to the compiler)
-                        Hood h2 = h; unsigned zi = 0u; asm volatile("" : "+v"(zi));
-                        h2.near_[0] = u2f(f2u(h.near_[0]) ^ zi);
-                        float k2; const float c2 = solve_node(h2, slow_at(id), geom, &k2);
-                        c = fminf(c, c2); k = fminf(k, k2);
-                    }
-#endif
                     ++evals;
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
