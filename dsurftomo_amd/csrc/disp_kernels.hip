@@ -16,7 +16,7 @@ constexpr int kMaxDepths = 64;
 template <int IFUNC>
 __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__ G, const float* __restrict__ vels, int ncol,
                                                    int npert, int igr, int kmax, const double* __restrict__ t,
-                                                   float* __restrict__ ws, size_t nlanes, double* __restrict__ curves)
+                                                   float* __restrict__ ws, size_t nlanes, double* __restrict__ curves, int layers_in_lds)
 {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= (size_t)ncol * npert) return;
@@ -35,21 +35,32 @@ __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__
         arr[i] = s ? base + 0.5f * dln * base : base - 0.5f * dln * base;
     }
     Layers m;
-    const size_t plane = (size_t)G->rmax * nlanes;
-    m.d = ws + tid; m.a = ws + plane + tid; m.b = ws + 2 * plane + tid; m.rho = ws + 3 * plane + tid;
-    m.stride = nlanes;
+    if (layers_in_lds) {
+        // the layer table of the 64 curves of this wavefront in LDS ([layer][lane]: conflict free): the secular function
+        // walks it once per evaluation, ~25 evaluations per root, and a curve is one dependent chain -- with the table in
+        // global scratch a call with few curves (324 columns) ran at the latency of those loads
+        extern __shared__ float lds_layers[];
+        const int lane = threadIdx.x, plane = G->rmax * 64;
+        m.d = lds_layers + lane; m.a = lds_layers + plane + lane; m.b = lds_layers + 2 * plane + lane; m.rho = lds_layers + 3 * plane + lane;
+        m.stride = 64;
+    } else {
+        const size_t plane = (size_t)G->rmax * nlanes;
+        m.d = ws + tid; m.a = ws + plane + tid; m.b = ws + 2 * plane + tid; m.rho = ws + 3 * plane + tid;
+        m.stride = nlanes;
+    }
     build_layers<IFUNC>(*G, vs, vp, rho, m);
     dispersion_curve<IFUNC>(m, igr, kmax, t, curves + (size_t)p * kmax * ncol + c, (size_t)ncol);
 }
 
 void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
-                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, hipStream_t stream)
+                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, hipStream_t stream)
 {
     const size_t n = (size_t)ncol * npert;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, 0, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves);
-    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, 0, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves);
+    const size_t lds = layers_in_lds ? (size_t)4 * rmax * 64 * sizeof(float) : 0;
+    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds);
+    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds);
 }
 
 // pv(c, k) = curve 0; sen_q(c, slot0 + k, i) = (cg(+) - cg(-)) / dble(dln * base_q(i)), CalSurfG.f90:76-150

@@ -89,6 +89,7 @@ struct Engine {
     DevBuf<LayerGeom> geom;
     DevBuf<double> pvstore, curves, tper;
     DevBuf<float> disp_ws;
+    int disp_layers_lds = -1;          // layer tables of k_dispersion: 1 LDS, 0 global scratch, -1 LDS when they fit
 
     // optional growing host destination of the COO rows (used when several engines share one call)
     std::vector<float>* grow_rw = nullptr;

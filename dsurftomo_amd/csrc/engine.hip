@@ -174,7 +174,9 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
     if (ensure(curves, nlanes * nper) || ensure(disp_ws, (size_t)4 * h_geom.rmax * nlanes) || ensure(tper, kMaxPeriods)) return status;
     HIP_TRY(this, hipMemcpyAsync(tper.p, t, (size_t)nper * 8, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipEventRecord(events[1], stream));
-    launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, stream);
+    // layer tables in LDS when they fit (64 curves x 4 arrays x rmax layers x 4 B <= 64 KB, i.e. rmax <= 64) -- see k_dispersion
+    const int in_lds = disp_layers_lds >= 0 ? disp_layers_lds : ((size_t)h_geom.rmax * 1024 <= (size_t)64 * 1024 ? 1 : 0);
+    launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, h_geom.rmax, in_lds, stream);
     launch_depth_kernels(vels_d.p, ncol, disp_nz, nper, curves.p, with_kernels, pvstore.p + (size_t)map_first * ncol, sen_vs.p, sen_vp.p, sen_rho.p,
                          disp_kmax_total, sen_slot, stream);
     HIP_TRY(this, hipEventRecord(events[2], stream));
@@ -642,6 +644,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
     if (n == "fim_lds_pad" && value >= 0 && value <= 64 * 1024) { en->fim_lds_pad = (int)value; return 0; }
     if (n == "fim_sorted" && (value == 0 || value == 1)) { en->fim_sorted = (int)value; return 0; }
+    if (n == "disp_layers_lds" && (value == -1 || value == 0 || value == 1)) { en->disp_layers_lds = (int)value; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "fim_threads" && (value == 128 || value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
