@@ -80,6 +80,9 @@ struct Engine {
     DevBuf<int> trace_ids, vlist, nvv, counts, offsets, coo_col, coo_iw;
     DevBuf<float> slabs, coo_rw;
     DevBuf<int32_t> rayinfo;
+    int ray_path_cap = 0;              // > 0: keep up to that many points of every traced ray (dsa_ray_paths)
+    DevBuf<float> paths;               // [traced ray][point][colatitude, longitude]
+    DevBuf<int> path_n;                // points of every traced ray
 
     // dispersion stage (disp_kernels.hip): Vs model -> pv maps + depth kernels, all resident
     bool disp_ready = false;

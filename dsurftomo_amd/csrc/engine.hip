@@ -64,7 +64,7 @@ Engine::~Engine()
     rel(src); rel(rays); rel(out); rel(err);
     rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
     rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(F_c); rel(seed_c); rel(nseed_c);
-    rel(prob_r); rel(prob_c); rel(info); rel(clocks); rel(lists);
+    rel(prob_r); rel(prob_c); rel(paths); rel(path_n); rel(info); rel(clocks); rel(lists);
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
@@ -515,7 +515,14 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
         const int m = (int)std::min(per, t1 - t);
         HIP_TRY(this, hipEventRecord(ea, stream));
         HIP_TRY(this, hipMemsetAsync(slabs.p, 0, (size_t)m * slab_stride * 4, stream));
-        launch_rays(g, batch(), first_unit, rays.p, trace_ids.p + t, m, veln.p, nfield, dpl, slabs.p, slab_stride, rayinfo.p, err.p, stream);
+        float* d_paths = nullptr;
+        int* d_path_n = nullptr;
+        if (ray_path_cap > 0) {     // the store covers all traced rays of the plan (position in h_trace)
+            if (ensure(paths, h_trace.size() * (size_t)ray_path_cap * 2) || ensure(path_n, h_trace.size())) return status;
+            d_paths = paths.p + t * (size_t)ray_path_cap * 2; d_path_n = path_n.p + t;
+        }
+        launch_rays(g, batch(), first_unit, rays.p, trace_ids.p + t, m, veln.p, nfield, dpl, slabs.p, slab_stride, rayinfo.p, err.p,
+                    d_paths, ray_path_cap, d_path_n, stream);
         HIP_TRY(this, hipEventRecord(eb, stream));
         RowArgs a{};
         a.rays = rays.p; a.trace_ids = trace_ids.p + t; a.n = m; a.src = src.p; a.unit_base = first_unit;
@@ -644,11 +651,37 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
     if (n == "fim_lds_pad" && value >= 0 && value <= 64 * 1024) { en->fim_lds_pad = (int)value; return 0; }
     if (n == "fim_sorted" && (value == 0 || value == 1)) { en->fim_sorted = (int)value; return 0; }
+    if (n == "ray_path_cap" && value >= 0 && value <= (1 << 24)) { en->ray_path_cap = (int)value; return 0; }
     if (n == "disp_layers_lds" && (value == -1 || value == 0 || value == 1)) { en->disp_layers_lds = (int)value; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "fim_threads" && (value == 128 || value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;
+}
+
+// ray paths of the last dsa_solve_rows (option ray_path_cap > 0): for every traced ray, in data order, its datum, its
+// point count and up to ray_path_cap (latitude, longitude) pairs in degrees -- the values the reference's disabled dump
+// writes to raypath.out (CalSurfG.f90:2276-2283: rayx = (pi/2 - rgx) 180/pi, rayz = rgz 180/pi, in single precision)
+int dsa_ray_paths(dsa_engine* e, int* datum, int* npts, float* latlon)
+{
+    if (!e || !datum || !npts || !latlon) return DSA_ERR_ARGUMENT;
+    Engine* en = reinterpret_cast<Engine*>(e);
+    const size_t nr = en->h_trace.size(), cap = (size_t)en->ray_path_cap;
+    if (cap == 0 || !en->paths.p || !en->path_n.p || en->paths.cap < nr * cap * 2) { en->fail(DSA_ERR_STATE, "ray_paths: set option ray_path_cap and call dsa_solve_rows first"); return DSA_ERR_STATE; }
+    if (hipSetDevice(en->device) != hipSuccess || hipMemcpy(npts, en->path_n.p, nr * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(latlon, en->paths.p, nr * cap * 8, hipMemcpyDeviceToHost) != hipSuccess) { en->fail(DSA_ERR_DEVICE, "ray_paths: copy failed"); return DSA_ERR_DEVICE; }
+    const float pi = 3.1415926535898f;                        // CalSurfG.f90:196
+    for (size_t r = 0; r < nr; ++r) {
+        datum[r] = en->h_rays[(size_t)en->h_trace[r]].data + 1;
+        const size_t np = std::min<size_t>((size_t)std::max(npts[r], 0), cap);
+        for (size_t k = 0; k < np; ++k) {
+            float* q = latlon + (r * cap + k) * 2;
+            const float x = q[0], z = q[1];
+            q[0] = (pi / 2 - x) * 180.0f / pi;
+            q[1] = z * 180.0f / pi;
+        }
+    }
+    return 0;
 }
 
 int dsa_set_maps(dsa_engine* e, int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int dicing, int nmaps, const double* pv)

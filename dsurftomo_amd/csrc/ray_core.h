@@ -88,10 +88,19 @@ DSA_HD bool refined_cell_alive(const SourceDesc& s, const int8_t* Sr, int ipxr, 
     return Sr[o] == 0 && Sr[o + 1] == 0 && Sr[o + s.rnz] == 0 && Sr[o + s.rnz + 1] == 0;
 }
 
+// Optional record of the ray's points (the reference's rgx / rgz arrays, CalSurfG.f90:1910-1911, :2043-2076: the receiver,
+// the end point of every step after clamping, finally the source), which its disabled dump would write to raypath.out
+// (:2276-2283): up to `cap` (colatitude, longitude) pairs in radians; n counts all points of the ray.
+struct RayPath {
+    float* pts = nullptr;
+    int cap = 0, n = 0;
+    DSA_HDM void push(float x, float z) { if (pts && n < cap) { pts[2 * n] = x; pts[2 * n + 1] = z; } n += 1; }
+};
+
 // returns 0, or -1 when the receiver lies outside the grid; *flags bit 0 = the ray was clamped at
 // the model edge (reference rbint), *nsteps = gradient steps taken
 DSA_HD int trace_ray(const GridDesc& g, const SourceDesc& s, const RayFields& f, float rcx, float rcz,
-                     float dpl_cell, float* slab, int* flags, int* nsteps)
+                     float dpl_cell, float* slab, int* flags, int* nsteps, RayPath* path = nullptr)
 {
     const int nnx = g.nnx, nnz = g.nnz;
     const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, earth = g.earth;
@@ -117,6 +126,7 @@ DSA_HD int trace_ray(const GridDesc& g, const SourceDesc& s, const RayFields& f,
     int ipzr = (int)((rcz - gozr) / dnzr) + 1;
     bool igref = refined_cell_alive(s, f.Sr, ipxr, ipzr);
     if (!sw && igref && ipxr == isx && ipzr == isz) sw = true;
+    if (path) { path->push(rgx, rgz); if (sw) path->push(scx, scz); }
 
     PatchAcc acc;
     acc.init(slab, g.nvx + 2);
@@ -164,6 +174,7 @@ DSA_HD int trace_ray(const GridDesc& g, const SourceDesc& s, const RayFields& f,
         if (ipx >= nnx) { rgx1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; *flags |= 1; }
         if (ipz < 1) { rgz1 = goz; ipz = 1; *flags |= 1; }
         if (ipz >= nnz) { rgz1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; *flags |= 1; }
+        if (path) { path->push(rgx1, rgz1); if (sw) path->push(scx, scz); }
 
         // split the segment where it crosses a vertex-cell face (reference :2112-2156)
         const int ivx = (ipx - 1) / gdx + 1, ivz = (ipz - 1) / gdz + 1;

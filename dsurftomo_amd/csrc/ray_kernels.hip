@@ -15,7 +15,8 @@ namespace dsa {
 __global__ __launch_bounds__(64) void k_rays(GridDesc g, BatchPtrs b, int unit_base, const RayDesc* __restrict__ rays,
                                              const int* __restrict__ trace_ids, int n, const float* __restrict__ veln_all,
                                              size_t field_stride, float dpl, float* __restrict__ slabs, size_t slab_stride,
-                                             int32_t* __restrict__ rayinfo, int32_t* __restrict__ err)
+                                             int32_t* __restrict__ rayinfo, int32_t* __restrict__ err,
+                                             float* __restrict__ paths, int path_cap, int* __restrict__ path_n)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -30,7 +31,10 @@ __global__ __launch_bounds__(64) void k_rays(GridDesc g, BatchPtrs b, int unit_b
     f.Tr = b.Tfin_r + slot * rr;
     f.Sr = b.S_r + slot * rr;
     int flags = 0, steps = 0;
-    const int rc = trace_ray(g, sd, f, rd.rx, rd.rz, dpl, slabs + (size_t)t * slab_stride, &flags, &steps);
+    RayPath path;
+    if (paths) { path.pts = paths + (size_t)t * (size_t)path_cap * 2; path.cap = path_cap; }
+    const int rc = trace_ray(g, sd, f, rd.rx, rd.rz, dpl, slabs + (size_t)t * slab_stride, &flags, &steps, paths ? &path : nullptr);
+    if (paths) path_n[t] = path.n;
     if (rc != 0) atomicExch(err, r + 1);
     rayinfo[2 * t] = flags;
     rayinfo[2 * t + 1] = steps;
@@ -38,11 +42,11 @@ __global__ __launch_bounds__(64) void k_rays(GridDesc g, BatchPtrs b, int unit_b
 
 void launch_rays(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, const int* d_trace_ids, int n,
                  const float* d_veln_all, size_t field_stride, float dpl, float* d_slabs, size_t slab_stride,
-                 int32_t* d_rayinfo, int32_t* d_err, hipStream_t stream)
+                 int32_t* d_rayinfo, int32_t* d_err, float* d_paths, int path_cap, int* d_path_n, hipStream_t stream)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_rays, dim3((n + 63) / 64), dim3(64), 0, stream, g, b, unit_base, d_rays, d_trace_ids, n, d_veln_all,
-                       field_stride, dpl, d_slabs, slab_stride, d_rayinfo, d_err);
+                       field_stride, dpl, d_slabs, slab_stride, d_rayinfo, d_err, d_paths, path_cap, d_path_n);
 }
 
 // ---------------------------------------------------------------------------------------------

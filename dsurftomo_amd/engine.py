@@ -59,6 +59,7 @@ def load_library():
     L.dsa_get_velocity.argtypes = [_vp, _i32, _vp]
     L.dsa_get_refined.argtypes = [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]
     L.dsa_get_stats.argtypes = [_vp, _vp]
+    L.dsa_ray_paths.argtypes = [_vp, _vp, _vp, _vp]
     L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]
     L.dsa_spmv.argtypes = [_vp, _i32, _vp, _vp]
     L.dsa_lsmr.argtypes = [_vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp] + [_vp] * 7
@@ -154,6 +155,17 @@ class Engine:
         self._check(self._L.dsa_solve_rows(self._h, _p(out), _p(rw), _p(iw), _p(col), capacity, C.byref(nar)))
         n = nar.value
         return out, rw[:n].copy(), iw[:n].copy(), col[:n].copy()
+
+    def ray_paths(self, cap):
+        """paths of the rays traced by the last solve_rows (set_option('ray_path_cap', cap) before it): list of
+        (datum, points) with points an (n, 2) array of (latitude, longitude) in degrees, receiver first, source last --
+        what the reference's disabled dump writes to raypath.out (CalSurfG.f90:2276-2283)"""
+        nr = int(self.stats()["rays"])
+        datum = np.zeros(nr, np.int32); npts = np.zeros(nr, np.int32); pts = np.zeros((nr, cap, 2), np.float32)
+        self._check(self._L.dsa_ray_paths(self._h, _p(datum), _p(npts), _p(pts)))
+        if (npts > cap).any():
+            raise RuntimeError("ray_paths: a ray has %d points, more than ray_path_cap = %d" % (int(npts.max()), cap))
+        return [(int(datum[r]), pts[r, :npts[r]].copy()) for r in range(nr)]
 
     # ---- dispersion stage ------------------------------------------------------------------------
     def dispersion_begin(self, vels, depz, minthk, kmax_total, nmaps_total):

@@ -166,3 +166,13 @@ def call_synthetic(c, noiselevel=0.0):
     if rc != 0:
         raise RuntimeError("dsa_synthetic: %s" % lib.dsa_dropin_error().decode())
     return obst
+
+
+def write_raypaths(path, paths):
+    """raypath.out as the reference's (disabled) dump writes it and its scripts/plotpath.py reads it
+    (CalSurfG.f90:2276-2283): '# nrp', then nrp lines 'latitude longitude' in degrees.  paths: Engine.ray_paths()."""
+    with open(path, "w") as fh:
+        for _, pts in paths:
+            fh.write(" # %11d\n" % len(pts))
+            for lat, lon in pts:
+                fh.write("  %14.7f  %14.7f\n" % (lat, lon))

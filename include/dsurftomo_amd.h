@@ -120,6 +120,12 @@ int dsa_solve(dsa_engine* e, float* dsurf);
 int dsa_solve_rows(dsa_engine* e, float* dsurf, float* rw, int* iw, int* col, long long capacity,
                    long long* nar);
 
+/* Ray paths (the reference's disabled raypath.out dump, CalSurfG.f90:2276-2283, read by its
+ * scripts/plotpath.py): with dsa_set_option(e, "ray_path_cap", C) the next dsa_solve_rows keeps up to C points per traced
+ * ray.  For the R traced rays (DSA_STAT_RAYS) in data order: datum[R] 1-based row, npts[R] points of the ray (may exceed
+ * C), latlon[R * C * 2] (latitude, longitude) in degrees: receiver first, source last. */
+int dsa_ray_paths(dsa_engine* e, int* datum, int* npts, float* latlon);
+
 /* ---- next to the path: the matrix-vector products of the inversion step (reference aprod.f90:7-60) ----
  * load: COO matrix (rw[k], 1-based row[k] <= m, col[k] <= n), kept on the device in row-major and
  * column-major order; spmv mode 1: y += A x, mode 2: x += A^T y on host vectors x[n], y[m].

@@ -685,6 +685,17 @@ static float cell_velocity(const dso_grid *g, const float *veln, int ipx, int ip
     return vel;
 }
 
+/* optional record of the ray's points rgx(j), rgz(j) (CalSurfG.f90:1910-1911, :2043-2076: receiver, every step's end
+ * point after clamping, finally the source) for dso_rpaths_path below: what the reference's disabled dump
+ * (:2276-2283, raypath.out) would write */
+static _Thread_local float *t_path = NULL;
+static _Thread_local int t_path_cap = 0, t_path_n = 0;
+static void path_push(float x, float z)
+{
+    if (t_path && t_path_n < t_path_cap) { t_path[2 * t_path_n] = x; t_path[2 * t_path_n + 1] = z; }
+    t_path_n += 1;
+}
+
 int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const float *ttn,
                const float *ttnr, const int *nstsr, float scx, float scz, float surfrcx, float surfrcz,
                float *fdm, int *rbint, int *nsteps)
@@ -712,10 +723,11 @@ int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const flo
     if (sw) return -1;
 
     float rgx = surfrcx, rgz = surfrcz;
+    path_push(rgx, rgz);
     float sred = p2((scx - rgx) * earth);
     sred = sred + p2((scz - rgz) * earth * sinf(rgx));
     sred = sqrtf(sred);
-    if (sred < 2.0f * dpl) sw = 1;
+    if (sred < 2.0f * dpl) { sw = 1; path_push(scx, scz); }
 
     int ipxr = (int)((surfrcx - goxr) / dnxr) + 1;
     int ipzr = (int)((surfrcz - gozr) / dnzr) + 1;
@@ -726,7 +738,7 @@ int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const flo
         if (AT(nstsr, ldr, ipzr, ipxr) != 0 || AT(nstsr, ldr, ipzr + 1, ipxr) != 0) igref = 0;
         if (AT(nstsr, ldr, ipzr, ipxr + 1) != 0 || AT(nstsr, ldr, ipzr + 1, ipxr + 1) != 0) igref = 0;
     }
-    if (!sw && igref && ipxr == isx && ipzr == isz) sw = 1;
+    if (!sw && igref && ipxr == isx && ipzr == isz) { sw = 1; path_push(scx, scz); }
 
     for (long j = 1; j <= maxrp; ++j) {
         if (sw) break;
@@ -775,6 +787,8 @@ int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const flo
         if (ipx >= nnx) { rgx1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; *rbint = 1; }
         if (ipz < 1) { rgz1 = goz; ipz = 1; *rbint = 1; }
         if (ipz >= nnz) { rgz1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; *rbint = 1; }
+        path_push(rgx1, rgz1);
+        if (sw) path_push(scx, scz);
 
         /* split the segment at B-spline cell faces (:2112-2156) */
         const int ivx = (ipx - 1) / gdx + 1, ivz = (ipz - 1) / gdz + 1;
@@ -851,6 +865,19 @@ int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const flo
         rgx = rgx1; rgz = rgz1;
     }
     return 0;
+}
+
+/* dso_rpaths plus the ray's points: path gets up to cap (colatitude, longitude) pairs in radians, *npath the number
+ * of points the ray has (it may exceed cap) */
+int dso_rpaths_path(const dso_grid *g, const dso_box *b, const float *veln, const float *ttn,
+                    const float *ttnr, const int *nstsr, float scx, float scz, float surfrcx, float surfrcz,
+                    float *fdm, int *rbint, int *nsteps, float *path, int cap, int *npath)
+{
+    t_path = path; t_path_cap = cap; t_path_n = 0;
+    const int rc = dso_rpaths(g, b, veln, ttn, ttnr, nstsr, scx, scz, surfrcx, surfrcz, fdm, rbint, nsteps);
+    *npath = t_path_n;
+    t_path = NULL; t_path_cap = 0;
+    return rc;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -74,6 +74,10 @@ int dso_srtimes(const dso_grid *g, const float *veln, const float *ttn,
 int dso_rpaths(const dso_grid *g, const dso_box *b, const float *veln, const float *ttn,
                const float *ttnr, const int *nstsr, float sx, float sz, float rx, float rz,
                float *fdm, int *rbint, int *nsteps);
+/* the same with the ray's points (what the reference's disabled raypath.out dump, CalSurfG.f90:2276-2283, would write) */
+int dso_rpaths_path(const dso_grid *g, const dso_box *b, const float *veln, const float *ttn,
+                    const float *ttnr, const int *nstsr, float scx, float scz, float surfrcx, float surfrcz,
+                    float *fdm, int *rbint, int *nsteps, float *path, int cap, int *npath);
 
 /* dispersion side (surfdisp_oracle.c) ------------------------------------------------------- */
 

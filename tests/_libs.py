@@ -152,6 +152,25 @@ def o_rpaths(g, sol, veln, sx, sz, rx, rz):
     return fdm, rb.value, ns.value
 
 
+def o_ray_path(g, sol, veln, sx, sz, rx, rz, cap=1 << 16):
+    """points of the ray (latitude, longitude in degrees, the reference's conversion at CalSurfG.f90:2279-2280)"""
+    O = oracle()
+    O.dso_rpaths_path.argtypes = [C.POINTER(Grid), C.POINTER(Box), vp, vp, vp, vp, f32, f32, f32, f32, vp, C.POINTER(i32), C.POINTER(i32), vp, i32, C.POINTER(i32)]
+    fdm = np.zeros((g.nvx + 2, g.nvz + 2), np.float32)
+    rb, ns, n = i32(0), i32(0), i32(0)
+    path = np.zeros((cap, 2), np.float32)
+    rc = O.dso_rpaths_path(C.byref(g), C.byref(sol["box"]), ptr(veln), ptr(sol["T"]), ptr(np.ascontiguousarray(sol["Tr"])),
+                           ptr(np.ascontiguousarray(sol["Sr"])), sx, sz, rx, rz, ptr(fdm), C.byref(rb), C.byref(ns), ptr(path), cap, C.byref(n))
+    if rc != 0:
+        raise ValueError("receiver outside grid")
+    assert n.value <= cap
+    p = path[:n.value]
+    pi = np.float32(3.1415926535898)
+    lat = (pi / np.float32(2) - p[:, 0]) * np.float32(180.0) / pi
+    lon = p[:, 1] * np.float32(180.0) / pi
+    return np.stack([lat, lon], axis=1).astype(np.float32)
+
+
 class RefWB:
     """White-box session on the reference library (module-global state: one at a time)."""
 

@@ -136,6 +136,57 @@ def test_engine_rows_from_host_kernels(max_chunk, ray_budget):
     assert st["rays"] == c["ndata"] and st["nar"] == rw.size
 
 
+@pytest.mark.parametrize("ray_budget", [0, 40000])
+def test_ray_paths_against_oracle(ray_budget, tmp_path):
+    """the points of every traced ray (option ray_path_cap; what the reference's disabled raypath.out dump would hold,
+    CalSurfG.f90:2276-2283) against the oracle's ray tracer, bit for bit; second variant: a few rays per launch"""
+    from dsurftomo_amd.engine import Engine
+    from dsurftomo_amd import io
+    c = synth.boundary_case(kRc=2, kRg=0, kLc=0, kLg=0)
+    vel = np.ascontiguousarray(c["vels"].T)
+    pv, svs, svp, srho = L.depthkernel("oracle", vel, c["depz"], float(c["minthk"]), 2, 0, c["tRc"])
+    maps, sx, sz, nrec, rx, rz, slot = [], [], [], [], [], [], []
+    for k in range(c["kmax"]):
+        for s in range(c["nsrcsurf1"][k]):
+            maps.append(c["periods"][s, k] - 1); sx.append(c["scxf"][s, k]); sz.append(c["sczf"][s, k]); slot.append(k)
+            nrec.append(c["nrc1"][s, k])
+            rx += list(c["rcxf"][:nrec[-1], s, k]); rz += list(c["rczf"][:nrec[-1], s, k])
+    cap = 4096
+    e = Engine(0)
+    try:
+        e.set_option("ray_budget", ray_budget)
+        e.set_option("ray_path_cap", cap)
+        e.set_maps(c["nx"], c["ny"], c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], pv)
+        e.set_depth_kernels(vel, c["depz"], svs, svp, srho)
+        e.plan(maps, sx, sz, nrec, rx, rz, sen_slot=slot)
+        e.solve_rows(c["ndata"] * c["nparpi"])
+        paths = e.ray_paths(cap)
+    finally:
+        e.close()
+    assert [d for d, _ in paths] == list(range(1, c["ndata"] + 1))
+    g = L.grid(c["nx"], c["ny"], c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], 8)
+    r = 0
+    for u in range(len(maps)):
+        veln = L.o_gridder(g, pv[maps[u]])
+        sol = L.o_solve(g, pv[maps[u]], veln, sx[u], sz[u])
+        for q in range(nrec[u]):
+            want = L.o_ray_path(g, sol, veln, sx[u], sz[u], rx[r], rz[r])
+            got = paths[r][1]
+            assert got.shape == want.shape and (got.view(np.uint32) == want.view(np.uint32)).all(), (u, q)
+            assert len(got) >= 2
+            r += 1
+    # receiver first, source last, in degrees
+    lat0 = 90.0 - np.degrees(rx[0]); lon0 = np.degrees(rz[0])
+    assert abs(paths[0][1][0, 0] - lat0) < 1e-4 and abs(paths[0][1][0, 1] - lon0) < 1e-4
+    assert abs(paths[0][1][-1, 0] - (90.0 - np.degrees(sx[0]))) < 1e-4
+    # the reference's file format: '# nrp' then one 'lat lon' line per point (its scripts/plotpath.py reads that)
+    out = str(tmp_path / "raypath.out")
+    io.write_raypaths(out, paths)
+    lines = open(out).read().split("\n")
+    assert lines[0].split() == ["#", str(len(paths[0][1]))] and len(lines[1].split()) == 2
+    assert sum(1 for l in lines if l.lstrip().startswith("#")) == len(paths)
+
+
 def test_fortran_shim(tmp_path):
     """calsurfg_ / synthetic_ through the flang-built shim and a Fortran caller"""
     exe = os.path.join(L.ROOT, "tests", "build", "shim_driver")
