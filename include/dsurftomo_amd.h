@@ -49,14 +49,16 @@ const char* dsa_error_string(const dsa_engine* e);   /* e may be NULL: last crea
 /* memory the engine may use for per-source fields (bytes, 0 = default: 60 % of free HBM, at most 150 GB) */
 int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 
-/* tuning knobs: "window_cells" (causal window of the fixed-point solve, in cell travel times,
- * default 0.4), "max_chunk" (cap on sources resident per chunk, 0 = memory budget only),
- * "list_cap" / "ready_cap" (active-list sizes of the solve kernel, 0 = derived from the grid),
- * "fim_threads" (workgroup size of the solve kernel: 256, 512 or 1024), "fim_sorted" (1, default = the
- * solve kernel that keeps its active set in tile masks and walks it in record order; 0 = the variant
- * with lists in activation order; same fixed point), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits
- * the workgroups resident per CU), "ray_budget" (bytes of
- * per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up to 8 GB) */
+/* options: "window_cells" (causal window of the fixed-point solve, in cell travel times, default 1.25),
+ * "max_chunk" (cap on sources resident per chunk, 0 = memory budget only), "list_cap" / "ready_cap" (active-list
+ * sizes of the list variant of the solve kernel, 0 = derived from the grid), "fim_threads" (workgroup size of the
+ * solve kernel: 128, 256 (default), 512 or 1024), "fim_sorted" (1, default = the solve kernel that keeps its active
+ * set in tile masks and walks it in record order; 0 = the variant with lists in activation order; same fixed
+ * point), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits the workgroups resident
+ * per CU), "ray_budget" (bytes of per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up
+ * to 8 GB), "ray_path_cap" (points kept per traced ray for dsa_ray_paths, 0 = none), "disp_layers_lds" (layer
+ * tables of the dispersion kernel: 1 LDS, 0 global scratch, -1 default = LDS when they fit), "lsmr_device_vectors"
+ * (dsa_lsmr: 0 default = ordered reductions on the host, 1 = all vectors on the device; same results) */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
 
 /* ---- engine level --------------------------------------------------------------------------- */
