@@ -43,6 +43,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(obj)
         extra = ["-D" + d for d in os.environ.get("DSA_DEFINES", "").split() if d]     # experiments only
+        extra += os.environ.get("DSA_EXTRA_FLAGS", "").split()                          # experiments only (compiler switches)
         cmd = [hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
