@@ -59,7 +59,7 @@ struct Engine {
     DevBuf<Rec> F_r, F_c;
     DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists;
     size_t lists_stride = 0;
-    int fim_threads = 256;
+    int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)
     int fim_lds_pad = 0;               // dynamic LDS bytes per workgroup of the solve kernel (occupancy limiter)
     int fim_sorted = 1;                // 1: k_fim_sorted (tile masks, record-order sweep), 0: k_fim (lists); same fixed point
     DevBuf<int8_t> S_r, cinit;

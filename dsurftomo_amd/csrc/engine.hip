@@ -447,7 +447,11 @@ FimLaunch Engine::launch_shape(int nnx, int nnz) const
     FimLaunch l;
     l.list_cap = list_cap > 0 ? list_cap : 16 * (nnx + nnz) + 4096;
     l.ready_cap = ready_cap > 0 ? ready_cap : 8 * (nnx + nnz) + 2048;
-    l.threads = fim_threads;
+    // workgroup size of the solve: a front of an N x N grid is a few N nodes long and a round evaluates about a third of
+    // it, so the lanes a front can use grow with N (measured: 1025^2 256 threads 7500 solves/s against 6300 with 512;
+    // 2049^2 512 threads 1890 against 1430 with 256 and 1580 with 1024; 4097^2 1024 threads 407 against 240 with 256)
+    const int longest = std::max(nnx, nnz);
+    l.threads = fim_threads > 0 ? fim_threads : (longest > 3000 ? 1024 : longest > 1500 ? 512 : 256);
     l.lds_pad = fim_lds_pad;
     // the ordered variant keeps a tile bitmap in LDS: up to 32 KB per workgroup (N <= 4097)
     const int ntile = tiles_of(nnx) * tiles_of(nnz);
@@ -654,7 +658,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "ray_path_cap" && value >= 0 && value <= (1 << 24)) { en->ray_path_cap = (int)value; return 0; }
     if (n == "disp_layers_lds" && (value == -1 || value == 0 || value == 1)) { en->disp_layers_lds = (int)value; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
-    if (n == "fim_threads" && (value == 128 || value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
+    if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;
 }

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     auto rec = [&](int id) -> GRec* { return (GRec*)(Fb + ((unsigned)id << 3)); };
     auto slow_at = [&](int id) -> float { return *(GCF32*)(slowb + ((unsigned)id << 2)); };
     auto mask_at = [&](int tile) -> GU64* { return (GU64*)(maskb + ((unsigned)tile << 3)); };
-    constexpr int rhalf = 1024;                              // ready nodes of one colour a round can take
+    constexpr int rhalf = NT * 4;                            // ready nodes of one colour a round can take (8 per thread: no gain)
     __shared__ int ready[2 * rhalf];                         // (the rest stay in their masks for the next round)
     unsigned* const tb = dyn_lds;                            // tile bitmap, nwords
     auto ld = [&](int id) { Rec r; r.T = rec(id)->T; r.tau = rec(id)->tau; return r; };
