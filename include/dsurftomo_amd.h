@@ -52,7 +52,7 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 /* options: "window_cells" (causal window of the fixed-point solve, in cell travel times, default 1.25),
  * "max_chunk" (cap on sources resident per chunk, 0 = memory budget only), "list_cap" / "ready_cap" (active-list
  * sizes of the list variant of the solve kernel, 0 = derived from the grid), "fim_threads" (workgroup size of the
- * solve kernel: 128, 256, 512 or 1024; 0 default = 256 up to 1500 nodes per side, 512 up to 3000, 1024 beyond), "fim_sorted" (1, default = the solve kernel that keeps its active
+ * solve kernel: 128, 256, 512 or 1024; 0 default = 128 up to 700 nodes per side, 256 up to 1500, 512 up to 3000, 1024 beyond), "fim_sorted" (1, default = the solve kernel that keeps its active
  * set in tile masks and walks it in record order; 0 = the variant with lists in activation order; same fixed
  * point), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits the workgroups resident
  * per CU), "ray_budget" (bytes of per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up
