@@ -16,9 +16,14 @@ constexpr int kMaxDepths = 64;
 template <int IFUNC>
 __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__ G, const float* __restrict__ vels, int ncol,
                                                    int npert, int igr, int kmax, const double* __restrict__ t,
-                                                   float* __restrict__ ws, size_t nlanes, double* __restrict__ curves, int layers_in_lds)
+                                                   float* __restrict__ ws, size_t nlanes, double* __restrict__ curves, int layers_in_lds,
+                                                   int gshift)
 {
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // gshift > 0 (Rayleigh, few curves): 2^gshift neighbouring lanes share one curve -- see Layers::gsize.  A curve is one
+    // dependent chain of ~20 000 layer matrices; with one lane per curve a call with 324 columns keeps a quarter of the
+    // SIMDs busy with one wavefront each.
+    const size_t lane_id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tid = lane_id >> gshift;                  // curve
     if (tid >= (size_t)ncol * npert) return;
     const int p = (int)(tid / ncol), c = (int)(tid - (size_t)p * ncol);
     const int nz = G->nz;
@@ -35,14 +40,19 @@ __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__
         arr[i] = s ? base + 0.5f * dln * base : base - 0.5f * dln * base;
     }
     Layers m;
+    extern __shared__ __attribute__((aligned(16))) float lds_layers[];
     if (layers_in_lds) {
-        // the layer table of the 64 curves of this wavefront in LDS ([layer][lane]: conflict free): the secular function
-        // walks it once per evaluation, ~25 evaluations per root, and a curve is one dependent chain -- with the table in
-        // global scratch a call with few curves (324 columns) ran at the latency of those loads
-        extern __shared__ float lds_layers[];
-        const int lane = threadIdx.x, plane = G->rmax * 64;
-        m.d = lds_layers + lane; m.a = lds_layers + plane + lane; m.b = lds_layers + 2 * plane + lane; m.rho = lds_layers + 3 * plane + lane;
-        m.stride = 64;
+        // the layer table of the curves of this wavefront in LDS ([layer][curve]: conflict free): the secular function
+        // walks it once per evaluation, ~25 evaluations per root (the lanes of a group write the same table)
+        const int slot = (int)(threadIdx.x >> gshift), per = 64 >> gshift, plane = G->rmax * per;
+        m.d = lds_layers + slot; m.a = lds_layers + plane + slot; m.b = lds_layers + 2 * plane + slot; m.rho = lds_layers + 3 * plane + slot;
+        m.stride = (size_t)per;
+        if (gshift > 0) {
+            m.gsize = 1 << gshift;
+            m.gsub = (int)(threadIdx.x & (m.gsize - 1));
+            double* xbase = reinterpret_cast<double*>(lds_layers + 4 * plane);                    // 16 * plane bytes in: 8-byte aligned
+            m.xch = xbase + (size_t)slot * m.gsize * 15;
+        }
     } else {
         const size_t plane = (size_t)G->rmax * nlanes;
         m.d = ws + tid; m.a = ws + plane + tid; m.b = ws + 2 * plane + tid; m.rho = ws + 3 * plane + tid;
@@ -53,14 +63,17 @@ __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__
 }
 
 void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
-                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, hipStream_t stream)
+                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, int gshift,
+                       hipStream_t stream)
 {
-    const size_t n = (size_t)ncol * npert;
+    const size_t n = ((size_t)ncol * npert) << gshift;
     if (n == 0) return;
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    const size_t lds = layers_in_lds ? (size_t)4 * rmax * 64 * sizeof(float) : 0;
-    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds);
-    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds);
+    const int per = 64 >> gshift;
+    size_t lds = layers_in_lds ? (size_t)4 * rmax * per * sizeof(float) : 0;
+    if (gshift > 0) lds += 8 + (size_t)64 * 15 * sizeof(double);
+    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, 0);
+    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift);
 }
 
 // pv(c, k) = curve 0; sen_q(c, slot0 + k, i) = (cg(+) - cg(-)) / dble(dln * base_q(i)), CalSurfG.f90:76-150

@@ -38,6 +38,11 @@ struct Layers {
     float* d; float* a; float* b; float* rho;
     size_t stride;
     int mmax, llw;
+    // Optional lane group (device, Rayleigh): `gsize` lanes of one wavefront work on the same curve, all running the same
+    // root search; inside the secular function lane `gsub` forms the layer matrix of every gsize-th layer and the lanes
+    // exchange the matrices through `xch` (15 doubles per lane, LDS).  gsize = 1: one lane per curve.
+    double* xch = nullptr;
+    int gsize = 1, gsub = 0;
     DSA_HDM float D(int k) const { return d[(size_t)k * stride]; }      // k 0-based
     DSA_HDM float A(int k) const { return a[(size_t)k * stride]; }
     DSA_HDM float B(int k) const { return b[(size_t)k * stride]; }
@@ -165,55 +170,57 @@ DSA_HD double dltar4(const Layers& m, double wvno, double omga)
         e3 = rho1 * rb;
         e4 = wvno2 - ra * rb;
     }
-    for (int k = mmax - 1; k >= m.llw; --k) {
+    const double tt = -2.0 * wvno2;
+    // layer matrix of layer k (compound matrix ca(i, j), named cIJ; the entries that are copies or tt-multiples of others
+    // are formed in the product step)
+    auto layer_matrix = [&](int k, double* c) {
         const double ak = (double)m.A(k - 1), bk = (double)m.B(k - 1);
-        xka = omega / ak;
-        xkb = omega / bk;
-        t = bk / omega;
-        gammk = 2.0 * t * t;
-        gam = gammk * wvno2;
-        wvnop = wvno + xka;
-        wvnom = fabs(wvno - xka);
-        ra = sqrt(wvnop * wvnom);
-        wvnop = wvno + xkb;
-        wvnom = fabs(wvno - xkb);
-        rb = sqrt(wvnop * wvnom);
+        const double xka_ = omega / ak;
+        const double xkb_ = omega / bk;
+        const double t_ = bk / omega;
+        const double gammk_ = 2.0 * t_ * t_;
+        const double gam_ = gammk_ * wvno2;
+        double wp = wvno + xka_;
+        double wm = fabs(wvno - xka_);
+        const double ra_ = sqrt(wp * wm);
+        wp = wvno + xkb_;
+        wm = fabs(wvno - xkb_);
+        const double rb_ = sqrt(wp * wm);
         const double dpth = (double)m.D(k - 1);
         const double rho = (double)m.R(k - 1);
-        layer_terms(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, o);
-        // compound matrix ca(i, j), named cIJ
+        LayerTerms o;
+        layer_terms(ra_ * dpth, rb_ * dpth, ra_, rb_, wvno, xka_, xkb_, dpth, o);
         const double one = 1.0, two = 2.0;
-        const double gamm1 = gam - one;
-        const double twgm1 = gam + gamm1;
-        const double gmgmk = gam * gammk;
-        const double gmgm1 = gam * gamm1;
+        const double gamm1 = gam_ - one;
+        const double twgm1 = gam_ + gamm1;
+        const double gmgmk = gam_ * gammk_;
+        const double gmgm1 = gam_ * gamm1;
         const double gm1sq = gamm1 * gamm1;
         const double rho2 = rho * rho;
         const double a0pq = o.a0 - o.cpcq;
-        const double c11 = o.cpcq - two * gmgm1 * a0pq - gmgmk * o.xz - wvno2 * gm1sq * o.wy;
-        const double c12 = (wvno2 * o.cpy - o.cqx) / rho;
-        const double c13 = -(twgm1 * a0pq + gammk * o.xz + wvno2 * gamm1 * o.wy) / rho;
-        const double c14 = (o.cpz - wvno2 * o.cqw) / rho;
-        const double c15 = -(two * wvno2 * a0pq + o.xz + wvno2 * wvno2 * o.wy) / rho2;
-        const double c21 = (gmgmk * o.cpz - gm1sq * o.cqw) * rho;
-        const double c22 = o.cpcq;
-        const double c23 = gammk * o.cpz - gamm1 * o.cqw;
-        const double c24 = -o.wz;
-        const double c25 = c14;
-        const double c41 = (gm1sq * o.cpy - gmgmk * o.cqx) * rho;
-        const double c42 = -o.xy;
-        const double c43 = gamm1 * o.cpy - gammk * o.cqx;
-        const double c44 = c22;
-        const double c45 = c12;
-        const double c51 = -(two * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * o.xz + gm1sq * gm1sq * o.wy) * rho2;
-        const double c52 = c41;
-        const double c53 = -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * o.xz + gamm1 * gm1sq * o.wy) * rho;
-        const double c54 = c21;
-        const double c55 = c11;
-        const double tt = -two * wvno2;
+        c[0] = o.cpcq - two * gmgm1 * a0pq - gmgmk * o.xz - wvno2 * gm1sq * o.wy;                      // c11
+        c[1] = (wvno2 * o.cpy - o.cqx) / rho;                                                          // c12
+        c[2] = -(twgm1 * a0pq + gammk_ * o.xz + wvno2 * gamm1 * o.wy) / rho;                           // c13
+        c[3] = (o.cpz - wvno2 * o.cqw) / rho;                                                          // c14
+        c[4] = -(two * wvno2 * a0pq + o.xz + wvno2 * wvno2 * o.wy) / rho2;                             // c15
+        c[5] = (gmgmk * o.cpz - gm1sq * o.cqw) * rho;                                                  // c21
+        c[6] = o.cpcq;                                                                                 // c22
+        c[7] = gammk_ * o.cpz - gamm1 * o.cqw;                                                         // c23
+        c[8] = -o.wz;                                                                                  // c24
+        c[9] = (gm1sq * o.cpy - gmgmk * o.cqx) * rho;                                                  // c41
+        c[10] = -o.xy;                                                                                 // c42
+        c[11] = gamm1 * o.cpy - gammk_ * o.cqx;                                                        // c43
+        c[12] = -(two * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * o.xz + gm1sq * gm1sq * o.wy) * rho2;    // c51
+        c[13] = -(gammk_ * gamm1 * twgm1 * a0pq + gam_ * gammk_ * gammk_ * o.xz + gamm1 * gm1sq * o.wy) * rho;   // c53
+        c[14] = o.a0 + two * (o.cpcq - c[0]);                                                          // c33
+    };
+    // e <- normalised e * ca
+    auto product_step = [&](const double* c) {
+        const double c11 = c[0], c12 = c[1], c13 = c[2], c14 = c[3], c15 = c[4], c21 = c[5], c22 = c[6], c23 = c[7], c24 = c[8];
+        const double c41 = c[9], c42 = c[10], c43 = c[11], c51 = c[12], c53 = c[13], c33 = c[14];
+        const double c25 = c14, c44 = c22, c45 = c12, c52 = c41, c54 = c21, c55 = c11;
         const double c31 = tt * c53;
         const double c32 = tt * c43;
-        const double c33 = o.a0 + two * (o.cpcq - c11);
         const double c34 = tt * c23;
         const double c35 = tt * c13;
         // ee(i) = sum_j e(j) ca(j, i), accumulated from zero in j order
@@ -231,6 +238,37 @@ DSA_HD double dltar4(const Layers& m, double wvno, double omga)
         if (fabs(n4) > t1) t1 = fabs(n4);
         if (t1 < 1.e-40) t1 = 1.0;
         e0 = n0 / t1; e1 = n1 / t1; e2 = n2 / t1; e3 = n3 / t1; e4 = n4 / t1;
+    };
+    if (m.gsize <= 1) {
+        for (int k = mmax - 1; k >= m.llw; --k) {
+            double c[15];
+            layer_matrix(k, c);
+            product_step(c);
+        }
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the lanes of a group take one layer each, park its matrix in LDS, then every lane multiplies the group's
+        // matrices in layer order (DS operations of a wavefront execute in order)
+        const int K = m.gsize;
+        for (int kb = mmax - 1; kb >= m.llw; kb -= K) {
+            const int k = kb - m.gsub;
+            if (k >= m.llw) {
+                double c[15];
+                layer_matrix(k, c);
+                double* mine = m.xch + m.gsub * 15;
+                for (int i = 0; i < 15; ++i) mine[i] = c[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const int nb = (kb - m.llw + 1) < K ? (kb - m.llw + 1) : K;
+            for (int j = 0; j < nb; ++j) {
+                double c[15];
+                const double* theirs = m.xch + j * 15;
+                for (int i = 0; i < 15; ++i) c[i] = theirs[i];
+                product_step(c);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+#endif
     }
     if (m.llw != 1) {
         // water layer on top

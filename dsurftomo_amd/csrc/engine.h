@@ -92,6 +92,7 @@ struct Engine {
     DevBuf<LayerGeom> geom;
     DevBuf<double> pvstore, curves, tper;
     DevBuf<float> disp_ws;
+    int disp_group_shift = -1;         // lanes per Rayleigh curve = 2^shift; -1 = by the number of curves, 0 = one lane per curve
     int disp_layers_lds = -1;          // layer tables of k_dispersion: 1 LDS, 0 global scratch, -1 LDS when they fit
 
     // optional growing host destination of the COO rows (used when several engines share one call)

@@ -9,6 +9,7 @@ c = synth.boundary_case(nx=nx, ny=nx, nz=nz, kRc=1, kRg=0, kLc=0, kLg=0, nsrc=1,
 vel = np.ascontiguousarray(c["vels"].T)
 t = np.linspace(2.0, 17.0, nper)
 e = Engine(0)
+if os.environ.get('DSA_DISP_GROUP'): e.set_option('disp_group_shift', int(os.environ['DSA_DISP_GROUP']))
 if os.environ.get('DSA_DISP_LDS'): e.set_option('disp_layers_lds', int(os.environ['DSA_DISP_LDS']))
 for iwave, igr, kern in ((2, 0, True), (2, 0, False), (2, 1, True), (1, 0, True)):
     e.dispersion_begin(vel, c["depz"], float(c["minthk"]), nper, nper)
