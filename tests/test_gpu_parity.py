@@ -43,7 +43,7 @@ CASES = [
 ]
 FRAC = [(0.43, 0.61), (1.4, 0.5), (0.985, 0.99), (5.0, 7.0), (0.93, 3.2), (0.5, 0.5), (16.0, 24.0), (1.0, 1.0), (0.0, 0.0),
         (0.21, 0.77), (0.66, 0.12),
-        # found by tools/fuzz_parity.py: 2.5 cells from the high-x edge at N = 121, where the refined stage ends early
+        # found by tests/tools/fuzz_parity.py: 2.5 cells from the high-x edge at N = 121, where the refined stage ends early
         # and the coarse tree starts out of order (a second-order leg must not use a node accepted after the
         # in-between node)
         (118.517, 70.504), (118.21, 27.555)]

@@ -74,7 +74,7 @@ def test_pipeline_against_oracle(H, nx, kind, gd):
     H.hc_gridder(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd, L.ptr(pv), L.ptr(vh))
     assert (bits(vh) != bits(veln)).sum() == 0
     frac = [(0.43 * N + 0.3, 0.61 * N + 0.6), (1.4, N / 2 + 0.2), (N - 2.5, N - 3.3), (N - 1.0, N - 1.0), (0.0, 0.0), (N * 0.7, N * 0.2),
-            (N - 2.483, 0.58 * N + 0.3)]       # out-of-order start of the coarse tree (found by tools/fuzz_parity.py)
+            (N - 2.483, 0.58 * N + 0.3)]       # out-of-order start of the coarse tree (found by tests/tools/fuzz_parity.py)
     worst, nbad = 0.0, 0
     for fx, fz in frac:
         sx = np.float32(g.gox + np.float32(fx) * g.dnx)

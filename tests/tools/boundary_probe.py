@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Whole-boundary probe on the GPU: dsa_calsurfg / dsa_synthetic / dispersion stage against the oracle.
 
-    python tools/boundary_probe.py [case ...]      (cases: default deep groups big)
+    python tests/tools/boundary_probe.py [case ...]      (cases: default deep groups big)
 Prints how many outputs are bit-identical and the largest differences.  Test infrastructure use of
 the oracle (tools are not part of the product path).
 """
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _libs as L      # noqa: E402

@@ -1,7 +1,7 @@
 """Fuzz the whole drop-in call against the oracle: random model sizes, period sets, station geometries.
-python tools/fuzz_boundary.py [ncases] [seed]"""
+python tests/tools/fuzz_boundary.py [ncases] [seed]"""
 import sys, os, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import synth, _libs as L
 from dsurftomo_amd import engine as E

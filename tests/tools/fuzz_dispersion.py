@@ -1,7 +1,7 @@
 """Fuzz the dispersion stage against the oracle: random depth grids, sublayering, velocity columns with
 low-velocity zones, short and long periods (where the root search may fail and the reference returns 0)."""
 import sys, os, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import synth, _libs as L
 from dsurftomo_amd.engine import Engine

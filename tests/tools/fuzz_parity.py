@@ -1,7 +1,7 @@
 """Fuzz the solve against the oracle: many random sources (incl. near edges / on nodes) on small grids,
-full-field comparison.  python tools/fuzz_parity.py [nsrc] [seed]"""
+full-field comparison.  python tests/tools/fuzz_parity.py [nsrc] [seed]"""
 import sys, os, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import synth, _libs as L
 from dsurftomo_amd.engine import Engine

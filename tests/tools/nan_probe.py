@@ -1,6 +1,6 @@
 """Robustness: a NaN / zero / negative velocity in the model must not hang the device (bounded loops)."""
 import sys, os, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import _libs as L, synth
 from dsurftomo_amd import engine as E
