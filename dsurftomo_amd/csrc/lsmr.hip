@@ -241,34 +241,47 @@ float host_nrm2(int n, const float* x)
 
 struct HostVectors {
     Engine* e; SpmvState& S; int m, n, localVecs; hipStream_t st;
-    std::vector<float> u, v, h, hbar, xs, localV;
+    float* u = nullptr; float* v = nullptr;        // pinned (SpmvState): they cross PCIe with every product
+    std::vector<float> h, hbar, xs, localV;
     HostVectors(Engine* e_, SpmvState& S_, int lv) : e(e_), S(S_), m(S_.m), n(S_.n), localVecs(lv), st(e_->stream) {}
+    int pinned(float** p, size_t* cap, size_t need)
+    {
+        if (*cap >= need) return 0;
+        if (*p) (void)hipHostFree(*p);
+        *p = nullptr; *cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(p), need * sizeof(float), hipHostMallocDefault) != hipSuccess) { e->fail(DSA_ERR_DEVICE, "lsmr: pinned host allocation of %zu floats failed", need); return DSA_ERR_DEVICE; }
+        *cap = need;
+        return 0;
+    }
     int setup(const float* b)
     {
         if (e->ensure(S.u, (size_t)m) || e->ensure(S.v, (size_t)n)) return e->status;
-        u.assign(b, b + m); v.assign((size_t)n, 0.0f); h.assign((size_t)n, 0.0f); hbar.assign((size_t)n, 0.0f); xs.assign((size_t)n, 0.0f);
+        if (pinned(&S.hu, &S.hu_cap, (size_t)m) || pinned(&S.hv, &S.hv_cap, (size_t)n)) return e->status;
+        u = S.hu; v = S.hv;
+        std::memcpy(u, b, (size_t)m * 4); std::fill(v, v + n, 0.0f);
+        h.assign((size_t)n, 0.0f); hbar.assign((size_t)n, 0.0f); xs.assign((size_t)n, 0.0f);
         localV.resize((size_t)n * (size_t)localVecs);
         return 0;
     }
-    int norm_u(float* out) { *out = host_nrm2(m, u.data()); return 0; }
-    int norm_v(float* out) { *out = host_nrm2(n, v.data()); return 0; }
+    int norm_u(float* out) { *out = host_nrm2(m, u); return 0; }
+    int norm_v(float* out) { *out = host_nrm2(n, v); return 0; }
     int norm_x(float* out) { *out = host_nrm2(n, xs.data()); return 0; }
     int scal_u(float a) { for (int i = 0; i < m; ++i) u[i] = a * u[i]; return 0; }
     int scal_v(float a) { for (int i = 0; i < n; ++i) v[i] = a * v[i]; return 0; }
     int product(int mode)
     {
-        LS_TRY(e, hipMemcpyAsync(S.u.p, u.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-        LS_TRY(e, hipMemcpyAsync(S.v.p, v.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        LS_TRY(e, hipMemcpyAsync(S.u.p, u, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        LS_TRY(e, hipMemcpyAsync(S.v.p, v, (size_t)n * 4, hipMemcpyHostToDevice, st));
         dsa::spmv_device(e, mode, S.v.p, S.u.p);
-        if (mode == 1) LS_TRY(e, hipMemcpyAsync(u.data(), S.u.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-        else LS_TRY(e, hipMemcpyAsync(v.data(), S.v.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        if (mode == 1) LS_TRY(e, hipMemcpyAsync(u, S.u.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+        else LS_TRY(e, hipMemcpyAsync(v, S.v.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         LS_TRY(e, hipGetLastError());
         LS_TRY(e, hipStreamSynchronize(st));
         return 0;
     }
     int aprod1() { return product(1); }
     int aprod2() { return product(2); }
-    int enqueue(int slot) { std::memcpy(localV.data() + (size_t)slot * (size_t)n, v.data(), (size_t)n * 4); return 0; }
+    int enqueue(int slot) { std::memcpy(localV.data() + (size_t)slot * (size_t)n, v, (size_t)n * 4); return 0; }
     int ortho(int lim)
     {
         for (int k = 0; k < lim; ++k) {
@@ -279,7 +292,7 @@ struct HostVectors {
         }
         return 0;
     }
-    int h_from_v() { h = v; return 0; }
+    int h_from_v() { h.assign(v, v + n); return 0; }
     int update(float c1, float c2, float c3)
     {
         for (int i = 0; i < n; ++i) {

@@ -205,6 +205,8 @@ void release_spmv(SpmvState* s)
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     rel(s->rowptr); rel(s->colptr); rel(s->val_r); rel(s->val_c); rel(s->x); rel(s->y); rel(s->col_r); rel(s->row_c);
     rel(s->u); rel(s->v); rel(s->h); rel(s->hbar); rel(s->xs); rel(s->localV); rel(s->scal);
+    if (s->hu) (void)hipHostFree(s->hu);
+    if (s->hv) (void)hipHostFree(s->hv);
     delete s;
 }
 }  // namespace dsa

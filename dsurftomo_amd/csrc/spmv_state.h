@@ -13,6 +13,9 @@ struct SpmvState {
     DevBuf<int> col_r, row_c;
     // LSMR work vectors (lsmr.hip)
     DevBuf<float> u, v, h, hbar, xs, localV, scal;
+    // pinned host copies of u and v for the host-vector placement (they cross PCIe twice per LSMR iteration)
+    float* hu = nullptr; float* hv = nullptr;
+    size_t hu_cap = 0, hv_cap = 0;
 };
 
 // y += A x (mode 1; x: n, y: m) or x += A^T y (mode 2) on device vectors, on the engine's stream; every output
