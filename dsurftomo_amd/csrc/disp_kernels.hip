@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__
                                                    float* __restrict__ ws, size_t nlanes, double* __restrict__ curves, int layers_in_lds,
                                                    int gshift)
 {
-    // gshift > 0 (Rayleigh, few curves): 2^gshift neighbouring lanes share one curve -- see Layers::gsize.  A curve is one
+    // gshift > 0 (few curves): 2^gshift neighbouring lanes share one curve -- see Layers::gsize.  A curve is one
     // dependent chain of ~20 000 layer matrices; with one lane per curve a call with 324 columns keeps a quarter of the
     // SIMDs busy with one wavefront each.
     const size_t lane_id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,7 +72,7 @@ void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, 
     const int per = 64 >> gshift;
     size_t lds = layers_in_lds ? (size_t)4 * rmax * per * sizeof(float) : 0;
     if (gshift > 0) lds += 8 + (size_t)64 * 15 * sizeof(double);
-    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, 0);
+    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift);
     else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift);
 }
 

@@ -63,28 +63,33 @@ DSA_HD double dltar1(const Layers& m, double wvno, double omega)
     double rb = sqrt(wvnop * wvnom);
     double e1 = rho1 * rb;
     double e2 = 1.0 / (beta1 * beta1);
-    for (int k = mmax - 1; k >= m.llw; --k) {
-        beta1 = (double)m.B(k - 1);
-        rho1 = (double)m.R(k - 1);
+    // propagator terms of layer k: xmu, y, z, cosq
+    auto layer_terms1 = [&](int k, double* c) {
+        const double beta = (double)m.B(k - 1);
+        const double rho = (double)m.R(k - 1);
         const double dk = (double)m.D(k - 1);
-        const double xmu = rho1 * beta1 * beta1;
-        xkb = omega / beta1;
-        wvnop = wvno + xkb;
-        wvnom = fabs(wvno - xkb);
-        rb = sqrt(wvnop * wvnom);
-        const double q = dk * rb;
+        const double xmu = rho * beta * beta;
+        const double xkb_ = omega / beta;
+        const double wp = wvno + xkb_;
+        const double wm = fabs(wvno - xkb_);
+        const double rb_ = sqrt(wp * wm);
+        const double q = dk * rb_;
         double sinq, y, z, cosq;
-        if (wvno < xkb) {
-            sinq = sin(q); y = sinq / rb; z = -rb * sinq; cosq = cos(q);
-        } else if (wvno == xkb) {
+        if (wvno < xkb_) {
+            sinq = sin(q); y = sinq / rb_; z = -rb_ * sinq; cosq = cos(q);
+        } else if (wvno == xkb_) {
             cosq = 1.0; y = dk; z = 0.0;
         } else {
             double fac = 0.0;
             if (q < 16) fac = exp(-2.0 * q);
             cosq = (1.0 + fac) * 0.5;
             sinq = (1.0 - fac) * 0.5;
-            y = sinq / rb; z = rb * sinq;
+            y = sinq / rb_; z = rb_ * sinq;
         }
+        c[0] = xmu; c[1] = y; c[2] = z; c[3] = cosq;
+    };
+    auto product_step1 = [&](const double* c) {
+        const double xmu = c[0], y = c[1], z = c[2], cosq = c[3];
         const double e10 = e1 * cosq + e2 * xmu * z;
         const double e20 = e1 * y / xmu + e2 * cosq;
         double xnor = fabs(e10);
@@ -93,6 +98,35 @@ DSA_HD double dltar1(const Layers& m, double wvno, double omega)
         if (xnor < 1.e-40) xnor = 1.0;
         e1 = e10 / xnor;
         e2 = e20 / xnor;
+    };
+    if (m.gsize <= 1) {
+        for (int k = mmax - 1; k >= m.llw; --k) {
+            double c[4];
+            layer_terms1(k, c);
+            product_step1(c);
+        }
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int K = m.gsize;                       // lane groups: see dltar4
+        for (int kb = mmax - 1; kb >= m.llw; kb -= K) {
+            const int k = kb - m.gsub;
+            if (k >= m.llw) {
+                double c[4];
+                layer_terms1(k, c);
+                double* mine = m.xch + m.gsub * 15;
+                for (int i = 0; i < 4; ++i) mine[i] = c[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const int nb = (kb - m.llw + 1) < K ? (kb - m.llw + 1) : K;
+            for (int j = 0; j < nb; ++j) {
+                double c[4];
+                const double* theirs = m.xch + j * 15;
+                for (int i = 0; i < 4; ++i) c[i] = theirs[i];
+                product_step1(c);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+#endif
     }
     return e1;
 }

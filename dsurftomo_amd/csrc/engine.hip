@@ -176,10 +176,10 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
     HIP_TRY(this, hipEventRecord(events[1], stream));
     // layer tables in LDS when they fit (64 curves x 4 arrays x rmax layers x 4 B <= 64 KB, i.e. rmax <= 64) -- see k_dispersion
     const int in_lds = disp_layers_lds >= 0 ? disp_layers_lds : ((size_t)h_geom.rmax * 1024 <= (size_t)64 * 1024 ? 1 : 0);
-    // Rayleigh curves of a small call share the lanes of a group (k_dispersion): 8 lanes per curve for a few thousand
+    // the curves of a small call share the lanes of a group (k_dispersion): 8 lanes per curve for a few thousand
     // curves, 4 up to 32 k curves, one lane per curve beyond (the group repeats the root search and the matrix products)
     int gshift = 0;
-    if (iwave == 2 && in_lds && disp_group_shift != 0) {
+    if (in_lds && disp_group_shift != 0) {
         if (disp_group_shift > 0) gshift = disp_group_shift;
         else gshift = nlanes <= 4096 ? 3 : nlanes <= 32768 ? 2 : 0;      // measured: 324 curves 21.6 -> 7.8 ms, 17 820 curves 22.7 -> 16.9 ms, 944 k curves 166 -> 285 ms
     }

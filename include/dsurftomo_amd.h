@@ -57,7 +57,7 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  * point), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits the workgroups resident
  * per CU), "ray_budget" (bytes of per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up
  * to 8 GB), "ray_path_cap" (points kept per traced ray for dsa_ray_paths, 0 = none), "disp_layers_lds" (layer
- * tables of the dispersion kernel: 1 LDS, 0 global scratch, -1 default = LDS when they fit), "disp_group_shift" (lanes per Rayleigh
+ * tables of the dispersion kernel: 1 LDS, 0 global scratch, -1 default = LDS when they fit), "disp_group_shift" (lanes per dispersion
  * curve = 2^shift, 0 = one lane per curve, -1 default = 8 lanes up to 4096 curves, 4 up to 32768), "lsmr_device_vectors"
  * (dsa_lsmr: 0 default = ordered reductions on the host, 1 = all vectors on the device; same results) */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
