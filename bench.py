@@ -11,23 +11,31 @@ is one pass of the hot path over the whole set: 16 000 solves (refine + two fixe
 plus 512 000 receiver times.  Velocity maps and source/receiver descriptors are resident in HBM
 before the timed region; the receiver times come back to the host inside it.
 
-With N > 1 the 16 000 units are split into N contiguous slices (whole periods per rank), every
-rank solves its slice, and the receiver-time vector is completed on every rank by an RCCL
-all-gather: total work is fixed ("strong" scaling, as configs[3] states).
+With N > 1 the 16 000 units are split into N contiguous slices (whole periods per rank, the loop
+nest of CalSurfG.f90:1144-1145), every rank solves its slice, and the receiver-time vector is
+completed on every rank by an RCCL all-gather: total work is fixed ("strong" scaling, as
+configs[3] states).  `python bench.py --gpus N` without a launcher starts the N ranks itself (one
+child process per GPU, before anything in the parent touches the GPU).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the coarse fixed-point
-solve) from HIP events recorded on the engine's own stream; `cpu_baseline` times the reference's
-own Fortran (oracle/_ref, single core) -- or the C oracle if that library is absent -- on a
-bounded sample of the same workload.
+Prints ONE JSON line on rank 0.
+  roofline      dominant kernel (the coarse fixed-point solve): algorithmic bytes / launch time from HIP
+                events recorded on the engine's own stream; `traffic` (fabric bytes per launch) and
+                `valu_issue` come from the rocprofv3 --pmc passes of tools/profile_bench.sh, which
+                records the hash of the kernel sources: a file made from other sources is ignored (null)
+  cpu_baseline  the reference's own Fortran (oracle/_ref, single core) -- or the C oracle if that library
+                is absent -- on a bounded sample of the same workload
+  max_abs_err   the parity half of the metric: largest |t_gpu - t_ref| over the receiver times of the
+                sampled units (the reference times are the ones cpu_baseline computes), with the count
+                beyond the 1e-4 s bar
 """
 import argparse
-import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -38,6 +46,8 @@ NPER = 16
 NSRC = 1000
 NREC = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TOL = 1e-4                   # north_star: travel times within 1e-4 s of the reference FMM
+KERNEL_SOURCES = ["fim_kernel.hip", "eikonal_core.h", "kernels.h", "engine.hip"]
 
 
 def bytes_per_solve(n):
@@ -46,41 +56,95 @@ def bytes_per_solve(n):
     return 8.0 * n * n + 129 * 129 * 8.0
 
 
-def cpu_baseline(budget_units=48):
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for n in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "dsurftomo_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(budget_units=96):
     """Reference CPU path on a bounded sample: per unit dicing (the reference re-dices per source,
-    CalSurfG.f90:1186), refined + coarse Fast Marching and the 32 receiver times; one core."""
+    CalSurfG.f90:1186), refined + coarse Fast Marching and the 32 receiver times; one core.
+    Returns (record, unit indices, reference receiver times [units, NREC])."""
+    import numpy as np
     import _libs as L
     import synth
     units = synth.units(NX, NSRC, NPER, NREC)
     pick = np.linspace(0, NSRC * NPER - 1, budget_units).astype(int)
+    times = np.zeros((len(pick), NREC), np.float32)
     ref = L.ref()
     if ref is not None:
         wb = L.RefWB(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
         t0 = time.perf_counter()
-        for u in pick:
+        for k, u in enumerate(pick):
             p = int(units["map_index"][u])
             wb.L.ref_wb_gridder(L.ptr(np.ascontiguousarray(synth.medium(NX, "smooth", p))))
             wb.L.ref_wb_solve(float(units["scx"][u]), float(units["scz"][u]))
             for r in range(NREC):
-                wb.L.ref_wb_srtimes(float(units["scx"][u]), float(units["scz"][u]),
-                                    float(units["rcx"][u * NREC + r]), float(units["rcz"][u * NREC + r]))
+                times[k, r] = wb.L.ref_wb_srtimes(float(units["scx"][u]), float(units["scz"][u]),
+                                                  float(units["rcx"][u * NREC + r]), float(units["rcz"][u * NREC + r]))
         dt = time.perf_counter() - t0
         wb.close()
         kind = "reference"
     else:
         g = L.grid(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
         t0 = time.perf_counter()
-        for u in pick:
+        for k, u in enumerate(pick):
             pv = synth.medium(NX, "smooth", int(units["map_index"][u]))
             veln = L.o_gridder(g, pv)
             sol = L.o_solve(g, pv, veln, units["scx"][u], units["scz"][u])
             for r in range(NREC):
-                L.o_srtimes(g, veln, sol["T"], units["scx"][u], units["scz"][u], units["rcx"][u * NREC + r], units["rcz"][u * NREC + r])
+                times[k, r] = L.o_srtimes(g, veln, sol["T"], units["scx"][u], units["scz"][u], units["rcx"][u * NREC + r], units["rcz"][u * NREC + r])
         dt = time.perf_counter() - t0
         kind = "port"
-    return {"value": round(len(pick) / dt, 4), "unit": "solves/s", "cores": 1, "kind": kind,
-            "sample": "%d of the %d (period, source) units, evenly spaced; dicing + refined/coarse FMM + %d receiver times each" % (len(pick), NSRC * NPER, NREC),
-            "seconds": round(dt, 2)}
+    rec = {"value": round(len(pick) / dt, 4), "unit": "solves/s", "cores": 1, "kind": kind,
+           "sample": "%d of the %d (period, source) units, evenly spaced; dicing + refined/coarse FMM + %d receiver times each" % (len(pick), NSRC * NPER, NREC),
+           "seconds": round(dt, 2)}
+    return rec, pick, times
+
+
+def pmc_record():
+    """Counters of the dominant kernel from tools/profile_bench.sh (separate rocprofv3 --pmc passes of this
+    very command); ignored unless they were taken from the kernel sources that are in the tree now."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return rec if rec.get("kernel_source_hash") == kernel_source_hash() else None
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` typed as is: start the N ranks as child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, as torch.distributed.run would), pass rank 0's line through, and exit with
+    the worst exit code.  The parent never touches the GPU and never replaces itself with another program."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
@@ -91,24 +155,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
+    import numpy as np
     import torch
     import synth
     from dsurftomo_amd import build, sharding
     from dsurftomo_amd.engine import Engine
 
+    # one rank per GPU over RCCL; with fewer devices than ranks (a 1-GPU box rehearsing the N-rank path) the
+    # ranks share devices and the exchange runs over gloo with host tensors -- same partition, same collective
+    ndev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % ndev
+    shared = world > ndev
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
     if rank == 0:
         build.build()
     if dist is not None:
@@ -122,11 +194,13 @@ def main():
     rsl = slice(lo * NREC, hi * NREC)
     pv = np.stack([synth.medium(NX, "smooth", p) for p in range(NPER)])
 
-    eng = Engine(local_rank)
+    eng = Engine(device_index)
     if os.environ.get("DSA_MAX_CHUNK"):
         eng.set_option("max_chunk", int(os.environ["DSA_MAX_CHUNK"]))
     if os.environ.get("DSA_MEM_BUDGET_GB"):
         eng.set_memory_budget(int(float(os.environ["DSA_MEM_BUDGET_GB"]) * 1e9))
+    elif shared:
+        eng.set_memory_budget(int(200e9 / ((world + ndev - 1) // ndev)))
     if os.environ.get("DSA_FIM_SORTED"):
         eng.set_option("fim_sorted", int(os.environ["DSA_FIM_SORTED"]))
     t_setup = time.perf_counter()
@@ -135,7 +209,7 @@ def main():
     setup_ms = 1000.0 * (time.perf_counter() - t_setup)      # host buffers -> HBM: maps, dicing, descriptors
     n = eng.nnx
 
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if shared else torch.device("cuda", device_index)
     counts = sharding.ray_counts(units["nrec"], world)
 
     def step():
@@ -156,8 +230,9 @@ def main():
            "evals_total": 0.0, "rounds_max": 0.0}
     fence()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step()
+        last = step()
         st = eng.stats()
         for k in acc:
             acc[k] = max(acc[k], st[k]) if k == "rounds_max" else acc[k] + st[k]
@@ -172,16 +247,15 @@ def main():
         solves = total_units * args.steps
         bps = bytes_per_solve(n)
         my_units = (hi - lo) * args.steps
+        launches = max(acc["launches_fim_coarse"], 1)
         kernel_s = acc["ms_fim_coarse"] / 1000.0
         achieved = my_units * bps / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            # PMC passes are separate runs (rocprofv3 --pmc); the committed per-solve figure is scaled to this launch
-            with open(tfile) as f:
-                per_solve = json.load(f).get("hbm_bytes_per_solve")
-            if per_solve:
-                traffic = round(per_solve * my_units / max(acc["launches_fim_coarse"], 1))
+        pmc = pmc_record()
+        traffic = valu = None
+        if pmc:
+            if pmc.get("fabric_bytes_per_solve"):
+                traffic = round(pmc["fabric_bytes_per_solve"] * my_units / launches)
+            valu = pmc.get("valu_issue")
         line = {
             "metric": "source-period FMM solves/sec on NxN grid; travel-time max-abs-err vs ref",
             "value": round(solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,22 +263,34 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 1025x1025 grid (nx=ny=131, dicing 8), 16 periods x 1000 sources, 32 receivers each, smooth +-10% velocity",
                        "grid": n, "units_per_step": total_units, "receivers_per_step": total_units * NREC,
-                       "parallelism": "units sharded over %d GPU(s), RCCL all-gather of receiver times" % world},
+                       "parallelism": "units sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "k_fim_sorted<256> (coarse fixed-point solve)", "bytes_per_solve": bps,
                          "launches": int(acc["launches_fim_coarse"]),
-                         "avg_launch_ms": round(acc["ms_fim_coarse"] / max(acc["launches_fim_coarse"], 1), 3),
-                         "solves_per_launch": round(my_units / max(acc["launches_fim_coarse"], 1), 1),
-                         "note": "achieved = algorithmic bytes / kernel time; the kernel moves ~100x more (traffic) because thousands of fronts in flight do not fit the caches; see DESIGN.md 7"},
+                         "avg_launch_ms": round(acc["ms_fim_coarse"] / launches, 3),
+                         "solves_per_launch": round(my_units / launches, 1),
+                         "valu_issue": valu,
+                         "note": "achieved = algorithmic bytes / kernel launch time (HIP events on the engine's stream). The solve is a dependency chain "
+                                 "of ~2400 rounds per front, so HBM is not what binds it: valu_issue (fraction of the SIMDs' issue cycles spent on VALU "
+                                 "instructions, from rocprofv3 --pmc) is the second roofline; traffic / valu_issue are null when profiles/pmc_latest.json "
+                                 "was not taken from the kernel sources in the tree"},
             "kernel_ms_per_step": {"fim_coarse": round(acc["ms_fim_coarse"] / args.steps, 2), "fim_refined": round(acc["ms_fim_refined"] / args.steps, 2),
                                    "stages": round(acc["ms_stages"] / args.steps, 2)},
             "evals_per_node": round(acc["evals_total"] / max(my_units, 1) / (n * n), 3),
             "setup_ms": round(setup_ms, 1),
             "value_incl_setup": round(solves / (dt + setup_ms / 1000.0), 2),
+            "max_abs_err": None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            rec, pick, ref_times = cpu_baseline()
+            line["cpu_baseline"] = rec
+            got = np.asarray(last, np.float32).reshape(total_units, NREC)[pick]
+            d = np.abs(got.astype(np.float64) - ref_times.astype(np.float64))
+            line["max_abs_err"] = float(d.max())
+            line["parity"] = {"checked_receiver_times": int(d.size), "units": int(len(pick)), "beyond_1e-4_s": int((d > TOL).sum()),
+                              "not_bit_identical": int((got.view(np.uint32) != ref_times.view(np.uint32)).sum()),
+                              "against": rec["kind"], "tolerance_s": TOL}
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

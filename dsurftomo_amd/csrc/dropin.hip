@@ -19,6 +19,7 @@
 namespace {
 
 std::string g_dropin_error = "";
+long long g_capacity = 0;             // entries rw / iw / col can take (dsa_dropin_set_capacity); 0: not told
 dsa_engine* g_engine = nullptr;
 
 int g_last_first[4] = { -1, -1, -1, -1 }, g_last_count[4] = { 0, 0, 0, 0 }, g_last_ncol = 0;   // maps of the last call: Rc, Rg, Lc, Lg
@@ -141,6 +142,14 @@ extern "C" {
 
 const char* dsa_dropin_error(void) { return g_dropin_error.c_str(); }
 
+// capacity (entries) of the rw / iw(2:) / col arrays handed to dsa_calsurfg from now on; 0 = unknown (DSA_MAXNAR or unlimited)
+int dsa_dropin_set_capacity(long long maxnar)
+{
+    if (maxnar < 0) { g_dropin_error = "dsa_dropin_set_capacity: negative capacity"; return DSA_ERR_ARGUMENT; }
+    g_capacity = maxnar;
+    return 0;
+}
+
 int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,
                  int* iw, float* rw, int* col, float* dsurf,
                  const float* goxdf, const float* gozdf, const float* dvxdf, const float* dvzdf,
@@ -159,8 +168,11 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     if (L.kRc + L.kRg + L.kLc + L.kLg != L.kmax) { g_dropin_error = "dsa_calsurfg: kmax must equal kmaxRc+kmaxRg+kmaxLc+kmaxLg"; return DSA_ERR_ARGUMENT; }
     Units U;
     if ((rc = make_units(L, true, *nsrcsurf, *nrcf, wavetype, igrt, periods, nrc1, nsrcsurf1, scxf, sczf, rcxf, rczf, U)) != 0) return rc;
-    long long cap = LLONG_MAX;             // the reference's interface carries no capacity for rw / iw / col
-    if (const char* s = getenv("DSA_MAXNAR")) cap = atoll(s);
+    // the reference's interface carries no capacity for rw / iw / col: the caller states it with dsa_dropin_set_capacity
+    // (the Python host does, per call) or, for an unchanged Fortran host, with DSA_MAXNAR in the environment
+    long long cap = LLONG_MAX;
+    if (g_capacity > 0) cap = g_capacity;
+    else if (const char* s = getenv("DSA_MAXNAR")) cap = atoll(s);
     *nar = 0;
 
     // Every engine runs the dispersion stage for the whole model (it is small next to the solves) and then
@@ -223,7 +235,7 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     for (int k = 0; k < ne; ++k) {
         if (part[k].rc != 0) { g_dropin_error = part[k].err; return part[k].rc; }
         if (ne > 1) {
-            if (n + part[k].n > cap) { g_dropin_error = "dsa_calsurfg: more matrix entries than DSA_MAXNAR"; return DSA_ERR_ARGUMENT; }
+            if (n + part[k].n > cap) { g_dropin_error = "dsa_calsurfg: more matrix entries than the stated capacity (increase sparsity fraction)"; return DSA_ERR_CAPACITY; }
             std::memcpy(rw + n, part[k].rw.data(), (size_t)part[k].n * 4);
             std::memcpy(iw + 1 + n, part[k].iw.data(), (size_t)part[k].n * 4);
             std::memcpy(col + n, part[k].col.data(), (size_t)part[k].n * 4);
@@ -241,8 +253,12 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
 // aprod with the reference's argument list (aprod.f90:7; LSMR calls it with the same matrix hundreds of times per
 // inversion step, lsmrModule.f90:390-497).  The matrix goes to the device the first time it is seen; it is
 // recognised again by its address, its size and a sample of its entries (`force`: load regardless).
+static bool g_matrix_stale = true;       // dsa_aprod_invalidate, or nothing loaded yet
+static int g_last_mode = 2;
+
 static int load_matrix_cached(int m, int n, const int* iw, const float* rw, bool force)
 {
+    if (g_matrix_stale) force = true;
     static const void *s_iw = nullptr, *s_rw = nullptr;
     static long long s_nar = -1;
     static int s_m = 0, s_n = 0;
@@ -255,6 +271,7 @@ static int load_matrix_cached(int m, int n, const int* iw, const float* rw, bool
         const int rc = dsa_spmv_load(g_engine, m, n, nar, rw, iw + 1, iw + 1 + nar);
         if (rc != 0) return rc;
         s_iw = iw; s_rw = rw; s_nar = nar; s_m = m; s_n = n; s_sum = sum;
+        g_matrix_stale = false;
     }
     return 0;
 }
@@ -266,8 +283,21 @@ int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, c
     if (!mode || !m || !n || !x || !y || !iw || !rw) { g_dropin_error = "dsa_aprod: null argument"; return DSA_ERR_ARGUMENT; }
     int rc = engine();
     if (rc != 0) return rc;
-    if ((rc = load_matrix_cached(*m, *n, iw, rw, false)) != 0) return fail(rc);
+    // Inside one LSMR solve the products alternate (lsmrModule.f90:390, then :484 / :497 per iteration: 2, 1, 2, 1, 2 ...)
+    // and a solve ends on mode 2, so two mode-2 products in a row mean a new solve -- the reference rebuilds rw / iw in
+    // place before each one (main.f90:361-466), same addresses, same size: reload.  Anything else a caller edits in
+    // place must be announced with dsa_aprod_invalidate().
+    const bool new_solve = *mode == 2 && g_last_mode == 2;
+    g_last_mode = *mode;
+    if ((rc = load_matrix_cached(*m, *n, iw, rw, new_solve)) != 0) return fail(rc);
     if ((rc = dsa_spmv(g_engine, *mode, x, y)) != 0) return fail(rc);
+    return 0;
+}
+
+// the matrix behind the next dsa_aprod call has been edited in place: upload it again
+int dsa_aprod_invalidate(void)
+{
+    g_matrix_stale = true;
     return 0;
 }
 

@@ -124,6 +124,7 @@ struct Engine {
     int trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, long long cap, long long* nar);
     BatchPtrs batch() const;
     FimLaunch launch_shape(int nnx, int nnz) const;
+    FimLaunch shape_c{}, shape_r{};    // launch shapes fixed by plan(): lists_stride is sized from them, solve() must use the same
     void launch_srtimes_chunk(int r0, int nr, int first_unit);
     int get_field(int unit, float* ttn);
     int fetch_tiled(const Rec* dev, int nnx, int nnz, int which, float* out);

@@ -307,7 +307,8 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     size_t budget = mem_budget ? mem_budget : std::min<size_t>((size_t)(0.6 * (double)free_b), (size_t)150 << 30);
     const size_t rr = (size_t)kRefMax * kRefMax;
     {   // the refined and the coarse solve of a unit share one list region: size it for the larger shape
-        const FimLaunch lc = launch_shape(g.nnx, g.nnz), lr = launch_shape(kRefMax, kRefMax);
+        shape_c = launch_shape(g.nnx, g.nnz); shape_r = launch_shape(kRefMax, kRefMax);
+        const FimLaunch &lc = shape_c, &lr = shape_r;
         lists_stride = std::max((size_t)4 * lc.list_cap + lc.ready_cap, (size_t)4 * lr.list_cap + lr.ready_cap);
         lists_stride = std::max(lists_stride, (size_t)2 * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile masks + one list
         lists_stride = (lists_stride + 1) & ~(size_t)1;      // the masks are 8-byte words
@@ -318,6 +319,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B)", budget, per_unit_bytes); return DSA_ERR_DEVICE; }
     chunk = (int)std::min<size_t>(c, (size_t)std::max(nunits, 1));
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
+    if (keep_fields && chunk < nunits) { fail(DSA_ERR_CAPACITY, "plan: keep_fields is set but only %d of the %d units fit one resident chunk (memory budget / max_chunk)", chunk, nunits); return DSA_ERR_CAPACITY; }
     const size_t C = (size_t)chunk;
     if (ensure(lists, C * lists_stride) || ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(ndata, 1)) || ensure(trace_ids, std::max<size_t>(h_trace.size(), 1)) || ensure(err, 4) ||
         ensure(slow_r, C * kRefRecs) || ensure(F_r, C * kRefRecs) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
@@ -325,6 +327,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(F_c, C * nrec_c) ||
         ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
+    HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
     if (!h_trace.empty()) HIP_TRY(this, hipMemcpyAsync(trace_ids.p, h_trace.data(), h_trace.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
@@ -381,12 +384,12 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));
-        launch_fim(prob_r.p, n, launch_shape(kRefMax, kRefMax), stream);
+        launch_fim(prob_r.p, n, shape_r, stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         launch_handoff(g, b, n, stream);
         launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
         HIP_TRY(this, hipEventRecord(events[4], stream));
-        launch_fim(prob_c.p, n, launch_shape(g.nnx, g.nnz), stream);
+        launch_fim(prob_c.p, n, shape_c, stream);
         HIP_TRY(this, hipEventRecord(events[5], stream));
         // receivers of this chunk
         const int r0 = h_src[first].first_ray;
@@ -547,7 +550,7 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
         h_info.resize((size_t)m * 2);
         HIP_TRY(this, hipMemcpyAsync(h_info.data(), rayinfo.p, (size_t)m * 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipStreamSynchronize(stream));
-        if (*nar + total > cap) { fail(DSA_ERR_ARGUMENT, "Frechet rows need more than the %lld entries provided", cap); return DSA_ERR_ARGUMENT; }
+        if (*nar + total > cap) { fail(DSA_ERR_CAPACITY, "Frechet rows need more than the %lld entries provided", cap); return DSA_ERR_CAPACITY; }
         if (total > 0 && grow_rw && grow_iw && grow_col) {
             grow_rw->resize((size_t)(*nar + total)); grow_iw->resize((size_t)(*nar + total)); grow_col->resize((size_t)(*nar + total));
             rw = grow_rw->data(); iw = grow_iw->data(); col = grow_col->data();
@@ -657,16 +660,16 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     const std::string n(name);
     if (n == "window_cells" && value > 0) { en->window_cells = (float)value; return 0; }
     if (n == "max_chunk" && value >= 0) { en->max_chunk = (int)value; return 0; }
-    if (n == "list_cap" && value >= 0) { en->list_cap = (int)value; return 0; }
-    if (n == "ready_cap" && value >= 0) { en->ready_cap = (int)value; return 0; }
+    if (n == "list_cap" && value >= 0) { en->planned = false; en->list_cap = (int)value; return 0; }
+    if (n == "ready_cap" && value >= 0) { en->planned = false; en->ready_cap = (int)value; return 0; }
     if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
-    if (n == "fim_lds_pad" && value >= 0 && value <= 64 * 1024) { en->fim_lds_pad = (int)value; return 0; }
-    if (n == "fim_sorted" && (value == 0 || value == 1)) { en->fim_sorted = (int)value; return 0; }
+    if (n == "fim_lds_pad" && value >= 0 && value <= 64 * 1024) { en->planned = false; en->fim_lds_pad = (int)value; return 0; }
+    if (n == "fim_sorted" && (value == 0 || value == 1)) { en->planned = false; en->fim_sorted = (int)value; return 0; }
     if (n == "ray_path_cap" && value >= 0 && value <= (1 << 24)) { en->ray_path_cap = (int)value; return 0; }
     if (n == "disp_group_shift" && value >= -1 && value <= 3) { en->disp_group_shift = (int)value; return 0; }
     if (n == "disp_layers_lds" && (value == -1 || value == 0 || value == 1)) { en->disp_layers_lds = (int)value; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
-    if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->fim_threads = (int)value; return 0; }
+    if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;
 }
@@ -780,8 +783,10 @@ int dsa_get_dims(const dsa_engine* e, int* nnx, int* nnz)
 int dsa_keep_fields(dsa_engine* e, int on)
 {
     if (!e) return DSA_ERR_ARGUMENT;
-    // with keep_fields the chunk is capped so that every planned unit stays resident
+    // with keep_fields every planned unit must stay resident (dsa_get_field / dsa_get_refined of any unit): dsa_plan fails
+    // with DSA_ERR_CAPACITY when the units do not fit one chunk
     reinterpret_cast<Engine*>(e)->keep_fields = on != 0;
+    reinterpret_cast<Engine*>(e)->planned = false;
     return 0;
 }
 

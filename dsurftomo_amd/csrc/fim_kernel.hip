@@ -766,7 +766,8 @@ void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l,
         return;
     }
     const size_t pad = (size_t)l.lds_pad;
-    if (l.threads == 256) hipLaunchKernelGGL(k_fim<256>, dim3(nproblems), dim3(256), pad, stream, d_problems, l.list_cap, l.ready_cap);
+    if (l.threads == 128) hipLaunchKernelGGL(k_fim<128>, dim3(nproblems), dim3(128), pad, stream, d_problems, l.list_cap, l.ready_cap);
+    else if (l.threads == 256) hipLaunchKernelGGL(k_fim<256>, dim3(nproblems), dim3(256), pad, stream, d_problems, l.list_cap, l.ready_cap);
     else if (l.threads == 512) hipLaunchKernelGGL(k_fim<512>, dim3(nproblems), dim3(512), pad, stream, d_problems, l.list_cap, l.ready_cap);
     else hipLaunchKernelGGL(k_fim<1024>, dim3(nproblems), dim3(1024), pad, stream, d_problems, l.list_cap, l.ready_cap);
 }

@@ -65,6 +65,8 @@ def load_library():
     L.dsa_lsmr.argtypes = [_vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp] + [_vp] * 7
     L.dsa_debug_field.argtypes = [_vp, _i32, _i32, _vp]
     L.dsa_dropin_error.restype = C.c_char_p
+    L.dsa_dropin_set_capacity.argtypes = [C.c_longlong]
+    L.dsa_aprod_invalidate.argtypes = []
     _lib = L
     return L
 

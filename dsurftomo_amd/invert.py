@@ -60,7 +60,7 @@ def iteration(lib, c, vsf, obst, log):
     nar = C.c_int(0)
     cc = dict(c); cc["vels"] = vsf
     head, tail = io._args(cc)
-    os.environ["DSA_MAXNAR"] = str(maxnar)
+    lib.dsa_dropin_set_capacity(maxnar)
     t0 = time.perf_counter()
     if lib.dsa_calsurfg(*head, _p(iw), _p(rw), _p(col), _p(dsyn), *tail, C.byref(nar)) != 0:
         raise RuntimeError("dsa_calsurfg: %s" % lib.dsa_dropin_error().decode())

@@ -149,7 +149,7 @@ def call_calsurfg(c, capacity=None):
     dsurf = np.zeros(nd, np.float32)
     nar = C.c_int(0)
     head, tail = _args(c)
-    os.environ.setdefault("DSA_MAXNAR", str(cap))
+    lib.dsa_dropin_set_capacity(cap)          # the arrays above: the library refuses to write past them (DSA_ERR_CAPACITY)
     rc = lib.dsa_calsurfg(*head, _ptr(iw), _ptr(rw), _ptr(col), _ptr(dsurf), *tail, C.byref(nar))
     if rc != 0:
         raise RuntimeError("dsa_calsurfg: %s" % lib.dsa_dropin_error().decode())

@@ -198,10 +198,21 @@ int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi
                   const float* rczf, const int* nrc1, const int* nsrcsurf1, const int* kmax,
                   const int* nsrcsurf, const int* nrcf, const float* noiselevel);
 
+/* Capacity (entries) of the rw / iw(2:) / col arrays handed to dsa_calsurfg from now on.  The reference's interface
+ * (CalSurfG.f90:939-943) does not carry it -- main.f90:287 sizes the arrays as spfra*dall*nx*ny*nz and only checks
+ * afterwards (main.f90:467); with it dsa_calsurfg returns DSA_ERR_CAPACITY instead of writing past the arrays.
+ * 0 = not stated (then DSA_MAXNAR from the environment, else unlimited). */
+int dsa_dropin_set_capacity(long long maxnar);
+
 /* the reference's aprod (aprod.f90:7-60: mode 1 y += A x, mode 2 x += A^T y; iw = [nar, rows, cols]) on the
  * device; the matrix is uploaded when first seen (dsurftomo_amd/fortran/aprod_shim.f90 exports `aprod_`) */
 int dsa_aprod(const int* mode, const int* m, const int* n, float* x, float* y, const int* leniw,
               const int* lenrw, const int* iw, const float* rw);
+/* Contract of the device copy behind dsa_aprod: the matrix is uploaded when its address, size or a sample of its
+ * entries changes, and whenever a new LSMR solve starts (two mode-2 products in a row: lsmrModule.f90:390 opens a
+ * solve with mode 2 and :497 ends every iteration with it) -- which covers the reference's main program, that rebuilds
+ * rw / iw in place before each solve (main.f90:361-466).  Any other in-place edit must be announced with this call. */
+int dsa_aprod_invalidate(void);
 
 /* the reference's LSMR with its own argument list (lsmrModule.f90:36-39: every argument by reference; iw = [nar,
  * rows, cols], nout ignored) on the device; dsurftomo_amd/fortran/lsmr_shim.f90 exports module lsmrModule with it */

@@ -13,6 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """The measured worst differences behind the parity assertions, whatever the verbosity."""
+    import parity_log
+    if not parity_log.LINES:
+        return
+    terminalreporter.section("parity: HIP path vs oracle, measured (bar: 1e-4 s)")
+    for line in parity_log.LINES:
+        terminalreporter.write_line(line)
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.txt"), "w") as f:
+            f.write("\n".join(parity_log.LINES) + "\n")
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def engine():
     """One engine per session; fails loudly when the HIP library or the GPU is missing."""

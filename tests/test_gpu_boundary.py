@@ -3,9 +3,9 @@ Fortran shim, and the dispersion stage, against the oracle and the committed gol
 
 Tolerances.  Travel times: 1e-4 s (north_star).  The eikonal solve can differ from Fast Marching
 only where two arrivals tie to the last bit, so rays, rows and dispersion -- which run
-the reference's arithmetic operation for operation -- are expected to be bit-identical almost
-everywhere; the assertions leave room for a tie changing a ray: at most 0.5 % of the matrix
-entries may differ, none by more than 2e-3 (entries are O(0.1)).  Dispersion runs in fp64 with the
+the reference's arithmetic operation for operation -- are bit-identical on every case of this file
+(measured: tests/tools/parity_table.py), and that is what is asserted: receiver times and every matrix
+entry equal to the oracle's, bit for bit (no case of this file is a tie case).  Dispersion runs in fp64 with the
 device's sin / cos / exp instead of libm's; a last-bit difference there can move an fp32-rounded
 phase velocity by one ulp (2.4e-7), i.e. a depth kernel by 2.4e-7 / (0.01 v) ~ 1e-5.
 """
@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 
 import _libs as L
+import parity_log
 import synth
 import taipei
 
@@ -43,13 +44,15 @@ def dense(r, ndata, npar):
     return G
 
 
-def check_rows(o, d, c):
-    assert np.abs(o["dsurf"] - d["dsurf"]).max() <= 1e-4
+def check_rows(o, d, c, name=""):
     Go, Gd = dense(o, c["ndata"], c["nparpi"]), dense(d, c["ndata"], c["nparpi"])
     differ = Go.view(np.uint32) != Gd.view(np.uint32)
-    assert differ.sum() <= 0.005 * max(o["nar"], 1), "%d of %d matrix entries differ" % (differ.sum(), o["nar"])
-    assert np.abs(Go - Gd).max() <= 2e-3
-    assert abs(o["nar"] - d["nar"]) <= 0.005 * o["nar"]
+    tdiff = int((o["dsurf"].view(np.uint32) != d["dsurf"].view(np.uint32)).sum())
+    parity_log.add("boundary %s: %d data, max |d dsurf| %.3g s (not bit-identical %d); nar %d vs %d, matrix entries differing %d (max %.3g)" %
+                   (name, c["ndata"], np.abs(o["dsurf"] - d["dsurf"]).max(), tdiff, o["nar"], d["nar"], int(differ.sum()), np.abs(Go - Gd).max()))
+    assert np.abs(o["dsurf"] - d["dsurf"]).max() <= 1e-4
+    assert differ.sum() == 0, "%d of %d matrix entries differ" % (differ.sum(), o["nar"])
+    assert o["nar"] == d["nar"]
     # the reference's order: rows ascending, columns ascending inside a row
     key = d["iw"].astype(np.int64) * (c["nparpi"] + 1) + d["col"]
     assert (np.diff(key) > 0).all()
@@ -62,7 +65,7 @@ def test_dropin_calsurfg_and_synthetic(lib, name):
     o = L.call_boundary(L.oracle().dso_calsurfg, c)
     d = L.call_boundary(lib.dsa_calsurfg, c)
     assert lib.dsa_dropin_error() == b"" or d["nar"] > 0, lib.dsa_dropin_error()
-    check_rows(o, d, c)
+    check_rows(o, d, c, name)
     so = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
     sd = L.call_boundary(lib.dsa_synthetic, c, synthetic=True)
     assert np.abs(so - sd).max() <= 1e-4
@@ -75,12 +78,12 @@ def test_taipei_example(lib):
     d = L.call_boundary(lib.dsa_calsurfg, c)
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "b_taipei.npz"))
     assert np.abs(d["dsurf"] - z["dsurf"]).max() <= 1e-4
-    assert abs(d["nar"] - int(z["nar"])) <= 0.005 * int(z["nar"])
+    assert d["nar"] == int(z["nar"])
     G = dense(d, c["ndata"], c["nparpi"])
     assert np.abs(G.sum(axis=1, dtype=np.float64) - z["row_sums"]).max() <= 5e-3
     assert np.abs(np.abs(G).sum(axis=0, dtype=np.float64) - z["col_abs_sums"]).max() <= 2e-2
     o = L.call_boundary(L.oracle().dso_calsurfg, c)
-    check_rows(o, d, c)
+    check_rows(o, d, c, "taipei")
 
 
 @pytest.mark.parametrize("iwave,igr", [(2, 0), (2, 1), (1, 0), (1, 1)])
@@ -262,7 +265,7 @@ for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, ns
     assert o["nar"] == d["nar"], (o["nar"], d["nar"])
     assert np.abs(o["dsurf"] - d["dsurf"]).max() <= 1e-4
     assert (o["iw"] == d["iw"]).all() and (o["col"] == d["col"]).all()
-    assert np.abs(o["rw"] - d["rw"]).max() <= 2e-3
+    assert (o["rw"].view(np.uint32) == d["rw"].view(np.uint32)).all()
 print("sharded ok")
 ''' % (L.ROOT, os.path.join(L.ROOT, "tests"))
     env = dict(os.environ, DSA_DEVICES="0,0,0")
@@ -292,7 +295,7 @@ def test_forward_cli_on_the_taipei_directory(tmp_path):
     assert tab.shape == (2061, 3)
     assert np.abs(tab[:, 1] - z["dsurf"]).max() <= 1e-4 + 1e-6          # the text file keeps 6 decimals
     G = np.load(out + ".G.npz")
-    assert abs(int(G["rw"].size) - int(z["nar"])) <= 0.005 * int(z["nar"]) and tuple(G["shape"]) == (2061, 2048)
+    assert int(G["rw"].size) == int(z["nar"]) and tuple(G["shape"]) == (2061, 2048)
     assert (np.diff(G["row"]) >= 0).all()
 
 

@@ -11,7 +11,11 @@
 import numpy as np
 import pytest
 
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import _libs as L
+import parity_log
 import synth
 
 pytestmark = pytest.mark.gpu
@@ -22,19 +26,19 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-# (nx, medium, period, receiver tolerance, field tolerance, largest fraction of nodes that may differ)
-# Generic media at the headline size: the north_star bar, 1e-4 s, over the whole field.
-# Homogeneous blocks aligned with the grid (configs[4]'s checkerboard) produce exact time ties; the
-# reference resolves them by heap order, this engine by local rules that follow the reference's insertion
-# order where that is known, and the reference's scheme carries a one-node difference far downstream
-# (measured in profiles/r01_fullsize_parity.log): isolated streaks of up to 4e-4 s at
-# 1025^2 and 7e-4 s at 4097^2 (T up to 150 s), 99.9 % of the nodes within 3e-4 s.
-FULL = [(131, "smooth", 3, 1e-4, 1e-4, 0.01), (131, "rough", 0, 1e-4, 1e-4, 0.03), (131, "homog", 0, 1e-4, 1e-4, 0.001),
-        (131, "checker", 0, 1e-4, 1e-3, 0.005), (259, "checker", 1, 1e-4, 2e-4, 0.02), (515, "checker", 2, 5e-4, 2e-3, 1.0)]
+# (nx, medium, period, field bound, largest fraction of nodes beyond 1e-4 s).  Receivers: 1e-4 s in every case.
+# Generic media: the north_star bar, 1e-4 s, over the whole field.  The checkerboard of configs[4] (homogeneous blocks
+# aligned with the grid) produces exact time ties between neighbouring narrow-band nodes; the reference's answer there
+# depends on which of the two its heap pops first (CalSurfG.f90:417-424, :768-921) and its scheme carries the one-node
+# difference downstream.  Those cases are named here with 1.5 x the measured figures
+# (tests/tools/parity_table.py, profiles/r02_parity_table.log): 1025^2 checkerboard 4.43e-4 s on 14 nodes; 4097^2
+# checkerboard (T up to 151 s, one ulp = 1.5e-5 s) 7.32e-4 s with 1.84 % of the nodes beyond 1e-4 s.
+FULL = [(131, "smooth", 3, 1e-4, 0.0), (131, "rough", 0, 1e-4, 0.0), (131, "homog", 0, 1e-4, 0.0),
+        (131, "checker", 0, 6.7e-4, 2.1e-5), (259, "checker", 1, 1e-4, 0.0), (515, "checker", 2, 1.1e-3, 0.028)]
 
 
-@pytest.mark.parametrize("nx,kind,period,rtol,ftol,fdiff", FULL)
-def test_one_unit_against_oracle(engine, nx, kind, period, rtol, ftol, fdiff):
+@pytest.mark.parametrize("nx,kind,period,ftol,fover", FULL)
+def test_one_unit_against_oracle(engine, nx, kind, period, ftol, fover):
     """configs[2] (1025^2 smooth) and configs[4] (4097^2 checkerboard +-8 %, 16-vertex squares) media"""
     g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
     pv = synth.medium(nx, kind, period)
@@ -51,12 +55,13 @@ def test_one_unit_against_oracle(engine, nx, kind, period, rtol, ftol, fdiff):
     assert (bits(engine.velocity(0)) != bits(veln)).sum() == 0
     t = engine.traveltimes([0], [sx], [sz], [32], rx, rz)
     ref = np.array([L.o_srtimes(g, veln, o["T"], sx, sz, rx[k], rz[k]) for k in range(32)], np.float32)
-    assert np.abs(t - ref).max() <= rtol
     T = engine.field(0)
     d = np.abs(T - o["T"])
+    parity_log.add(f"full N={N} {kind}: receivers max |dt| {np.abs(t - ref).max():.3g} s (32) | field max {d.max():.3g} s, beyond 1e-4 s {100.0 * (d > TOL).mean():.4f} %, "
+                   f"not bit-identical {100.0 * (bits(T) != bits(o['T'])).mean():.3f} %" + (" [named tie case]" if ftol > TOL else ""))
+    assert np.abs(t - ref).max() <= TOL
     assert d.max() <= ftol
-    assert np.quantile(d, 0.999) <= 3e-4
-    assert (bits(T) != bits(o["T"])).mean() <= fdiff
+    assert (d > TOL).mean() <= fover
 
 
 def test_config1_homogeneous_256(engine):
@@ -109,3 +114,29 @@ def test_scaling_is_exact_at_headline_size(engine):
         full[i, np.arange(8) != i] = t[i]
     off = ~np.eye(8, dtype=bool)
     assert np.abs(full - full.T)[off].max() <= 0.01 * full[off].min() + 0.02
+
+
+@pytest.mark.parametrize("kind", ["smooth", "rough"])
+def test_receivers_at_scale(engine, kind):
+    """256 units x 32 receivers at the headline size (1025^2; smooth = configs[2]'s medium, rough = +-10 % random vertices)
+    against the oracle's Fast Marching (pinned to the reference at this size: tests/test_oracle_vs_ref.py), the oracle
+    solves spread over the host cores: every one of the 8192 receiver times within 1e-4 s"""
+    nx, nsrc, nper, nrec = 131, 128, 2, 32
+    u = synth.units(nx, nsrc, nper, nrec)
+    pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)])
+    engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    t = engine.traveltimes(**u).reshape(nsrc * nper, nrec)
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    veln = [L.o_gridder(g, pv[p]) for p in range(nper)]
+
+    def one(k):
+        p = int(u["map_index"][k])
+        o = L.o_solve(g, pv[p], veln[p], u["scx"][k], u["scz"][k])
+        return np.array([L.o_srtimes(g, veln[p], o["T"], u["scx"][k], u["scz"][k], u["rcx"][k * nrec + r], u["rcz"][k * nrec + r]) for r in range(nrec)], np.float32)
+
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:      # ctypes releases the GIL; the oracle keeps no global state
+        ref = np.stack(list(ex.map(one, range(nsrc * nper))))
+    d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
+    parity_log.add(f"receivers at scale N=1025 {kind}: {d.size} receiver times of {nsrc * nper} units, max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())}, "
+                   f"not bit-identical {int((bits(t) != bits(ref)).sum())}")
+    assert d.max() <= TOL

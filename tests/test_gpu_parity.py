@@ -9,10 +9,21 @@ import numpy as np
 import pytest
 
 import _libs as L
+import parity_log
 import synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+
+# The only fields of this file that leave the 1e-4 s bar, by (nx, medium, dicing, source index): (bound on the field's
+# max |dT| = 1.5 x measured, bound on the nodes beyond 1e-4 s = 1.5 x measured).  Each is an exact-tie case: two
+# neighbouring narrow-band nodes carry bit-equal times, the reference pops one of them first (which one is decided by
+# its heap layout, CalSurfG.f90:417-424 / :768-921) and re-evaluates the other against it at the double root of the
+# two-sided quadratic; this engine accepts both without using either in the other's stencil.  Measured with
+# tests/tools/parity_table.py (profiles/r02_parity_table.log).  Every other (case, source) asserts 1e-4 s over the field.
+TIE_CASES = {
+    (35, "checker4", 8, 3): (6.2e-4, 62),     # source on the node (5, 7) of a +-13 % checkerboard: measured 4.13e-4 s, 41 of 66 049 nodes
+}
 
 
 def bits(a):
@@ -70,9 +81,17 @@ def test_fields_match_oracle(engine, nx, kind, gd):
     nbad_nodes = 0
     for u, (src, o) in enumerate(zip(srcs, sols)):
         T = engine.field(u)
-        d = float(np.abs(T - o["T"]).max())
+        dT = np.abs(T - o["T"])
+        d = float(dT.max())
+        over = int((dT > TOL).sum())
         worst = max(worst, d)
         nbad_nodes += int((bits(T) != bits(o["T"])).sum())
+        bound, nbound = TIE_CASES.get((nx, kind, gd, u), (TOL, 0))
+        if d > 0:
+            parity_log.add(f"fixture nx={nx} {kind} gd={gd} source {u} {FRAC[u]}: field max |dT| {d:.3g} s, nodes beyond 1e-4 s {over}"
+                           + (" [named tie case]" if (nx, kind, gd, u) in TIE_CASES else ""))
+        assert d <= bound, (nx, kind, gd, u, d)
+        assert over <= nbound, (nx, kind, gd, u, over)
         Tr, Sr = engine.refined(u)
         cls_o = np.sign(o["Sr"]).clip(-1, 1)
         # status classes may differ only at exact time ties (symmetric media); values where both alive agree
@@ -83,12 +102,8 @@ def test_fields_match_oracle(engine, nx, kind, gd):
             ref = L.o_srtimes(g, veln, o["T"], src[0], src[1], rcx[u, k], rcz[u, k])
             assert abs(float(t[2 * u + k]) - float(ref)) <= TOL, (u, k, t[2 * u + k], ref)
     total = len(srcs) * g.nnx * g.nnz
-    print(f"[{kind} nx={nx} gd={gd}] worst |dT| {worst:.3g} s, nodes not bit-identical {nbad_nodes} of {total}")
-    # Field level: bit-identical except for streaks that start at an exact time tie between two
-    # narrow-band nodes, where the reference's pop order depends on its heap layout (DESIGN.md
-    # "ties"); those are bounded but can exceed 1e-4 s at isolated nodes.  Receivers (above) hold 1e-4.
-    assert nbad_nodes <= 0.005 * total
-    assert worst <= 2e-3
+    parity_log.add(f"fixture nx={nx} {kind} gd={gd}: {len(srcs)} sources, worst field |dT| {worst:.3g} s, nodes not bit-identical {nbad_nodes} of {total}")
+    assert nbad_nodes <= 0.001 * total
 
 
 def test_sorted_variant_identical(engine):

@@ -47,6 +47,35 @@ def test_fields_rays_bitwise(nx, kind, gd):
         wb.close()
 
 
+@pytest.mark.parametrize("nx,kind,period", [(131, "smooth", 3), (131, "rough", 0), (131, "checker", 0)])
+def test_fields_bitwise_at_headline_size(nx, kind, period):
+    """1025^2 (BASELINE.json configs[2] size): the oracle's field, refined snapshot and receiver times against
+    the reference's travel / srtimes (CalSurfG.f90:288-487, :1636-1759), every bit -- the GPU parity tests at
+    this size compare with an oracle that is pinned at this size"""
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    wb = L.RefWB(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    try:
+        pv = synth.medium(nx, kind, period)
+        vr, vo = wb.gridder(pv), L.o_gridder(g, pv)
+        assert (bits(vr) != bits(vo)).sum() == 0
+        N = g.nnx
+        rng = synth.LCG(7 + nx)
+        for fx, fz in ((0.37 * (N - 1) + 0.3, 0.58 * (N - 1) + 0.6), (N - 9.25, 300.5)):
+            sx = np.float32(g.gox + np.float32(fx) * g.dnx)
+            sz = np.float32(g.goz + np.float32(fz) * g.dnz)
+            r, o = wb.solve(sx, sz), L.o_solve(g, pv, vo, sx, sz)
+            assert (bits(r["T"]) != bits(o["T"])).sum() == 0
+            live = r["Sr"] >= 0
+            assert (bits(r["Tr"])[live] != bits(o["Tr"])[live]).sum() == 0
+            v = rng.uniform(16)
+            for i in range(8):
+                rx = np.float32(g.gox + np.float32(0.2 + v[2 * i] * (N - 1.4)) * g.dnx)
+                rz = np.float32(g.goz + np.float32(0.2 + v[2 * i + 1] * (N - 1.4)) * g.dnz)
+                assert wb.srtimes(sx, sz, rx, rz).view(np.uint32) == L.o_srtimes(g, vo, o["T"], sx, sz, rx, rz).view(np.uint32)
+    finally:
+        wb.close()
+
+
 def bits64(a):
     return np.ascontiguousarray(a, np.float64).view(np.uint64)
 

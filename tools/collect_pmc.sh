@@ -1,22 +1,45 @@
 #!/bin/bash
-# PMC passes for the coarse fixed-point kernel; one counter set per run (rocprofv3 --pmc, no traces).
-# usage (on the GPU box, from the repo root): bash tools/collect_pmc.sh <tag>
+# rocprofv3 --pmc passes of one command (counters never share a run with trace domains other than kernel-trace).
+#   bash tools/collect_pmc.sh <tag> <groups> [lib] [-- program args...]
+# <groups>: comma-separated names from the table below (each is one pass = one run of the command), e.g. "insts,busy,wait"
+# [lib]: A/B build to load (DSA_LIB_PATH); default command: python3 tools/perf_probe.py 131 1024 1.25 smooth 256
+# Output: gpurun_out/<tag>/summary.txt (per-kernel counter sums of every pass) -- copy what should be judged into profiles/.
 set -u
-TAG=${1:-pmc}
+TAG=${1:-pmc}; GROUPS_=${2:-insts,busy,wait}; shift 2 || true
+LIB=""
+if [ $# -gt 0 ] && [ "$1" != "--" ]; then LIB=$1; shift; fi
+[ $# -gt 0 ] && [ "$1" == "--" ] && shift
+if [ $# -gt 0 ]; then CMD=("$@"); else CMD=(python3 tools/perf_probe.py 131 1024 1.25 smooth 256); fi
+[ -n "$LIB" ] && export DSA_LIB_PATH=$LIB
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-run() {   # name, counters...
-  local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" -d $OUT/$name -o r -- python3 tools/perf_probe.py 131 256 3 smooth 256 > $OUT/$name.log 2>&1
-}
-run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
-run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
-run tcc1 FETCH_SIZE
-run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum
-for n in sq1 sq2 tcc1 tcc2 tcp; do
-  db=$(find $OUT/$n -name "*.db" | head -1)
-  echo "== $n ($db)"; tail -3 $OUT/$n.log
-  [ -n "$db" ] && python3 tools/rocpd_pmc.py $db | grep -v "^#" | head -40
-done > $OUT/summary.txt 2>&1
+declare -A SETS=(
+  [insts]="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM"
+  [busy]="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
+  [wait]="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_WAVES"
+  [lds]="SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"
+  [vmem]="SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"
+  [fetch]="FETCH_SIZE"
+  [write]="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
+  [tcc]="TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_ATOMIC_sum"
+  [tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum"
+  [icache]="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH"
+)
+: > $OUT/rc.txt
+IFS=',' read -ra GS <<< "$GROUPS_"
+for g in "${GS[@]}"; do
+  c=${SETS[$g]:-}
+  if [ -z "$c" ]; then echo "unknown group $g" >> $OUT/rc.txt; continue; fi
+  timeout 600 rocprofv3 --pmc $c -d $OUT/$g -o r -- "${CMD[@]}" > $OUT/$g.log 2>&1
+  echo "$g rc=$?" >> $OUT/rc.txt
+done
+{
+  echo "# rocprofv3 --pmc, one pass per group; command: ${CMD[*]}  lib: ${LIB:-default}"
+  for g in "${GS[@]}"; do
+    db=$(find $OUT/$g -name "*.db" 2>/dev/null | head -1)
+    echo "== $g"; grep -E "solves/s|\"metric\"" $OUT/$g.log | cut -c1-240
+    [ -n "$db" ] && python3 tools/rocpd_pmc.py $db | grep -v "^#" | head -40
+  done
+} > $OUT/summary.txt 2>&1
+cat $OUT/rc.txt $OUT/summary.txt

@@ -1,16 +1,24 @@
 #!/bin/bash
-# rocprofv3 on the bench command itself: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own passes.
-# usage (GPU box, repo root): bash tools/profile_bench.sh <tag>
+# rocprofv3 on the bench command itself: kernel trace + stats, then the counter groups in their own passes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass).  usage (GPU box, repo root): bash tools/profile_bench.sh <tag>
+# Leaves gpurun_out/<tag>/summary.txt and gpurun_out/<tag>/pmc_latest.json: copy them to profiles/ (r0N_rocprof_bench.txt,
+# pmc_latest.json) -- bench.py reads profiles/pmc_latest.json and ignores it when the kernel sources have changed since.
 set -u
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r -- python3 bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
-timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o r -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $OUT/fetch.log 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/write -o r -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $OUT/write.log 2>&1
+for g in "fetch FETCH_SIZE" "write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "busy SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+         "insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "wait SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES"; do
+  set -- $g; n=$1; shift
+  timeout 900 rocprofv3 --pmc "$@" -d $OUT/pmc/$n -o r -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $OUT/$n.log 2>&1
+done
 {
-  echo "== kernel trace (rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline)"; grep '"metric"' $OUT/trace.log | cut -c1-400
+  echo "== kernel trace (rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline)"; grep '"metric"' $OUT/trace.log | cut -c1-600
   python3 tools/rocpd_summary.py $(find $OUT/trace -name "*.db" | head -1)
-  for n in fetch write; do echo "== pmc $n"; grep '"metric"' $OUT/$n.log | cut -c1-200; python3 tools/rocpd_pmc.py $(find $OUT/$n -name "*.db" | head -1) | grep "k_fim_sorted<256>"; done
+  for n in fetch write busy insts wait; do echo "== pmc $n"; grep '"metric"' $OUT/$n.log | cut -c1-200; python3 tools/rocpd_pmc.py $(find $OUT/pmc/$n -name "*.db" | head -1) | grep "k_fim"; done
+  echo "== pmc_latest.json"
+  python3 tools/pmc_to_json.py $OUT/pmc 16000 $OUT/pmc_latest.json
 } > $OUT/summary.txt 2>&1
+tail -30 $OUT/summary.txt

@@ -5,8 +5,8 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
-print("# per-kernel statistics (durations in ns)")
-print("%-12s %-14s %-14s %-8s  %s" % ("calls", "total_ns", "avg_ns", "pct", "kernel"))
+print("# per-kernel statistics (durations in us, as the top_kernels view of rocpd reports them)")
+print("%-12s %-14s %-14s %-8s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
 for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     print("%-12d %-14.0f %-14.0f %-8.3f  %s" % (calls, total, avg, pct, name[:110]))
 top = cur.execute("select name from top_kernels limit 1").fetchone()[0]
