@@ -78,7 +78,7 @@ def test_row_capacity_is_checked(eng):
     eng.plan([0], [c["scxf"][0, 0]], [c["sczf"][0, 0]], [2], c["rcxf"][:2, 0, 0], c["rczf"][:2, 0, 0], sen_slot=[0])
     with pytest.raises(EngineError) as ex:
         eng.solve_rows(3)
-    assert ex.value.code == -2 and "entries" in str(ex.value)
+    assert ex.value.code == -6 and "entries" in str(ex.value)          # DSA_ERR_CAPACITY
     t, rw, iw, col = eng.solve_rows(10000)                       # and the same plan still works with room
     assert rw.size > 3 and set(iw.tolist()) == {1, 2}
 

@@ -21,12 +21,12 @@
 typedef unsigned long long u64;
 __device__ __forceinline__ size_t gid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
 
-__global__ void rd_stream16(const uint4* p, size_t n, u64* sink) { size_t i = gid(); u64 a = 0; if (i < n) { uint4 v = p[i]; a = v.x + v.y + v.z + v.w; } if (a == 0x123456789ull) *sink = a; }
-__global__ void rd_stream8(const uint2* p, size_t n, u64* sink) { size_t i = gid(); u64 a = 0; if (i < n) { uint2 v = p[i]; a = v.x + v.y; } if (a == 0x123456789ull) *sink = a; }
-__global__ void rd_line1(const uint2* p, size_t nlines, u64* sink) { size_t i = gid(); u64 a = 0; if (i < nlines) { uint2 v = p[i * 16 + (i % 7)]; a = v.x + v.y; } if (a == 0x123456789ull) *sink = a; }
-__global__ void rd_line2same(const uint2* p, size_t nlines, u64* sink) { size_t i = gid(); u64 a = 0; if (i < nlines) { uint2 v = p[i * 16 + (i % 3)], w = p[i * 16 + 4 + (i % 3)]; a = v.x + v.y + w.x + w.y; } if (a == 0x123456789ull) *sink = a; }
-__global__ void rd_line2diff(const uint2* p, size_t nlines, u64* sink) { size_t i = gid(); u64 a = 0; if (i < nlines) { uint2 v = p[i * 16 + (i % 7)], w = p[i * 16 + 8 + (i % 5)]; a = v.x + v.y + w.x + w.y; } if (a == 0x123456789ull) *sink = a; }
-__global__ void rd_tile1(const uint2* p, size_t ntiles, u64* sink) { size_t i = gid(); u64 a = 0; if (i < ntiles) { size_t t = (i * 2654435761ull) % ntiles; uint2 v = p[t * 64 + ((t * 40503ull) & 63)]; a = v.x + v.y; } if (a == 0x123456789ull) *sink = a; }
+__global__ void rd_stream16(const uint4* p, size_t n, u64* sink) { size_t i = gid(); unsigned a = 0; if (i < n) { uint4 v = p[i]; a = v.x + v.y + v.z + v.w; } if (a == 0x12345679u) *sink = a; }
+__global__ void rd_stream8(const uint2* p, size_t n, u64* sink) { size_t i = gid(); unsigned a = 0; if (i < n) { uint2 v = p[i]; a = v.x + v.y; } if (a == 0x12345679u) *sink = a; }
+__global__ void rd_line1(const uint2* p, size_t nlines, u64* sink) { size_t i = gid(); unsigned a = 0; if (i < nlines) { uint2 v = p[i * 16 + (i % 7)]; a = v.x + v.y; } if (a == 0x12345679u) *sink = a; }
+__global__ void rd_line2same(const uint2* p, size_t nlines, u64* sink) { size_t i = gid(); unsigned a = 0; if (i < nlines) { uint2 v = p[i * 16 + (i % 3)], w = p[i * 16 + 4 + (i % 3)]; a = v.x + v.y + w.x + w.y; } if (a == 0x12345679u) *sink = a; }
+__global__ void rd_line2diff(const uint2* p, size_t nlines, u64* sink) { size_t i = gid(); unsigned a = 0; if (i < nlines) { uint2 v = p[i * 16 + (i % 7)], w = p[i * 16 + 8 + (i % 5)]; a = v.x + v.y + w.x + w.y; } if (a == 0x12345679u) *sink = a; }
+__global__ void rd_tile1(const uint2* p, size_t ntiles, u64* sink) { size_t i = gid(); unsigned a = 0; if (i < ntiles) { size_t t = (i * 2654435761ull) % ntiles; uint2 v = p[t * 64 + ((t * 40503ull) & 63)]; a = v.x + v.y; } if (a == 0x12345679u) *sink = a; }
 __global__ void wr_stream16(uint4* p, size_t n) { size_t i = gid(); if (i < n) p[i] = make_uint4((unsigned)i, 1, 2, 3); }
 __global__ void wr_line1(uint2* p, size_t nlines) { size_t i = gid(); if (i < nlines) p[i * 16 + (i % 7)] = make_uint2((unsigned)i, 7); }
 __global__ void wr_line2diff(uint2* p, size_t nlines) { size_t i = gid(); if (i < nlines) { p[i * 16 + (i % 7)] = make_uint2((unsigned)i, 7); p[i * 16 + 8 + (i % 5)] = make_uint2((unsigned)i, 9); } }
