@@ -109,6 +109,9 @@ __device__ __forceinline__ float wave_min(float v)
 #ifndef DSA_FIM_WAVES
 #define DSA_FIM_WAVES 4
 #endif
+#ifndef DSA_ODD_CLEAR
+#define DSA_ODD_CLEAR 0             // 0: every ready node leaves the active set in pass A; 1 / 2: the odd ones after the even sub-pass (before / behind its barrier)
+#endif
 #ifndef DSA_FIM_GROUP_SHIFT
 #define DSA_FIM_GROUP_SHIFT 4      // log2 of the bitmap words per group handed to a wave (pass A of k_fim_sorted)
 #endif
@@ -456,9 +459,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     }
     __syncthreads();
 
-    int rounds = 0, stall = 0, freezes = 0, max_cnt = 0;
+    int rounds = 0, stall = 0, freezes = 0;
     unsigned hist[4] = { 1u, 2u, 3u, 4u };
+    // Phase clocks and list statistics (thread 0) are probe instrumentation: seven 64-bit accumulators are fourteen VGPRs the
+    // solver's live set does not have, so they exist only in builds with DSA_PHASE_CLOCKS (tools/perf_probe.py prints them).
+#ifdef DSA_PHASE_CLOCKS
+    int max_cnt = 0;
     unsigned long long tA = 0, tB0 = 0, tB1 = 0, tE = 0, t0 = wall_clock64(), sum_cnt = 0, sum_ready = 0;
+#define DSA_PHASE(acc, extra) do { const unsigned long long t1 = wall_clock64(); acc += t1 - t0; t0 = t1; extra; } while (0)
+#else
+#define DSA_PHASE(acc, extra) do { } while (0)
+#endif
     float best_tmin = -kInf;
     unsigned evals = 0, nchanged = 0;                        // per lane (a lane evaluates < 2^32 nodes)
 #ifdef DSA_PASSA_CLOCKS
@@ -576,7 +587,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     base_e += __popcll(be[i]); base_o += __popcll(bo[i]);
                     const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
                     if (got) ready[want_o ? rhalf + po : pe] = id[i];
+#if DSA_ODD_CLEAR
+                    // an odd node stays in the active set until its own sub-pass starts: what the even half activates in between
+                    // is seen by that evaluation anyway and must not queue the node again (tests/tools/sched_lab.cpp mode 6:
+                    // -15 % evaluations at the same fixed point)
+                    if ((got && !want_o) || frozen[i]) atomicOr(&clr[2 * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
+#else
                     if (got || frozen[i]) atomicOr(&clr[2 * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
+#endif
                     if (have && !frozen[i] && !got) tmin_lane = fminf(tmin_lane, lb[i]);
                 }
                 DSA_TICK(4);
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         __syncthreads();
         const int cnt = sc[SC_CUR];
         if (cnt == 0) break;
-        { const unsigned long long t1 = wall_clock64(); tA += t1 - t0; t0 = t1; sum_cnt += cnt; if (cnt > max_cnt) max_cnt = cnt; }
+        DSA_PHASE(tA, sum_cnt += cnt; if (cnt > max_cnt) max_cnt = cnt);
 
         // ---- pass B: evaluate, even nodes first
         const int nready_even = sc[SC_READY] < rhalf ? sc[SC_READY] : rhalf;
@@ -683,30 +701,43 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     want[4 + q] = changed && h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) &&
                                   t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q];
                 }
-                // the eight dependents lie in the node's own tile and in at most one other tile per direction (when
-                // the near one has left the tile, the outer one is in the same neighbour tile): five atomics at most
+                // The eight dependents lie in the node's own tile and in at most one other tile per direction (when the near one
+                // has left the tile, the outer one is in the same neighbour tile): five atomics at most.  Their mask bits are
+                // constant shifts of the node's own bit b = 1 << r (record r = 8 (ix & 7) + (iz & 7)): a step in x moves a
+                // whole byte, a step in z one bit inside the byte; what a shift pushes out of the byte / word is exactly the
+                // part that belongs to the neighbouring tile, where it reappears shifted the other way.
                 const int own_tile = id >> 6;
-                unsigned long long own_bits = 0ull;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int near_tile = nid[d] >> 6;
-                    const int far_tile = near_tile != own_tile ? near_tile : nid[4 + d] >> 6;      // (the outer one may lie outside the grid)
-                    unsigned long long far_bits = 0ull;
-                    if (want[d]) { const unsigned long long b = 1ull << (nid[d] & 63); if (near_tile == own_tile) own_bits |= b; else far_bits |= b; }
-                    if (want[4 + d]) { const unsigned long long b = 1ull << (nid[4 + d] & 63); if ((nid[4 + d] >> 6) == own_tile) own_bits |= b; else far_bits |= b; }
-                    if (far_bits) {
-                        atomicOr((unsigned long long*)mask_at(far_tile), far_bits);
-                        atomicOr(&tb[far_tile >> 5], 1u << (far_tile & 31));
+                const unsigned long long b = 1ull << (id & 63);
+                auto sel = [](bool w, unsigned long long v) -> unsigned long long { return w ? v : 0ull; };
+                unsigned long long own_bits, fxm, fxp, fzm, fzp;
+                own_bits = sel(want[0], b >> 8) | sel(want[4], b >> 16) | sel(want[1], b << 8) | sel(want[5], b << 16) |
+                           sel(want[2], (b >> 1) & 0x7f7f7f7f7f7f7f7full) | sel(want[6], (b >> 2) & 0x3f3f3f3f3f3f3f3full) |
+                           sel(want[3], (b << 1) & 0xfefefefefefefefeull) | sel(want[7], (b << 2) & 0xfcfcfcfcfcfcfcfcull);
+                fxm = sel(want[0], b << 56) | sel(want[4], b << 48);
+                fxp = sel(want[1], b >> 56) | sel(want[5], b >> 48);
+                fzm = sel(want[2], (b << 7) & 0x8080808080808080ull) | sel(want[6], (b << 6) & 0xc0c0c0c0c0c0c0c0ull);
+                fzp = sel(want[3], (b >> 7) & 0x0101010101010101ull) | sel(want[7], (b >> 6) & 0x0303030303030303ull);
+                auto activate = [&](int tile, unsigned long long bits) {
+                    if (bits) {
+                        atomicOr((unsigned long long*)mask_at(tile), bits);
+                        atomicOr(&tb[tile >> 5], 1u << (tile & 31));
                     }
-                }
-                if (own_bits) {
-                    atomicOr((unsigned long long*)mask_at(own_tile), own_bits);
-                    atomicOr(&tb[own_tile >> 5], 1u << (own_tile & 31));
-                }
+                };
+                activate(own_tile - nbz, fxm);
+                activate(own_tile + nbz, fxp);
+                activate(own_tile - 1, fzm);
+                activate(own_tile + 1, fzp);
+                activate(own_tile, own_bits);
                 // change hash and earliest change: accumulated per lane, reduced once per round (below)
                 if (changed) { hv_lane += ((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u); kmin_lane = fminf(kmin_lane, k); }
                 DSA_TICK(7);
             }
+#if DSA_ODD_CLEAR == 1
+            // the odd ready nodes leave the active set: issued by every wave as it finishes its even trips (the workgroup's
+            // vector memory operations reach the masks in issue order, so these land before anything the odd half activates)
+            if (half == 0)
+                for (int j = tid; j < nready_odd; j += NT) { const int oid = ready[rhalf + j]; atomicAnd((unsigned long long*)mask_at(oid >> 6), ~(1ull << (oid & 63))); }
+#endif
             if (half == 1) {
                 const unsigned hv = wave_sum(hv_lane);
                 const float kmin = wave_min(kmin_lane);
@@ -716,9 +747,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 }
             }
             __syncthreads();
-            { const unsigned long long t1 = wall_clock64(); (half ? tB1 : tB0) += t1 - t0; t0 = t1; }
+#if DSA_ODD_CLEAR == 2
+            if (half == 0) {
+                for (int j = tid; j < nready_odd; j += NT) { const int oid = ready[rhalf + j]; atomicAnd((unsigned long long*)mask_at(oid >> 6), ~(1ull << (oid & 63))); }
+                __syncthreads();
+            }
+#endif
+            DSA_PHASE((half ? tB1 : tB0), );
         }
+#ifdef DSA_PHASE_CLOCKS
         sum_ready += nready_even + nready_odd;
+#endif
         if (tid == 0) {
             sc[SC_READY] = 0; sc[SC_READY_ODD] = 0; sc[SC_CUR] = 0;
             const float tmin = u2f((unsigned)sc[SC_TMIN]);
@@ -734,7 +773,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         }
         ++rounds;
         __syncthreads();
-        { const unsigned long long t1 = wall_clock64(); tE += t1 - t0; t0 = t1; }
+        DSA_PHASE(tE, );
         if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
     }
     {
@@ -744,7 +783,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     }
     if (tid == 0) {
         p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
+#ifdef DSA_PHASE_CLOCKS
         if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }
+#endif
 #ifdef DSA_PASSA_CLOCKS
         if (p.clocks) { p.clocks[0] = sub[0] + sub[1]; p.clocks[1] = sub[2] + sub[3]; p.clocks[2] = sub[4]; p.clocks[3] = sub[5]; p.clocks[4] = sub[6]; p.clocks[5] = sub[7]; }
 #endif

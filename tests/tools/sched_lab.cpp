@@ -12,6 +12,7 @@
 //   8  like 6, the colour that goes first alternates from round to round
 //   9  like 6, a node is ready when its SECOND earliest neighbour is inside the window, or its earliest one lies param per cent of a window back
 //   10 four colours (ix & 1, iz & 1) in the order given by param's decimal digits, each leaving the active set right before its sub-pass
+//   11 like 6 with a window steered towards `param` ready nodes per round (proportional control, 0.25 .. 4 x the given window)
 //   5  lazy: a node waits for the acceptance time of the neighbour that activated it to enter the window (key routing), parity sub-passes
 // build: g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -msse2 -mfpmath=sse -o tests/tools/libsched_lab.so tests/tools/sched_lab.cpp
 #include <algorithm>
@@ -70,7 +71,8 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     for (int ix = 0; ix < nnx; ++ix) for (int iz = 0; iz < nnz; ++iz)
         if (t_pinned(F[rec_index(nbz, iz, ix)].T)) { act(iz, ix - 1, 0.f); act(iz, ix + 1, 0.f); act(iz - 1, ix, 0.f); act(iz + 1, ix, 0.f); }
     cur.swap(next);
-    float theta = kInf; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0;
+    float theta = kInf; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, trips256 = 0, trips128 = 0;
+    float wnow = window;
     float best_tmin = -kInf, freeze = -kInf; int stall = 0; long freezes = 0;
     unsigned hist[4] = { 1u, 2u, 3u, 4u }, hsh = 0u;
     auto tv = [&](int iz0, int ix0) { return (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) ? kInf : tau_value(F[rec_index(nbz, iz0, ix0)].tau); };
@@ -151,6 +153,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
         }
         else if (mode == 1 || mode >= 5) {
             for (int p = 0; p < 2; ++p) {
+                { long cnt = 0; for (auto& r : ready) if (parity(r.id) == p) ++cnt; trips256 += (cnt + 255) / 256; trips128 += (cnt + 127) / 128; }
                 const int want = (mode == 8 && (rounds & 1)) ? p ^ 1 : p;
                 sub.clear(); for (auto& r : ready) if (parity(r.id) == want) sub.push_back(r.id);
                 if (mode >= 6 && p == 1) for (int id : sub) queued[id] = 0;
@@ -178,11 +181,16 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = hsh; hsh = 0u;
             if (repeat) { if (++stall >= 8) { freeze = best_tmin + window; stall = 0; ++freezes; } } else stall = 0;
         }
-        cur.swap(next); next.clear(); theta = tmin + window; ++rounds;
+        if (mode == 11) {
+            const float ratio = (float)param / (float)std::max<size_t>(ready.size(), 1);
+            wnow = wnow * fminf(fmaxf(ratio, 0.7f), 1.4f);
+            wnow = fminf(fmaxf(wnow, 0.25f * window), 4.0f * window);
+        }
+        cur.swap(next); next.clear(); theta = tmin + wnow; ++rounds;
         if (rounds >= max_rounds) break;
     }
     for (int ix = 0; ix < nnx; ++ix)
         for (int iz = 0; iz < nnz; ++iz) { const Rec r = F[rec_index(nbz, iz, ix)]; Tio[(size_t)ix * nnz + iz] = r.T; tauio[(size_t)ix * nnz + iz] = r.tau; }
-    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready;
+    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready; out[8] = trips256; out[9] = trips128;
     return cur.empty() ? 0 : -1;
 }

@@ -25,7 +25,12 @@ for wc, nt, var in [(w, t, v) for v in variants for t in threads for w in window
     t0 = time.time(); t = e.solve(); dt = time.time() - t0
     st = e.stats(); n = nsrc * nper
     same = 'first' if ref is None else f'identical={np.array_equal(ref.view(np.uint32), t.view(np.uint32))} maxdiff={np.abs(ref - t).max():.2g}'
-    if ref is None: ref = t
+    if ref is None:
+        ref = t
+        if os.environ.get('DSA_SAVE'): np.save(os.environ['DSA_SAVE'], t)
+        if os.environ.get('DSA_COMPARE') and os.path.exists(os.environ['DSA_COMPARE']):
+            other = np.load(os.environ['DSA_COMPARE'])
+            print(f'      against {os.environ["DSA_COMPARE"]}: identical={np.array_equal(other.view(np.uint32), t.view(np.uint32))} differing={int((other.view(np.uint32) != t.view(np.uint32)).sum())} maxdiff={np.abs(other - t).max():.3g}', flush=True)
     print(f'N={e.nnx} {kind} variant {var:2d} units {n:5d} wg {nt:4d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
           f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} changes/node {st["changes_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} freezes {st["freezes"]:.0f} | {same}', flush=True)
     pt = np.array(st["phase_ticks"]); tot = pt[:4].sum()
