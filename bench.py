@@ -48,6 +48,8 @@ NREC = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 TOL = 1e-4                   # north_star: travel times within 1e-4 s of the reference FMM
 KERNEL_SOURCES = ["fim_kernel.hip", "eikonal_core.h", "kernels.h", "engine.hip"]
+DISP_SOURCES = ["disp_kernels.hip", "dispersion_core.h"]
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector FP64 = half the 157.3 TFLOP/s vector FP32 peak of MI355X_MICROARCH.md
 
 
 def bytes_per_solve(n):
@@ -56,9 +58,9 @@ def bytes_per_solve(n):
     return 8.0 * n * n + 129 * 129 * 8.0
 
 
-def kernel_source_hash():
+def kernel_source_hash(names=None):
     h = hashlib.sha256()
-    for n in KERNEL_SOURCES:
+    for n in (names or KERNEL_SOURCES):
         with open(os.path.join(ROOT, "dsurftomo_amd", "csrc", n), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -117,6 +119,28 @@ def pmc_record():
     except (OSError, ValueError):
         return None
     return rec if rec.get("kernel_source_hash") == kernel_source_hash() else None
+
+
+def dispersion_secondary(eng):
+    """Secondary kernel: the dispersion stage at the headline model size, bounded by FP64 vector / transcendental
+    throughput, not by HBM.  Timed with the engine's HIP events; flops per root come from the FP64 instruction counters of
+    tools/collect_pmc.sh (profiles/pmc_dispersion.json), ignored when taken from other kernel sources."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import disp_roofline
+    rec = disp_roofline.run(eng, reps=2)
+    out = {"kernel": "k_dispersion + k_depth_kernels (surfdisp96.f:223-305, 807-843 under CalSurfG.f90:1-169)",
+           "workload": "nx=ny=131, nz=9, 16 Rayleigh phase periods with depth kernels: 17161 columns x 55 models x 16 roots",
+           "roots": rec["roots"], "ms": rec["ms"], "roots_per_s": rec["roots_per_s"],
+           "roofline": {"bound": "fp64 vector", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": None, "frac": None, "flops_per_root": None}}
+    path = os.path.join(ROOT, "profiles", "pmc_dispersion.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            pmc = json.load(f)
+        if pmc.get("kernel_source_hash") == kernel_source_hash(DISP_SOURCES) and pmc.get("fp64_flops_per_root"):
+            ach = pmc["fp64_flops_per_root"] * rec["roots_per_s"] / 1e12
+            out["roofline"].update({"flops_per_root": round(pmc["fp64_flops_per_root"], 1), "transcendentals_per_root": pmc.get("fp64_transcendentals_per_root"),
+                                    "achieved": round(ach, 3), "frac": round(ach / FP64_VECTOR_PEAK_TFLOPS, 4)})
+    return out
 
 
 def free_port():
@@ -291,6 +315,11 @@ def main():
             line["parity"] = {"checked_receiver_times": int(d.size), "units": int(len(pick)), "beyond_1e-4_s": int((d > TOL).sum()),
                               "not_bit_identical": int((got.view(np.uint32) != ref_times.view(np.uint32)).sum()),
                               "against": rec["kind"], "tolerance_s": TOL}
+        if world == 1:
+            try:
+                line["secondary"] = {"dispersion": dispersion_secondary(eng)}
+            except Exception as ex:                                     # the headline line must not depend on the secondary one
+                line["secondary"] = {"dispersion": {"error": str(ex)[:200]}}
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

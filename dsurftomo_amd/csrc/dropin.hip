@@ -142,6 +142,10 @@ extern "C" {
 
 const char* dsa_dropin_error(void) { return g_dropin_error.c_str(); }
 
+// the process-wide engine of the drop-in level (created on first use), for the engine-level calls that continue a drop-in
+// call on the device: dsa_iteration_system_device, dsa_lsmr, dsa_get_stats
+dsa_engine* dsa_dropin_engine(void) { return engine() == 0 ? g_engine : nullptr; }
+
 // capacity (entries) of the rw / iw(2:) / col arrays handed to dsa_calsurfg from now on; 0 = unknown (DSA_MAXNAR or unlimited)
 int dsa_dropin_set_capacity(long long maxnar)
 {
@@ -161,9 +165,13 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
                  const int* nsrcsurf, const int* nrcf, int* nar)
 {
     (void)nparpi;
-    if (!nx || !ny || !nz || !vels || !iw || !rw || !col || !dsurf || !kmax || !nar) { g_dropin_error = "dsa_calsurfg: null argument"; return DSA_ERR_ARGUMENT; }
+    // rw, iw and col may be null TOGETHER: the rows then stay on the device (extension; dsa_iteration_system_device / dsa_lsmr
+    // on dsa_dropin_engine() continue from there)
+    const bool device_rows = !iw && !rw && !col;
+    if (!nx || !ny || !nz || !vels || (!device_rows && (!iw || !rw || !col)) || !dsurf || !kmax || !nar) { g_dropin_error = "dsa_calsurfg: null argument"; return DSA_ERR_ARGUMENT; }
     int rc = engine();
     if (rc != 0) return rc;
+    if (device_rows && g_pool.size() != 1) { g_dropin_error = "dsa_calsurfg: rows can only stay on the device with one engine (DSA_DEVICES unset)"; return DSA_ERR_STATE; }
     const Layout L = make_layout(*kmaxRc, *kmaxRg, *kmaxLc, *kmaxLg, *kmax, true);
     if (L.kRc + L.kRg + L.kLc + L.kLg != L.kmax) { g_dropin_error = "dsa_calsurfg: kmax must equal kmaxRc+kmaxRg+kmaxLc+kmaxLg"; return DSA_ERR_ARGUMENT; }
     Units U;
@@ -214,7 +222,8 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
         if ((r = dsa_plan_units(e, b - a, U.map.data() + a, U.sx.data() + a, U.sz.data() + a, U.nrec.data() + a, U.rx.data() + ray0[a],
                                 U.rz.data() + ray0[a], U.mode.data() + a, U.slot.data() + a, U.data.data() + a)) != 0) return bad(r);
         if (ne == 1) {
-            r = dsa_solve_rows(e, dsurf, rw, iw + 1, col, cap, &P.n);          // the reference fills iw(nar+1)
+            en->rows_on_device = device_rows;
+            r = dsa_solve_rows(e, dsurf, rw, device_rows ? nullptr : iw + 1, col, cap, &P.n);          // the reference fills iw(nar+1)
         } else {
             en->grow_rw = &P.rw; en->grow_iw = &P.iw; en->grow_col = &P.col;
             r = en->solve(dsurf, nullptr, nullptr, nullptr, cap, &P.n);

@@ -100,6 +100,14 @@ struct Engine {
     std::vector<int>* grow_iw = nullptr;
     std::vector<int>* grow_col = nullptr;
 
+    // COO rows kept on the device across the chunks of a solve (rows_on_device): what dsa_iteration_system_device and LSMR
+    // work on without the matrix ever visiting the host (reference: rw / iw / col of main.f90:349-359, 487-489)
+    bool rows_on_device = false;
+    DevBuf<float> G_rw;
+    DevBuf<int> G_row, G_col;          // 1-based datum (row) and model parameter (column)
+    long long G_nar = 0;
+    template <class T> int ensure_keep(DevBuf<T>& b, size_t n, size_t used);
+
     SpmvState* spmv = nullptr;         // device copy of a COO matrix for dsa_spmv (spmv.hip)
     int lsmr_device_vectors = 0;       // dsa_lsmr: 1 = vectors and ordered reductions on the device, 0 = on the host (lsmr.hip)
 

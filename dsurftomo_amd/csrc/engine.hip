@@ -49,6 +49,23 @@ int Engine::ensure(DevBuf<T>& b, size_t n)
     return 0;
 }
 
+// like ensure, but the first `used` elements survive a reallocation (growth by at least a half)
+template <class T>
+int Engine::ensure_keep(DevBuf<T>& b, size_t n, size_t used)
+{
+    if (b.cap >= n) return 0;
+    const size_t want = std::max(n, b.cap + b.cap / 2);
+    T* q = nullptr;
+    HIP_TRY(this, hipMalloc(reinterpret_cast<void**>(&q), want * sizeof(T)));
+    if (b.p && used) HIP_TRY(this, hipMemcpyAsync(q, b.p, used * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    if (b.p) HIP_TRY(this, hipFree(b.p));
+    b.p = q; b.cap = want;
+    return 0;
+}
+template int Engine::ensure_keep<float>(DevBuf<float>&, size_t, size_t);
+template int Engine::ensure_keep<int>(DevBuf<int>&, size_t, size_t);
+
 void release_spmv(SpmvState* s);
 
 template int Engine::ensure<long long>(DevBuf<long long>&, size_t);
@@ -66,7 +83,7 @@ Engine::~Engine()
     rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(F_c); rel(seed_c); rel(nseed_c);
     rel(prob_r); rel(prob_c); rel(paths); rel(path_n); rel(info); rel(clocks); rel(lists);
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
-    rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo);
+    rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
@@ -350,10 +367,11 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
 {
     if (!planned) { fail(DSA_ERR_STATE, "solve: call dsa_plan first"); return DSA_ERR_STATE; }
     const bool grow = grow_rw && grow_iw && grow_col;
-    const bool rows = ((rw && iw && col) || grow) && nar;
+    const bool rows = ((rw && iw && col) || grow || rows_on_device) && nar;
     if (rows && !have_sens) { fail(DSA_ERR_STATE, "solve: Frechet rows need the depth kernels (dsa_set_depth_kernels / dsa_depthkernel) first"); return DSA_ERR_STATE; }
     if (rows) {
         *nar = 0;
+        G_nar = 0;
         for (const SourceDesc& s : h_src)
             if (s.sen_slot < 0 || s.sen_slot >= sens_kmax) { fail(DSA_ERR_ARGUMENT, "solve: a unit uses depth-kernel slot %d of %d", s.sen_slot, sens_kmax); return DSA_ERR_ARGUMENT; }
     }
@@ -555,7 +573,19 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
             grow_rw->resize((size_t)(*nar + total)); grow_iw->resize((size_t)(*nar + total)); grow_col->resize((size_t)(*nar + total));
             rw = grow_rw->data(); iw = grow_iw->data(); col = grow_col->data();
         }
-        if (total > 0) {
+        if (total > 0 && rows_on_device) {
+            // the launch writes its rows straight behind the ones already resident; the host copy is optional
+            const size_t need = (size_t)(*nar + total);
+            if (ensure_keep(G_rw, need, (size_t)*nar) || ensure_keep(G_row, need, (size_t)*nar) || ensure_keep(G_col, need, (size_t)*nar)) return status;
+            a.rw = G_rw.p + *nar; a.iw = G_row.p + *nar; a.col = G_col.p + *nar;
+            launch_row_emit(g, a, true, stream);
+            if (rw && iw && col) {
+                HIP_TRY(this, hipMemcpyAsync(rw + *nar, a.rw, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(this, hipMemcpyAsync(iw + *nar, a.iw, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(this, hipMemcpyAsync(col + *nar, a.col, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+            }
+            G_nar = *nar + total;
+        } else if (total > 0) {
             if (ensure(coo_rw, (size_t)total) || ensure(coo_iw, (size_t)total) || ensure(coo_col, (size_t)total)) return status;
             a.rw = coo_rw.p; a.iw = coo_iw.p; a.col = coo_col.p;
             launch_row_emit(g, a, true, stream);
@@ -668,6 +698,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "ray_path_cap" && value >= 0 && value <= (1 << 24)) { en->ray_path_cap = (int)value; return 0; }
     if (n == "disp_group_shift" && value >= -1 && value <= 3) { en->disp_group_shift = (int)value; return 0; }
     if (n == "disp_layers_lds" && (value == -1 || value == 0 || value == 1)) { en->disp_layers_lds = (int)value; return 0; }
+    if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
@@ -768,8 +799,12 @@ int dsa_solve(dsa_engine* e, float* dsurf)
 
 int dsa_solve_rows(dsa_engine* e, float* dsurf, float* rw, int* iw, int* col, long long capacity, long long* nar)
 {
-    if (!e || !rw || !iw || !col || !nar) return DSA_ERR_ARGUMENT;
-    return reinterpret_cast<Engine*>(e)->solve(dsurf, rw, iw, col, capacity, nar);
+    if (!e || !nar) return DSA_ERR_ARGUMENT;
+    Engine* en = reinterpret_cast<Engine*>(e);
+    // with option rows_on_device the three arrays may be null: the rows stay on the device (dsa_iteration_system_device)
+    if ((!rw || !iw || !col) && !en->rows_on_device) return DSA_ERR_ARGUMENT;
+    if (!rw || !iw || !col) { rw = nullptr; iw = nullptr; col = nullptr; }
+    return en->solve(dsurf, rw, iw, col, capacity, nar);
 }
 
 int dsa_get_dims(const dsa_engine* e, int* nnx, int* nnz)

@@ -8,9 +8,19 @@ namespace dsa {
 struct SpmvState {
     int m = 0, n = 0;
     long long nar = 0;
-    DevBuf<long long> rowptr, colptr;
-    DevBuf<float> val_r, val_c, x, y;
-    DevBuf<int> col_r, row_c;
+    // One ordering of the matrix (by row for A x, by column for A^T y) in slices of 64 segments, longest segments first:
+    // entry k of the segment held by lane l of slice j sits at off[j] + 64 k + l, so the 64 lanes of a wavefront read 64
+    // consecutive values / indices per step (coalesced) while every lane adds the entries of ITS segment in storage order.
+    struct Sliced {
+        DevBuf<long long> off;       // nslices + 1 slice offsets (entries)
+        DevBuf<int> seg, len;        // per (slice, lane): segment (row / column) and its entry count; nslices * 64
+        DevBuf<float> val;
+        DevBuf<int> idx;             // 0-based index into the input vector
+        int nslices = 0;
+        long long padded = 0;        // entries of storage (>= nar)
+    };
+    Sliced by_row, by_col;
+    DevBuf<float> x, y;
     // LSMR work vectors (lsmr.hip)
     DevBuf<float> u, v, h, hbar, xs, localV, scal;
     // pinned host copies of u and v for the host-vector placement (they cross PCIe twice per LSMR iteration)

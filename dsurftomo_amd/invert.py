@@ -3,8 +3,10 @@
     python -m dsurftomo_amd.invert <directory with DSurfTomo.in, the data file and MOD> [--maxiter N] [--out DIR]
 
 Per outer iteration: CalSurfG on the device (dsa_calsurfg: dispersion, depth kernels, eikonal solves, rays, Frechet rows),
-the host glue of main.f90:361-466 (dsa_iteration_system: residuals, percentile weights, DWS, regularisation rows), LSMR on
-the device (dsa_lsmr_dropin, bit-identical to the reference's LSMR), the model update of main.f90:520-535
+the glue of main.f90:361-466 (residuals, percentile weights, DWS, regularisation rows), LSMR on the device (bit-identical
+to the reference's LSMR), the model update of main.f90:520-535.  By default the matrix never leaves the device
+(dsa_calsurfg with null rw / iw / col -> dsa_iteration_system_device -> dsa_lsmr); --host-rows hands it through host
+arrays the way the reference does (dsa_calsurfg -> dsa_iteration_system -> dsa_lsmr_dropin), with the same numbers.  Then
 (dsa_model_update), and the reference's output files: residualFirst.dat / residualLast.dat (main.f90:397-411),
 <input>Measure.dat.iterNNN (main.f90:537-546) and <input>Measure.dat (:575-584), in the reference's formats.
 Synthetic tests (ifsyn = 1, main.f90:326-343) forward-model MOD.true; the noise there comes from this module's own
@@ -49,8 +51,55 @@ def write_residuals(path, c, dsyn, obst, datweight):
     np.savetxt(path, np.column_stack([c["dist"], dsyn, obst, dsyn * datweight, obst * datweight, datweight]), fmt="%16.8f")
 
 
+def iteration_device(lib, c, vsf, obst, log):
+    """One pass of main.f90:349-535 with the matrix resident on the device from CalSurfG to LSMR: dsa_calsurfg leaves the
+    rows there (null rw / iw / col), dsa_iteration_system_device applies weights / appends the regularisation rows / builds
+    both orderings in place, dsa_lsmr solves.  Same numbers as iteration() (tests/test_gpu_lsmr.py compares every bit)."""
+    f = np.float32
+    nx, ny, nz, dall = c["nx"], c["ny"], c["nz"], c["ndata"]
+    maxvp = c["nparpi"]
+    dsyn = np.zeros(dall, f)
+    nar = C.c_int(0)
+    cc = dict(c); cc["vels"] = vsf
+    head, tail = io._args(cc)
+    lib.dsa_dropin_set_capacity(0)
+    t0 = time.perf_counter()
+    if lib.dsa_calsurfg(*head, None, None, None, _p(dsyn), *tail, C.byref(nar)) != 0:
+        raise RuntimeError("dsa_calsurfg: %s" % lib.dsa_dropin_error().decode())
+    t_fwd = time.perf_counter() - t0
+    eng = lib.dsa_dropin_engine()
+    cbst = np.zeros(dall + maxvp, f); datweight = np.zeros(dall, f); norm = np.zeros(maxvp, f); dws = np.zeros(2, f)
+    m, nar2 = C.c_int(0), C.c_longlong(0)
+    t0 = time.perf_counter()
+    rc = lib.dsa_iteration_system_device(eng, nx, ny, nz, dall, _p(obst), _p(dsyn), c["threshold0"], c["weight0"], _p(cbst), _p(datweight), _p(norm),
+                                         C.byref(m), C.byref(nar2), _p(dws))
+    if rc != 0:
+        raise RuntimeError("dsa_iteration_system_device failed (%d): %s" % (rc, lib.dsa_error_string(eng).decode()))
+    t_glue = time.perf_counter() - t0
+    log("Maximum and Average DWS values: %g %g" % (dws[0], dws[1]))
+    dv = np.zeros(maxvp, f)
+    ii = [C.c_int(0), C.c_int(0)]
+    ff = [C.c_float(0) for _ in range(5)]
+    t0 = time.perf_counter()
+    rc = lib.dsa_lsmr(eng, _p(cbst), C.c_float(c["damp"]), C.c_float(1e-6), C.c_float(1e-6), C.c_float(100.0), 400, 10, _p(dv),
+                      C.byref(ii[0]), C.byref(ii[1]), *[C.byref(v) for v in ff])
+    if rc != 0:
+        raise RuntimeError("dsa_lsmr: %s" % lib.dsa_error_string(eng).decode())
+    t_lsmr = time.perf_counter() - t0
+    r = cbst[:dall]
+    mean = f(r.sum(dtype=f) / f(dall))
+    std = f(np.sqrt(f((r * r).sum(dtype=f) / f(dall)) - mean * mean))
+    rms = f(np.sqrt((r.astype(np.float64) ** 2).sum()) / np.sqrt(dall))
+    dv_raw = (f(dv.min()), f(dv.max()))
+    lib.dsa_model_update(nx, ny, nz, _p(dv), _p(vsf), c["minvel"], c["maxvel"])
+    return dict(dsyn=dsyn, datweight=datweight, mean_ms=1e3 * float(mean), std_ms=1e3 * float(std), rms=float(rms), dv_min=float(dv_raw[0]),
+                dv_max=float(dv_raw[1]), itn=ii[1].value, istop=ii[0].value, nar=nar2.value, m=m.value, dws=(float(dws[0]), float(dws[1])),
+                seconds=dict(forward=t_fwd, glue=t_glue, lsmr=t_lsmr), dv=dv, norm=norm, cbst=cbst)
+
+
 def iteration(lib, c, vsf, obst, log):
-    """One pass of main.f90:349-535 on the model vsf (updated in place).  Returns the statistics of the pass."""
+    """One pass of main.f90:349-535 on the model vsf (updated in place), the matrix going through host arrays like in the
+    reference (dsa_calsurfg -> dsa_iteration_system -> dsa_lsmr_dropin).  Returns the statistics of the pass."""
     f = np.float32
     nx, ny, nz, dall = c["nx"], c["ny"], c["nz"], c["ndata"]
     maxvp = c["nparpi"]
@@ -94,13 +143,23 @@ def iteration(lib, c, vsf, obst, log):
     lib.dsa_model_update(nx, ny, nz, _p(dv), _p(vsf), c["minvel"], c["maxvel"])
     return dict(dsyn=dsyn, datweight=datweight, mean_ms=1e3 * float(mean), std_ms=1e3 * float(std), rms=float(rms), dv_min=float(dv_raw[0]),
                 dv_max=float(dv_raw[1]), itn=ii[1].value, istop=ii[0].value, nar=n, m=m.value, dws=(float(dws[0]), float(dws[1])),
-                seconds=dict(forward=t_fwd, glue=t_glue, lsmr=t_lsmr))
+                seconds=dict(forward=t_fwd, glue=t_glue, lsmr=t_lsmr), dv=dv, norm=norm, cbst=cbst)
 
 
-def run(directory, maxiter=None, out_dir=".", log=print, seed=1):
-    lib = load_library()
+def bind(lib):
     lib.dsa_iteration_system.argtypes = [C.c_int] * 4 + [C.c_longlong] * 2 + [C.c_void_p] * 5 + [C.c_float] * 2 + [C.c_void_p] * 6
+    lib.dsa_iteration_system_device.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_float] * 2 + [C.c_void_p] * 6
     lib.dsa_model_update.argtypes = [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_float] * 2
+    lib.dsa_dropin_engine.restype = C.c_void_p
+    lib.dsa_dropin_engine.argtypes = []
+    lib.dsa_lsmr.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_int] * 2 + [C.c_void_p] * 8
+    lib.dsa_error_string.restype = C.c_char_p
+    lib.dsa_error_string.argtypes = [C.c_void_p]
+    return lib
+
+
+def run(directory, maxiter=None, out_dir=".", log=print, seed=1, host_rows=False):
+    lib = bind(load_library())
     c = io.load(directory)
     maxiter = c["maxiter"] if maxiter is None else maxiter
     vsf = np.asfortranarray(c["vels"].copy())
@@ -115,7 +174,7 @@ def run(directory, maxiter=None, out_dir=".", log=print, seed=1):
     name = os.path.join(out_dir, "DSurfTomo.in")
     history = []
     for it in range(1, maxiter + 1):
-        st = iteration(lib, c, vsf, obst, log)
+        st = (iteration if host_rows else iteration_device)(lib, c, vsf, obst, log)
         log("%2dth iteration..." % it)
         log(" mean,std_devs and rms of residual after weighting: %8.1fms %8.2fms %8.3f" % (st["mean_ms"], st["std_ms"], st["rms"]))
         log(" min and max velocity variation %7.4f%7.4f" % (st["dv_min"], st["dv_max"]))
@@ -126,7 +185,7 @@ def run(directory, maxiter=None, out_dir=".", log=print, seed=1):
         if it == maxiter:
             write_residuals(os.path.join(out_dir, "residualLast.dat"), c, st["dsyn"], obst, st["datweight"])
         write_model(name + "Measure.dat.iter%03d" % it, c, vsf)
-        history.append({k: v for k, v in st.items() if k not in ("dsyn", "datweight")})
+        history.append({k: v for k, v in st.items() if k not in ("dsyn", "datweight", "dv", "norm", "cbst")})
     if vsftrue is not None:
         write_model(os.path.join(out_dir, "Vs_model.real"), c, vsftrue)
         write_model(name + "Syn.dat", c, vsf)
@@ -141,9 +200,10 @@ def main(argv=None):
     ap.add_argument("directory")
     ap.add_argument("--maxiter", type=int, default=None)
     ap.add_argument("--out", default=".")
+    ap.add_argument("--host-rows", action="store_true", help="hand the matrix through host arrays like the reference (default: it stays on the device)")
     args = ap.parse_args(argv)
     os.makedirs(args.out, exist_ok=True)
-    run(args.directory, args.maxiter, args.out)
+    run(args.directory, args.maxiter, args.out, host_rows=args.host_rows)
     return 0
 
 

@@ -155,6 +155,14 @@ int dsa_iteration_system(int nx, int ny, int nz, int dall, long long nar_in, lon
                          int* col, const float* obst, const float* dsyn, float threshold0, float weight0, float* cbst,
                          float* datweight, float* norm, int* m_out, long long* nar_out, float* dws);
 int dsa_model_update(int nx, int ny, int nz, float* dv, float* vsf, float minvel, float maxvel);
+/* The same system built where the rows are: on the COO rows that dsa_solve_rows (option rows_on_device) or dsa_calsurfg
+ * (called with null rw / iw / col) left on the device.  Weights, regularisation rows, DWS and both orderings of the matrix
+ * are made on the device; the matrix (12 bytes per entry) never crosses PCIe (reference: main.f90:349-359 -> :361-466 ->
+ * :487-489 all on host arrays).  cbst has dall + maxvp elements; afterwards dsa_lsmr(e, cbst, ...) solves on that matrix.
+ * Bit-identical to dsa_iteration_system + dsa_spmv_load. */
+int dsa_iteration_system_device(dsa_engine* e, int nx, int ny, int nz, int dall, const float* obst, const float* dsyn,
+                                float threshold0, float weight0, float* cbst, float* datweight, float* norm, int* m_out,
+                                long long* nar_out, float* dws);
 
 /* copy one unit's coarse travel-time field (nnz, nnx column-major) back; valid after dsa_solve
  * for units of the last chunk only unless keep_fields was requested */
@@ -227,6 +235,8 @@ int dsa_dropin_velocity_maps(const int* which, double* pv);
 
 /* text of the last error of the process-wide engine used by the drop-in level */
 const char* dsa_dropin_error(void);
+/* that engine (created on first use; null if no GPU), for engine-level calls that continue a drop-in call on the device */
+dsa_engine* dsa_dropin_engine(void);
 
 #ifdef __cplusplus
 }

@@ -132,3 +132,27 @@ def test_taipei_inversion_driver_known_answer(tmp_path):
     for name in ("residualFirst.dat", "residualLast.dat", "DSurfTomo.inMeasure.dat", "DSurfTomo.inMeasure.dat.iter002"):
         assert (tmp_path / name).exists()
     assert np.loadtxt(str(tmp_path / "residualFirst.dat")).shape == (c["ndata"], 6)
+
+
+def test_device_resident_rows_match_the_host_path():
+    """One outer iteration of the Taipei example twice: the matrix handed through host arrays like the reference
+    (dsa_calsurfg -> dsa_iteration_system -> dsa_lsmr_dropin) and resident on the device from CalSurfG to LSMR
+    (dsa_calsurfg with null rw / iw / col -> dsa_iteration_system_device -> dsa_lsmr): every output bit for bit --
+    travel times, weights, DWS column sums, right-hand side, LSMR solution and counters, updated model"""
+    from dsurftomo_amd import invert
+    lib = invert.bind(load_library())
+    c = taipei.load()
+    obst = np.ascontiguousarray(c["obst"])
+    out = []
+    for fn in (invert.iteration, invert.iteration_device):
+        vsf = np.asfortranarray(c["vels"].copy())
+        st = fn(lib, c, vsf, obst, lambda *_: None)
+        out.append((st, vsf))
+    (a, va), (b, vb) = out
+    print("taipei iteration, host rows: forward %.3f s system %.3f s LSMR %.3f s | device rows: forward %.3f s system %.3f s LSMR %.3f s | %d entries" %
+          (a["seconds"]["forward"], a["seconds"]["glue"], a["seconds"]["lsmr"], b["seconds"]["forward"], b["seconds"]["glue"], b["seconds"]["lsmr"], b["nar"]))
+    assert a["nar"] == b["nar"] and a["m"] == b["m"] and a["itn"] == b["itn"] and a["istop"] == b["istop"]
+    for k in ("dsyn", "datweight", "norm", "cbst", "dv"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert a["dws"] == b["dws"]
+    assert np.array_equal(va.view(np.uint32), vb.view(np.uint32))
