@@ -428,6 +428,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipStreamSynchronize(stream));
         for (int u = 0; u < n; ++u) {
             for (int q = 0; q < 6; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * 8 + q];
+            phase_ticks[7] += (double)h_clk[(size_t)u * 8 + 7];
             phase_ticks[6] = std::max(phase_ticks[6], (double)h_clk[(size_t)u * 8 + 6]);
         }
         float ms = 0;
@@ -860,7 +861,7 @@ int dsa_get_stats(const dsa_engine* e, double* out)
     std::memcpy(out, reinterpret_cast<const Engine*>(e)->stats, sizeof(double) * DSA_STAT_COUNT);
     // phase clocks of the coarse solve, summed over units (100 MHz wall clock ticks): pass A, even half,
     // odd half, round end; then the summed list lengths and ready counts
-    for (int q = 0; q < 7; ++q) out[DSA_STAT_COUNT + q] = reinterpret_cast<const Engine*>(e)->phase_ticks[q];
+    for (int q = 0; q < 8; ++q) out[DSA_STAT_COUNT + q] = reinterpret_cast<const Engine*>(e)->phase_ticks[q];
     return 0;
 }
 

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         if (p.clocks) { p.clocks[0] = tA; p.clocks[1] = tB0; p.clocks[2] = tB1; p.clocks[3] = tE; p.clocks[4] = sum_cnt; p.clocks[5] = sum_ready; p.clocks[6] = (unsigned long long)max_cnt; }
 #endif
 #ifdef DSA_PASSA_CLOCKS
-        if (p.clocks) { p.clocks[0] = sub[0] + sub[1]; p.clocks[1] = sub[2] + sub[3]; p.clocks[2] = sub[4]; p.clocks[3] = sub[5]; p.clocks[4] = sub[6]; p.clocks[5] = sub[7]; }
+        if (p.clocks) { p.clocks[7] = sub[2]; p.clocks[0] = sub[0] + sub[1]; p.clocks[1] = sub[2] + sub[3]; p.clocks[2] = sub[4]; p.clocks[3] = sub[5]; p.clocks[4] = sub[6]; p.clocks[5] = sub[7]; }
 #endif
     }
 }

@@ -24,7 +24,10 @@ namespace dsa {
 // One LANE per segment: the reference's accumulation is a serial chain per output element, so a wavefront runs 64 chains
 // side by side.  The storage is transposed per slice of 64 segments (spmv_state.h), which makes the value / index loads of a
 // step one coalesced 256-B read each; the input vector (0.5-1 MB) is gathered from L2.  HBM-bound: 8 bytes per entry.
-// The loads of UNROLL steps are issued before the first addition needs them.
+// The loads of UNROLL steps are issued before the first addition needs them.  Measured on the headline matrix (190 M entries, 128 k
+// rows x 133 k columns, profiles/r02_spmv_trace.txt): 0.87 ms per product = 1.75 TB/s of the 8 B per entry; what binds it is not HBM
+// but the gathers of the input vector: 64 lanes = 64 unrelated rows, so every 4-byte operand pulls its own 128-B line out of L2
+// (UNROLL = 32 is slower, 1.11 ms: more lines in flight, same L2 line rate).  Next step: input vector staged in LDS per column block.
 template <bool ABS>
 __global__ __launch_bounds__(256) void k_spmv_sliced(int nslices, const long long* __restrict__ off, const int* __restrict__ seg, const int* __restrict__ len,
                                                      const float* __restrict__ val, const int* __restrict__ idx, const float* __restrict__ in, float* __restrict__ out)
@@ -47,6 +50,15 @@ __global__ __launch_bounds__(256) void k_spmv_sliced(int nslices, const long lon
         for (int u = 0; u < UNROLL; ++u) pin[u] = ABS ? 1.0f : in[pi[u]];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) acc = acc + (ABS ? fabsf(pv[u]) : pv[u] * pin[u]);
+    }
+    for (; k + 4 <= mylen; k += 4) {
+        float pv[4]; int pi[4]; float pin[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { pv[u] = v[(size_t)(k + u) * 64]; pi[u] = ix[(size_t)(k + u) * 64]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pin[u] = ABS ? 1.0f : in[pi[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = acc + (ABS ? fabsf(pv[u]) : pv[u] * pin[u]);
     }
     for (; k < mylen; ++k) { const float a = v[(size_t)k * 64]; acc = acc + (ABS ? fabsf(a) : a * in[ix[(size_t)k * 64]]); }
     out[s] = acc;

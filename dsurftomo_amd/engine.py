@@ -262,5 +262,5 @@ class Engine:
         out = np.zeros(32, np.float64)
         self._check(self._L.dsa_get_stats(self._h, _p(out)))
         d = dict(zip(STAT_NAMES, out[:len(STAT_NAMES)].tolist()))
-        d["phase_ticks"] = out[len(STAT_NAMES):len(STAT_NAMES) + 7].tolist()
+        d["phase_ticks"] = out[len(STAT_NAMES):len(STAT_NAMES) + 8].tolist()
         return d

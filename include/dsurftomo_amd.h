@@ -183,7 +183,7 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_FREEZES, DSA_STAT_RAYS, DSA_STAT_RAY_STEPS,
        DSA_STAT_RAYS_CLAMPED, DSA_STAT_MS_RAYS, DSA_STAT_MS_ROWS, DSA_STAT_NAR, DSA_STAT_MS_DISPERSION,
        DSA_STAT_CURVES, DSA_STAT_CHANGES_TOTAL, DSA_STAT_COUNT };
-int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 7: counters, then 7 phase-clock sums */);
+int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */
 int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi, const float* vels,

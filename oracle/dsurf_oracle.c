@@ -400,6 +400,17 @@ static void updtree(fmm *f, int iz, int ix)
     }
 }
 
+/* Diagnostic only (never used for parity): DSO_TIE_POLICY=1 in the environment makes the sift-down of downtree prefer the RIGHT child
+ * when the two children carry bit-equal keys (the reference prefers the left one, `>` below).  Both are valid binary heaps and both
+ * are valid Fast Marching orders; they differ only in which of two exactly tied narrow-band nodes is accepted first.  Comparing the
+ * two fields measures how far the reference's own answer depends on that accident (tests/tools/tie_sensitivity.py). */
+static int tie_policy(void)
+{
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("DSO_TIE_POLICY"); mode = (e && e[0] == '1') ? 1 : 0; }
+    return mode;
+}
+
 static void downtree(fmm *f)
 {
     if (f->ntr == 1) { f->ntr = 0; return; }
@@ -408,7 +419,7 @@ static void downtree(fmm *f)
     f->ntr -= 1;
     int tpp = 1, tpc = 2;
     while (tpc < f->ntr) {
-        if (hkey(f, tpc) > hkey(f, tpc + 1)) tpc += 1;
+        if (hkey(f, tpc) > hkey(f, tpc + 1) || (tie_policy() && hkey(f, tpc) == hkey(f, tpc + 1))) tpc += 1;
         if (hkey(f, tpc) < hkey(f, tpp)) {
             ST(f, f->hz[tpp], f->hx[tpp]) = tpc;
             ST(f, f->hz[tpc], f->hx[tpc]) = tpp;

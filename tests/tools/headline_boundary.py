@@ -104,5 +104,47 @@ def main():
         e.close()
 
 
+    if "--device-rows" in sys.argv:
+        # the same outer iteration with the matrix resident on the device from CalSurfG to LSMR
+        from dsurftomo_amd import invert
+        invert.bind(lib)
+        eng = lib.dsa_dropin_engine()
+        dsurf2 = np.zeros(nd, np.float32)
+        nar_d = C.c_int(0)
+        lib.dsa_dropin_set_capacity(0)
+        for k in range(2):
+            t0 = time.perf_counter()
+            rc = lib.dsa_calsurfg(i32(c["nx"]), i32(c["ny"]), i32(c["nz"]), i32(npar), L.ptr(c["vels"]), None, None, None, L.ptr(dsurf2),
+                                  f32(c["goxd"]), f32(c["gozd"]), f32(c["dvxd"]), f32(c["dvzd"]), i32(c["kRc"]), i32(0), i32(0), i32(0),
+                                  L.ptr(c["tRc"]), L.ptr(c["tRg"]), L.ptr(c["tLc"]), L.ptr(c["tLg"]), L.ptr(c["wavetype"]), L.ptr(c["igrt"]), L.ptr(c["periods"]),
+                                  L.ptr(c["depz"]), f32(c["minthk"]), L.ptr(c["scxf"]), L.ptr(c["sczf"]), L.ptr(c["rcxf"]), L.ptr(c["rczf"]), L.ptr(c["nrc1"]),
+                                  L.ptr(c["nsrcsurf1"]), i32(c["kmax"]), i32(c["nsrcsurf"]), i32(c["nrcf"]), C.byref(nar_d))
+            print("dsa_calsurfg, rows left on the device, pass %d: rc %d, %.2f s wall, nar %d; dsurf identical to the host-array call: %s" %
+                  (k, rc, time.perf_counter() - t0, nar_d.value, bool((dsurf2.view(np.uint32) == dsurf.view(np.uint32)).all())), flush=True)
+        r = synth.LCG(9)
+        obst = (dsurf * (1.0 + 0.02 * (r.uniform(nd) - 0.5))).astype(np.float32)
+        maxvp = npar
+        cbst_d = np.zeros(nd + maxvp, np.float32); dw_d = np.zeros(nd, np.float32); norm_d = np.zeros(maxvp, np.float32); dws_d = np.zeros(2, np.float32)
+        m, n2 = C.c_int(0), C.c_longlong(0)
+        t0 = time.perf_counter()
+        rc = lib.dsa_iteration_system_device(eng, c["nx"], c["ny"], c["nz"], nd, L.ptr(obst), L.ptr(dsurf2), 3.0, 4.0, L.ptr(cbst_d), L.ptr(dw_d), L.ptr(norm_d),
+                                             C.byref(m), C.byref(n2), L.ptr(dws_d))
+        print("dsa_iteration_system_device: rc %d, %.2f s (weights, regularisation rows, both orderings, DWS); m %d nar %d; DWS %g %g" %
+              (rc, time.perf_counter() - t0, m.value, n2.value, dws_d[0], dws_d[1]), flush=True)
+        if "--lsmr" in sys.argv:
+            print("  same as the host system: cbst %s datweight %s norm %s dws %s" % (np.array_equal(cbst_d.view(np.uint32), cbst.view(np.uint32)),
+                  np.array_equal(dw_d, dw), np.array_equal(norm_d.view(np.uint32), norm.view(np.uint32)), bool((dws_d == dws).all())), flush=True)
+        dv = np.zeros(maxvp, np.float32)
+        ii = [C.c_int(0), C.c_int(0)]; ff = [C.c_float(0) for _ in range(5)]
+        t0 = time.perf_counter()
+        rc = lib.dsa_lsmr(eng, L.ptr(cbst_d), C.c_float(1.0), C.c_float(1e-6), C.c_float(1e-6), C.c_float(100.0), 400, 10, L.ptr(dv),
+                          C.byref(ii[0]), C.byref(ii[1]), *[C.byref(v) for v in ff])
+        dt = time.perf_counter() - t0
+        print("dsa_lsmr on the resident matrix: rc %d, %d iterations, istop %d, %.3f s (%.2f ms per iteration); |dv| max %.4f" %
+              (rc, ii[1].value, ii[0].value, dt, 1e3 * dt / max(ii[1].value, 1), np.abs(dv).max()), flush=True)
+        if "--lsmr" in sys.argv:
+            print("  solution identical to the host-array path: %s" % bool((dv.view(np.uint32) == full["x"].view(np.uint32)).all()), flush=True)
+
+
 if __name__ == "__main__":
     main()

@@ -2,7 +2,7 @@
 # rocprofv3 --pmc passes of one command (counters never share a run with trace domains other than kernel-trace).
 #   bash tools/collect_pmc.sh <tag> <groups> [lib] [-- program args...]
 # <groups>: comma-separated names from the table below (each is one pass = one run of the command), e.g. "insts,busy,wait"
-# [lib]: A/B build to load (DSA_LIB_PATH); default command: python3 tools/perf_probe.py 131 1024 1.25 smooth 256
+# [lib]: A/B build to load (DSA_LIB_PATH), or - for the default library; default command: python3 tools/perf_probe.py 131 1024 1.25 smooth 256
 # Output: gpurun_out/<tag>/summary.txt (per-kernel counter sums of every pass) -- copy what should be judged into profiles/.
 set -u
 TAG=${1:-pmc}; GROUPS_=${2:-insts,busy,wait}; shift 2 || true
@@ -10,7 +10,7 @@ LIB=""
 if [ $# -gt 0 ] && [ "$1" != "--" ]; then LIB=$1; shift; fi
 [ $# -gt 0 ] && [ "$1" == "--" ] && shift
 if [ $# -gt 0 ]; then CMD=("$@"); else CMD=(python3 tools/perf_probe.py 131 1024 1.25 smooth 256); fi
-[ -n "$LIB" ] && export DSA_LIB_PATH=$LIB
+[ -n "$LIB" ] && [ "$LIB" != "-" ] && export DSA_LIB_PATH=$LIB
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -26,6 +26,7 @@ declare -A SETS=(
   [tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum"
   [icache]="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH"
   [fp64]="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"
+  [flops64]="SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_FLOPS_FP64_TRANS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"
   [fp32]="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32"
 )
 : > $OUT/rc.txt

@@ -1,7 +1,7 @@
 """The dispersion stage (k_dispersion + k_depth_kernels; reference surfdisp96.f:223-305, 807-843 under depthkernel, CalSurfG.f90:1-169)
 at the headline size: nx = ny = 131, nz = 9, 16 Rayleigh phase periods with depth kernels = 17 161 columns x 55 models x 16 roots.
     python3 tools/disp_roofline.py            -> one JSON line (roots, ms)
-    bash tools/collect_pmc.sh disp fp64,busy dummy -- python3 tools/disp_roofline.py     (FP64 instruction counters of the same run)
+    bash tools/collect_pmc.sh disp fp64,busy - -- python3 tools/disp_roofline.py     (FP64 instruction counters of the same run)
 """
 import json, os, sys, time
 import numpy as np

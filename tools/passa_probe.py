@@ -13,5 +13,5 @@ e.plan(**u); t0 = time.time(); e.solve(); dt = time.time() - t0
 st = e.stats(); n = 2 * nsrc
 pt = np.array(st["phase_ticks"], dtype=float)
 r = st['rounds_max']
-print('units %d wg %d: %.1f solves/s fim %.1f ms; per round (us, thread 0, avg over units): pass A collect+masks %.2f expand+tau loads %.2f route %.2f | eval passes: loads %.2f solve %.2f store+activate %.2f | rounds %d' %
-      (n, nt, n / dt, st['ms_fim_coarse'], *(pt[:6] / n / r / 100), r))
+print('units %d wg %d: %.1f solves/s fim %.1f ms; per round (us, thread 0, avg over units): pass A collect+masks %.2f expand+tau loads %.2f route %.2f | eval passes: loads %.2f solve %.2f store+activate %.2f | rounds %d | of expand+tau: expansion alone %.2f' %
+      (n, nt, n / dt, st['ms_fim_coarse'], *(pt[:6] / n / r / 100), r, pt[7] / n / r / 100))

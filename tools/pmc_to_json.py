@@ -43,7 +43,31 @@ def counters(dbdir, kernel_substr):
     return out
 
 
+def dispersion(d, roots, dst):
+    """profiles/pmc_dispersion.json: FP64 work of k_dispersion per root.  SQ_INSTS_VALU_FLOPS_FP64 counts flops per wave
+    instruction (2 per FMA, 1 per ADD / MUL / transcendental); x 64 lanes x lane fill, the lane fill being
+    SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) of the same pass."""
+    import bench
+    c = counters(d, "k_dispersion")
+    need = ("SQ_INSTS_VALU_FLOPS_FP64", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")
+    if not all(k in c for k in need):
+        raise SystemExit("missing counters: have %s" % sorted(c))
+    fill = c["SQ_THREAD_CYCLES_VALU"]["max_per_dispatch"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]["max_per_dispatch"])
+    flops = c["SQ_INSTS_VALU_FLOPS_FP64"]["max_per_dispatch"] * 64.0 * fill
+    rec = {"kernel_source_hash": bench.kernel_source_hash(bench.DISP_SOURCES), "kernel": "k_dispersion", "roots": roots, "counters": c, "lane_fill": round(fill, 4),
+           "fp64_flops_per_root": flops / roots,
+           "fp64_transcendentals_per_root": c.get("SQ_INSTS_VALU_FLOPS_FP64_TRANS", {}).get("max_per_dispatch", 0) * 64.0 * fill / roots,
+           "command": "bash tools/collect_pmc.sh <tag> flops64 - -- python3 tools/disp_roofline.py 1"}
+    if "SQ_BUSY_CYCLES" in c:
+        rec["valu_issue"] = round(c["SQ_ACTIVE_INST_VALU"]["max_per_dispatch"] / (8.0 * c["SQ_BUSY_CYCLES"]["max_per_dispatch"]), 4)
+    with open(dst, "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps({k: v for k, v in rec.items() if k != "counters"}, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--dispersion":
+        return dispersion(sys.argv[2], float(sys.argv[3]), sys.argv[4])
     d, solves, dst = sys.argv[1], float(sys.argv[2]), sys.argv[3]
     kernel = sys.argv[4] if len(sys.argv) > 4 else "k_fim"
     import bench
