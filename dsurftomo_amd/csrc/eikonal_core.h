@@ -73,6 +73,52 @@ DSA_HD void rec_stencil(int nbz, int id, int* nid)
     nid[3] = id + 1 + (rz == 7 ? dz : 0);  nid[7] = id + 2 + (rz > 5 ? dz : 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compact field of the COARSE solve.  tau differs from T at ~0.02 % of the nodes of a field (the ~150 nodes pinned by the
+// serial prologue, which carry their accept number, and the non-causal nodes along colliding fronts), so the coarse solve
+// stores ONE float per node, tiled like the records: v = +inf unreached; v >= 0: T = tau = v; sign bit set: an exceptional
+// node, T = |v|, whose tau (and whether it is pinned) sits in a per-field open-addressing table keyed by the record index.
+// Half the bytes, half the cache lines per tile, half the footprint of the thousand fronts a launch keeps in flight.
+// Table entry: low word = key (record index, kExcPinned for a pinned node; -1 = empty), high word = tau bits.  A writer
+// stores the entry first and the field value second; entries are never removed (a node that turns causal again simply
+// stops being looked up), so the capacity bounds the nodes that were ever exceptional: overflow is reported, not ignored.
+constexpr int kExcPinned = 0x40000000;
+constexpr unsigned long long kExcEmpty = 0x00000000ffffffffull;
+DSA_HD unsigned long long exc_pack(int key, float tau)
+{
+    union { float f; uint32_t u; } a; a.f = tau;
+    return ((unsigned long long)a.u << 32) | (uint32_t)key;
+}
+DSA_HD int exc_key(unsigned long long e) { return (int)(uint32_t)e; }
+DSA_HD float exc_tau(unsigned long long e) { union { float f; uint32_t u; } a; a.u = (uint32_t)(e >> 32); return a.f; }
+DSA_HD unsigned exc_hash(int id, int log2cap) { return ((uint32_t)id * 2654435761u) >> (32 - log2cap); }
+DSA_HD int exc_log2cap_of(int nnx, int nnz) { int l = 10; while ((1 << l) < 4 * (nnx + nnz) + 1024) ++l; return l; }
+// serial insert (prologue, one lane per field; host tools): returns false when the table is full
+DSA_HD bool exc_insert_serial(unsigned long long* tab, int log2cap, int key, float tau)
+{
+    const unsigned mask = (1u << log2cap) - 1u;
+    unsigned h = exc_hash(key & 0x3fffffff, log2cap);
+    for (unsigned n = 0; n <= mask; ++n, h = (h + 1u) & mask) {
+        const int k = exc_key(tab[h]);
+        if (k == -1 || (k & 0x3fffffff) == (key & 0x3fffffff)) { tab[h] = exc_pack(key, tau); return true; }
+    }
+    return false;
+}
+// lookup: tau of node `id`, *pinned set; +inf when absent (cannot happen for a flagged node: the entry is written first)
+DSA_HD float exc_find(const unsigned long long* tab, int log2cap, int id, bool* pinned)
+{
+    const unsigned mask = (1u << log2cap) - 1u;
+    unsigned h = exc_hash(id, log2cap);
+    for (unsigned n = 0; n <= mask; ++n, h = (h + 1u) & mask) {
+        const unsigned long long e = tab[h];
+        const int k = exc_key(e);
+        if (k == -1) break;
+        if ((k & 0x3fffffff) == id) { *pinned = (k & kExcPinned) != 0; return exc_tau(e); }
+    }
+    *pinned = false;
+    return kInf;
+}
+
 // Geometry of one node column (depends on ix only); reference CalSurfG.f90:613-615.
 struct NodeGeom {
     float ri;     // earth radius
@@ -302,7 +348,8 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
 // arrays.  `status`: -1 far, 0 alive, >0 slot in the tree.
 // ---------------------------------------------------------------------------------------------
 struct MarchView {
-    Rec* F;               // tiled (T, tau) records of the full grid; the march uses T only
+    Rec* F;               // (T, tau) records: tiled over the full grid, or -- `window` set -- only the status window, (wnz, wnx) column-major
+    int window;           // 1: F covers the status window only (coarse band march: the coarse field itself is the compact one)
     const float* slow;    // tiled slowness
     int nbz;              // tiles per column of the full grid
     const float* risti;   // per-ix table, 1-based index ix -> risti[ix-1]
@@ -318,7 +365,11 @@ struct MarchView {
     float clock;          // number of accepts so far (see mv_accept_root)
 };
 
-DSA_HD float& mv_T(MarchView& m, int iz, int ix) { return m.F[rec_index(m.nbz, iz - 1, ix - 1)].T; }
+DSA_HD Rec& mv_rec(MarchView& m, int iz, int ix)
+{
+    return m.window ? m.F[(size_t)(ix - 1 - m.wx0) * (size_t)m.wnz + (size_t)(iz - 1 - m.wz0)] : m.F[rec_index(m.nbz, iz - 1, ix - 1)];
+}
+DSA_HD float& mv_T(MarchView& m, int iz, int ix) { return mv_rec(m, iz, ix).T; }
 DSA_HD float mv_slow(const MarchView& m, int iz, int ix) { return m.slow[rec_index(m.nbz, iz - 1, ix - 1)]; }
 DSA_HD bool mv_inwin(const MarchView& m, int iz, int ix)
 {
@@ -425,7 +476,7 @@ DSA_HD bool mv_accept_root(MarchView& m)
 {
     const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
     m.clock += 1.0f;
-    m.F[rec_index(m.nbz, iz - 1, ix - 1)].tau = m.clock * kSeqClock;
+    mv_rec(m, iz, ix).tau = m.clock * kSeqClock;
     mv_set(m, iz, ix, 0);
     mv_pop_root(m);
     for (int i = ix - 1; i <= ix + 1; i += 2) {

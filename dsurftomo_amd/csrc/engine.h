@@ -56,7 +56,10 @@ struct Engine {
     DevBuf<float> out;
     DevBuf<int32_t> err;
     DevBuf<float> slow_r, Tfin_r, risti_r, vcorner;
-    DevBuf<Rec> F_r, F_c;
+    DevBuf<Rec> F_r, W_c;              // refined records; records of the coarse march windows
+    DevBuf<float> T_c;                 // compact coarse fields (eikonal_core.h)
+    DevBuf<unsigned long long> exc_c;  // their exception tables
+    int exc_log2cap = 0;
     DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists;
     size_t lists_stride = 0;
     int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)
@@ -136,6 +139,7 @@ struct Engine {
     void launch_srtimes_chunk(int r0, int nr, int first_unit);
     int get_field(int unit, float* ttn);
     int fetch_tiled(const Rec* dev, int nnx, int nnz, int which, float* out);
+    int fetch_compact(int slot, int which, float* out);
     int get_refined(int unit, int* rnx, int* rnz, float* ttnr, int8_t* st);
     int get_velocity(int map, float* out_v);
 };

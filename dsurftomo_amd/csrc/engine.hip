@@ -72,6 +72,7 @@ template int Engine::ensure<long long>(DevBuf<long long>&, size_t);
 template int Engine::ensure<float>(DevBuf<float>&, size_t);
 template int Engine::ensure<int>(DevBuf<int>&, size_t);
 template int Engine::ensure<unsigned char>(DevBuf<unsigned char>&, size_t);
+template int Engine::ensure<unsigned long long>(DevBuf<unsigned long long>&, size_t);
 
 Engine::~Engine()
 {
@@ -80,7 +81,7 @@ Engine::~Engine()
     rel(velv); rel(veln); rel(slow); rel(risti_c); rel(cbasis); rel(rbasis);
     rel(src); rel(rays); rel(out); rel(err);
     rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
-    rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(F_c); rel(seed_c); rel(nseed_c);
+    rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(T_c); rel(exc_c); rel(W_c); rel(seed_c); rel(nseed_c);
     rel(prob_r); rel(prob_c); rel(paths); rel(path_n); rel(info); rel(clocks); rel(lists);
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
@@ -325,12 +326,16 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     const size_t rr = (size_t)kRefMax * kRefMax;
     {   // the refined and the coarse solve of a unit share one list region: size it for the larger shape
         shape_c = launch_shape(g.nnx, g.nnz); shape_r = launch_shape(kRefMax, kRefMax);
+        shape_c.sorted = shape_c.tile_words * 4 <= 36 * 1024 ? 1 : 0;      // the coarse solve runs on the compact field: ordered variant only
+        if (!shape_c.sorted) { fail(DSA_ERR_ARGUMENT, "plan: a %d x %d grid needs %d bytes of LDS tile bitmap (limit 36 KB): the coarse solve has no other variant", g.nnx, g.nnz, shape_c.tile_words * 4); return DSA_ERR_ARGUMENT; }
+        shape_c.compact = 1; shape_r.compact = 0;
+        exc_log2cap = exc_log2cap_of(g.nnx, g.nnz);
         const FimLaunch &lc = shape_c, &lr = shape_r;
         lists_stride = std::max((size_t)4 * lc.list_cap + lc.ready_cap, (size_t)4 * lr.list_cap + lr.ready_cap);
         lists_stride = std::max(lists_stride, (size_t)2 * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile masks + one list
         lists_stride = (lists_stride + 1) & ~(size_t)1;      // the masks are 8-byte words
     }
-    per_unit_bytes = nrec_c * 8 + lists_stride * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
+    per_unit_bytes = nrec_c * 4 + ((size_t)8 << exc_log2cap) + (size_t)kCWinMax * kCWinMax * 8 + lists_stride * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
                      (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(SourceDesc);
     size_t c = budget / per_unit_bytes;
     if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B)", budget, per_unit_bytes); return DSA_ERR_DEVICE; }
@@ -342,7 +347,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(slow_r, C * kRefRecs) || ensure(F_r, C * kRefRecs) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
-        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(F_c, C * nrec_c) ||
+        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, C * nrec_c) || ensure(exc_c, C << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
         ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
     HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
@@ -358,7 +363,7 @@ BatchPtrs Engine::batch() const
     BatchPtrs b;
     b.src = src.p; b.slow_r = slow_r.p; b.F_r = F_r.p; b.Tfin_r = Tfin_r.p; b.S_r = S_r.p; b.risti_r = risti_r.p;
     b.vcorner = vcorner.p; b.seed_r = seed_r.p; b.nseed_r = nseed_r.p; b.rst = rst.p; b.cst = cst.p; b.cinit = cinit.p;
-    b.heap = heap.p; b.flags = flags.p; b.F_c = F_c.p; b.seed_c = seed_c.p; b.nseed_c = nseed_c.p;
+    b.heap = heap.p; b.flags = flags.p; b.T_c = T_c.p; b.exc_c = exc_c.p; b.exc_log2cap = exc_log2cap; b.W_c = W_c.p; b.seed_c = seed_c.p; b.nseed_c = nseed_c.p;
     b.lists = lists.p; b.lists_stride = lists_stride;
     return b;
 }
@@ -397,7 +402,8 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipMemcpyAsync(src.p, h_src.data() + first, (size_t)n * sizeof(SourceDesc), hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipMemcpyAsync(risti_r.p, h_risti_r.data() + (size_t)first * kRefMax, (size_t)n * kRefMax * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipEventRecord(events[1], stream));
-        launch_fill(reinterpret_cast<float*>(F_c.p), (size_t)n * nrec_c * 2, kInf, stream);      // (T, tau) = (+inf, +inf)
+        launch_fill(T_c.p, (size_t)n * nrec_c, kInf, stream);                                   // every node unreached
+        launch_fill64(exc_c.p, (size_t)n << exc_log2cap, kExcEmpty, stream);                      // exception tables empty
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         launch_refined_startup(g, b, n, stream);
@@ -452,8 +458,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             stats[DSA_STAT_CHANGES_TOTAL] += (double)ev;
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
-            if (fi[2] < 0 || fi[10] < 0) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
-            if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
+            if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
+            if (fi[10] == -2) { fail(DSA_ERR_INTERNAL, "unit %d: the exception table of the compact field overflowed (%d entries): more nodes off the causal order than 4 (nnx + nnz) + 1024", first + u, 1 << exc_log2cap); return DSA_ERR_INTERNAL; }
+            if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
         }
         last_chunk_first = first;
         last_chunk_n = n;
@@ -486,6 +493,7 @@ FimLaunch Engine::launch_shape(int nnx, int nnz) const
     const int ntile = tiles_of(nnx) * tiles_of(nnz);
     l.tile_words = (ntile + 31) / 32;
     l.sorted = (fim_sorted && l.tile_words * 4 <= 36 * 1024) ? 1 : 0;
+    l.compact = 0;
     return l;
 }
 
@@ -622,11 +630,33 @@ int Engine::fetch_tiled(const Rec* dev, int nnx, int nnz, int which, float* out)
     return 0;
 }
 
+// coarse field of a resident unit, untiled: which = 0 -> T (sign bit = pinned), 1 -> tau (from the field and its exception table)
+int Engine::fetch_compact(int slot, int which, float* out)
+{
+    std::vector<float> h(nrec_c);
+    std::vector<unsigned long long> x((size_t)1 << exc_log2cap);
+    HIP_TRY(this, hipMemcpy(h.data(), T_c.p + (size_t)slot * nrec_c, nrec_c * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(this, hipMemcpy(x.data(), exc_c.p + ((size_t)slot << exc_log2cap), x.size() * 8, hipMemcpyDeviceToHost));
+    for (int ix = 0; ix < g.nnx; ++ix)
+        for (int iz = 0; iz < g.nnz; ++iz) {
+            const int id = rec_index(g.nbz, iz, ix);
+            const float v = h[id];
+            float T = v, tau = v;
+            if (__builtin_signbit(v)) {
+                bool pin = false;
+                tau = exc_find(x.data(), exc_log2cap, id, &pin);
+                T = pin ? v : -v;
+            }
+            out[(size_t)ix * g.nnz + iz] = which ? tau : T;
+        }
+    return 0;
+}
+
 int Engine::get_field(int unit, float* ttn)
 {
     if (last_chunk_first < 0 || unit < last_chunk_first || unit >= last_chunk_first + last_chunk_n) { fail(DSA_ERR_STATE, "get_field: unit %d is not resident (last chunk covers %d..%d)", unit, last_chunk_first, last_chunk_first + last_chunk_n - 1); return DSA_ERR_STATE; }
     HIP_TRY(this, hipSetDevice(device));
-    if (fetch_tiled(F_c.p + (size_t)(unit - last_chunk_first) * nrec_c, g.nnx, g.nnz, 0, ttn)) return status;
+    if (fetch_compact(unit - last_chunk_first, 0, ttn)) return status;
     for (size_t k = 0; k < nfield; ++k) ttn[k] = fabsf(ttn[k]);
     return 0;
 }
@@ -695,7 +725,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "ready_cap" && value >= 0) { en->planned = false; en->ready_cap = (int)value; return 0; }
     if (n == "ray_budget" && value >= 0) { en->ray_budget = (size_t)value; return 0; }
     if (n == "fim_lds_pad" && value >= 0 && value <= 64 * 1024) { en->planned = false; en->fim_lds_pad = (int)value; return 0; }
-    if (n == "fim_sorted" && (value == 0 || value == 1)) { en->planned = false; en->fim_sorted = (int)value; return 0; }
+    if (n == "fim_sorted" && (value == 0 || value == 1)) { en->planned = false; en->fim_sorted = (int)value; return 0; }   // (refined boxes only: the coarse solve exists in the ordered variant only)
     if (n == "ray_path_cap" && value >= 0 && value <= (1 << 24)) { en->ray_path_cap = (int)value; return 0; }
     if (n == "disp_group_shift" && value >= -1 && value <= 3) { en->disp_group_shift = (int)value; return 0; }
     if (n == "disp_layers_lds" && (value == -1 || value == 0 || value == 1)) { en->disp_layers_lds = (int)value; return 0; }
@@ -850,7 +880,7 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out)
     Engine* en = reinterpret_cast<Engine*>(e);
     if (en->last_chunk_first < 0 || unit < en->last_chunk_first || unit >= en->last_chunk_first + en->last_chunk_n) return DSA_ERR_STATE;
     const size_t slot = (size_t)(unit - en->last_chunk_first);
-    if (which < 2) return en->fetch_tiled(en->F_c.p + slot * en->nrec_c, en->g.nnx, en->g.nnz, which, out);
+    if (which < 2) return en->fetch_compact((int)slot, which, out);
     const dsa::SourceDesc& s = en->h_src[unit];
     return en->fetch_tiled(en->F_r.p + slot * dsa::kRefRecs, s.rnx, s.rnz, which - 2, out);
 }

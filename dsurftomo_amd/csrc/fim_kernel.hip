@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 // window and the cycle freeze are those of k_fim; results are bit-identical (same fixed point).
 typedef __attribute__((address_space(1))) unsigned long long GU64;
 
-template <int NT>
+template <int NT, bool COMPACT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVES, DSA_FIM_WAVES))) void k_fim_sorted(const FimProblem* __restrict__ problems, int cap, int rcap)
 {
     extern __shared__ unsigned dyn_lds[];
@@ -407,7 +407,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     // base from scalar registers and one VGPR of offset instead of a 64-bit address pair computed on the VALU
     // (the largest field, 513^2 tiles of 512 B, is 135 MB).
     typedef __attribute__((address_space(1))) char GChar;
-    GChar* const Fb = (GChar*)p.F;
+    // COMPACT (coarse problems): one float per node plus the exception table (eikonal_core.h); else (T, tau) records
+    GChar* const Fb = COMPACT ? (GChar*)p.Tc : (GChar*)p.F;
+    GChar* const excb = (GChar*)p.exc;
+    const int xlog = p.exc_log2cap;
     GChar* const slowb = (GChar*)p.slow;
     GCF32* const risti = (GCF32*)p.risti;
     const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
@@ -420,6 +423,38 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     __shared__ int ready[2 * rhalf];                         // (the rest stay in their masks for the next round)
     unsigned* const tb = dyn_lds;                            // tile bitmap, nwords
     auto ld = [&](int id) { Rec r; r.T = rec(id)->T; r.tau = rec(id)->tau; return r; };
+    typedef __attribute__((address_space(1))) float GF32;
+    auto tc = [&](int id) -> GF32* { return (GF32*)(Fb + ((unsigned)id << 2)); };
+    auto exc_at = [&](unsigned h) -> GU64* { return (GU64*)(excb + ((size_t)h << 3)); };
+    // tau (and the pinned flag) of an exceptional node of the compact field: rare (~0.02 % of the nodes, most of them
+    // around the source), so the probe loop is only entered by the waves that meet one
+    auto exc_lookup = [&](int id, bool* pinned) -> float {
+        const unsigned mask = (1u << xlog) - 1u;
+        unsigned h = exc_hash(id, xlog);
+        for (unsigned n = 0; n <= mask; ++n, h = (h + 1u) & mask) {
+            const unsigned long long e = *exc_at(h);
+            const int k = exc_key(e);
+            if (k == -1) break;
+            if ((k & 0x3fffffff) == id) { *pinned = (k & kExcPinned) != 0; return exc_tau(e); }
+        }
+        *pinned = false;
+        return kInf;
+    };
+    // new or changed entry of a node this lane owns (never a pinned one); false: table full
+    auto exc_upsert = [&](int id, float tau) -> bool {
+        const unsigned mask = (1u << xlog) - 1u;
+        unsigned h = exc_hash(id, xlog);
+        const unsigned long long mine = exc_pack(id, tau);
+        for (unsigned n = 0; n <= mask; ++n, h = (h + 1u) & mask) {
+            unsigned long long e = *exc_at(h);
+            if (exc_key(e) == -1) {
+                e = atomicCAS((unsigned long long*)exc_at(h), kExcEmpty, mine);
+                if (e == kExcEmpty) return true;
+            }
+            if ((exc_key(e) & 0x3fffffff) == id) { *exc_at(h) = mine; return true; }
+        }
+        return false;
+    };
     // tile -> (bx, bz) without an integer division: floor(t / nbz) = hi32(t * ceil(2^32 / nbz)) while t * nbz < 2^32
     const bool by_mul = nbz > 1 && (unsigned long long)ntile * (unsigned long long)nbz < (1ull << 32);
     const unsigned nbz_inv = by_mul ? 0xffffffffu / (unsigned)nbz + 1u : 0u;
@@ -439,14 +474,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     }
     __syncthreads();
     const int nseed = *p.seed_count;
+    if (COMPACT && nseed > p.seed_cap) { if (tid == 0) p.info[2] = -1; return; }        // (cannot happen: kSeedC covers the march window)
     if (nseed <= p.seed_cap) {
         for (int i = tid; i < nseed; i += NT) {
             const int id = p.seed[i];
-            atomicAnd((unsigned*)&rec(id)->tau, ~kQueuedBit);
+            if (!COMPACT) atomicAnd((unsigned*)&rec(id)->tau, ~kQueuedBit);
             atomicOr((unsigned long long*)mask_at(id >> 6), 1ull << (id & 63));
             atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31));
         }
-    } else {
+    } else if (!COMPACT) {
         // more seeds than the prologue's list holds: they are flagged on the field (queued bit of tau)
         for (int id = tid; id < ntile * kTileRecs; id += NT) {
             const unsigned w = __hip_atomic_load((unsigned*)&rec(id)->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -549,11 +585,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     if (have) {
                         int nid[8];
                         rec_stencil(nbz, id[i], nid);
-                        const float a = ix > 0 ? rec(nid[0])->tau : kInf;
-                        const float b2 = ix + 1 < nnx ? rec(nid[1])->tau : kInf;
-                        const float c2 = iz > 0 ? rec(nid[2])->tau : kInf;
-                        const float d2 = iz + 1 < nnz ? rec(nid[3])->tau : kInf;
-                        if (frozen_any) own[i] = rec(id[i])->tau;
+                        float a, b2, c2, d2;
+                        if (COMPACT) {
+                            a = ix > 0 ? *tc(nid[0]) : kInf; b2 = ix + 1 < nnx ? *tc(nid[1]) : kInf;
+                            c2 = iz > 0 ? *tc(nid[2]) : kInf; d2 = iz + 1 < nnz ? *tc(nid[3]) : kInf;
+                            if (frozen_any) own[i] = *tc(id[i]);
+                        } else {
+                            a = ix > 0 ? rec(nid[0])->tau : kInf; b2 = ix + 1 < nnx ? rec(nid[1])->tau : kInf;
+                            c2 = iz > 0 ? rec(nid[2])->tau : kInf; d2 = iz + 1 < nnz ? rec(nid[3])->tau : kInf;
+                            if (frozen_any) own[i] = rec(id[i])->tau;
+                        }
+                        if (COMPACT && (__builtin_signbit(a) || __builtin_signbit(b2) || __builtin_signbit(c2) || __builtin_signbit(d2) || __builtin_signbit(own[i]))) {
+                            bool pin;
+                            if (__builtin_signbit(a)) a = exc_lookup(nid[0], &pin);
+                            if (__builtin_signbit(b2)) b2 = exc_lookup(nid[1], &pin);
+                            if (__builtin_signbit(c2)) c2 = exc_lookup(nid[2], &pin);
+                            if (__builtin_signbit(d2)) d2 = exc_lookup(nid[3], &pin);
+                            if (__builtin_signbit(own[i])) own[i] = exc_lookup(id[i], &pin);
+                        }
                         lb[i] = fminf(fminf(a, b2), fminf(c2, d2));
                     }
                 }
@@ -669,14 +718,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 h.in[3] = act && iz + 1 < nnz;    h.in_outer[3] = act && iz + 2 < nnz;
                 int nid[8];
                 rec_stencil(nbz, id, nid);
+                Rec own;
+                if (COMPACT) {
+                    bool flagged = false;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const Rec a = h.in[q] ? ld(nid[q]) : Rec{ kInf, kInf };
-                    const Rec b = h.in_outer[q] ? ld(nid[4 + q]) : Rec{ kInf, kInf };
-                    h.near_[q] = a.T; h.near_tau[q] = a.tau;
-                    h.outer[q] = b.T; h.outer_tau[q] = b.tau;
+                    for (int q = 0; q < 4; ++q) {
+                        const float a = h.in[q] ? *tc(nid[q]) : kInf;
+                        const float b = h.in_outer[q] ? *tc(nid[4 + q]) : kInf;
+                        h.near_[q] = a; h.near_tau[q] = a; h.outer[q] = b; h.outer_tau[q] = b;
+                        flagged = flagged || __builtin_signbit(a) || __builtin_signbit(b);
+                    }
+                    const float vo = act ? *tc(id) : 0.0f;
+                    own = Rec{ vo, vo };
+                    if (!act) own.T = -1.0f;                              // inactive lanes read as pinned
+                    flagged = flagged || (act && __builtin_signbit(vo));
+                    if (flagged) {                                       // exceptional nodes in the neighbourhood: tau (and pinned) from the table
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bool pin;
+                            if (__builtin_signbit(h.near_[q])) { const float v = h.near_[q]; h.near_tau[q] = exc_lookup(nid[q], &pin); h.near_[q] = pin ? v : -v; }
+                            if (__builtin_signbit(h.outer[q])) { const float v = h.outer[q]; h.outer_tau[q] = exc_lookup(nid[4 + q], &pin); h.outer[q] = pin ? v : -v; }
+                        }
+                        if (act && __builtin_signbit(vo)) { bool pin; own.tau = exc_lookup(id, &pin); own.T = pin ? vo : -vo; }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const Rec a = h.in[q] ? ld(nid[q]) : Rec{ kInf, kInf };
+                        const Rec b = h.in_outer[q] ? ld(nid[4 + q]) : Rec{ kInf, kInf };
+                        h.near_[q] = a.T; h.near_tau[q] = a.tau;
+                        h.outer[q] = b.T; h.outer_tau[q] = b.tau;
+                    }
+                    own = act ? ld(id) : Rec{ -1.0f, 0.0f };
                 }
-                const Rec own = act ? ld(id) : Rec{ -1.0f, 0.0f };
                 DSA_TICK(5);
                 const float t_old = own.T;
                 const float k_old = own.tau;
@@ -689,7 +763,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
                 DSA_TICK(6);
-                if (changed) { rec(id)->T = c; rec(id)->tau = k; ++nchanged; }
+                if (changed) {
+                    if (COMPACT) {
+                        // causal node (the rule): one float.  Else the table entry first, then the flagged value.
+                        if (f2u(c) == f2u(k)) *tc(id) = c;
+                        else { if (!exc_upsert(id, k)) p.info[2] = -2; *tc(id) = -c; }
+                    } else { rec(id)->T = c; rec(id)->tau = k; }
+                    ++nchanged;
+                }
                 // dependents: same pruning as k_fim; the tile mask's old value tells whether the node was
                 // already active and whether its tile has to enter the bitmap
                 const float t_lo = fminf(t_value(t_old), c), k_lo = fminf(k_old, k);
@@ -800,10 +881,15 @@ void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l,
     if (nproblems <= 0) return;
     if (l.sorted) {
         const size_t lds = fim_lds_bytes(l);
-        if (l.threads == 128) hipLaunchKernelGGL(k_fim_sorted<128>, dim3(nproblems), dim3(128), lds, stream, d_problems, l.list_cap, l.ready_cap);
-        else if (l.threads == 256) hipLaunchKernelGGL(k_fim_sorted<256>, dim3(nproblems), dim3(256), lds, stream, d_problems, l.list_cap, l.ready_cap);
-        else if (l.threads == 512) hipLaunchKernelGGL(k_fim_sorted<512>, dim3(nproblems), dim3(512), lds, stream, d_problems, l.list_cap, l.ready_cap);
-        else hipLaunchKernelGGL(k_fim_sorted<1024>, dim3(nproblems), dim3(1024), lds, stream, d_problems, l.list_cap, l.ready_cap);
+#define DSA_LAUNCH_SORTED(NT, C) hipLaunchKernelGGL((k_fim_sorted<NT, C>), dim3(nproblems), dim3(NT), lds, stream, d_problems, l.list_cap, l.ready_cap)
+        if (l.compact) {
+            if (l.threads == 128) DSA_LAUNCH_SORTED(128, true); else if (l.threads == 256) DSA_LAUNCH_SORTED(256, true);
+            else if (l.threads == 512) DSA_LAUNCH_SORTED(512, true); else DSA_LAUNCH_SORTED(1024, true);
+        } else {
+            if (l.threads == 128) DSA_LAUNCH_SORTED(128, false); else if (l.threads == 256) DSA_LAUNCH_SORTED(256, false);
+            else if (l.threads == 512) DSA_LAUNCH_SORTED(512, false); else DSA_LAUNCH_SORTED(1024, false);
+        }
+#undef DSA_LAUNCH_SORTED
         return;
     }
     const size_t pad = (size_t)l.lds_pad;

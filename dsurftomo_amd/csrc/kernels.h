@@ -13,8 +13,11 @@ namespace dsa {
 // are never recomputed, every other node starts at +inf.  `seed` lists the record indices to
 // evaluate first (their queued bit, the sign bit of tau, is already set).
 struct FimProblem {
-    Rec* F;
-    const float* slow;     // tiled like F
+    Rec* F;                // refined problems: tiled (T, tau) records
+    float* Tc;             // coarse problems: the compact field (one float per node, eikonal_core.h) ...
+    unsigned long long* exc;   // ... and its exception table of 2^exc_log2cap entries
+    int exc_log2cap;
+    const float* slow;     // tiled like the field
     const float* risti;
     const int* seed;
     const int* seed_count;
@@ -32,7 +35,8 @@ struct FimLaunch {
     int list_cap;          // entries per active list
     int ready_cap;         // entries of the dense ready list
     int threads;           // workgroup size: 256, 512 or 1024
-    int sorted;            // 1: k_fim_sorted (tile masks + LDS tile bitmap), 0: k_fim (lists in activation order)
+    int sorted;            // 1: k_fim_sorted (tile masks + LDS tile bitmap), 0: k_fim (lists in activation order; refined problems only)
+    int compact;           // 1: coarse problems on the compact field (k_fim_sorted only)
     int tile_words;        // words of the LDS tile bitmap (sorted variant)
     int lds_pad;           // extra dynamic LDS per workgroup (bytes): limits the workgroups resident per CU
 };
@@ -59,14 +63,18 @@ struct BatchPtrs {
     int32_t* heap;               // stride kHeapCap
     int32_t* flags;              // stride 4: [0] ended early, [1] error, [2] e* iz, [3] e* ix
     // coarse, per source
-    Rec* F_c;                    // stride nbx*nbz*64 (tiled records)
+    float* T_c;                  // compact coarse field, stride nbx*nbz*64 (tiled, one float per node)
+    unsigned long long* exc_c;   // exception tables of the coarse fields, stride 2^exc_log2cap
+    int exc_log2cap;
+    Rec* W_c;                    // (T, tau) records of the coarse march window, stride kCWinMax*kCWinMax
     int* seed_c; int* nseed_c;   // stride kSeedC / 1
     int* lists; size_t lists_stride;   // active-list scratch, shared by the refined and the coarse solve
 };
 constexpr int kSeedR = kRWin * kRWin;              // the start-up march cannot pin more than its window
-constexpr int kSeedC = kCWinMax * kCWinMax;
+constexpr int kSeedC = kCWinMax * kCWinMax + 4 * kCWinMax;    // every node of the window at most once, plus its outer rim
 
 void launch_fill(float* d, size_t n, float v, hipStream_t stream);
+void launch_fill64(unsigned long long* d, size_t n, unsigned long long v, hipStream_t stream);
 void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_velv_all, size_t velv_stride,
                    const float* d_rbasis, hipStream_t stream);
 void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);

@@ -41,7 +41,7 @@ DSA_HD float sinf_libm(float y)
 // What a ray reads: the coarse field (tiled records), the diced velocity (x-major rows) and the
 // refined snapshot of its source (x-major, leading dimension rnz; status 0 = alive at hand-off)
 struct RayFields {
-    const Rec* F;
+    const float* F;       // compact coarse field (one float per node, sign bit = exceptional node: eikonal_core.h)
     const float* veln;
     const float* Tr;
     const int8_t* Sr;
@@ -143,8 +143,8 @@ DSA_HD int trace_ray(const GridDesc& g, const SourceDesc& s, const RayFields& f,
             dtz = dtz + t11 - t10;
             dtz = dtz / (2.0f * earth * sin_rgx * dnzr);
         } else {
-            const float t00 = t_value(f.F[rec_index(g.nbz, ipz - 1, ipx - 1)].T), t01 = t_value(f.F[rec_index(g.nbz, ipz, ipx - 1)].T);
-            const float t10 = t_value(f.F[rec_index(g.nbz, ipz - 1, ipx)].T), t11 = t_value(f.F[rec_index(g.nbz, ipz, ipx)].T);
+            const float t00 = t_value(f.F[rec_index(g.nbz, ipz - 1, ipx - 1)]), t01 = t_value(f.F[rec_index(g.nbz, ipz, ipx - 1)]);
+            const float t10 = t_value(f.F[rec_index(g.nbz, ipz - 1, ipx)]), t11 = t_value(f.F[rec_index(g.nbz, ipz, ipx)]);
             dtx = t10 - t00;
             dtx = dtx + t11 - t01;
             dtx = dtx / (2.0f * earth * dnx);

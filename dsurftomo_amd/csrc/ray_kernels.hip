@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_rays(GridDesc g, BatchPtrs b, int unit_b
     const SourceDesc sd = b.src[slot];
     const size_t rr = (size_t)kRefMax * kRefMax;
     RayFields f;
-    f.F = b.F_c + (size_t)slot * g.nbx * g.nbz * kTileRecs;
+    f.F = b.T_c + (size_t)slot * g.nbx * g.nbz * kTileRecs;
     f.veln = veln_all + (size_t)sd.period * field_stride;
     f.Tr = b.Tfin_r + slot * rr;
     f.Sr = b.S_r + slot * rr;

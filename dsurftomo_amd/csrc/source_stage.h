@@ -120,7 +120,7 @@ DSA_HD float coarse_velocity(const GridDesc& g, const float* velv, const float* 
 DSA_HD int refined_startup(const GridDesc& g, const SourceDesc& s, SourceScratch& w)
 {
     MarchView m;
-    m.F = w.F_r; m.slow = w.slow_r; m.nbz = s.nbz_r; m.risti = w.risti_r;
+    m.F = w.F_r; m.window = 0; m.slow = w.slow_r; m.nbz = s.nbz_r; m.risti = w.risti_r;
     m.status = w.rst; m.wz0 = s.rwz0; m.wx0 = s.rwx0; m.wnz = kRWin; m.wnx = kRWin;
     m.nnz = s.rnz; m.nnx = s.rnx; m.ri = g.earth; m.dnx = s.rdnx; m.dnz = s.rdnz;
     m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0; m.clock = 0.0f;
@@ -247,14 +247,15 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
 
 // ---------------------------------------------------------------------------------------------
 // Band march on the coarse grid: travel(urg=2) from the injected state until every node that
-// started in the tree has been accepted.  T_c is the coarse field of this source (plain values
-// inside the window on entry for status >= 0), slow_c (tiled) / risti_c the period's coarse tables.
-// Serial.  On return: alive nodes of the window are pinned (sign bit), all others +inf (T and tau).
-DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, Rec* F_c,
+// started in the tree has been accepted.  W holds the (T, tau) records of the coarse march window only, (cwnz, cwnx)
+// column-major (the hand-off put plain values there for status >= 0, +inf elsewhere); slow_c (tiled) / risti_c are the
+// period's coarse tables.  Serial.  On return: alive nodes of the window are pinned (sign bit of T; tau = their accept
+// number, 0 for the hand-off's alive nodes), all others +inf (T and tau).
+DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, Rec* W,
                               const float* slow_c, const float* risti_c)
 {
     MarchView m;
-    m.F = F_c; m.slow = slow_c; m.nbz = g.nbz; m.risti = risti_c;
+    m.F = W; m.window = 1; m.slow = slow_c; m.nbz = g.nbz; m.risti = risti_c;
     m.status = w.cst; m.wz0 = s.cwz0; m.wx0 = s.cwx0; m.wnz = s.cwnz; m.wnx = s.cwnx;
     m.nnz = g.nnz; m.nnx = g.nnx; m.ri = g.earth; m.dnx = g.dnx; m.dnz = g.dnz;
     m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0; m.clock = 0.0f;
@@ -264,8 +265,7 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
         for (int lz = 0; lz < s.cwnz; ++lz) {
             const int q = lx * s.cwnz + lz;
             w.cinit[q] = 0;
-            if (w.cst[q] == 0) F_c[rec_index(g.nbz, s.cwz0 + lz, s.cwx0 + lx)].tau = 0.0f;      // alive before the march
-
+            if (w.cst[q] == 0) W[q].tau = 0.0f;      // alive before the march
             if (w.cst[q] > 0) { w.cinit[q] = 1; ++ninit; mv_add(m, s.cwz0 + lz + 1, s.cwx0 + lx + 1); }
         }
     while (m.ntr > 0 && ninit > 0 && m.error == 0) {
@@ -275,14 +275,37 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
         if (!mv_accept_root(m)) break;
     }
     if (m.error) w.flags[1] = 16 + m.error;
+    for (int q = 0; q < s.cwnx * s.cwnz; ++q) {
+        Rec& r = W[q];
+        if (w.cst[q] == 0) { r.T = -t_value(r.T); }          // tau: accept number of the march, 0 for the hand-off's alive nodes
+        else { r.T = kInf; r.tau = kInf; }
+    }
+}
+
+// the window's pinned nodes into a full-field record array (+inf everywhere else on entry): host tools / CPU checks
+DSA_HD void export_window_records(const GridDesc& g, const SourceDesc& s, const Rec* W, Rec* F_c)
+{
     for (int lx = 0; lx < s.cwnx; ++lx)
         for (int lz = 0; lz < s.cwnz; ++lz) {
-            const int ix = s.cwx0 + lx + 1, iz = s.cwz0 + lz + 1;
-            Rec& r = F_c[rec_index(g.nbz, iz - 1, ix - 1)];
-            const int st = w.cst[lx * s.cwnz + lz];
-            if (st == 0) { r.T = -t_value(r.T); }          // tau: accept number of the march, 0 for the hand-off's alive nodes
-            else { r.T = kInf; r.tau = kInf; }
+            const Rec r = W[lx * s.cwnz + lz];
+            if (t_pinned(r.T)) F_c[rec_index(g.nbz, s.cwz0 + lz, s.cwx0 + lx)] = r;
         }
+}
+
+// the window's pinned nodes into the compact coarse field (+inf everywhere on entry) and its exception table (empty on
+// entry); returns false when the table overflows (cannot: the window has at most kCWinMax^2 nodes)
+DSA_HD bool export_window_compact(const GridDesc& g, const SourceDesc& s, const Rec* W, float* Tc, unsigned long long* exc, int log2cap)
+{
+    bool ok = true;
+    for (int lx = 0; lx < s.cwnx; ++lx)
+        for (int lz = 0; lz < s.cwnz; ++lz) {
+            const Rec r = W[lx * s.cwnz + lz];
+            if (!t_pinned(r.T)) continue;
+            const int id = rec_index(g.nbz, s.cwz0 + lz, s.cwx0 + lx);
+            ok = exc_insert_serial(exc, log2cap, id | kExcPinned, r.tau) && ok;
+            Tc[id] = r.T;                                      // -T: the sign bit marks the exceptional node
+        }
+    return ok;
 }
 
 }  // namespace dsa

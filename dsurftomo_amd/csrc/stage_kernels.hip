@@ -43,6 +43,20 @@ __global__ void k_fill(float* __restrict__ d, size_t n, float v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
 }
 
+__global__ void k_fill64(unsigned long long* __restrict__ d, size_t n, unsigned long long v)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
+}
+
+void launch_fill64(unsigned long long* d, size_t n, unsigned long long v, hipStream_t stream)
+{
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_fill64, dim3((unsigned)blocks), dim3(256), 0, stream, d, n, v);
+}
+
 void launch_fill(float* d, size_t n, float v, hipStream_t stream)
 {
     if (n == 0) return;
@@ -190,9 +204,9 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     }
     // coarse window: everything far, then every 8th refined node, then band promotion
     const int wn = sd.cwnx * sd.cwnz;
-    for (int q = tid; q < wn; q += 256) w.cst[q] = -1;
+    Rec* W = b.W_c + (size_t)s * kCWinMax * kCWinMax;           // records of the coarse march window, (cwnz, cwnx) column-major
+    for (int q = tid; q < wn; q += 256) { w.cst[q] = -1; W[q] = Rec{ kInf, kInf }; }
     __syncthreads();
-    Rec* F_c = b.F_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
     const int bxn = (sd.rnx - 1) / kSgdl + 1, bzn = (sd.rnz - 1) / kSgdl + 1;
     for (int q = tid; q < bxn * bzn; q += 256) {
         const int l = (q / bzn) * kSgdl + 1, k = (q % bzn) * kSgdl + 1;
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
         const int id = (l - 1) * sd.rnz + (k - 1);
         const int st = w.S_r[id];
         w.cst[(cx - 1 - sd.cwx0) * sd.cwnz + (cz - 1 - sd.cwz0)] = (int16_t)st;
-        if (st >= 0) F_c[rec_index(g.nbz, cz - 1, cx - 1)].T = Tfin[id];
+        if (st >= 0) W[(cx - 1 - sd.cwx0) * sd.cwnz + (cz - 1 - sd.cwz0)].T = Tfin[id];
     }
     __syncthreads();
     // alive nodes that touch a far node go back into the band. A promoted node reads as "not far"
@@ -235,11 +249,16 @@ __global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* _
     if (s >= nsrc) return;
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
-    Rec* F_c = b.F_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
+    Rec* W = b.W_c + (size_t)s * kCWinMax * kCWinMax;
+    float* T_c = b.T_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
+    unsigned long long* exc = b.exc_c + ((size_t)s << b.exc_log2cap);
     const float* slow_c = slow_all + (size_t)sd.period * field_stride;      // tiled slowness of this period
-    coarse_band_march(g, sd, w, F_c, slow_c, risti_c);
+    coarse_band_march(g, sd, w, W, slow_c, risti_c);
+    if (!export_window_compact(g, sd, W, T_c, exc, b.exc_log2cap)) w.flags[1] = 32;
+    // seeds of the fixed-point solve: the neighbours of the pinned nodes (cinit, free after the march, marks the ones taken)
     int* seed = b.seed_c + (size_t)s * kSeedC;
     int nseed = 0;
+    for (int q = 0; q < sd.cwnx * sd.cwnz; ++q) w.cinit[q] = 0;
     for (int lx = 0; lx < sd.cwnx; ++lx)
         for (int lz = 0; lz < sd.cwnz; ++lz) {
             if (w.cst[lx * sd.cwnz + lz] != 0) continue;
@@ -247,8 +266,14 @@ __global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* _
             const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
             for (int q = 0; q < 4; ++q) {
                 if (nx[q] < 1 || nx[q] > g.nnx || nz[q] < 1 || nz[q] > g.nnz) continue;
-                if (t_pinned(F_c[rec_index(g.nbz, nz[q] - 1, nx[q] - 1)].T)) continue;
-                seed_node(F_c, g.nbz, seed, &nseed, kSeedC, nz[q], nx[q]);
+                const bool inwin = nz[q] > sd.cwz0 && nz[q] <= sd.cwz0 + sd.cwnz && nx[q] > sd.cwx0 && nx[q] <= sd.cwx0 + sd.cwnx;
+                if (inwin) {
+                    const int wq = (nx[q] - 1 - sd.cwx0) * sd.cwnz + (nz[q] - 1 - sd.cwz0);
+                    if (w.cst[wq] == 0 || w.cinit[wq]) continue;            // pinned, or already a seed
+                    w.cinit[wq] = 1;
+                }
+                if (nseed < kSeedC) seed[nseed] = rec_index(g.nbz, nz[q] - 1, nx[q] - 1);      // (a node outside the window may repeat: harmless)
+                nseed += 1;
             }
         }
     b.nseed_c[s] = nseed;
@@ -270,6 +295,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     if (s >= nsrc) return;
     const SourceDesc sd = b.src[s];
     FimProblem r;
+    r.Tc = nullptr; r.exc = nullptr; r.exc_log2cap = 0;
     r.F = b.F_r + (size_t)s * kRefRecs; r.slow = b.slow_r + (size_t)s * kRefRecs; r.risti = b.risti_r + (size_t)s * kRefMax;
     r.seed = b.seed_r + (size_t)s * kSeedR; r.seed_count = b.nseed_r + s; r.seed_cap = kSeedR; r.lists = b.lists + (size_t)s * b.lists_stride;
     r.nnx = sd.rnx; r.nnz = sd.rnz; r.nbx = sd.nbx_r; r.nbz = sd.nbz_r;
@@ -279,7 +305,8 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     r.info = info + (size_t)s * 16;
     prob_r[s] = r;
     FimProblem c;
-    c.F = b.F_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
+    c.F = nullptr;
+    c.Tc = b.T_c + (size_t)s * g.nbx * g.nbz * kTileRecs; c.exc = b.exc_c + ((size_t)s << b.exc_log2cap); c.exc_log2cap = b.exc_log2cap;
     c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
     c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.seed_cap = kSeedC; c.lists = b.lists + (size_t)s * b.lists_stride;
     c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
@@ -313,7 +340,7 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
     if (!(rd.flags & kRayTime)) return;
     const int slot = rd.src - unit_base;
     const SourceDesc sd = b.src[slot];
-    const Rec* F = b.F_c + (size_t)slot * g.nbx * g.nbz * kTileRecs;
+    const float* Tc = b.T_c + (size_t)slot * g.nbx * g.nbz * kTileRecs;
     const float* veln = veln_all + (size_t)sd.period * field_stride;
     const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, earth = g.earth;
     const float rcx1 = rd.rx, rcz1 = rd.rz, scx = sd.scx, scz = sd.scz;
@@ -357,7 +384,7 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
             for (int l = 1; l <= 2; ++l) {
                 const float produ = (1.0f - fabsf(((float)(l - 1) * dnz - drz) / dnz)) *
                                     (1.0f - fabsf(((float)(k - 1) * dnx - drx) / dnx));
-                trr = trr + t_value(F[rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1)].T) * produ;
+                trr = trr + t_value(Tc[rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1)]) * produ;
             }
     }
     // A source inside the last cell next to a high model edge ends the reference's refined stage at once and

@@ -166,14 +166,15 @@ int prepare(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int 
             const size_t id = (size_t)(ix - 1) * s.rnz + (iz - 1);
             P.S_r[id] = (int8_t)handoff_node(g, s, w, ended, rstar, ez, ex, iz, ix, &P.Tfin[id]);
         }
-    // injection + band promotion into the coarse window / field
+    // injection + band promotion into the coarse window (records of the window only, like on the device)
+    std::vector<Rec> W((size_t)s.cwnx * s.cwnz, Rec{ kInf, kInf });
     auto cs = [&](int iz, int ix) -> int16_t& { return P.cst[(size_t)(ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0)]; };
     for (int k = 1; k <= s.rnz; k += kSgdl)
         for (int l = 1; l <= s.rnx; l += kSgdl) {
             const int cz = s.vnt + (k - 1) / kSgdl, cx = s.vnl + (l - 1) / kSgdl;
             const size_t id = (size_t)(l - 1) * s.rnz + (k - 1);
             cs(cz, cx) = P.S_r[id];
-            if (P.S_r[id] >= 0) P.F_c[rec_index(g.nbz, cz - 1, cx - 1)].T = P.Tfin[id];
+            if (P.S_r[id] >= 0) W[(size_t)(cx - 1 - s.cwx0) * s.cwnz + (cz - 1 - s.cwz0)].T = P.Tfin[id];
         }
     auto far = [&](int iz, int ix) {
         if (ix < 1 || ix > g.nnx || iz < 1 || iz > g.nnz) return false;
@@ -183,13 +184,18 @@ int prepare(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int 
     for (int ix = s.vnl; ix <= s.vnr; ++ix)
         for (int iz = s.vnt; iz <= s.vnb; ++iz)
             if (cs(iz, ix) == 0 && (far(iz - 1, ix) || far(iz + 1, ix) || far(iz, ix - 1) || far(iz, ix + 1))) cs(iz, ix) = 1;
-    if (inj_t) untile(g.nnx, g.nnz, P.F_c.data(), inj_t, nullptr);
+    if (inj_t) {
+        for (size_t k = 0; k < (size_t)g.nnx * g.nnz; ++k) inj_t[k] = kInf;
+        for (int ix = s.cwx0 + 1; ix <= s.cwx0 + s.cwnx; ++ix)
+            for (int iz = s.cwz0 + 1; iz <= s.cwz0 + s.cwnz; ++iz) inj_t[(size_t)(ix - 1) * g.nnz + (iz - 1)] = W[(size_t)(ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0)].T;
+    }
     if (inj_s) {
         for (size_t k = 0; k < (size_t)g.nnx * g.nnz; ++k) inj_s[k] = -1;
         for (int ix = s.cwx0 + 1; ix <= s.cwx0 + s.cwnx; ++ix)
             for (int iz = s.cwz0 + 1; iz <= s.cwz0 + s.cwnz; ++iz) inj_s[(size_t)(ix - 1) * g.nnz + (iz - 1)] = cs(iz, ix);
     }
-    coarse_band_march(g, s, w, P.F_c.data(), P.slow_c.data(), P.risti_c.data());
+    coarse_band_march(g, s, w, W.data(), P.slow_c.data(), P.risti_c.data());
+    export_window_records(g, s, W.data(), P.F_c.data());
     P.err = flags[1];
     return 0;
 }
@@ -261,9 +267,9 @@ int hc_trace_ray(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd,
     GridDesc g; make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
     SourceDesc s;
     if (make_source(g, sx, sz, s) != 0) return -2;
-    std::vector<Rec> F((size_t)g.nbx * g.nbz * kTileRecs, Rec{ kInf, kInf });
+    std::vector<float> F((size_t)g.nbx * g.nbz * kTileRecs, kInf);          // compact coarse field: one float per node, tiled
     for (int ix = 0; ix < g.nnx; ++ix)
-        for (int iz = 0; iz < g.nnz; ++iz) F[rec_index(g.nbz, iz, ix)].T = ttn[(size_t)ix * g.nnz + iz];
+        for (int iz = 0; iz < g.nnz; ++iz) F[rec_index(g.nbz, iz, ix)] = ttn[(size_t)ix * g.nnz + iz];
     std::vector<int8_t> S((size_t)s.rnx * s.rnz);
     for (size_t k = 0; k < S.size(); ++k) S[k] = (int8_t)(nstsr[k] > 0 ? 1 : (nstsr[k] < 0 ? -1 : 0));
     std::vector<float> slab((size_t)(g.nvx + 2) * (g.nvz + 2), 0.0f);

@@ -107,7 +107,8 @@ def test_fields_match_oracle(engine, nx, kind, gd):
 
 
 def test_sorted_variant_identical(engine):
-    """the tile-mask / ordered-sweep variant of the solve kernel reaches the same fixed point, bit for bit"""
+    """the list variant of the solve kernel (option fim_sorted = 0; it serves the refined boxes only, the coarse solve runs on
+    the compact field in the ordered variant) reaches the same fixed point as the tile-mask / ordered-sweep one, bit for bit"""
     nx = 35
     pv = np.stack([synth.medium(nx, "checker4"), synth.medium(nx, "smooth")])
     u = synth.units(nx, 12, 2, 6)

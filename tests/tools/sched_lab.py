@@ -31,3 +31,10 @@ for w in windows:
         if ref is None: ref = np.abs(T)
         print("N=%d %s window %.2f mode %d:%d rc %d: rounds %5d subpasses %6d evals/node %.3f changes/node %.3f ready/round %6.0f listed/round %6.0f max ready %5d freezes %d trips256 %d trips128 %d model_us %.0f | %s (%.1f s)" %
               (N, kind, w, mode, param, rc, out[0], out[4], out[1] / (N * N), out[2] / (N * N), out[5] / max(out[0], 1), out[6] / max(out[0], 1), out[7], out[3], out[8], out[9], (out[0] * 19.0 + out[8] * 6.4) / 1000.0, same, time.time() - t0), flush=True)
+if os.environ.get("LAB_TAU_STATS"):
+    Tf, kf = np.abs(T), np.abs(tau)
+    fin = np.isfinite(Tf)
+    ne = (Tf != kf) & fin
+    pinned = np.signbit(T)
+    print("tau != T at %d of %d nodes (%.4f %%), of which pinned %d; tau > T: %d, tau < T: %d; max tau - T %.3g" %
+          (ne.sum(), fin.sum(), 100.0 * ne.mean(), (ne & pinned).sum(), ((kf > Tf) & fin).sum(), ((kf < Tf) & fin).sum(), (kf - Tf)[ne & ~pinned].max() if (ne & ~pinned).any() else 0))
