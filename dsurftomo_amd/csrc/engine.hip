@@ -332,7 +332,8 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         exc_log2cap = exc_log2cap_of(g.nnx, g.nnz);
         const FimLaunch &lc = shape_c, &lr = shape_r;
         lists_stride = std::max((size_t)4 * lc.list_cap + lc.ready_cap, (size_t)4 * lr.list_cap + lr.ready_cap);
-        lists_stride = std::max(lists_stride, (size_t)2 * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile masks + one list
+        lists_stride = std::max(lists_stride, (size_t)kFimMaskInts * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile records + one list
+        lists_stride = std::max(lists_stride, (size_t)kFimMaskInts * kRefTiles * kRefTiles + 2);
         lists_stride = (lists_stride + 1) & ~(size_t)1;      // the masks are 8-byte words
     }
     per_unit_bytes = nrec_c * 4 + ((size_t)8 << exc_log2cap) + (size_t)kCWinMax * kCWinMax * 8 + lists_stride * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +

@@ -109,9 +109,12 @@ __device__ __forceinline__ float wave_min(float v)
 #ifndef DSA_FIM_WAVES
 #define DSA_FIM_WAVES 4
 #endif
-#ifndef DSA_ODD_CLEAR
-#define DSA_ODD_CLEAR 0             // 0: every ready node leaves the active set in pass A; 1 / 2: the odd ones after the even sub-pass (before / behind its barrier)
-#endif
+// DSA_ODD_CLEAR (kernels.h): 1 = an odd node that is evaluated in a round ignores what the even half of that round activated
+// (its evaluation has seen those changes): -16 % evaluations at the same fixed point (tests/tools/sched_lab.cpp mode 6).  The
+// active set of a tile is then three masks and a stamp, {E, O, R, round}: activations of the even half go to E, those of the odd
+// half to O, R holds the nodes the odd half of round `round - 1` evaluated; pass A takes (E & ~R) | O and rewrites the record
+// with plain stores (a tile has one owner in pass A and nobody activates then).  [Clearing the odd nodes' bits with atomics
+// after the even half, in three placements, lost: the mask lines are cold by then and every clear went to memory.]
 #ifndef DSA_FIM_GROUP_SHIFT
 #define DSA_FIM_GROUP_SHIFT 4      // log2 of the bitmap words per group handed to a wave (pass A of k_fim_sorted)
 #endif
@@ -395,9 +398,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     __shared__ int smem[SC_COUNT];
     constexpr int kWaveBuf = 256;                            // nodes a wave expands at a time (128: -4 %, 512: -6 %)
     __shared__ int wbuf[(NT / 64) * kWaveBuf];
-    constexpr int kTileBuf = 256;                            // tiles a wave gathers at a time
+    constexpr int kTileBuf = NT > 512 ? 128 : 256;           // tiles a wave gathers at a time (16 waves: the per-tile scratch has to fit the LDS)
     __shared__ int wtile[(NT / 64) * kTileBuf];
-    __shared__ unsigned wclr[(NT / 64) * kTileBuf * 2];      // per gathered tile: the node bits that leave the active set
+    __shared__ unsigned wclr[(NT / 64) * kTileBuf * (DSA_ODD_CLEAR ? 4 : 2)];      // per gathered tile: the node bits that leave the active set (and the odd ones evaluated this round)
     const FimProblem p = problems[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* sc = smem;
@@ -418,7 +421,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     GChar* const maskb = (GChar*)p.lists;                    // ntile node masks
     auto rec = [&](int id) -> GRec* { return (GRec*)(Fb + ((unsigned)id << 3)); };
     auto slow_at = [&](int id) -> float { return *(GCF32*)(slowb + ((unsigned)id << 2)); };
-    auto mask_at = [&](int tile) -> GU64* { return (GU64*)(maskb + ((unsigned)tile << 3)); };
+    constexpr bool kOddR = DSA_ODD_CLEAR != 0;
+    constexpr int kMaskShift = kOddR ? 5 : 3, kClrWords = kOddR ? 4 : 2;
+    auto mask_at = [&](int tile) -> GU64* { return (GU64*)(maskb + ((size_t)(unsigned)tile << kMaskShift)); };
     constexpr int rhalf = NT * 4;                            // ready nodes of one colour a round can take (8 per thread: no gain)
     __shared__ int ready[2 * rhalf];                         // (the rest stay in their masks for the next round)
     unsigned* const tb = dyn_lds;                            // tile bitmap, nwords
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         *iz0 = (int)(bz << kTileShift) + rec_iz_in_tile(id);
     };
 
-    for (int i = tid; i < ntile; i += NT) *mask_at(i) = 0ull;
+    for (int i = tid; i < (ntile << (kMaskShift - 3)); i += NT) *(GU64*)(maskb + ((size_t)i << 3)) = 0ull;
     for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
     if (tid == 0) {
         sc[SC_READY] = 0; sc[SC_READY_ODD] = 0; sc[SC_TMIN] = 0x7f800000; sc[SC_THETA] = 0x7f800000;
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         float tmin_lane = kInf;
         int* const nbuf = wbuf + wave * kWaveBuf;
         int* const tbuf = wtile + wave * kTileBuf;
-        unsigned* const clr = wclr + wave * kTileBuf * 2;
+        unsigned* const clr = wclr + wave * kTileBuf * kClrWords;
         constexpr int NW = NT / 64;
         constexpr int kQ = kTileBuf / 64, kI = kWaveBuf / 64;
         auto sweep_tiles = [&](int ntiles) {
@@ -542,13 +547,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 tl[q] = q * 64 + lane < ntiles ? tbuf[q * 64 + lane] : -1;
-                m[q] = tl[q] >= 0 ? *mask_at(tl[q]) : 0ull;
-                if (q * 64 < ntiles) { clr[2 * (q * 64 + lane)] = 0u; clr[2 * (q * 64 + lane) + 1] = 0u; }
+                if (kOddR) {
+                    m[q] = 0ull;
+                    if (tl[q] >= 0) {
+                        GU64* const rec4 = mask_at(tl[q]);
+                        const unsigned long long E = rec4[0], O = rec4[1], R = rec4[2];
+                        const unsigned stamp = (unsigned)rec4[3];
+                        m[q] = (E & ~(stamp == (unsigned)rounds ? R : 0ull)) | O;
+                    }
+                } else m[q] = tl[q] >= 0 ? *mask_at(tl[q]) : 0ull;
+                if (q * 64 < ntiles)
+                    for (int w4 = 0; w4 < kClrWords; ++w4) clr[kClrWords * (q * 64 + lane) + w4] = 0u;
             }
             DSA_TICK(1);
             int off[kQ], total = 0;
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
+                off[q] = total;
+                if (q * 64 >= ntiles) continue;                           // wave-uniform: no tiles in this group
                 if (tl[q] >= 0 && m[q] == 0ull) atomicAnd(&tb[tl[q] >> 5], ~(1u << (tl[q] & 31)));      // the tile has drained
                 const int n = __popcll(m[q]);
                 const int incl = wave_scan_incl(n);
@@ -574,6 +590,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 float lb[kI], own[kI];
 #pragma unroll
                 for (int i = 0; i < kI; ++i) {
+                    id[i] = -1; par[i] = 0; slot[i] = 0; lb[i] = kInf; own[i] = kInf;
+                    if (i * 64 >= nn) continue;                           // wave-uniform: this group of 64 is empty
                     const bool have = i * 64 + lane < nn;
                     const int e = have ? nbuf[i * 64 + lane] : 0;
                     slot[i] = e >> 6;
@@ -613,6 +631,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 int ne = 0, no = 0;
 #pragma unroll
                 for (int i = 0; i < kI; ++i) {
+                    be[i] = 0ull; bo[i] = 0ull; frozen[i] = false;
+                    if (i * 64 >= nn) continue;
                     const bool have = id[i] >= 0;
                     frozen[i] = have && frozen_any && own[i] < freeze;
                     const bool want = have && !frozen[i] && (open || lb[i] < theta);
@@ -630,20 +650,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
                 for (int i = 0; i < kI; ++i) {
+                    if (i * 64 >= nn) continue;
                     const bool have = id[i] >= 0;
                     const bool want_e = (be[i] >> lane) & 1ull, want_o = (bo[i] >> lane) & 1ull;
                     const int pe = base_e + __popcll(be[i] & below), po = base_o + __popcll(bo[i] & below);
                     base_e += __popcll(be[i]); base_o += __popcll(bo[i]);
                     const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
                     if (got) ready[want_o ? rhalf + po : pe] = id[i];
-#if DSA_ODD_CLEAR
-                    // an odd node stays in the active set until its own sub-pass starts: what the even half activates in between
-                    // is seen by that evaluation anyway and must not queue the node again (tests/tools/sched_lab.cpp mode 6:
-                    // -15 % evaluations at the same fixed point)
-                    if ((got && !want_o) || frozen[i]) atomicOr(&clr[2 * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
-#else
-                    if (got || frozen[i]) atomicOr(&clr[2 * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
-#endif
+                    if ((got && !(kOddR && want_o)) || frozen[i]) atomicOr(&clr[kClrWords * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
+                    if (kOddR && got && want_o) atomicOr(&clr[kClrWords * slot[i] + 2 + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));     // evaluated by this round's odd half
                     if (have && !frozen[i] && !got) tmin_lane = fminf(tmin_lane, lb[i]);
                 }
                 DSA_TICK(4);
@@ -653,8 +668,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #pragma unroll
             for (int q = 0; q < kQ; ++q)
                 if (tl[q] >= 0) {
-                    const unsigned long long c = (unsigned long long)clr[2 * (q * 64 + lane)] | ((unsigned long long)clr[2 * (q * 64 + lane) + 1] << 32);
-                    if (c) atomicAnd((unsigned long long*)mask_at(tl[q]), ~c);
+                    const unsigned* const cw = clr + kClrWords * (q * 64 + lane);
+                    const unsigned long long c = (unsigned long long)cw[0] | ((unsigned long long)cw[1] << 32);
+                    if (kOddR) {
+                        // the tile's record for the next round: what stays queued, nothing from an odd half yet, and who is evaluated by this round's odd half
+                        const unsigned long long ro = (unsigned long long)cw[2] | ((unsigned long long)cw[3] << 32);
+                        GU64* const rec4 = mask_at(tl[q]);
+                        rec4[0] = m[q] & ~c & ~ro; rec4[1] = 0ull; rec4[2] = ro; rec4[3] = (unsigned long long)(unsigned)(rounds + 1);
+                    } else if (c) atomicAnd((unsigned long long*)mask_at(tl[q]), ~c);
                 }
         };
         int ntw = 0;                                                               // tiles collected, wave-uniform
@@ -708,6 +729,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #endif
                 const int j = j0 + tid;
                 const bool act = j < nready;
+                if (j0 + (tid & ~63) >= nready) continue;                 // wave-uniform: none of this wave's 64 slots holds a node
                 const int id = act ? ready[half ? rhalf + j : j] : 0;
                 int iz, ix;
                 coords(id, &iz, &ix);
@@ -759,6 +781,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 if (!t_pinned(t_old)) {
                     const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
                     c = solve_node(h, slow_at(id), geom, &k);
+#ifdef DSA_PROBE_SOLVE2
+                    {   // instruction-count probe: the solver once more on (opaquely) the same inputs; SQ_INSTS_VALU difference = its share
+                        Hood h2 = h;
+                        asm volatile("" : "+v"(h2.near_[0]), "+v"(h2.near_tau[1]), "+v"(h2.outer[2]));
+                        float k2;
+                        const float c2 = solve_node(h2, slow_at(id), geom, &k2);
+                        if (f2u(c2) != f2u(c) || f2u(k2) != f2u(k)) p.info[5] = 1;
+                    }
+#endif
                     ++evals;
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
@@ -800,7 +831,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 fzp = sel(want[3], (b >> 7) & 0x0101010101010101ull) | sel(want[7], (b >> 6) & 0x0303030303030303ull);
                 auto activate = [&](int tile, unsigned long long bits) {
                     if (bits) {
-                        atomicOr((unsigned long long*)mask_at(tile), bits);
+                        atomicOr((unsigned long long*)(mask_at(tile) + (kOddR ? half : 0)), bits);
                         atomicOr(&tb[tile >> 5], 1u << (tile & 31));
                     }
                 };
@@ -813,12 +844,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 if (changed) { hv_lane += ((unsigned)id * 2654435761u) ^ (f2u(c) * 40503u) ^ (f2u(k) * 2246822519u); kmin_lane = fminf(kmin_lane, k); }
                 DSA_TICK(7);
             }
-#if DSA_ODD_CLEAR == 1
-            // the odd ready nodes leave the active set: issued by every wave as it finishes its even trips (the workgroup's
-            // vector memory operations reach the masks in issue order, so these land before anything the odd half activates)
-            if (half == 0)
-                for (int j = tid; j < nready_odd; j += NT) { const int oid = ready[rhalf + j]; atomicAnd((unsigned long long*)mask_at(oid >> 6), ~(1ull << (oid & 63))); }
-#endif
             if (half == 1) {
                 const unsigned hv = wave_sum(hv_lane);
                 const float kmin = wave_min(kmin_lane);
@@ -828,12 +853,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 }
             }
             __syncthreads();
-#if DSA_ODD_CLEAR == 2
-            if (half == 0) {
-                for (int j = tid; j < nready_odd; j += NT) { const int oid = ready[rhalf + j]; atomicAnd((unsigned long long*)mask_at(oid >> 6), ~(1ull << (oid & 63))); }
-                __syncthreads();
-            }
-#endif
             DSA_PHASE((half ? tB1 : tB0), );
         }
 #ifdef DSA_PHASE_CLOCKS

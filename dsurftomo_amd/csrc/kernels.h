@@ -31,6 +31,11 @@ struct FimProblem {
     int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [3] stall freezes, [4..5] evaluations (u64)
 };
 
+#ifndef DSA_ODD_CLEAR
+#define DSA_ODD_CLEAR 1            // fim_kernel.hip: 1 = tile records {E, O, R, round} (default), 0 = one mask per tile (see there)
+#endif
+constexpr int kFimMaskInts = DSA_ODD_CLEAR ? 8 : 2;     // ints of active-set record per tile in the per-problem scratch
+
 struct FimLaunch {
     int list_cap;          // entries per active list
     int ready_cap;         // entries of the dense ready list
