@@ -290,7 +290,7 @@ def main():
                        "parallelism": "units sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "k_fim_sorted<256> (coarse fixed-point solve)", "bytes_per_solve": bps,
+                         "kernel": "k_fim_sorted<256, compact> (coarse fixed-point solve)", "bytes_per_solve": bps,
                          "launches": int(acc["launches_fim_coarse"]),
                          "avg_launch_ms": round(acc["ms_fim_coarse"] / launches, 3),
                          "solves_per_launch": round(my_units / launches, 1),
