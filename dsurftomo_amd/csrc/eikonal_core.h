@@ -138,6 +138,38 @@ struct Stencil {
 
 DSA_HD float sq(float x) { return x * x; }
 
+// x / 3.0f, correctly rounded, in three instructions instead of the eleven of an IEEE division: q = RN(x c) with c = RN(1/3), the
+// exact residual r = x - 3 q by one FMA, q + r c by another.  Checked against x / 3.0f over ALL finite floats (2^32 patterns:
+// bit-identical except x = -0, which gives +0; the arguments below are sums with a positive square-root term).  The FMAs are
+// explicit: -ffp-contract=off, the numerical contract of this file, only forbids the compiler to fuse on its own.
+// sqrtf for an argument known to be a normal positive number (the one-sided steps below: slowness^2 times grid constants, far
+// from the denormal range and from zero): the hardware's v_sqrt_f32 (1 ulp) plus the compiler's own +-1 ulp correction with two
+// exact FMA residuals, WITHOUT the range scaling and the zero / infinity class test it wraps around them (9 instructions
+// instead of 16).  Correctly rounded, i.e. bit-identical to sqrtf, over the whole range 1e-30 .. 1e30 (tools/micro/exact_math_check.hip
+// compares all 1.7e9 patterns on the device).  The host build (CPU checks) uses libm's correctly rounded sqrtf.
+DSA_HD float sqrt_pos(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float r1 = fmaf(-sm, s, x);
+    float out = (0.0f >= r1) ? sm : s;
+    const float r2 = fmaf(-sp, s, x);
+    out = (0.0f < r2) ? sp : out;
+    return out;
+#else
+    return sqrtf(x);
+#endif
+}
+
+DSA_HD float div3(float x)
+{
+    const float c = 0x1.555556p-2f;
+    const float q = x * c;
+    const float r = fmaf(-3.0f, q, x);
+    return fmaf(r, c, q);
+}
+
 // One evaluation of the mixed first/second-order upwind update; returns +inf when no quadrant
 // has an alive neighbour.
 //
@@ -174,9 +206,9 @@ DSA_HD float fouds2(const Stencil& s, float slown, const NodeGeom& g)
             float trav;
             if (swj[j]) {
                 const float u = 2.0f * ri * dnx;
-                trav = ((4.0f * s.tj[j] - s.tj2[j]) + sqrtf(sq(u) * s2)) / 3.0f;
+                trav = div3((4.0f * s.tj[j] - s.tj2[j]) + sqrt_pos(sq(u) * s2));
             } else {
-                trav = s.tj[j] + sqrtf(s2 * sq(ri) * sq(dnx));
+                trav = s.tj[j] + sqrt_pos(s2 * sq(ri) * sq(dnx));
             }
             best = (trav < best) ? trav : best;
         }
@@ -186,9 +218,9 @@ DSA_HD float fouds2(const Stencil& s, float slown, const NodeGeom& g)
             float trav;
             if (swk[k]) {
                 const float u = 2.0f * risti * dnz;
-                trav = ((4.0f * s.tk[k] - s.tk2[k]) + sqrtf(sq(u) * s2)) / 3.0f;
+                trav = div3((4.0f * s.tk[k] - s.tk2[k]) + sqrt_pos(sq(u) * s2));
             } else {
-                trav = s.tk[k] + sqrtf(s2 * sq(risti) * sq(dnz));
+                trav = s.tk[k] + sqrt_pos(s2 * sq(risti) * sq(dnz));
             }
             best = (trav < best) ? trav : best;
         }
@@ -244,7 +276,7 @@ DSA_HD float fouds2(const Stencil& s, float slown, const NodeGeom& g)
             if (rd1 < 0.0f) rd1 = 0.0f;
             const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
             float trav = tref + tdsh;
-            if (third) trav = trav / 3.0f;
+            if (third) trav = div3(trav);
             best = (trav < best) ? trav : best;
         }
     }
