@@ -73,6 +73,7 @@ template int Engine::ensure<float>(DevBuf<float>&, size_t);
 template int Engine::ensure<int>(DevBuf<int>&, size_t);
 template int Engine::ensure<unsigned char>(DevBuf<unsigned char>&, size_t);
 template int Engine::ensure<unsigned long long>(DevBuf<unsigned long long>&, size_t);
+template int Engine::ensure<unsigned short>(DevBuf<unsigned short>&, size_t);
 
 Engine::~Engine()
 {

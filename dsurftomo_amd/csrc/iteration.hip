@@ -75,27 +75,19 @@ long long regularisation_rows(int nvx, int nvz, int nl, float weight0, int dall,
     return nar;
 }
 
-// rw[k] *= w[row[k] - 1] (main.f90:379), and the number of data entries per column
-__global__ void k_scale_rows(long long nar, float* __restrict__ rw, const int* __restrict__ row, const int* __restrict__ col, const float* __restrict__ w,
-                             int* __restrict__ count)
+// rw[k] *= w[row[k] - 1] (main.f90:379)
+__global__ void k_scale_rows(long long nar, float* __restrict__ rw, const int* __restrict__ row, const float* __restrict__ w)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nar) return;
     rw[k] = rw[k] * w[row[k] - 1];
-    atomicAdd(&count[col[k] - 1], 1);
-}
-// per (slice, lane) of the column ordering: how many of the column's entries are data entries (they come first in storage order)
-__global__ void k_data_lengths(int nslots, const int* __restrict__ seg, const int* __restrict__ len, const int* __restrict__ count, int* __restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nslots) out[i] = len[i] > 0 ? count[seg[i]] : 0;
 }
 
 }  // namespace
 
 namespace dsa {
-int spmv_load_from_device(Engine* e, int m, int n, long long nar, const float* d_rw, const int* d_row, const int* d_col);
-void spmv_abs_column_sums(Engine* e, const int* d_len, float* d_out);
+int spmv_load_from_device(Engine* e, int m, int n, long long nar, const float* d_rw, const int* d_row, const int* d_col, long long nar_data);
+void spmv_abs_column_sums(Engine* e, float* d_out);
 }
 
 extern "C" {
@@ -158,29 +150,23 @@ int dsa_iteration_system_device(dsa_engine* h, int nx, int ny, int nz, int dall,
     std::vector<int> hrow((size_t)nreg), hcol((size_t)nreg);
     regularisation_rows(nvx, nvz, nl, weight0, dall, hrw.data(), hrow.data(), hcol.data());
     dsa::DevBuf<float> d_w, d_norm;
-    dsa::DevBuf<int> d_count, d_len;
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
-    auto done = [&](int rc) { rel(d_w); rel(d_norm); rel(d_count); rel(d_len); return rc; };
+    auto done = [&](int rc) { rel(d_w); rel(d_norm); return rc; };
 #define IT_TRY(call) do { if ((call) != hipSuccess) { e->fail(DSA_ERR_DEVICE, "iteration_system_device: %s failed", #call); return done(DSA_ERR_DEVICE); } } while (0)
-    if (e->ensure(d_w, (size_t)dall) || e->ensure(d_norm, (size_t)maxvp) || e->ensure(d_count, (size_t)maxvp) ||
+    if (e->ensure(d_w, (size_t)dall) || e->ensure(d_norm, (size_t)maxvp) ||
         e->ensure_keep(e->G_rw, (size_t)nar, (size_t)nar_in) || e->ensure_keep(e->G_row, (size_t)nar, (size_t)nar_in) || e->ensure_keep(e->G_col, (size_t)nar, (size_t)nar_in)) return done(e->status);
     IT_TRY(hipMemcpyAsync(d_w.p, datweight, (size_t)dall * 4, hipMemcpyHostToDevice, e->stream));
-    IT_TRY(hipMemsetAsync(d_count.p, 0, (size_t)maxvp * 4, e->stream));
     IT_TRY(hipMemsetAsync(d_norm.p, 0, (size_t)maxvp * 4, e->stream));
     if (nar_in > 0)
-        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((nar_in + 255) / 256)), dim3(256), 0, e->stream, nar_in, e->G_rw.p, e->G_row.p, e->G_col.p, d_w.p, d_count.p);
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((nar_in + 255) / 256)), dim3(256), 0, e->stream, nar_in, e->G_rw.p, e->G_row.p, d_w.p);
     IT_TRY(hipMemcpyAsync(e->G_rw.p + nar_in, hrw.data(), (size_t)nreg * 4, hipMemcpyHostToDevice, e->stream));
     IT_TRY(hipMemcpyAsync(e->G_row.p + nar_in, hrow.data(), (size_t)nreg * 4, hipMemcpyHostToDevice, e->stream));
     IT_TRY(hipMemcpyAsync(e->G_col.p + nar_in, hcol.data(), (size_t)nreg * 4, hipMemcpyHostToDevice, e->stream));
     IT_TRY(hipStreamSynchronize(e->stream));
     const int m = dall + (int)maxvp;
-    { const int rc = dsa::spmv_load_from_device(e, m, (int)maxvp, nar, e->G_rw.p, e->G_row.p, e->G_col.p); if (rc != 0) return done(rc); }
+    { const int rc = dsa::spmv_load_from_device(e, m, (int)maxvp, nar, e->G_rw.p, e->G_row.p, e->G_col.p, nar_in); if (rc != 0) return done(rc); }
     // DWS (main.f90:378-392): per column the sum of |entry| over the DATA entries, which lead every column in storage order
-    const dsa::SpmvState::Sliced& L = e->spmv->by_col;
-    const int nslots = L.nslices * 64;
-    if (e->ensure(d_len, (size_t)std::max(nslots, 1))) return done(e->status);
-    hipLaunchKernelGGL(k_data_lengths, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, e->stream, nslots, L.seg.p, L.len.p, d_count.p, d_len.p);
-    dsa::spmv_abs_column_sums(e, d_len.p, d_norm.p);
+    dsa::spmv_abs_column_sums(e, d_norm.p);
     IT_TRY(hipMemcpyAsync(norm, d_norm.p, (size_t)maxvp * 4, hipMemcpyDeviceToHost, e->stream));
     IT_TRY(hipStreamSynchronize(e->stream));
     IT_TRY(hipGetLastError());

@@ -1,6 +1,8 @@
 // Device copy of a COO matrix in row order and in column order (spmv.hip builds it, lsmr.hip uses it).
 #pragma once
 
+#include <vector>
+
 #include "engine.h"
 
 namespace dsa {
@@ -15,11 +17,23 @@ struct SpmvState {
         DevBuf<long long> off;       // nslices + 1 slice offsets (entries)
         DevBuf<int> seg, len;        // per (slice, lane): segment (row / column) and its entry count; nslices * 64
         DevBuf<float> val;
-        DevBuf<int> idx;             // 0-based index into the input vector
+        DevBuf<int> idx;             // 0-based index into the input vector (the unblocked part), or
+        DevBuf<unsigned short> idx16; // block-local index (blocks of 32768 input elements)
         int nslices = 0;
         long long padded = 0;        // entries of storage (>= nar)
     };
-    Sliced by_row, by_col;
+    // One orientation of the matrix: the input vector is cut into blocks of `block` elements that fit the LDS; block b holds,
+    // slice-transposed, the entries whose input index falls into it, for the segments whose entries are stored in ascending
+    // input order (every data row and every column are; the reference's regularisation rows are not), and a product runs the
+    // blocks one after the other -- so every output element still adds its entries in storage order, but the gathers of the
+    // input vector are LDS reads instead of one 128-B L2 line per 4-byte operand.  blocks[nblocks] holds the other segments with
+    // global indices (gathers from L2).  data_len: per block, how many entries of each (slice, lane) are data entries (DWS).
+    struct Ordering {
+        int block = 0, nblocks = 0, ninput = 0;
+        std::vector<Sliced> blocks;
+        std::vector<DevBuf<int>> data_len;
+    };
+    Ordering by_row, by_col;
     DevBuf<float> x, y;
     // LSMR work vectors (lsmr.hip)
     DevBuf<float> u, v, h, hbar, xs, localV, scal;
