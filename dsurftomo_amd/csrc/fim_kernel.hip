@@ -116,7 +116,7 @@ __device__ __forceinline__ float wave_min(float v)
 // with plain stores (a tile has one owner in pass A and nobody activates then).  [Clearing the odd nodes' bits with atomics
 // after the even half, in three placements, lost: the mask lines are cold by then and every clear went to memory.]
 #ifndef DSA_FIM_GROUP_SHIFT
-#define DSA_FIM_GROUP_SHIFT 4      // log2 of the bitmap words per group handed to a wave (pass A of k_fim_sorted)
+#define DSA_FIM_GROUP_SHIFT -1     // log2 of the bitmap words per group handed to a wave (pass A of k_fim_sorted); -1: one tile column
 #endif
 // One workgroup of NT threads per problem.  The solver wants ~124 VGPRs, i.e. 4 waves per SIMD: tell the
 // compiler so, otherwise it targets 8 waves/SIMD (64 VGPRs) and spills the solver.
@@ -682,7 +682,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         // 64 bitmap words of this wave per trip: groups of 2^gs consecutive words dealt round-robin to the waves,
         // ascending (16-word groups on large grids: -2.5 % against single words at 1025^2; single words on the small
         // refined grids, whose whole bitmap is a dozen words)
-        const int gs = nwords >= 64 * NW ? DSA_FIM_GROUP_SHIFT : 0;
+        // Round 2: a group is about one tile column (nbz / 32 words: 4 at 1025^2, 16 at 4097^2), so that a front, which crosses every
+        // column, spreads evenly over the waves (the wait at the pass's barrier was a seventh of the round with 16-word groups at
+        // 1025^2: -2 % time at full occupancy, -7 % at half, profiles/r02_ab_group_shift.txt).
+        const int colw = nbz >> 5;
+        const int gs_col = colw >= 16 ? 4 : colw >= 8 ? 3 : colw >= 4 ? 2 : colw >= 2 ? 1 : 0;
+        const int gs = nwords >= 64 * NW ? (DSA_FIM_GROUP_SHIFT >= 0 ? DSA_FIM_GROUP_SHIFT : gs_col) : 0;
         for (int wb = 0; ((wb * (64 >> gs) * NW + wave) << gs) < nwords; ++wb) {
             const int w = (((wb * (64 >> gs) + (lane >> gs)) * NW + wave) << gs) + (lane & ((1 << gs) - 1));
             const unsigned bits = w < nwords ? tb[w] : 0u;
