@@ -55,6 +55,9 @@ def medium(nx, kind, period=0):
     elif kind == "rough":
         r = LCG(SEED + 7 + period).uniform(nx * ny).reshape(ny, nx)
         v = 3.0 * (1.0 + 0.10 * (2 * r - 1))
+    elif kind == "wild":         # +-45 % random vertices: many colliding fronts (stress for the exception table of the compact field)
+        r = LCG(SEED + 13 + period).uniform(nx * ny).reshape(ny, nx)
+        v = 3.0 * (1.0 + 0.45 * (2 * r - 1))
     else:
         raise ValueError(kind)
     return np.ascontiguousarray(v.reshape(-1), np.float64)
