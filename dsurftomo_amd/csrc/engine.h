@@ -60,7 +60,8 @@ struct Engine {
     DevBuf<float> T_c;                 // compact coarse fields (eikonal_core.h)
     DevBuf<unsigned long long> exc_c;  // their exception tables
     int exc_log2cap = 0;
-    DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists;
+    DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists, launch_rank;
+    std::vector<int> h_launch_rank;
     size_t lists_stride = 0;
     int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)
     int fim_lds_pad = 0;               // dynamic LDS bytes per workgroup of the solve kernel (occupancy limiter)

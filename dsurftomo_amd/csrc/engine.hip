@@ -81,7 +81,7 @@ Engine::~Engine()
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     rel(velv); rel(veln); rel(slow); rel(risti_c); rel(cbasis); rel(rbasis);
     rel(src); rel(rays); rel(out); rel(err);
-    rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r);
+    rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r); rel(launch_rank);
     rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(T_c); rel(exc_c); rel(W_c); rel(seed_c); rel(nseed_c);
     rel(prob_r); rel(prob_c); rel(paths); rel(path_n); rel(info); rel(clocks); rel(lists);
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
@@ -350,7 +350,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, C * nrec_c) || ensure(exc_c, C << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
-        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
+        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
     HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
     if (!h_trace.empty()) HIP_TRY(this, hipMemcpyAsync(trace_ids.p, h_trace.data(), h_trace.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -406,7 +406,22 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipEventRecord(events[1], stream));
         launch_fill(T_c.p, (size_t)n * nrec_c, kInf, stream);                                   // every node unreached
         launch_fill64(exc_c.p, (size_t)n << exc_log2cap, kExcEmpty, stream);                      // exception tables empty
-        launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, stream);
+        {   // Launch order of the coarse solves: a launch ends with its slowest workgroups, and the rounds of a solve grow with the
+            // distance from the source to the farthest corner of the grid, so the units with the longest fronts get the lowest
+            // workgroup numbers (dispatched first) and the short ones fill the tail.
+            h_launch_rank.resize((size_t)n);
+            std::vector<std::pair<float, int>> far((size_t)n);
+            for (int u = 0; u < n; ++u) {
+                const SourceDesc& s = h_src[first + u];
+                const float fx = (s.scx - g.gox) / g.dnx, fz = (s.scz - g.goz) / g.dnz;
+                const float dx = std::max(fx, (float)(g.nnx - 1) - fx), dz = std::max(fz, (float)(g.nnz - 1) - fz);
+                far[u] = { -(dx * dx + dz * dz), u };
+            }
+            std::stable_sort(far.begin(), far.end());
+            for (int r = 0; r < n; ++r) h_launch_rank[(size_t)far[r].second] = r;
+            HIP_TRY(this, hipMemcpyAsync(launch_rank.p, h_launch_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        }
+        launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));

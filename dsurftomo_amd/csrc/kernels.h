@@ -89,7 +89,7 @@ void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
-                          hipStream_t stream);
+                          const int* d_launch_rank, hipStream_t stream);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
 // data = 0-based index of the datum (travel time / Frechet row) this ray belongs to;
