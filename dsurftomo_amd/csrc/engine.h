@@ -60,6 +60,7 @@ struct Engine {
     DevBuf<float> T_c;                 // compact coarse fields (eikonal_core.h)
     DevBuf<unsigned long long> exc_c;  // their exception tables
     int exc_log2cap = 0;
+    int exc_log2cap_opt = 0;           // option exc_log2cap: initial table size (0 = from the grid); the table grows by itself when it overflows
     DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists, launch_rank;
     std::vector<int> h_launch_rank;
     size_t lists_stride = 0;

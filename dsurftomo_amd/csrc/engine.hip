@@ -330,7 +330,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         shape_c.sorted = shape_c.tile_words * 4 <= 36 * 1024 ? 1 : 0;      // the coarse solve runs on the compact field: ordered variant only
         if (!shape_c.sorted) { fail(DSA_ERR_ARGUMENT, "plan: a %d x %d grid needs %d bytes of LDS tile bitmap (limit 36 KB): the coarse solve has no other variant", g.nnx, g.nnz, shape_c.tile_words * 4); return DSA_ERR_ARGUMENT; }
         shape_c.compact = 1; shape_r.compact = 0;
-        exc_log2cap = exc_log2cap_of(g.nnx, g.nnz);
+        exc_log2cap = exc_log2cap_opt > 0 ? exc_log2cap_opt : exc_log2cap_of(g.nnx, g.nnz);
         const FimLaunch &lc = shape_c, &lr = shape_r;
         lists_stride = std::max((size_t)4 * lc.list_cap + lc.ready_cap, (size_t)4 * lr.list_cap + lr.ready_cap);
         lists_stride = std::max(lists_stride, (size_t)kFimMaskInts * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile records + one list
@@ -400,6 +400,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     std::vector<int32_t> h_info, h_flags;
     for (int first = 0; first < nunits; first += chunk) {
         const int n = std::min(chunk, nunits - first);
+        bool redo_chunk = false;
+      do {
+        redo_chunk = false;
         const BatchPtrs b = batch();
         HIP_TRY(this, hipMemcpyAsync(src.p, h_src.data() + first, (size_t)n * sizeof(SourceDesc), hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipMemcpyAsync(risti_r.p, h_risti_r.data() + (size_t)first * kRefMax, (size_t)n * kRefMax * 4, hipMemcpyHostToDevice, stream));
@@ -476,12 +479,24 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
             if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
-            if (fi[10] == -2) { fail(DSA_ERR_INTERNAL, "unit %d: the exception table of the compact field overflowed (%d entries): more nodes off the causal order than 4 (nnx + nnz) + 1024", first + u, 1 << exc_log2cap); return DSA_ERR_INTERNAL; }
+            if (fi[10] == -2) {
+                // more nodes off the causal order than the table holds: four times the table and the chunk once more
+                if (exc_log2cap + 2 > 26 || ensure(exc_c, (size_t)chunk << (exc_log2cap + 2))) {
+                    fail(DSA_ERR_INTERNAL, "unit %d: the exception table of the compact field overflowed (%d entries) and cannot grow", first + u, 1 << exc_log2cap);
+                    return DSA_ERR_INTERNAL;
+                }
+                exc_log2cap += 2;
+                stats[DSA_STAT_RESCANS] += 1;
+                redo_chunk = true;
+                break;
+            }
             if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
         }
+        if (redo_chunk) continue;
         last_chunk_first = first;
         last_chunk_n = n;
         if (rows && trace_chunk(first, n, rw, iw, col, cap, nar) != 0) return status;
+      } while (redo_chunk);
     }
     HIP_TRY(this, hipEventRecord(events[7], stream));
     HIP_TRY(this, hipEventSynchronize(events[7]));
@@ -746,6 +761,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "ray_path_cap" && value >= 0 && value <= (1 << 24)) { en->ray_path_cap = (int)value; return 0; }
     if (n == "disp_group_shift" && value >= -1 && value <= 3) { en->disp_group_shift = (int)value; return 0; }
     if (n == "disp_layers_lds" && (value == -1 || value == 0 || value == 1)) { en->disp_layers_lds = (int)value; return 0; }
+    if (n == "exc_log2cap" && (value == 0 || (value >= 6 && value <= 24))) { en->planned = false; en->exc_log2cap_opt = (int)value; return 0; }
     if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }

@@ -140,3 +140,42 @@ def test_receivers_at_scale(engine, kind):
     parity_log.add(f"receivers at scale N=1025 {kind}: {d.size} receiver times of {nsrc * nper} units, max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())}, "
                    f"not bit-identical {int((bits(t) != bits(ref)).sum())}")
     assert d.max() <= TOL
+
+
+def test_wild_medium_keeps_the_exception_table_small(engine):
+    """+-45 % random vertices at 1025^2: several hundred non-causal nodes (tau != T) along colliding fronts, i.e. the worst case for
+    the exception table of the compact coarse field (capacity 16 384 here).  The solve must go through, the receivers must hold the
+    bar, and the field may differ from Fast Marching only by tie noise."""
+    nx = 131
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    pv = synth.medium(nx, "wild")
+    veln = L.o_gridder(g, pv)
+    N = g.nnx
+    sx = np.float32(g.gox + np.float32(0.41 * (N - 1) + 0.3) * g.dnx)
+    sz = np.float32(g.goz + np.float32(0.52 * (N - 1) + 0.6) * g.dnz)
+    o = L.o_solve(g, pv, veln, sx, sz)
+    u = synth.LCG(77).uniform(64)
+    rx = (g.gox + (0.5 + u[0::2] * (N - 2)).astype(np.float32) * g.dnx).astype(np.float32)
+    rz = (g.goz + (0.5 + u[1::2] * (N - 2)).astype(np.float32) * g.dnz).astype(np.float32)
+    engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    t = engine.traveltimes([0], [sx], [sz], [32], rx, rz)
+    ref = np.array([L.o_srtimes(g, veln, o["T"], sx, sz, rx[k], rz[k]) for k in range(32)], np.float32)
+    T = engine.field(0)
+    tau = engine.debug_field(0, 1)
+    d = np.abs(T - o["T"])
+    nexc = int((np.abs(tau) != T).sum())
+    parity_log.add(f"wild N={N}: receivers max |dt| {np.abs(t - ref).max():.3g} s | field max {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())} nodes | nodes with tau != T: {nexc}")
+    assert np.abs(t - ref).max() <= TOL
+    assert nexc >= 100                      # the case does exercise the table
+    assert d.max() <= 2e-3 and (d > TOL).mean() <= 1e-4
+    # a table that is far too small (256 entries) overflows, grows by itself (x4 per attempt) and gives the same field
+    engine.set_option("exc_log2cap", 8)
+    try:
+        engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        t2 = engine.traveltimes([0], [sx], [sz], [32], rx, rz)
+        T2 = engine.field(0)
+        grown = engine.stats()["rescans"]
+    finally:
+        engine.set_option("exc_log2cap", 0)
+    assert grown >= 1
+    assert np.array_equal(bits(t2), bits(t)) and np.array_equal(bits(T2), bits(T))
