@@ -318,20 +318,38 @@ struct Hood {
 // its heap layout and cannot be derived locally ("ties").
 // Everything below is indexed with compile-time constants only: runtime-indexed local arrays would
 // live in scratch memory, and this function is the inner loop of the solve kernel.
+//
+// Round 2 form.  The walk evaluates the stencil once per neighbour it takes in, and 64 lanes never agree on which of
+// `fouds2`'s variants they are in, so a wave used to execute all of them, five times over (450 VALU instructions per trip, 45 %
+// of the kernel's).  Here the stencil is restated for the walk (`fouds2` above stays the literal form; the serial marches use it):
+//   * one copy of the evaluation inside a loop over the walk's steps (lanes leave the loop when their walk stops);
+//   * what depends on the node only -- the squares of the grid steps, their products with the squared slowness, the four
+//     one-sided increments with their square roots -- is computed once, not per evaluation;
+//   * one-sided candidates are selects, no branches;
+//   * the two-sided candidate of a quadrant is ONE formula whose operands are selected by (second order in x, second order in z):
+//         em = (p - q) + r,  b = kb2 ((kb1 em) U),  c = kc (U (em^2 - S)),  t = tref + (-b + sqrt(max(b^2 - (4a) c, 0))) / (2a)
+//     with p, q, r, U, S, a, tref and the power-of-two factors from the table in the code; every product and sum is the one
+//     `fouds2` rounds (the factors 2, 4, 8 it applies to u, v before squaring are exact and are applied after, 4 t - t2 is one FMA
+//     because 4 t is exact), and a lane visits only the quadrants in which both its neighbours are alive (one, as a rule).
+// tests/test_hostcheck.py compares this with the step-by-step form around `fouds2` (tests/solve_node_walk_ref.h) on 2e7 random
+// neighbourhoods, bit for bit, and the fields it produces with the oracle's.
 DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* tau_out)
 {
-    float tn[4], key[4];
+    float tn[4], t2[4], ko[4], key[4];
     int idx[4] = { 0, 1, 2, 3 };
-    unsigned alive = 0u;            // bit q: near neighbour q is alive
-    float tnow = -kInf;             // clock of the most recent neighbour acceptance taken into account
+    unsigned alive = 0u, inside = 0u;   // bit q: near neighbour q is alive / inside the grid
+    float tnow = -kInf;                 // clock of the most recent neighbour acceptance taken into account
     for (int q = 0; q < 4; ++q) {
         const bool in = h.in[q];
         const float raw = in ? h.near_[q] : kInf;
         tn[q] = t_value(raw);
         const bool pin = in && t_pinned(raw);
         const float k = in ? tau_value(h.near_tau[q]) : kInf;
+        if (in) inside |= 1u << q;
         if (pin) { alive |= 1u << q; tnow = k > tnow ? k : tnow; }
         key[q] = (in && !pin) ? k : kInf;          // +inf: not a candidate of the walk
+        t2[q] = h.in_outer[q] ? t_value(h.outer[q]) : kInf;
+        ko[q] = h.in_outer[q] ? tau_value(h.outer_tau[q]) : kInf;
     }
     // sort the candidates by (acceptance time, index): 5-comparator network, same order as a stable sort
 #define DSA_CE(a, b)                                                                         \
@@ -344,30 +362,82 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
     DSA_CE(0, 1); DSA_CE(2, 3); DSA_CE(0, 2); DSA_CE(1, 3); DSA_CE(1, 2);
 #undef DSA_CE
 
-    auto eval = [&](void) -> float {
-        Stencil s;
-        for (int d = 0; d < 2; ++d) {
-            s.tj[d] = tn[d];           s.tk[d] = tn[2 + d];
-            s.ej[d] = h.in[d];         s.ek[d] = h.in[2 + d];
-            s.aj[d] = (alive >> d) & 1u;
-            s.ak[d] = (alive >> (2 + d)) & 1u;
-            const float oxr = h.in_outer[d] ? h.outer[d] : kInf;
-            const float ozr = h.in_outer[2 + d] ? h.outer[2 + d] : kInf;
-            s.tj2[d] = t_value(oxr);   s.tk2[d] = t_value(ozr);
-            const float kox = tau_value(h.outer_tau[d]), koz = tau_value(h.outer_tau[2 + d]);
-            s.oj[d] = h.in_outer[d] && (kox < tnow || kox == 0.0f);       // 0: alive before any march
-            s.ok[d] = h.in_outer[2 + d] && (koz < tnow || koz == 0.0f);
-        }
-        return fouds2(s, slown, g);
-    };
+    // node constants (x: colatitude direction, neighbours 0/1; z: longitude direction, neighbours 2/3)
+    const float s2 = sq(slown);
+    const float A = sq(g.ri * g.dnx), B = sq(g.risti * g.dnz);          // u^2 of the first-order forms; second order: 4A, 4B
+    const float s2A = A * s2, s2B = B * s2;
+    const float c1x = sqrt_pos(s2 * sq(g.ri) * sq(g.dnx)), c1z = sqrt_pos(s2 * sq(g.risti) * sq(g.dnz));   // first-order one-sided steps
+    const float c2x = sqrt_pos(4.0f * s2A), c2z = sqrt_pos(4.0f * s2B);                                   // second-order ones (before the / 3)
+    const float a00 = A + B, a11 = 4.0f * a00;                          // a of the quadratic: neither / both sides second order
+    const float a10 = 4.0f * A + 9.0f * B, a01 = 4.0f * B + 9.0f * A;   // x only / z only
 
     float c = kInf;
-    if (alive) c = eval();
-    bool go = true;
-#define DSA_STEP(i)                                                                          \
-    if (go && key[i] < kInf && c > key[i]) { alive |= 1u << idx[i]; tnow = key[i]; c = eval(); } else go = false
-    DSA_STEP(0); DSA_STEP(1); DSA_STEP(2); DSA_STEP(3);
-#undef DSA_STEP
+    bool first = alive != 0u;           // pinned neighbours are alive from the start: one evaluation before the walk
+    for (;;) {
+        if (!first) {
+            const float nk = key[0];
+            if (!(nk < kInf && c > nk)) break;
+            alive |= 1u << idx[0];
+            tnow = nk;
+            key[0] = key[1]; key[1] = key[2]; key[2] = key[3]; key[3] = kInf;
+            idx[0] = idx[1]; idx[1] = idx[2]; idx[2] = idx[3];
+        }
+        first = false;
+
+        bool sw[4];
+        float P[4];
+        for (int q = 0; q < 4; ++q) {
+            const bool o = ko[q] < tnow || ko[q] == 0.0f;                // outer node alive (0: alive before any march)
+            sw[q] = ((alive >> q) & 1u) && o && tn[q] > t2[q];
+            P[q] = fmaf(4.0f, tn[q], -t2[q]);                            // 4 t - t2 (4 t is exact)
+        }
+        const unsigned aj = alive & 3u, ak = (alive >> 2) & 3u;
+        const bool k_dead = (((inside >> 2) & 3u) & ~ak) != 0u;          // some z neighbour inside the grid is not alive
+        const bool j_dead = ((inside & 3u) & ~aj) != 0u;
+        float best = kInf;
+        for (int q = 0; q < 4; ++q) {
+            const bool x = q < 2;
+            const float one = sw[q] ? div3(P[q] + (x ? c2x : c2z)) : tn[q] + (x ? c1x : c1z);
+            const bool have = ((alive >> q) & 1u) && (x ? k_dead : j_dead);
+            best = (have && one < best) ? one : best;
+        }
+        unsigned pm = ((aj & 1u) ? ak : 0u) | ((aj & 2u) ? (ak << 2) : 0u);   // bit 2 j + k: quadrant with both neighbours alive
+        while (pm) {
+            const bool j1 = (pm & 3u) == 0u;                             // lowest set bit: quadrant (j, k)
+            const unsigned pj = j1 ? (pm >> 2) : pm;
+            const bool k1 = (pj & 1u) == 0u;
+            pm &= pm - 1u;
+            const float tj = j1 ? tn[1] : tn[0], tj2 = j1 ? t2[1] : t2[0], Pj = j1 ? P[1] : P[0];
+            const float tk = k1 ? tn[3] : tn[2], tk2 = k1 ? t2[3] : t2[2];
+            const bool sj = j1 ? sw[1] : sw[0], sk = k1 ? sw[3] : sw[2];
+            //            sj & sk            sj only            sk only            neither
+            //  p         4 tj - tj2         3 tk               3 tj               tk
+            //  q         4 tk               4 tj               4 tk               tj
+            //  r         tk2                tj2                tk2                0
+            //  U         A  (kb2 8, kc 4)   B                  A                  A  (kb2 -2)
+            //  S         4 s2 B             4 s2 A             4 s2 B             s2 B
+            //  a         4 (A + B)          4 A + 9 B          4 B + 9 A          A + B
+            //  tref      4 tj - tj2         tk                 tj                 tj          (sj & sk: the sum is divided by 3)
+            const bool both = sj && sk, one = sj != sk;
+            const float p = sj ? (sk ? Pj : 3.0f * tk) : (sk ? 3.0f * tj : tk);
+            const float q_ = (sj && !sk) ? 4.0f * tj : (sk ? 4.0f * tk : tj);
+            const float r = sk ? tk2 : (sj ? tj2 : 0.0f);
+            const float U = (sj && !sk) ? B : A;
+            const float S = (sj && !sk) ? 4.0f * s2A : (sk ? 4.0f * s2B : s2B);
+            const float a = sj ? (sk ? a11 : a10) : (sk ? a01 : a00);
+            const float tref = sj ? (sk ? Pj : tk) : tj;
+            const float em = (p - q_) + r;
+            const float b = (both ? 8.0f : (one ? 1.0f : -2.0f)) * (((one ? 6.0f : 1.0f) * em) * U);
+            const float cc = (both ? 4.0f : 1.0f) * (U * (sq(em) - S));
+            float rd1 = sq(b) - 4.0f * a * cc;
+            if (rd1 < 0.0f) rd1 = 0.0f;
+            const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+            float trav = tref + tdsh;
+            if (both) trav = div3(trav);
+            best = (trav < best) ? trav : best;
+        }
+        c = best;
+    }
     *tau_out = (c > tnow) ? c : tnow;
     return c;
 }

@@ -786,6 +786,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 if (!t_pinned(t_old)) {
                     const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
                     c = solve_node(h, slow_at(id), geom, &k);
+#ifdef DSA_PROBE_EXTRA_READ
+                    if (COMPACT) {   // bandwidth probe: one more cold line per evaluated node group (the slowness half a grid away); result unused
+                        const float extra = slow_at(id < 524288 ? id + 524288 : id - 524288);
+                        if (extra == 12345.678f) p.info[5] = 1;
+                    }
+#endif
 #ifdef DSA_PROBE_SOLVE2
                     {   // instruction-count probe: the solver once more on (opaquely) the same inputs; SQ_INSTS_VALU difference = its share
                         Hood h2 = h;

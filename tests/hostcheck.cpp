@@ -11,6 +11,7 @@
 
 #include "../dsurftomo_amd/csrc/host_geometry.h"
 #include "../dsurftomo_amd/csrc/ray_core.h"
+#include "solve_node_walk_ref.h"
 
 using namespace dsa;
 
@@ -446,4 +447,66 @@ extern "C" int hc_coarse_problem(int nx, int ny, float goxd, float gozd, float d
     std::memcpy(risti_c, P.risti_c.data(), 4 * (size_t)g.nnx);
     geom[0] = g.earth; geom[1] = g.dnx; geom[2] = g.dnz; geom[3] = min_cell_km(g) * P.hmin;
     return 0;
+}
+
+// The product's solve_node against round 1's step-by-step form (tests/solve_node_walk_ref.h) on n random neighbourhoods: realistic
+// fronts plus the awkward cases (ties, unreached and pinned neighbours, grid edges, outer nodes accepted at time 0 or late).
+// Returns the number of neighbourhoods whose (T, tau) bits differ; `stat[0..3]` = evaluations that ended with 0, 1, 2, 3+ walk steps' worth of
+// finite results (coverage only).
+extern "C" long hc_solve_node_compare(unsigned long long seed, long n, long* stat)
+{
+    unsigned long long st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(st >> 33); };
+    auto uni = [&]() { return (float)(rnd() & 0xffffff) / 16777216.0f; };
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        NodeGeom g;
+        g.ri = 6371.0f - 40.0f * uni();
+        g.risti = g.ri * sinf(0.3f + 1.2f * uni());
+        g.dnx = 5e-5f + 6e-4f * uni();
+        g.dnz = (rnd() & 3) ? g.dnx * (0.7f + 0.6f * uni()) : g.dnx;
+        const float slown = 1.0f / (1.5f + 3.5f * uni());
+        const float hx = g.ri * g.dnx * slown, hz = g.risti * g.dnz * slown;      // one-cell travel times
+        const float t0 = (rnd() & 7) ? 300.0f * uni() : 2.0f * uni();
+        const int mode = rnd() & 15;
+        Hood h;
+        for (int q = 0; q < 4; ++q) {
+            const float hq = q < 2 ? hx : hz;
+            const unsigned r = rnd();
+            h.in[q] = (r & 31) != 0;
+            h.in_outer[q] = h.in[q] && ((r >> 5) & 15) != 0;
+            float t = t0 + hq * (2.4f * uni() - 1.2f);
+            if (mode == 1) t = t0;                                               // all equal
+            if (mode == 2 && (q & 1)) t = t0 + hq * 0.25f;                       // pairs equal
+            if (t < 0.0f) t = 0.0f;
+            float tau = ((r >> 9) & 3) ? t : t + hq * 0.3f * uni();              // accepted late now and then
+            if (((r >> 11) & 7) == 0) { t = kInf; tau = kInf; }                  // not reached
+            const bool pin = ((r >> 14) & 15) == 0 && t < kInf;
+            h.near_[q] = pin ? -t : t;
+            h.near_tau[q] = (((r >> 18) & 7) == 0 && t < kInf) ? -tau : tau;      // the list variant's queued bit: must be ignored
+            float o = t + hq * (1.6f * uni() - 1.1f);
+            if (mode == 3) o = t;                                                // tn == t2: first order
+            if (o < 0.0f) o = 0.0f;
+            float otau = ((r >> 21) & 3) ? o : o + hq * 0.5f * uni();
+            if (((r >> 23) & 15) == 0) otau = 0.0f;                              // alive before any march
+            if (((r >> 27) & 7) == 0 || t == kInf) { o = kInf; otau = kInf; }
+            const bool opin = ((r >> 30) & 1) && ((r >> 14) & 3) == 0 && o < kInf;
+            h.outer[q] = h.in_outer[q] ? (opin ? -o : o) : kInf;
+            h.outer_tau[q] = h.in_outer[q] ? otau : kInf;
+            if (!h.in[q]) { h.near_[q] = kInf; h.near_tau[q] = kInf; }
+        }
+        float ka, kb;
+        const float a = solve_node(h, slown, g, &ka), b = solve_node_walk_ref(h, slown, g, &kb);
+        if (std::memcmp(&a, &b, 4) != 0 || std::memcmp(&ka, &kb, 4) != 0) {
+            if (bad < 5)
+                std::fprintf(stderr, "solve_node differs at case %ld: T %.9g vs %.9g, tau %.9g vs %.9g\n", i, (double)a, (double)b, (double)ka, (double)kb);
+            ++bad;
+        }
+        if (stat) {
+            int alive = 0;
+            for (int q = 0; q < 4; ++q) alive += h.in[q] && tau_value(h.near_tau[q]) < kb + 0.0f && tau_value(h.near_tau[q]) < kInf;
+            stat[a < kInf ? (alive > 3 ? 3 : alive) : 4] += 1;
+        }
+    }
+    return bad;
 }

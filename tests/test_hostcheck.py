@@ -20,6 +20,7 @@ SO = os.path.join(HERE, "libhostcheck.so")
 def H():
     src = os.path.join(HERE, "hostcheck.cpp")
     hdr = [os.path.join(L.ROOT, "dsurftomo_amd", "csrc", n) for n in ("eikonal_core.h", "source_stage.h", "host_geometry.h")]
+    hdr.append(os.path.join(HERE, "solve_node_walk_ref.h"))
     if L._stale(SO, [src] + hdr):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-msse2",
                                "-mfpmath=sse", "-shared", "-o", SO, src, "-lm"])
@@ -31,11 +32,22 @@ def H():
     h.hc_coarse_problem.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.f32, L.f32] + [L.vp] * 5
     h.hc_device_schedule.argtypes = [L.i32, L.i32, L.vp, L.vp, L.vp, L.vp, L.f32, L.f32, L.f32, L.f32, L.i32, L.i32, L.vp, L.vp, L.i32]
     h.hc_device_schedule.restype = C.c_long
+    h.hc_solve_node_compare.argtypes = [C.c_ulonglong, C.c_long, L.vp]
+    h.hc_solve_node_compare.restype = C.c_long
     return h
 
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_solve_node_equals_the_step_by_step_form(H):
+    """the product's solve_node (one evaluation body in a loop, operand-selected quadratic) == round 1's walk around the literal
+    fouds2, bit for bit, on 2e7 random neighbourhoods"""
+    stat = np.zeros(5, np.int64)
+    bad = H.hc_solve_node_compare(20261002, 20_000_000, L.ptr(stat))
+    assert bad == 0
+    assert stat[1] > 1e5 and stat[2] > 1e6 and stat[3] > 1e5, stat      # the walk really takes one, two, three and more neighbours
 
 
 def test_stencil_bitwise_against_oracle(H):

@@ -34,5 +34,9 @@ for wc, nt, var in [(w, t, v) for v in variants for t in threads for w in window
     print(f'N={e.nnx} {kind} variant {var:2d} units {n:5d} wg {nt:4d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
           f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} changes/node {st["changes_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} freezes {st["freezes"]:.0f} | {same}', flush=True)
     pt = np.array(st["phase_ticks"]); tot = pt[:4].sum()
+    if os.environ.get('DSA_PASSA_PRINT') and tot > 0:      # DSA_PASSA_CLOCKS build: thread 0's sub-phase clocks (100 MHz), us per round
+        r = max(st["rounds_max"], 1) * n * 100.0
+        print('      us/round (thread 0, with a full wait at every tick): sweep+records %.2f | expand+tau loads %.2f (expand %.2f) | route %.2f | B: hood loads %.2f solve %.2f store+activate %.2f'
+              % (pt[0] / r, pt[1] / r, pt[7] / r, pt[2] / r, pt[3] / r, pt[4] / r, pt[5] / r), flush=True)
     if tot > 0:
         print(f'      phase share: passA {pt[0]/tot:.2f} evalEven {pt[1]/tot:.2f} evalOdd {pt[2]/tot:.2f} roundEnd {pt[3]/tot:.2f} | us/unit {tot/n/100:.0f} | avg list {pt[4]/n/max(st["rounds_max"],1):.0f} avg ready/round {pt[5]/n/max(st["rounds_max"],1):.0f} max list {pt[6]:.0f}', flush=True)
