@@ -519,6 +519,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #else
 #define DSA_TICK(k) do { } while (0)
 #endif
+    // Barrier probe (DSA_BARRIER_CLOCKS builds only): how long each wave sits at each of the round's four barriers, i.e. how uneven
+    // the waves' shares of a phase are; summed over waves into clocks[0..3], thread 0's total into clocks[4].
+#ifdef DSA_BARRIER_CLOCKS
+    unsigned long long bwait[4] = { 0, 0, 0, 0 };
+    const unsigned long long bstart = wall_clock64();
+#define DSA_SYNC(k) do { const unsigned long long b0_ = wall_clock64(); __syncthreads(); bwait[k] += wall_clock64() - b0_; } while (0)
+#else
+#define DSA_SYNC(k) __syncthreads()
+#endif
     for (;;) {
         const float theta = u2f((unsigned)sc[SC_THETA]);
         const bool open = !(theta < kInf);
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
             if (tmin_lane < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(tmin_lane));
             if (seen) atomicAdd(&sc[SC_CUR], seen);
         }
-        __syncthreads();
+        DSA_SYNC(0);
         const int cnt = sc[SC_CUR];
         if (cnt == 0) break;
         DSA_PHASE(tA, sum_cnt += cnt; if (cnt > max_cnt) max_cnt = cnt);
@@ -863,7 +872,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     if (kmin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[SC_TMIN]), f2u(kmin));
                 }
             }
-            __syncthreads();
+            if (half) DSA_SYNC(2); else DSA_SYNC(1);
             DSA_PHASE((half ? tB1 : tB0), );
         }
 #ifdef DSA_PHASE_CLOCKS
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
             else stall = 0;
         }
         ++rounds;
-        __syncthreads();
+        DSA_SYNC(3);
         DSA_PHASE(tE, );
         if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
     }
@@ -892,6 +901,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         for (int o = 32; o > 0; o >>= 1) { e64 += __shfl_xor(e64, o); c64 += __shfl_xor(c64, o); }
         if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), e64); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), c64); }
     }
+#ifdef DSA_BARRIER_CLOCKS
+    if (p.clocks && lane == 0) {
+        for (int q = 0; q < 4; ++q) atomicAdd(p.clocks + q, bwait[q]);
+        if (tid == 0) p.clocks[4] = wall_clock64() - bstart;
+    }
+#endif
     if (tid == 0) {
         p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
 #ifdef DSA_PHASE_CLOCKS

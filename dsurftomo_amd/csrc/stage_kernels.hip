@@ -316,6 +316,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.info = info + (size_t)s * 16 + 8;
     prob_c[launch_rank ? launch_rank[s] : s] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
     for (int q = 0; q < 16; ++q) info[(size_t)s * 16 + q] = 0;
+    if (clocks) for (int q = 0; q < 8; ++q) clocks[(size_t)s * 8 + q] = 0ull;      // probe builds accumulate into them
 }
 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,

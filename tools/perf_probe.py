@@ -34,6 +34,10 @@ for wc, nt, var in [(w, t, v) for v in variants for t in threads for w in window
     print(f'N={e.nnx} {kind} variant {var:2d} units {n:5d} wg {nt:4d} window {wc:5.1f}: {n/dt:8.1f} solves/s | fim_coarse {st["ms_fim_coarse"]:8.1f} ms fim_ref {st["ms_fim_refined"]:7.1f} stages {st["ms_stages"]:6.1f} '
           f'rounds_max {st["rounds_max"]:6.0f} evals/node {st["evals_total"]/n/(e.nnx*e.nnz):5.2f} changes/node {st["changes_total"]/n/(e.nnx*e.nnz):5.2f} rescans {st["rescans"]:.0f} freezes {st["freezes"]:.0f} | {same}', flush=True)
     pt = np.array(st["phase_ticks"]); tot = pt[:4].sum()
+    if os.environ.get('DSA_BARRIER_PRINT') and pt[4] > 0:   # DSA_BARRIER_CLOCKS build: waves' waits at the round's barriers
+        nw = nt // 64
+        print('      share of a wave\'s time spent at the barriers (mean over waves): after pass A %.3f | even half %.3f | odd half %.3f | round end %.3f | total %.3f'
+              % tuple(list(pt[:4] / (nw * pt[4])) + [pt[:4].sum() / (nw * pt[4])]), flush=True)
     if os.environ.get('DSA_PASSA_PRINT') and tot > 0:      # DSA_PASSA_CLOCKS build: thread 0's sub-phase clocks (100 MHz), us per round
         r = max(st["rounds_max"], 1) * n * 100.0
         print('      us/round (thread 0, with a full wait at every tick): sweep+records %.2f | expand+tau loads %.2f (expand %.2f) | route %.2f | B: hood loads %.2f solve %.2f store+activate %.2f'
