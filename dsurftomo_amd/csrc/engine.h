@@ -82,7 +82,8 @@ struct Engine {
     std::vector<int> h_trace;          // ids of the rays to trace (flag kRayPath), ascending
     size_t ndata = 0;                  // data (travel times / rows) addressed by the planned rays
     size_t ray_budget = 0;             // bytes for ray slabs per launch (0 = default)
-    DevBuf<int> trace_ids, vlist, nvv, counts, offsets, coo_col, coo_iw;
+    DevBuf<int> trace_ids, vlist, nvv, counts, coo_col, coo_iw;
+    DevBuf<long long> offsets;
     DevBuf<float> slabs, coo_rw;
     DevBuf<int32_t> rayinfo;
     int ray_path_cap = 0;              // > 0: keep up to that many points of every traced ray (dsa_ray_paths)

@@ -575,10 +575,9 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
     if (!budget) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
-        budget = std::min<size_t>((size_t)8 << 30, free_b / 4 + slabs.cap * 4 + vlist.cap * 4);
+        budget = std::min<size_t>((size_t)40 << 30, free_b / 3 + slabs.cap * 4 + vlist.cap * 4);
     }
     size_t per = std::max<size_t>(budget / per_ray, 64);
-    per = std::min<size_t>(per, (size_t)0x7fffffff / (vlist_stride * (size_t)(sens_nz - 1)));   // int offsets
     per = std::max<size_t>(std::min(per, t1 - t0), 1);
     if (ensure(slabs, per * slab_stride) || ensure(vlist, per * vlist_stride) || ensure(nvv, per) || ensure(counts, per) ||
         ensure(offsets, per + 1) || ensure(rayinfo, per * 2)) return status;
@@ -604,8 +603,8 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
         launch_row_list(g, a, stream);
         launch_row_emit(g, a, false, stream);
         launch_scan(counts.p, m, offsets.p, stream);
-        int total = 0;
-        HIP_TRY(this, hipMemcpyAsync(&total, offsets.p + m, 4, hipMemcpyDeviceToHost, stream));
+        long long total = 0;
+        HIP_TRY(this, hipMemcpyAsync(&total, offsets.p + m, 8, hipMemcpyDeviceToHost, stream));
         h_info.resize((size_t)m * 2);
         HIP_TRY(this, hipMemcpyAsync(h_info.data(), rayinfo.p, (size_t)m * 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipStreamSynchronize(stream));

@@ -120,13 +120,13 @@ struct RowArgs {
     int* vlist; size_t vlist_stride; int* nv;              // kept vertices per ray (scan order jj outer, kk inner)
     const double* S; int kmax, nz;
     int* counts;                                           // entries per ray
-    const int* offsets;                                    // exclusive scan of counts
+    const long long* offsets;                              // exclusive scan of counts (64-bit: a launch may hold every ray of a call)
     float* rw; int* iw; int* col;                          // COO out: value, 1-based row, 1-based column
 };
 void launch_row_list(const GridDesc& g, const RowArgs& a, hipStream_t stream);
 void launch_row_emit(const GridDesc& g, const RowArgs& a, bool write, hipStream_t stream);
 // offsets[0..n] = exclusive prefix sums of counts[0..n-1]
-void launch_scan(const int* d_counts, int n, int* d_offsets, hipStream_t stream);
+void launch_scan(const int* d_counts, int n, long long* d_offsets, hipStream_t stream);
 
 // dispersion (disp_kernels.hip) ---------------------------------------------------------------------
 struct LayerGeom;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_row_emit(GridDesc g, RowArgs a)
     const int* vl = a.vlist + (size_t)t * a.vlist_stride;
     const int nv = a.nv[t];
     const int nvx = g.nvx, ldx = g.nvx + 2, ncol = g.nx * g.ny, layer = g.nvx * g.nvz;
-    const int off = WRITE ? a.offsets[t] : 0;
+    const long long off = WRITE ? a.offsets[t] : 0;
     int cnt = 0;
     for (int k = 0; k < a.nz - 1; ++k) {
         const double* Sk = a.S + ((size_t)k * a.kmax + slot) * ncol;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_row_emit(GridDesc g, RowArgs a)
             }
             const unsigned long long m = __ballot(keep);
             if (WRITE && keep) {
-                const int p = off + cnt + lanes_below(m);
+                const long long p = off + cnt + lanes_below(m);
                 a.rw[p] = val;
                 a.iw[p] = rd.data + 1;
                 a.col[p] = k * layer + i + 1;
@@ -160,28 +160,28 @@ void launch_row_emit(const GridDesc& g, const RowArgs& a, bool write, hipStream_
 }
 
 // one workgroup: per-thread segment sums, scan of the 1024 sums in LDS, segment rewrite
-__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ counts, int n, int* __restrict__ offsets)
+__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ counts, int n, long long* __restrict__ offsets)
 {
-    __shared__ int s_sum[1024];
+    __shared__ long long s_sum[1024];
     const int tid = threadIdx.x;
     const int per = (n + 1023) / 1024;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
-    int s = 0;
+    long long s = 0;
     for (int i = lo; i < hi; ++i) s += counts[i];
     s_sum[tid] = s;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        const int v = tid >= d ? s_sum[tid - d] : 0;
+        const long long v = tid >= d ? s_sum[tid - d] : 0;
         __syncthreads();
         s_sum[tid] += v;
         __syncthreads();
     }
-    int run = s_sum[tid] - s;
+    long long run = s_sum[tid] - s;
     for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
     if (tid == 1023) offsets[n] = s_sum[1023];
 }
 
-void launch_scan(const int* d_counts, int n, int* d_offsets, hipStream_t stream)
+void launch_scan(const int* d_counts, int n, long long* d_offsets, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, d_counts, n, d_offsets);
 }

@@ -55,8 +55,8 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  * solve kernel: 128, 256, 512 or 1024; 0 default = 128 up to 700 nodes per side, 256 up to 1500, 512 up to 3000, 1024 beyond), "fim_sorted" (1, default = the solve kernel that keeps its active
  * set in tile masks and walks it in record order; 0 = the variant with lists in activation order; same fixed
  * point), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits the workgroups resident
- * per CU), "ray_budget" (bytes of per-ray vertex slabs per launch of the ray tracer, 0 = a quarter of free HBM up
- * to 8 GB), "ray_path_cap" (points kept per traced ray for dsa_ray_paths, 0 = none), "disp_layers_lds" (layer
+ * per CU), "ray_budget" (bytes of per-ray vertex slabs per launch of the ray tracer, 0 = a third of free HBM up
+ * to 40 GB: the tracer runs one lane per ray, so a launch should hold every ray of the call), "ray_path_cap" (points kept per traced ray for dsa_ray_paths, 0 = none), "disp_layers_lds" (layer
  * tables of the dispersion kernel: 1 LDS, 0 global scratch, -1 default = LDS when they fit), "disp_group_shift" (lanes per dispersion
  * curve = 2^shift, 0 = one lane per curve, -1 default = 8 lanes up to 4096 curves, 4 up to 32768), "lsmr_device_vectors"
  * (dsa_lsmr: 0 default = ordered reductions on the host, 1 = all vectors on the device; same results) */
