@@ -19,6 +19,17 @@
 
 namespace dsa {
 
+// sin and cos of one argument: on the device one call shares the argument reduction (same bits as the two calls, fewer
+// instructions); the host build keeps libm's two calls.
+DSA_HD void sin_cos(double x, double* s, double* c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(x, s, c);
+#else
+    *s = sin(x); *c = cos(x);
+#endif
+}
+
 constexpr int kMaxLayers = 200;     // reference NL
 constexpr int kMaxPeriods = 60;     // reference NP
 
@@ -76,7 +87,7 @@ DSA_HD double dltar1(const Layers& m, double wvno, double omega)
         const double q = dk * rb_;
         double sinq, y, z, cosq;
         if (wvno < xkb_) {
-            sinq = sin(q); y = sinq / rb_; z = -rb_ * sinq; cosq = cos(q);
+            sin_cos(q, &sinq, &cosq); y = sinq / rb_; z = -rb_ * sinq;
         } else if (wvno == xkb_) {
             cosq = 1.0; y = dk; z = 0.0;
         } else {
@@ -138,7 +149,7 @@ DSA_HD void layer_terms(double p, double q, double ra, double rb, double wvno, d
 {
     double pex = 0.0, sex = 0.0, sinp, x, sinq, y, z, cosq, fac, w, cosp;
     if (wvno < xka) {
-        sinp = sin(p); w = sinp / ra; x = -ra * sinp; cosp = cos(p);
+        sin_cos(p, &sinp, &cosp); w = sinp / ra; x = -ra * sinp;
     } else if (wvno == xka) {
         cosp = 1.0; w = dpth; x = 0.0;
     } else {
@@ -149,7 +160,7 @@ DSA_HD void layer_terms(double p, double q, double ra, double rb, double wvno, d
         w = sinp / ra; x = ra * sinp;
     }
     if (wvno < xkb) {
-        sinq = sin(q); y = sinq / rb; z = -rb * sinq; cosq = cos(q);
+        sin_cos(q, &sinq, &cosq); y = sinq / rb; z = -rb * sinq;
     } else if (wvno == xkb) {
         cosq = 1.0; y = dpth; z = 0.0;
     } else {

@@ -16,4 +16,12 @@ for iwave, igr, kern in ((2, 0, True), (2, 0, False), (2, 1, True), (1, 0, True)
     t0 = time.perf_counter(); e.dispersion_run(iwave, igr, t, kern, 0, 0); dt = time.perf_counter() - t0
     st = e.stats()
     roots = st["curves"] * nper * (2 if igr else 1)
+    if os.environ.get('DSA_DISP_SAVE') or os.environ.get('DSA_DISP_COMPARE'):      # bit comparison between library builds
+        got = e.dispersion_fetch(0, nper, kern, 0)
+        blob = np.concatenate([np.ravel(a) for a in (got if kern else (got,))])
+        tag = "%d_%d_%d" % (iwave, igr, kern)
+        if os.environ.get('DSA_DISP_SAVE'): np.save(os.environ['DSA_DISP_SAVE'] + tag + ".npy", blob)
+        else:
+            ref = np.load(os.environ['DSA_DISP_COMPARE'] + tag + ".npy")
+            print("      against the saved run: identical=%s (%d of %d values differ)" % (np.array_equal(ref.view(np.uint64), blob.view(np.uint64)), int((ref.view(np.uint64) != blob.view(np.uint64)).sum()), blob.size), flush=True)
     print("nx %d nz %d nper %d iwave %d igr %d kernels %d: %.1f ms, %d curves, %.2f M roots/s" % (nx, nz, nper, iwave, igr, kern, 1e3 * dt, st["curves"], roots / dt / 1e6), flush=True)
