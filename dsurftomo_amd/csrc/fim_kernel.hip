@@ -528,6 +528,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #else
 #define DSA_SYNC(k) __syncthreads()
 #endif
+    // Issue priorities of a wave's phases (s_setprio; four waves share a SIMD's issue port): the phases that put loads in flight go
+    // first, the solver -- several hundred VALU instructions that need nothing from memory -- yields to them, so another front's loads
+    // are on their way while this one computes.  -3.9 % kernel time at full occupancy (profiles/r02_ab_priorities.txt; the inverse
+    // assignment changes nothing, the variants around this one lie within 1 %).
+#ifndef DSA_NO_PRIO
+#define DSA_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define DSA_PRIO(n) do { } while (0)
+#endif
+#ifndef DSA_PRIO_A
+#define DSA_PRIO_A 3     // pass A: record loads, neighbour loads
+#define DSA_PRIO_R 2     // pass A: routing
+#define DSA_PRIO_BL 3    // pass B: the neighbourhood's loads
+#define DSA_PRIO_S 0     // pass B: solve_node
+#define DSA_PRIO_W 1     // pass B: store, activation
+#endif
     for (;;) {
         const float theta = u2f((unsigned)sc[SC_THETA]);
         const bool open = !(theta < kInf);
@@ -551,6 +567,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         constexpr int kQ = kTileBuf / 64, kI = kWaveBuf / 64;
         auto sweep_tiles = [&](int ntiles) {
             DSA_TICK(0);
+            DSA_PRIO(DSA_PRIO_A);
             int tl[kQ];
             unsigned long long m[kQ];
 #pragma unroll
@@ -595,6 +612,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 }
                 const int nn = min(total - base, kWaveBuf);
                 DSA_TICK(2);
+                DSA_PRIO(DSA_PRIO_A);
                 int id[kI], par[kI], slot[kI];
                 float lb[kI], own[kI];
 #pragma unroll
@@ -634,6 +652,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     }
                 }
                 DSA_TICK(3);
+                DSA_PRIO(DSA_PRIO_R);
                 // routing: one slot allocation per colour for the whole window
                 unsigned long long be[kI], bo[kI];
                 bool frozen[kI];
@@ -746,6 +765,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 if (j0 + (tid & ~63) >= nready) continue;                 // wave-uniform: none of this wave's 64 slots holds a node
                 const int id = act ? ready[half ? rhalf + j : j] : 0;
                 int iz, ix;
+                DSA_PRIO(DSA_PRIO_BL);
                 coords(id, &iz, &ix);
                 Hood h;
                 h.in[0] = act && ix > 0;          h.in_outer[0] = act && ix > 1;
@@ -788,6 +808,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     own = act ? ld(id) : Rec{ -1.0f, 0.0f };
                 }
                 DSA_TICK(5);
+                DSA_PRIO(DSA_PRIO_S);
                 const float t_old = own.T;
                 const float k_old = own.tau;
                 bool changed = false;
@@ -814,6 +835,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     changed = f2u(c) != f2u(t_old) || f2u(k) != f2u(k_old);
                 }
                 DSA_TICK(6);
+                DSA_PRIO(DSA_PRIO_W);
                 if (changed) {
                     if (COMPACT) {
                         // causal node (the rule): one float.  Else the table entry first, then the flagged value.
