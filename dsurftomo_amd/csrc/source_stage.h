@@ -251,14 +251,39 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
 // column-major (the hand-off put plain values there for status >= 0, +inf elsewhere); slow_c (tiled) / risti_c are the
 // period's coarse tables.  Serial.  On return: alive nodes of the window are pinned (sign bit of T; tau = their accept
 // number, 0 for the hand-off's alive nodes), all others +inf (T and tau).
-DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, Rec* W,
-                              const float* slow_c, const float* risti_c)
+// The pieces of the band march (the device kernel runs the loops over the window with a whole wavefront and only the tree with one lane):
+DSA_HD MarchView band_march_view(const GridDesc& g, const SourceDesc& s, const SourceScratch& w, Rec* W, const float* slow_c, const float* risti_c)
 {
     MarchView m;
     m.F = W; m.window = 1; m.slow = slow_c; m.nbz = g.nbz; m.risti = risti_c;
     m.status = w.cst; m.wz0 = s.cwz0; m.wx0 = s.cwx0; m.wnz = s.cwnz; m.wnx = s.cwnx;
     m.nnz = g.nnz; m.nnx = g.nnx; m.ri = g.earth; m.dnx = g.dnx; m.dnz = g.dnz;
     m.heap = w.heap; m.cap = kHeapCap; m.ntr = 0; m.error = 0; m.clock = 0.0f;
+    return m;
+}
+// accept steps until the nodes that were in the tree at the start (cinit, `ninit` of them) are popped
+DSA_HD void band_march_run(MarchView& m, const SourceDesc& s, SourceScratch& w, int ninit)
+{
+    while (m.ntr > 0 && ninit > 0 && m.error == 0) {
+        const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
+        const int q = (ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0);
+        if (w.cinit[q]) { w.cinit[q] = 0; --ninit; }
+        if (!mv_accept_root(m)) break;
+    }
+    if (m.error) w.flags[1] = 16 + m.error;
+}
+// window node q after the march: alive -> pinned (tau: accept number of the march, 0 for the hand-off's alive nodes), else unreached
+DSA_HD void band_march_finish_node(const SourceScratch& w, Rec* W, int q)
+{
+    Rec& r = W[q];
+    if (w.cst[q] == 0) { r.T = -t_value(r.T); }
+    else { r.T = kInf; r.tau = kInf; }
+}
+
+DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScratch& w, Rec* W,
+                              const float* slow_c, const float* risti_c)
+{
+    MarchView m = band_march_view(g, s, w, W, slow_c, risti_c);
     int ninit = 0;
     // tree start order of the reference: ix outer, iz inner (:341-347)
     for (int lx = 0; lx < s.cwnx; ++lx)
@@ -268,18 +293,8 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
             if (w.cst[q] == 0) W[q].tau = 0.0f;      // alive before the march
             if (w.cst[q] > 0) { w.cinit[q] = 1; ++ninit; mv_add(m, s.cwz0 + lz + 1, s.cwx0 + lx + 1); }
         }
-    while (m.ntr > 0 && ninit > 0 && m.error == 0) {
-        const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
-        const int q = (ix - 1 - s.cwx0) * s.cwnz + (iz - 1 - s.cwz0);
-        if (w.cinit[q]) { w.cinit[q] = 0; --ninit; }
-        if (!mv_accept_root(m)) break;
-    }
-    if (m.error) w.flags[1] = 16 + m.error;
-    for (int q = 0; q < s.cwnx * s.cwnz; ++q) {
-        Rec& r = W[q];
-        if (w.cst[q] == 0) { r.T = -t_value(r.T); }          // tau: accept number of the march, 0 for the hand-off's alive nodes
-        else { r.T = kInf; r.tau = kInf; }
-    }
+    band_march_run(m, s, w, ninit);
+    for (int q = 0; q < s.cwnx * s.cwnz; ++q) band_march_finish_node(w, W, q);
 }
 
 // the window's pinned nodes into a full-field record array (+inf everywhere else on entry): host tools / CPU checks

@@ -241,11 +241,14 @@ void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2d: band march on the coarse grid, one lane per source, then seed the coarse solve
-__global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* __restrict__ slow_all,
-                               size_t field_stride, const float* __restrict__ risti_c)
+// K2d: band march on the coarse grid, then the seeds of the coarse solve.  One wavefront per source: the loops over the status
+// window (up to 65 x 65 nodes: tree start, pinning, export into the compact field, seeds) run on all 64 lanes, the tree itself
+// (a few dozen accept steps) on lane 0.  [Round 1 ran everything on one lane per source: four serial sweeps of the window in
+// global memory, 5.8 ms for the 449 sources of the Taipei example and 10 ms for any number up to 16 000.]
+__global__ __launch_bounds__(64) void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* __restrict__ slow_all,
+                                                     size_t field_stride, const float* __restrict__ risti_c)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= nsrc) return;
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
@@ -253,37 +256,83 @@ __global__ void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* _
     float* T_c = b.T_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
     unsigned long long* exc = b.exc_c + ((size_t)s << b.exc_log2cap);
     const float* slow_c = slow_all + (size_t)sd.period * field_stride;      // tiled slowness of this period
-    coarse_band_march(g, sd, w, W, slow_c, risti_c);
-    if (!export_window_compact(g, sd, W, T_c, exc, b.exc_log2cap)) w.flags[1] = 32;
-    // seeds of the fixed-point solve: the neighbours of the pinned nodes (cinit, free after the march, marks the ones taken)
+    const int nw = sd.cwnx * sd.cwnz;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    // tree start in the reference's order (ix outer, iz inner = ascending q, CalSurfG.f90:341-347): the lanes classify 64 nodes,
+    // lane 0 adds the close ones in order
+    MarchView m = band_march_view(g, sd, w, W, slow_c, risti_c);
+    int ninit = 0;
+    for (int base = 0; base < nw; base += 64) {
+        const int q = base + lane;
+        int st = -1;
+        if (q < nw) {
+            st = w.cst[q];
+            w.cinit[q] = st > 0 ? 1 : 0;
+            if (st == 0) W[q].tau = 0.0f;             // alive before the march
+        }
+        unsigned long long close = __ballot(st > 0);
+        if (lane == 0)
+            while (close) {
+                const int qq = base + __ffsll((long long)close) - 1;
+                close &= close - 1ull;
+                ++ninit;
+                mv_add(m, sd.cwz0 + qq % sd.cwnz + 1, sd.cwx0 + qq / sd.cwnz + 1);
+            }
+    }
+    __threadfence_block();
+    if (lane == 0) band_march_run(m, sd, w, ninit);
+    __threadfence_block();
+    // pinning and export: the window's alive nodes into the compact field (+inf everywhere on entry) and its exception table
+    bool ok = true;
+    for (int q = lane; q < nw; q += 64) {
+        band_march_finish_node(w, W, q);
+        const Rec r = W[q];
+        if (!t_pinned(r.T)) continue;
+        const int lx = q / sd.cwnz, lz = q - lx * sd.cwnz;
+        const int id = rec_index(g.nbz, sd.cwz0 + lz, sd.cwx0 + lx);
+        const unsigned long long mine = exc_pack(id | kExcPinned, r.tau);
+        const unsigned mask = (1u << b.exc_log2cap) - 1u;
+        unsigned h = exc_hash(id, b.exc_log2cap);
+        bool placed = false;
+        for (unsigned n = 0; n <= mask && !placed; ++n, h = (h + 1u) & mask)
+            placed = atomicCAS(exc + h, kExcEmpty, mine) == kExcEmpty;      // (every node is inserted once: no key to match)
+        ok = ok && placed;
+        T_c[id] = r.T;                                      // -T: the sign bit marks the exceptional node
+    }
+    if (!ok) w.flags[1] = 32;
+    // seeds of the fixed-point solve: every node of the grid that is not itself pinned and has a pinned neighbour; they lie in the
+    // window or in the ring around it, so each candidate is looked at by one lane and listed once
     int* seed = b.seed_c + (size_t)s * kSeedC;
     int nseed = 0;
-    for (int q = 0; q < sd.cwnx * sd.cwnz; ++q) w.cinit[q] = 0;
-    for (int lx = 0; lx < sd.cwnx; ++lx)
-        for (int lz = 0; lz < sd.cwnz; ++lz) {
-            if (w.cst[lx * sd.cwnz + lz] != 0) continue;
-            const int ix = sd.cwx0 + lx + 1, iz = sd.cwz0 + lz + 1;
-            const int nx[4] = { ix - 1, ix + 1, ix, ix }, nz[4] = { iz, iz, iz - 1, iz + 1 };
-            for (int q = 0; q < 4; ++q) {
-                if (nx[q] < 1 || nx[q] > g.nnx || nz[q] < 1 || nz[q] > g.nnz) continue;
-                const bool inwin = nz[q] > sd.cwz0 && nz[q] <= sd.cwz0 + sd.cwnz && nx[q] > sd.cwx0 && nx[q] <= sd.cwx0 + sd.cwnx;
-                if (inwin) {
-                    const int wq = (nx[q] - 1 - sd.cwx0) * sd.cwnz + (nz[q] - 1 - sd.cwz0);
-                    if (w.cst[wq] == 0 || w.cinit[wq]) continue;            // pinned, or already a seed
-                    w.cinit[wq] = 1;
-                }
-                if (nseed < kSeedC) seed[nseed] = rec_index(g.nbz, nz[q] - 1, nx[q] - 1);      // (a node outside the window may repeat: harmless)
-                nseed += 1;
+    const int enz = sd.cwnz + 2, ncand = (sd.cwnx + 2) * enz;
+    auto pinned_at = [&](int lx, int lz) { return lx >= 0 && lx < sd.cwnx && lz >= 0 && lz < sd.cwnz && w.cst[lx * sd.cwnz + lz] == 0; };
+    for (int base = 0; base < ncand; base += 64) {
+        const int c = base + lane;
+        bool is_seed = false;
+        int id = 0;
+        if (c < ncand) {
+            const int lx = c / enz - 1, lz = c - (lx + 1) * enz - 1;
+            const int ix = sd.cwx0 + lx + 1, iz = sd.cwz0 + lz + 1;            // 1-based grid indices
+            if (ix >= 1 && ix <= g.nnx && iz >= 1 && iz <= g.nnz && !pinned_at(lx, lz) &&
+                (pinned_at(lx - 1, lz) || pinned_at(lx + 1, lz) || pinned_at(lx, lz - 1) || pinned_at(lx, lz + 1))) {
+                is_seed = true;
+                id = rec_index(g.nbz, iz - 1, ix - 1);
             }
         }
-    b.nseed_c[s] = nseed;
+        const unsigned long long sm = __ballot(is_seed);
+        const int pos = nseed + __popcll(sm & below);
+        if (is_seed && pos < kSeedC) seed[pos] = id;
+        nseed += __popcll(sm);
+    }
+    if (lane == 0) b.nseed_c[s] = nseed;
 }
 
 void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                          size_t field_stride, const float* d_risti_c, hipStream_t stream)
 {
     if (nsrc <= 0) return;
-    hipLaunchKernelGGL(k_coarse_march, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all, field_stride, d_risti_c);
+    hipLaunchKernelGGL(k_coarse_march, dim3(nsrc), dim3(64), 0, stream, g, b, nsrc, d_slow_all, field_stride, d_risti_c);
 }
 
 // ---------------------------------------------------------------------------------------------
