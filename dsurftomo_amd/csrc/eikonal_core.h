@@ -333,7 +333,17 @@ struct Hood {
 //     because 4 t is exact), and a lane visits only the quadrants in which both its neighbours are alive (one, as a rule).
 // tests/test_hostcheck.py compares this with the step-by-step form around `fouds2` (tests/solve_node_walk_ref.h) on 2e7 random
 // neighbourhoods, bit for bit, and the fields it produces with the oracle's.
-DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* tau_out)
+//
+// Round 3.  (1) The first step of a walk that starts without pinned neighbours takes in ONE neighbour: no quadrant has both
+// sides alive, and of the four one-sided candidates only that neighbour's exists -- it is evaluated by its own formula in front of
+// the loop (the same operations on the same operands, so the same bits), and the loop runs one trip less for the whole wave.
+// (2) TIE = true (the tie detector of the engine option `exact_ties`): when the walk stops at an exact tie, c == tau(next) bit for
+// bit, Fast Marching would accept one of the two nodes first and re-evaluate the other against it, and which one is decided by the
+// layout of the reference's heap.  The detector takes the tied neighbour in for one more trip of the same body and
+// reports |c' - c| in *tie_out (>= 0; -1 when the walk did not end on a tie); the returned (T, tau) are those of the walk that
+// stopped at the tie, as before.
+template <bool TIE>
+DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* tau_out, float* tie_out)
 {
     float tn[4], t2[4], ko[4], key[4];
     int idx[4] = { 0, 1, 2, 3 };
@@ -373,10 +383,32 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
 
     float c = kInf;
     bool first = alive != 0u;           // pinned neighbours are alive from the start: one evaluation before the walk
+    if (!first && key[0] < kInf) {      // no pinned neighbour: the walk's first neighbour alone (c = +inf > its key)
+        const int a = idx[0];
+        const bool x = a < 2;
+        const float tna = a == 0 ? tn[0] : a == 1 ? tn[1] : a == 2 ? tn[2] : tn[3];
+        const float t2a = a == 0 ? t2[0] : a == 1 ? t2[1] : a == 2 ? t2[2] : t2[3];
+        const float koa = a == 0 ? ko[0] : a == 1 ? ko[1] : a == 2 ? ko[2] : ko[3];
+        alive = 1u << a;
+        tnow = key[0];
+        key[0] = key[1]; key[1] = key[2]; key[2] = key[3]; key[3] = kInf;
+        idx[0] = idx[1]; idx[1] = idx[2]; idx[2] = idx[3];
+        const bool o = koa < tnow || koa == 0.0f;
+        const bool sw1 = o && tna > t2a;
+        const bool have = x ? ((inside >> 2) & 3u) != 0u : (inside & 3u) != 0u;    // a neighbour of the other direction exists (none is alive)
+        const float one = sw1 ? div3(fmaf(4.0f, tna, -t2a) + (x ? c2x : c2z)) : tna + (x ? c1x : c1z);
+        c = (have && one < kInf) ? one : kInf;
+    }
+    bool probing = false;               // TIE: the trip after a tie
+    float c_keep = 0.0f, tnow_keep = 0.0f;
+    if (TIE) *tie_out = -1.0f;
     for (;;) {
         if (!first) {
             const float nk = key[0];
-            if (!(nk < kInf && c > nk)) break;
+            if (!(nk < kInf && c > nk)) {
+                if (!(TIE && nk < kInf && c == nk)) break;
+                probing = true; c_keep = c; tnow_keep = tnow;     // an exact tie: one more trip with the tied neighbour alive
+            }
             alive |= 1u << idx[0];
             tnow = nk;
             key[0] = key[1]; key[1] = key[2]; key[2] = key[3]; key[3] = kInf;
@@ -437,9 +469,14 @@ DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* ta
             best = (trav < best) ? trav : best;
         }
         c = best;
+        if (TIE && probing) { *tie_out = fabsf(c - c_keep); c = c_keep; tnow = tnow_keep; break; }
     }
     *tau_out = (c > tnow) ? c : tnow;
     return c;
+}
+DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* tau_out)
+{
+    return solve_node_t<false>(h, slown, g, tau_out, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -497,6 +497,11 @@ extern "C" long hc_solve_node_compare(unsigned long long seed, long n, long* sta
         }
         float ka, kb;
         const float a = solve_node(h, slown, g, &ka), b = solve_node_walk_ref(h, slown, g, &kb);
+        float kc, tie;
+        const float c3 = solve_node_t<true>(h, slown, g, &kc, &tie);     // the detector must not change the result
+        if (std::memcmp(&a, &c3, 4) != 0 || std::memcmp(&ka, &kc, 4) != 0) { if (bad < 5) std::fprintf(stderr, "solve_node_t<true> differs at case %ld\n", i); ++bad; }
+        if (stat && tie >= 0.0f) stat[5] += 1;
+        if (stat && tie > 0.0f) stat[6] += 1;
         if (std::memcmp(&a, &b, 4) != 0 || std::memcmp(&ka, &kb, 4) != 0) {
             if (bad < 5)
                 std::fprintf(stderr, "solve_node differs at case %ld: T %.9g vs %.9g, tau %.9g vs %.9g\n", i, (double)a, (double)b, (double)ka, (double)kb);

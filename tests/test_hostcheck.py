@@ -44,10 +44,11 @@ def bits(a):
 def test_solve_node_equals_the_step_by_step_form(H):
     """the product's solve_node (one evaluation body in a loop, operand-selected quadratic) == round 1's walk around the literal
     fouds2, bit for bit, on 2e7 random neighbourhoods"""
-    stat = np.zeros(5, np.int64)
+    stat = np.zeros(8, np.int64)
     bad = H.hc_solve_node_compare(20261002, 20_000_000, L.ptr(stat))
     assert bad == 0
     assert stat[1] > 1e5 and stat[2] > 1e6 and stat[3] > 1e5, stat      # the walk really takes one, two, three and more neighbours
+    assert stat[5] > 100 and stat[6] > 20, stat                        # the tie detector (same (T, tau) with it) met ties, some with influence
 
 
 def test_stencil_bitwise_against_oracle(H):

@@ -13,6 +13,8 @@
 //   9  like 6, a node is ready when its SECOND earliest neighbour is inside the window, or its earliest one lies param per cent of a window back
 //   10 four colours (ix & 1, iz & 1) in the order given by param's decimal digits, each leaving the active set right before its sub-pass
 //   11 like 6 with a window steered towards `param` ready nodes per round (proportional control, 0.25 .. 4 x the given window)
+//   12 key slots (no lower bounds at all): a node is due when the time slot (width window / param%100 ... see code) of the smallest acceptance
+//      time among the neighbours that activated it since its last evaluation lies inside the window; odd rule as in 6
 //   5  lazy: a node waits for the acceptance time of the neighbour that activated it to enter the window (key routing), parity sub-passes
 // build: g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -msse2 -mfpmath=sse -o tests/tools/libsched_lab.so tests/tools/sched_lab.cpp
 #include <algorithm>
@@ -61,8 +63,10 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     std::vector<float> curkey, nextkey;
     std::vector<unsigned char> queued(n, 0);
     std::vector<float> key(n, kInf);
+    float slot_w = 0.0f; long slotB = 0; int ring = 1 << 30, Wslots = 2;
     auto act = [&](int iz0, int ix0, float k) {
         if (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) return;
+        if (slot_w > 0.0f) { long a = (long)floorf(k / slot_w); if (a < slotB) a = slotB; if (a > slotB + ring - 1) a = slotB + ring - 1; k = (float)a; }   // the key becomes a slot number
         const int id = rec_index(nbz, iz0, ix0);
         if (t_pinned(F[id].T)) return;
         if (queued[id]) { if (k < key[id]) key[id] = k; return; }
@@ -96,7 +100,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             if (zx < 0 || zx >= nnx || zz < 0 || zz >= nnz) continue;
             if (!(tau_value(y.tau) < kInf)) continue;
             const Rec zr = F[rec_index(nbz, zz, zx)];
-            if (t_value(y.T) > t_lo && k_lo < tau_value(zr.tau)) act(zz, zx, tau_value(y.tau));
+            if (t_value(y.T) > t_lo && k_lo < tau_value(zr.tau)) act(zz, zx, (mode == 12 && param / 10000) ? k : tau_value(y.tau));
         }
         tmin = fminf(tmin, k);
     };
@@ -111,6 +115,8 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
         }
         for (size_t k = 0; k < sub.size(); ++k) apply(sub[k], nT[k], nK[k]);
     };
+    if (mode == 12) { Wslots = param % 100 ? param % 100 : 2; ring = (param / 100) % 100 ? (param / 100) % 100 : 4; slot_w = window / (float)Wslots;
+        for (int id : cur) key[id] = 0.0f; }
     while (!cur.empty()) {
         tmin = kInf; ready.clear();
         sum_listed += (long)cur.size();
@@ -119,6 +125,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
             float lb = fminf(fminf(tv(iz0, ix0 - 1), tv(iz0, ix0 + 1)), fminf(tv(iz0 - 1, ix0), tv(iz0 + 1, ix0)));
             if (mode == 5) lb = fmaxf(lb, fminf(key[id], kInf));            // lazy: route by the activator's acceptance time
+            if (mode == 12) lb = key[id] * slot_w;                         // slot lower edge
             float lb2 = lb;
             if (mode == 9) {
                 float a[4] = { tv(iz0, ix0 - 1), tv(iz0, ix0 + 1), tv(iz0 - 1, ix0), tv(iz0 + 1, ix0) };
@@ -130,6 +137,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             float th = theta;
             if (mode == 7 && par == 0 && theta < kInf) th = theta - window * (1.0f - 0.01f * (float)param);
             bool rdy = !(theta < kInf) || lb < th;
+            if (mode == 12) rdy = !(theta < kInf) || (long)key[id] < slotB + Wslots;
             if (mode == 9 && theta < kInf) rdy = lb2 < theta || lb < theta - window * 0.01f * (float)param;
             if (rdy) {
                 ready.push_back(R{ id, lb });
@@ -186,6 +194,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             wnow = wnow * fminf(fmaxf(ratio, 0.7f), 1.4f);
             wnow = fminf(fmaxf(wnow, 0.25f * window), 4.0f * window);
         }
+        if (mode == 12) slotB = (long)floorf(tmin / slot_w);
         cur.swap(next); next.clear(); theta = tmin + wnow; ++rounds;
         if (rounds >= max_rounds) break;
     }
