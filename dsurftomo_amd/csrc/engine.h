@@ -67,6 +67,18 @@ struct Engine {
     int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)
     int fim_lds_pad = 0;               // dynamic LDS bytes per workgroup of the solve kernel (occupancy limiter)
     int fim_sorted = 1;                // 1: k_fim_sorted (tile masks, record-order sweep), 0: k_fim (lists); same fixed point
+    // exact mode (exact_kernel.hip): 0 off; 1 = units whose fixed-point solve met an exact time tie (or froze a cycle) are solved
+    // again by the literal Fast Marching; 2 = every unit by the literal Fast Marching only
+    int exact_ties = 0;
+    float tie_threshold = 0.0f;        // a tie counts when taking the tied neighbour in moves the node's value by more than this (s)
+    int exact_lds_slots = 2048;        // tree slots kept in LDS per marching unit (8 bytes each)
+    int exact_pool = 0;                // units marching at a time (0 = by free memory, at most 4096)
+    DevBuf<unsigned long long> X_pool, X_heap;   // per marching unit: (T, status) records of the whole grid; tree slots beyond the LDS part
+    DevBuf<int> x_units;
+    DevBuf<int32_t> xinfo, tieinfo;
+    std::vector<unsigned char> h_unit_flags;     // per planned unit after a solve: bit 0 tie met, bit 1 solved by the exact mode
+    std::vector<float> h_unit_tie;               // largest tie influence of the unit (s)
+    int run_exact(int first, int n, const std::vector<int>& local_units);
     DevBuf<int8_t> S_r, cinit;
     DevBuf<int16_t> rst, cst;
     DevBuf<int32_t> heap, flags, info;

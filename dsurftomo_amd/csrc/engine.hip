@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -87,6 +88,7 @@ Engine::~Engine()
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
+    rel(X_pool); rel(X_heap); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -350,7 +352,10 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, C * nrec_c) || ensure(exc_c, C << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
-        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8)) return status;
+        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8) ||
+        ensure(tieinfo, C * 4) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
+    h_unit_flags.assign((size_t)nunits, 0);
+    h_unit_tie.assign((size_t)nunits, 0.0f);
     HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
     if (!h_trace.empty()) HIP_TRY(this, hipMemcpyAsync(trace_ids.p, h_trace.data(), h_trace.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -424,17 +429,48 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             for (int r = 0; r < n; ++r) h_launch_rank[(size_t)far[r].second] = r;
             HIP_TRY(this, hipMemcpyAsync(launch_rank.p, h_launch_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
         }
-        launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p, stream);
+        const bool detect = exact_ties == 1;
+        launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
+                             detect ? tieinfo.p : nullptr, tie_threshold, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
-        launch_refined_startup(g, b, n, stream);
+        FimLaunch sr = shape_r, sc = shape_c;
+        sr.tie = sc.tie = detect ? 1 : 0;
+        if (exact_ties != 2) launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));
-        launch_fim(prob_r.p, n, shape_r, stream);
+        if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
-        launch_handoff(g, b, n, stream);
-        launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
+        if (exact_ties != 2) {
+            launch_handoff(g, b, n, stream);
+            launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
+        }
         HIP_TRY(this, hipEventRecord(events[4], stream));
-        launch_fim(prob_c.p, n, shape_c, stream);
+        if (exact_ties != 2) launch_fim(prob_c.p, n, sc, stream);
         HIP_TRY(this, hipEventRecord(events[5], stream));
+        if (exact_ties) {
+            // which units go through the literal march: all (2), or those whose fixed point met a tie / froze a cycle (1)
+            std::vector<int> xl;
+            if (exact_ties == 2) { xl.resize((size_t)n); for (int u = 0; u < n; ++u) xl[(size_t)u] = u; }
+            else {
+                std::vector<int32_t> h_tie((size_t)n * 4), h_inf((size_t)n * 16);
+                HIP_TRY(this, hipMemcpyAsync(h_tie.data(), tieinfo.p, (size_t)n * 16, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(this, hipMemcpyAsync(h_inf.data(), info.p, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(this, hipStreamSynchronize(stream));
+                for (int u = 0; u < n; ++u) {
+                    const int32_t* t = &h_tie[(size_t)u * 4];
+                    float a, c2;
+                    std::memcpy(&a, t + 1, 4); std::memcpy(&c2, t + 3, 4);
+                    h_unit_tie[(size_t)(first + u)] = std::max(a, c2);
+                    const bool frozen = h_inf[(size_t)u * 16 + 3] + h_inf[(size_t)u * 16 + 11] > 0;
+                    if (t[0] > 0 || t[2] > 0 || frozen) { h_unit_flags[(size_t)(first + u)] |= 1; xl.push_back(u); }
+                }
+                stats[DSA_STAT_TIE_UNITS] += (double)xl.size();
+            }
+            if (!xl.empty()) {
+                const auto w0 = std::chrono::steady_clock::now();
+                if (run_exact(first, n, xl) != 0) return status;
+                stats[DSA_STAT_MS_EXACT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+            }
+        }
         // receivers of this chunk
         const int r0 = h_src[first].first_ray;
         const int r1 = h_src[first + n - 1].first_ray + h_src[first + n - 1].nrec;
@@ -509,6 +545,44 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     return 0;
 }
 
+// literal Fast Marching (exact_kernel.hip) for the chunk-local units `xl` of the resident chunk [first, first + n), in batches of
+// as many units as the pool holds
+int Engine::run_exact(int first, int n, const std::vector<int>& xl)
+{
+    (void)n;
+    const int lcap = std::max(64, exact_lds_slots);
+    const int gcap = 16 * (g.nnx + g.nnz) + 4096;
+    const size_t per = nrec_c * 8 + (size_t)gcap * 8;
+    size_t pool = (size_t)exact_pool;
+    if (!pool) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+        const size_t have = X_pool.cap * 8 + X_heap.cap * 8;
+        pool = std::min<size_t>(4096, std::max<size_t>(1, (size_t)(0.5 * (double)(free_b + have)) / per));
+    }
+    pool = std::min(pool, xl.size());
+    if (ensure(X_pool, pool * nrec_c) || ensure(X_heap, pool * (size_t)gcap)) return status;
+    if (exact_lds_bytes(lcap) > 64 * 1024) { fail(DSA_ERR_ARGUMENT, "exact_lds_slots %d needs more than 64 KB of LDS", lcap); return DSA_ERR_ARGUMENT; }
+    HIP_TRY(this, hipMemcpyAsync(x_units.p, xl.data(), xl.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipMemsetAsync(xinfo.p, 0, (size_t)n * 16, stream));
+    for (size_t k = 0; k < xl.size(); k += pool) {
+        const int m = (int)std::min(pool, xl.size() - k);
+        launch_exact(g, batch(), x_units.p + k, m, slow.p, nrec_c, risti_c.p, X_pool.p, nrec_c, X_heap.p, gcap, lcap, xinfo.p, stream);
+    }
+    HIP_TRY(this, hipGetLastError());
+    std::vector<int32_t> h_x((size_t)n * 4);
+    HIP_TRY(this, hipMemcpyAsync(h_x.data(), xinfo.p, (size_t)n * 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    for (int u : xl) {
+        const int32_t* x = &h_x[(size_t)u * 4];
+        if (x[2]) { fail(DSA_ERR_INTERNAL, "unit %d: exact march guard %d (1 tree capacity %d, 2 step log)", first + u, x[2], lcap + gcap); return DSA_ERR_INTERNAL; }
+        stats[DSA_STAT_EXACT_POPS] += (double)x[0] + (double)x[1];
+        h_unit_flags[(size_t)(first + u)] |= 2;
+    }
+    stats[DSA_STAT_EXACT_UNITS] += (double)xl.size();
+    return 0;
+}
+
 FimLaunch Engine::launch_shape(int nnx, int nnz) const
 {
     // the active band is a few node layers along the front's perimeter (peak ~13 k nodes at 1025^2)
@@ -526,6 +600,7 @@ FimLaunch Engine::launch_shape(int nnx, int nnz) const
     l.tile_words = (ntile + 31) / 32;
     l.sorted = (fim_sorted && l.tile_words * 4 <= 36 * 1024) ? 1 : 0;
     l.compact = 0;
+    l.tie = 0;
     return l;
 }
 
@@ -763,6 +838,10 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "exc_log2cap" && (value == 0 || (value >= 6 && value <= 24))) { en->planned = false; en->exc_log2cap_opt = (int)value; return 0; }
     if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
+    if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
+    if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
+    if (n == "exact_lds_slots" && value >= 64 && value <= 8000) { en->exact_lds_slots = (int)value; return 0; }
+    if (n == "exact_pool" && value >= 0) { en->exact_pool = (int)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;
@@ -915,6 +994,15 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out)
     if (which < 2) return en->fetch_compact((int)slot, which, out);
     const dsa::SourceDesc& s = en->h_src[unit];
     return en->fetch_tiled(en->F_r.p + slot * dsa::kRefRecs, s.rnx, s.rnz, which - 2, out);
+}
+
+int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    const Engine* en = reinterpret_cast<const Engine*>(e);
+    if (nunits < 0 || (size_t)nunits > en->h_unit_flags.size()) return DSA_ERR_ARGUMENT;
+    for (int u = 0; u < nunits; ++u) { if (flags) flags[u] = en->h_unit_flags[(size_t)u]; if (influence) influence[u] = en->h_unit_tie[(size_t)u]; }
+    return 0;
 }
 
 int dsa_get_stats(const dsa_engine* e, double* out)

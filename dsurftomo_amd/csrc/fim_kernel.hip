@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 // window and the cycle freeze are those of k_fim; results are bit-identical (same fixed point).
 typedef __attribute__((address_space(1))) unsigned long long GU64;
 
-template <int NT, bool COMPACT>
+template <int NT, bool COMPACT, bool TIE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVES, DSA_FIM_WAVES))) void k_fim_sorted(const FimProblem* __restrict__ problems, int cap, int rcap)
 {
     extern __shared__ unsigned dyn_lds[];
@@ -513,6 +513,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #endif
     float best_tmin = -kInf;
     unsigned evals = 0, nchanged = 0;                        // per lane (a lane evaluates < 2^32 nodes)
+    unsigned tie_n = 0;                                      // TIE: evaluations that ended on an exact tie with influence, and the largest influence
+    float tie_max = 0.0f;
 #ifdef DSA_PASSA_CLOCKS
     unsigned long long sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tsub = wall_clock64();
 #define DSA_TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = wall_clock64(); sub[k] += t1_ - tsub; tsub = t1_; } while (0)
@@ -815,7 +817,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 float c = 0.0f, k = kInf;
                 if (!t_pinned(t_old)) {
                     const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
-                    c = solve_node(h, slow_at(id), geom, &k);
+                    if (TIE) {
+                        float tie;
+                        c = solve_node_t<true>(h, slow_at(id), geom, &k, &tie);
+                        if (tie > p.tie_threshold) { ++tie_n; tie_max = fmaxf(tie_max, tie); }
+                    } else c = solve_node(h, slow_at(id), geom, &k);
 #ifdef DSA_PROBE_EXTRA_READ
                     if (COMPACT) {   // bandwidth probe: one more cold line per evaluated node group (the slowness half a grid away); result unused
                         const float extra = slow_at(id < 524288 ? id + 524288 : id - 524288);
@@ -923,6 +929,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         for (int o = 32; o > 0; o >>= 1) { e64 += __shfl_xor(e64, o); c64 += __shfl_xor(c64, o); }
         if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), e64); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), c64); }
     }
+    if (TIE && p.tie) {
+        const unsigned tn = wave_sum(tie_n);
+        const float tm = -wave_min(-tie_max);
+        if (lane == 0 && tn) { atomicAdd((unsigned*)p.tie, tn); atomicMax((unsigned*)p.tie + 1, f2u(tm)); }
+    }
 #ifdef DSA_BARRIER_CLOCKS
     if (p.clocks && lane == 0) {
         for (int q = 0; q < 4; ++q) atomicAdd(p.clocks + q, bwait[q]);
@@ -948,7 +959,8 @@ void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l,
     if (nproblems <= 0) return;
     if (l.sorted) {
         const size_t lds = fim_lds_bytes(l);
-#define DSA_LAUNCH_SORTED(NT, C) hipLaunchKernelGGL((k_fim_sorted<NT, C>), dim3(nproblems), dim3(NT), lds, stream, d_problems, l.list_cap, l.ready_cap)
+#define DSA_LAUNCH_SORTED_T(NT, C, T) hipLaunchKernelGGL((k_fim_sorted<NT, C, T>), dim3(nproblems), dim3(NT), lds, stream, d_problems, l.list_cap, l.ready_cap)
+#define DSA_LAUNCH_SORTED(NT, C) do { if (l.tie) DSA_LAUNCH_SORTED_T(NT, C, true); else DSA_LAUNCH_SORTED_T(NT, C, false); } while (0)
         if (l.compact) {
             if (l.threads == 128) DSA_LAUNCH_SORTED(128, true); else if (l.threads == 256) DSA_LAUNCH_SORTED(256, true);
             else if (l.threads == 512) DSA_LAUNCH_SORTED(512, true); else DSA_LAUNCH_SORTED(1024, true);
@@ -957,6 +969,7 @@ void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l,
             else if (l.threads == 512) DSA_LAUNCH_SORTED(512, false); else DSA_LAUNCH_SORTED(1024, false);
         }
 #undef DSA_LAUNCH_SORTED
+#undef DSA_LAUNCH_SORTED_T
         return;
     }
     const size_t pad = (size_t)l.lds_pad;

@@ -29,6 +29,8 @@ struct FimProblem {
     int max_rounds;
     unsigned long long* clocks;   // optional, 8 u64: phase clocks of thread 0 (wall_clock64 ticks) + list sizes
     int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [3] stall freezes, [4..5] evaluations (u64)
+    int32_t* tie;          // tie detector (kernels launched with FimLaunch::tie): [0] evaluations that ended on an exact tie whose influence exceeds tie_threshold, [1] largest influence (float bits)
+    float tie_threshold;
 };
 
 #ifndef DSA_ODD_CLEAR
@@ -44,6 +46,7 @@ struct FimLaunch {
     int compact;           // 1: coarse problems on the compact field (k_fim_sorted only)
     int tile_words;        // words of the LDS tile bitmap (sorted variant)
     int lds_pad;           // extra dynamic LDS per workgroup (bytes): limits the workgroups resident per CU
+    int tie;               // 1: the variant with the tie detector (k_fim_sorted only; eikonal_core.h solve_node_t<true>)
 };
 
 size_t fim_lds_bytes(const FimLaunch& l);
@@ -89,7 +92,15 @@ void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
-                          const int* d_launch_rank, hipStream_t stream);
+                          const int* d_launch_rank, int32_t* d_tie, float tie_threshold, hipStream_t stream);
+
+// exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), one wavefront each,
+// workgroup j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per slot beyond the lcap in LDS);
+// xinfo[4 u ..]: accepts of the refined / coarse stage, error code (1 tree capacity, 2 log capacity)
+size_t exact_lds_bytes(int lcap);
+void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
+                  const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, int32_t* d_xinfo,
+                  hipStream_t stream);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
 // data = 0-based index of the datum (travel time / Frechet row) this ray belongs to;

@@ -338,7 +338,8 @@ void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const 
 // ---------------------------------------------------------------------------------------------
 __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* slow_all, size_t field_stride,
                                 const float* risti_c, float window_r, float window_c, FimProblem* prob_r,
-                                FimProblem* prob_c, int32_t* info, unsigned long long* clocks, const int* __restrict__ launch_rank)
+                                FimProblem* prob_c, int32_t* info, unsigned long long* clocks, const int* __restrict__ launch_rank,
+                                int32_t* tie, float tie_threshold)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -352,6 +353,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     r.max_rounds = 64 * (sd.rnx + sd.rnz) + 4096;
     r.clocks = nullptr;
     r.info = info + (size_t)s * 16;
+    r.tie = tie ? tie + (size_t)s * 4 : nullptr; r.tie_threshold = tie_threshold;
     prob_r[s] = r;
     FimProblem c;
     c.F = nullptr;
@@ -363,19 +365,21 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.max_rounds = 64 * (g.nnx + g.nnz) + 4096;
     c.clocks = clocks ? clocks + (size_t)s * 8 : nullptr;
     c.info = info + (size_t)s * 16 + 8;
+    c.tie = tie ? tie + (size_t)s * 4 + 2 : nullptr; c.tie_threshold = tie_threshold;
     prob_c[launch_rank ? launch_rank[s] : s] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
     for (int q = 0; q < 16; ++q) info[(size_t)s * 16 + q] = 0;
+    if (tie) for (int q = 0; q < 4; ++q) tie[(size_t)s * 4 + q] = 0;
     if (clocks) for (int q = 0; q < 8; ++q) clocks[(size_t)s * 8 + q] = 0ull;      // probe builds accumulate into them
 }
 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
-                          const int* d_launch_rank, hipStream_t stream)
+                          const int* d_launch_rank, int32_t* d_tie, float tie_threshold, hipStream_t stream)
 {
     if (nsrc <= 0) return;
     hipLaunchKernelGGL(k_make_problems, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all,
-                       field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks, d_launch_rank);
+                       field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks, d_launch_rank, d_tie, tie_threshold);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DSA_LIB_PATH") or os.path.join(_HERE, "libdsurftomo_a
 
 STAT_NAMES = ("ms_total", "ms_fim_coarse", "ms_fim_refined", "ms_stages", "launches_fim_coarse", "units",
               "rounds_max", "evals_total", "chunk", "rescans", "freezes", "rays", "ray_steps", "rays_clamped",
-              "ms_rays", "ms_rows", "nar", "ms_dispersion", "curves", "changes_total")
+              "ms_rays", "ms_rows", "nar", "ms_dispersion", "curves", "changes_total", "tie_units", "exact_units", "exact_pops", "ms_exact")
 
 _f32, _i32, _vp = C.c_float, C.c_int, C.c_void_p
 _lib = None
@@ -59,6 +59,7 @@ def load_library():
     L.dsa_get_velocity.argtypes = [_vp, _i32, _vp]
     L.dsa_get_refined.argtypes = [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]
     L.dsa_get_stats.argtypes = [_vp, _vp]
+    L.dsa_unit_ties.argtypes = [_vp, _i32, _vp, _vp]
     L.dsa_ray_paths.argtypes = [_vp, _vp, _vp, _vp]
     L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]
     L.dsa_spmv.argtypes = [_vp, _i32, _vp, _vp]
@@ -125,6 +126,7 @@ class Engine:
         if not (scx.size == n and scz.size == n and nrec.size == n):
             raise ValueError("per-unit arrays differ in length")
         self._nrays = int(nrec.sum())
+        self._nrec_of_plan = nrec
         if rcx.size != self._nrays or rcz.size != self._nrays:
             raise ValueError("receiver arrays must hold sum(nrec) entries")
         opt = [None if a is None else np.ascontiguousarray(a, np.int32) for a in (mode, sen_slot, data_first)]
@@ -258,8 +260,15 @@ class Engine:
         self._check(self._L.dsa_debug_field(self._h, int(unit), int(which), _p(out)))
         return out
 
+    def unit_ties(self):
+        """per unit of the last solve: flags (bit 0 met an exact tie, bit 1 solved by the literal march) and the largest tie influence (s)"""
+        n = len(self._nrec_of_plan)
+        fl = np.zeros(n, np.int32); inf = np.zeros(n, np.float32)
+        self._check(self._L.dsa_unit_ties(self._h, n, _p(fl), _p(inf)))
+        return fl, inf
+
     def stats(self):
-        out = np.zeros(32, np.float64)
+        out = np.zeros(40, np.float64)
         self._check(self._L.dsa_get_stats(self._h, _p(out)))
         d = dict(zip(STAT_NAMES, out[:len(STAT_NAMES)].tolist()))
         d["phase_ticks"] = out[len(STAT_NAMES):len(STAT_NAMES) + 8].tolist()

@@ -177,12 +177,24 @@ int dsa_get_refined(dsa_engine* e, int unit, int* rnx, int* rnz, float* ttnr, in
  * tau (sign bit = queued), 2 refined T, 3 refined tau (rnx*rnz floats, leading dimension rnz) */
 int dsa_debug_field(dsa_engine* e, int unit, int which, float* out);
 
+/* Exact time ties: the fixed-point solve lands on the reference's Fast-Marching travel times except downstream of
+ * bit-equal times of two neighbouring narrow-band nodes, where the reference's own answer depends on the layout of its binary
+ * tree (CalSurfG.f90:417-485, :768-921).  Option "exact_ties": 0 (default) fixed point only; 1 = the solve kernel detects such
+ * ties (option "tie_threshold", seconds: the influence on the node's value a tie must have to count; default 0 = any) and the
+ * units that met one are solved again by the reference's march itself, replayed on the device one wavefront per unit -- their
+ * fields are then bit-identical to the reference's; 2 = every unit by the literal march.  Options "exact_lds_slots" (tree slots
+ * in LDS per marching unit, default 2048) and "exact_pool" (units marching at a time, 0 = by free memory).
+ * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: met a tie, bit 1: solved by the literal march) and the largest
+ * tie influence in seconds (either array may be NULL). */
+int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence);
+
 /* counters of the last dsa_solve: see DSA_STAT_* */
 enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, DSA_STAT_MS_STAGES,
        DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_EVALS_TOTAL,
        DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_FREEZES, DSA_STAT_RAYS, DSA_STAT_RAY_STEPS,
        DSA_STAT_RAYS_CLAMPED, DSA_STAT_MS_RAYS, DSA_STAT_MS_ROWS, DSA_STAT_NAR, DSA_STAT_MS_DISPERSION,
-       DSA_STAT_CURVES, DSA_STAT_CHANGES_TOTAL, DSA_STAT_COUNT };
+       DSA_STAT_CURVES, DSA_STAT_CHANGES_TOTAL, DSA_STAT_TIE_UNITS, DSA_STAT_EXACT_UNITS, DSA_STAT_EXACT_POPS,
+       DSA_STAT_MS_EXACT, DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */

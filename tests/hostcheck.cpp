@@ -12,6 +12,7 @@
 #include "../dsurftomo_amd/csrc/host_geometry.h"
 #include "../dsurftomo_amd/csrc/ray_core.h"
 #include "solve_node_walk_ref.h"
+#include "../dsurftomo_amd/csrc/exact_march.h"
 
 using namespace dsa;
 
@@ -514,4 +515,93 @@ extern "C" long hc_solve_node_compare(unsigned long long seed, long n, long* sta
         }
     }
     return bad;
+}
+
+
+// Exact mode (csrc/exact_march.h) on the CPU: the same march functions the device kernel k_exact runs, sequenced like the kernel
+// (refined stage, snapshot, hand-off, coarse stage); `lcap` tree slots in the "LDS" part, the rest in the "global" part, so that
+// the split is exercised.  Outputs row-major like hc_solve_source; returns 0, or the march's error code.
+extern "C" int hc_exact_solve(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const double* pv, float x, float z,
+                              int lcap, int gcap, float* T, float* Tr, int* Sr, int* box, long* stat)
+{
+    GridDesc g; SourceDesc s;
+    make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
+    if (make_source(g, x, z, s) != 0) return -1;
+    std::vector<float> velv((size_t)nx * ny), cbasis(4 * (gd + 1)), rbasis(4 * (gd * kSgdl + 1)), vcorner(4);
+    for (int k = 0; k < nx * ny; ++k) velv[k] = (float)pv[k];
+    basis_table(gd, cbasis.data());
+    basis_table(gd * kSgdl, rbasis.data());
+    const size_t nrc = (size_t)g.nbx * g.nbz * kTileRecs;
+    std::vector<float> slow_c(nrc, 1.0f), slow_r(kRefRecs, 1.0f), risti_c(g.nnx), risti_r(kRefMax);
+    for (int ix = 1; ix <= g.nnx; ++ix)
+        for (int iz = 1; iz <= g.nnz; ++iz) slow_c[rec_index(g.nbz, iz - 1, ix - 1)] = 1.0f / coarse_velocity(g, velv.data(), cbasis.data(), iz, ix);
+    risti_table(g.gox, g.dnx, g.earth, g.nnx, risti_c.data());
+    risti_table(s.rgox, s.rdnx, g.earth, s.rnx, risti_r.data());
+    for (int lx = 1; lx <= s.rnx; ++lx)
+        for (int kz = 1; kz <= s.rnz; ++kz) {
+            const float v = refined_velocity(g, s, velv.data(), rbasis.data(), kz, lx);
+            slow_r[rec_index(s.nbz_r, kz - 1, lx - 1)] = 1.0f / v;
+            if ((lx == s.isx_r || lx == s.isx_r + 1) && (kz == s.isz_r || kz == s.isz_r + 1)) vcorner[(lx - s.isx_r) * 2 + (kz - s.isz_r)] = v;
+        }
+    std::vector<XEntry> hl((size_t)lcap + 1), hg((size_t)gcap + 1);
+    std::vector<int> log(2 * kXLogCap);
+    XMarch m;
+    m.hl = hl.data(); m.lcap = lcap; m.hg = hg.data(); m.gcap = gcap; m.log = log.data();
+    m.ntr = 0; m.error = 0; m.nlog = 0; m.pops = 0u; m.ri = g.earth;
+    std::vector<XRec> Fr(kRefRecs, XRec{ 0.0f, -1 });
+    m.F = Fr.data(); m.slow = slow_r.data(); m.risti = risti_r.data();
+    m.nbz = s.nbz_r; m.nnx = s.rnx; m.nnz = s.rnz; m.dnx = s.rdnx; m.dnz = s.rdnz;
+    x_refined_start(m, s, vcorner.data());
+    x_march<true>(m, s);
+    if (m.error) return m.error;
+    if (stat) stat[0] = (long)m.pops;
+    box[0] = s.vnl; box[1] = s.vnr; box[2] = s.vnt; box[3] = s.vnb; box[4] = s.rnx; box[5] = s.rnz;
+    for (int ix = 0; ix < s.rnx; ++ix)
+        for (int iz = 0; iz < s.rnz; ++iz) {
+            const XRec r = Fr[rec_index(s.nbz_r, iz, ix)];
+            Sr[(size_t)ix * s.rnz + iz] = r.st < 0 ? -1 : r.st == 0 ? 0 : 1;
+            Tr[(size_t)ix * s.rnz + iz] = r.st >= 0 ? r.T : kInf;
+        }
+    const int bxn = (s.rnx - 1) / kSgdl + 1, bzn = (s.rnz - 1) / kSgdl + 1;
+    std::vector<int> st(bxn * bzn), pr(bxn * bzn, 0);
+    std::vector<float> sT(bxn * bzn);
+    for (int q = 0; q < bxn * bzn; ++q) {
+        const XRec r = Fr[rec_index(s.nbz_r, (q % bzn) * kSgdl, (q / bzn) * kSgdl)];
+        st[q] = r.st < 0 ? -1 : r.st == 0 ? 0 : 1; sT[q] = r.T;
+    }
+    for (int q = 0; q < bxn * bzn; ++q) {
+        if (st[q] != 0) continue;
+        const int bx = q / bzn, bz = q % bzn, cx = s.vnl + bx, cz = s.vnt + bz;
+        const int dx[4] = { -1, 1, 0, 0 }, dz[4] = { 0, 0, -1, 1 };
+        for (int d = 0; d < 4; ++d) {
+            const int nx2 = cx + dx[d], nz2 = cz + dz[d];
+            if (nx2 < 1 || nx2 > g.nnx || nz2 < 1 || nz2 > g.nnz) continue;
+            const int ox = bx + dx[d], oz = bz + dz[d];
+            const bool inbox = ox >= 0 && ox < bxn && oz >= 0 && oz < bzn;
+            if (!inbox || st[ox * bzn + oz] == -1) pr[q] = 1;
+        }
+    }
+    for (int q = 0; q < bxn * bzn; ++q) if (pr[q]) st[q] = 1;
+    std::vector<XRec> Fc(nrc, XRec{ 0.0f, -1 });
+    m.F = Fc.data(); m.slow = slow_c.data(); m.risti = risti_c.data();
+    m.nbz = g.nbz; m.nnx = g.nnx; m.nnz = g.nnz; m.dnx = g.dnx; m.dnz = g.dnz;
+    m.ntr = 0; m.nlog = 0; m.pops = 0u;
+    for (int q = 0; q < bxn * bzn; ++q)
+        if (st[q] == 0) Fc[rec_index(g.nbz, s.vnt + q % bzn - 1, s.vnl + q / bzn - 1)] = XRec{ sT[q], 0 };
+    for (int q = 0; q < bxn * bzn; ++q) {
+        if (st[q] <= 0) continue;
+        const int node = ((s.vnt + q % bzn) << 16) | (s.vnl + q / bzn);
+        Fc[x_id(m, node)].T = sT[q];
+        x_add(m, node, sT[q]);
+    }
+    int maxtree = m.ntr;
+    while (m.ntr > 0 && m.error == 0) { x_accept_root(m, xh_get(m, 1)); if (m.ntr > maxtree) maxtree = m.ntr; }
+    if (m.error) return m.error;
+    if (stat) { stat[1] = (long)m.pops; stat[2] = maxtree; }
+    for (int ix = 0; ix < g.nnx; ++ix)
+        for (int iz = 0; iz < g.nnz; ++iz) {
+            const XRec r = Fc[rec_index(g.nbz, iz, ix)];
+            T[(size_t)ix * g.nnz + iz] = r.st == 0 ? r.T : kInf;
+        }
+    return 0;
 }

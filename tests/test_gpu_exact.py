@@ -1,0 +1,128 @@
+"""Exact mode (engine option exact_ties; csrc/exact_kernel.hip): the reference's Fast Marching replayed on the device.
+
+* exact_ties = 2 (every unit by the literal march): coarse field, refined snapshot, statuses and receiver times are the
+  oracle's bit for bit -- on the media whose exact time ties keep the fixed-point solve off the 1e-4 s bar too
+  (tests/test_gpu_parity.py: TIE_CASES, tests/test_gpu_fullsize.py: FULL).
+* exact_ties = 1 (tie detector + literal march for the flagged units): flagged units are bit-identical; what the detector
+  lets through is reported, and asserted to be within 1e-4 s.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import _libs as L
+import parity_log
+import synth
+from test_gpu_parity import FRAC, positions
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture()
+def exact(engine):
+    yield engine
+    engine.set_option("exact_ties", 0)
+    engine.set_option("tie_threshold", 0)
+    engine.set_option("exact_lds_slots", 2048)
+
+
+@pytest.mark.parametrize("nx,kind,gd,lds", [(18, "homog", 8, 2048), (35, "checker4", 8, 64), (35, "smooth", 5, 2048), (35, "rough", 8, 300), (35, "homog", 8, 2048)])
+def test_literal_march_is_the_oracle_bit_for_bit(exact, nx, kind, gd, lds):
+    e = exact
+    srcs = positions(nx, gd, FRAC)
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+    pv = synth.medium(nx, kind)
+    veln = L.o_gridder(g, pv)
+    e.set_option("exact_ties", 2)
+    e.set_option("exact_lds_slots", lds)          # small values push part of the tree into global memory
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv, dicing=gd)
+    n = len(srcs)
+    N = g.nnx
+    rcx = np.array([[srcs[(i + 3) % n][0], np.float32(s[0] + np.float32(0.3) * g.dnx)] for i, s in enumerate(srcs)], np.float32)
+    rcz = np.array([[srcs[(i + 3) % n][1], np.float32(s[1] + np.float32(0.2) * g.dnz)] for i, s in enumerate(srcs)], np.float32)
+    rcx = np.clip(rcx, g.gox, np.float32(g.gox + np.float32(N - 1.01) * g.dnx)).astype(np.float32)
+    rcz = np.clip(rcz, g.goz, np.float32(g.goz + np.float32(N - 1.01) * g.dnz)).astype(np.float32)
+    t = e.traveltimes(np.zeros(n, np.int32), [s[0] for s in srcs], [s[1] for s in srcs], np.full(n, 2, np.int32), rcx.reshape(-1), rcz.reshape(-1))
+    st = e.stats()
+    assert st["exact_units"] == n
+    nbad = 0
+    for u, src in enumerate(srcs):
+        o = L.o_solve(g, pv, veln, src[0], src[1])
+        T = e.field(u)
+        nbad += int((bits(T) != bits(o["T"])).sum())
+        assert (bits(T) != bits(o["T"])).sum() == 0, (nx, kind, u)
+        Tr, Sr = e.refined(u)
+        cls_o = np.sign(o["Sr"]).clip(-1, 1)
+        assert (cls_o != Sr).sum() == 0
+        alive = cls_o == 0
+        assert (bits(Tr[alive]) != bits(o["Tr"][alive])).sum() == 0
+        for k in range(2):
+            ref = L.o_srtimes(g, veln, o["T"], src[0], src[1], rcx[u, k], rcz[u, k])
+            assert np.float32(t[2 * u + k]).view(np.uint32) == np.float32(ref).view(np.uint32)
+    parity_log.add(f"exact mode nx={nx} {kind} gd={gd} (tree slots in LDS {lds}): {n} sources, fields / refined snapshots / receiver times bit-identical to the oracle "
+                   f"({int(st['exact_pops'])} accepts)")
+
+
+@pytest.mark.parametrize("nx,kind,period", [(131, "checker", 0), (131, "rough", 0), (131, "smooth", 3)])
+def test_literal_march_at_headline_size(exact, nx, kind, period):
+    """1025^2: the checkerboard of configs[4] (the named tie case of the fixed-point solve: 4.4e-4 s), a rough and the smooth medium"""
+    e = exact
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    pv = synth.medium(nx, kind, period)
+    veln = L.o_gridder(g, pv)
+    N = g.nnx
+    srcs = [(np.float32(g.gox + np.float32(0.37 * (N - 1) + 0.3) * g.dnx), np.float32(g.goz + np.float32(0.58 * (N - 1) + 0.6) * g.dnz)),
+            (np.float32(g.gox + np.float32(0.08 * (N - 1)) * g.dnx), np.float32(g.goz + np.float32(0.91 * (N - 1) + 0.25) * g.dnz))]
+    u = synth.LCG(nx).uniform(64)
+    rx = (g.gox + (0.5 + u[0::2] * (N - 2)).astype(np.float32) * g.dnx).astype(np.float32)
+    rz = (g.goz + (0.5 + u[1::2] * (N - 2)).astype(np.float32) * g.dnz).astype(np.float32)
+    e.set_option("exact_ties", 2)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    t = e.traveltimes([0, 0], [s[0] for s in srcs], [s[1] for s in srcs], [16, 16], rx, rz).reshape(2, 16)
+    for k, s in enumerate(srcs):
+        o = L.o_solve(g, pv, veln, s[0], s[1])
+        T = e.field(k)
+        assert (bits(T) != bits(o["T"])).sum() == 0
+        ref = np.array([L.o_srtimes(g, veln, o["T"], s[0], s[1], rx[16 * k + r], rz[16 * k + r]) for r in range(16)], np.float32)
+        assert (bits(t[k]) != bits(ref)).sum() == 0
+    parity_log.add(f"exact mode N={N} {kind}: 2 sources, whole field and 32 receiver times bit-identical to the oracle")
+
+
+@pytest.mark.parametrize("kind,nsrc", [("checker", 48), ("rough", 48), ("smooth", 48)])
+def test_tie_detector_and_exact_redo_at_headline_size(exact, kind, nsrc):
+    """exact_ties = 1 at 1025^2: the units the detector flags are marched literally.  Receiver times of ALL units against the
+    oracle: the flagged ones must be bit-identical; the rest (no tie with influence met) must hold the 1e-4 s bar, and how many
+    of them are bit-identical is reported."""
+    e = exact
+    nx, nrec = 131, 32
+    u = synth.units(nx, nsrc, 1, nrec, seed=synth.SEED + 5)
+    pv = synth.medium(nx, kind, 0)[None, :]
+    e.set_option("exact_ties", 1)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    t = e.traveltimes(**u).reshape(nsrc, nrec)
+    st = e.stats()
+    flags, infl = e.unit_ties()
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    veln = L.o_gridder(g, pv[0])
+
+    def one(k):
+        o = L.o_solve(g, pv[0], veln, u["scx"][k], u["scz"][k])
+        return np.array([L.o_srtimes(g, veln, o["T"], u["scx"][k], u["scz"][k], u["rcx"][k * nrec + r], u["rcz"][k * nrec + r]) for r in range(nrec)], np.float32)
+
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        ref = np.stack(list(ex.map(one, range(nsrc))))
+    d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
+    exact_u = (flags & 2) != 0
+    same = (bits(t) == bits(ref)).all(axis=1)
+    parity_log.add(f"exact_ties=1 N=1025 {kind}: {int(exact_u.sum())} of {nsrc} units flagged and marched literally (largest tie influence {infl.max():.3g} s); "
+                   f"flagged units bit-identical {int(same[exact_u].sum())}/{int(exact_u.sum())}; unflagged units bit-identical {int(same[~exact_u].sum())}/{int((~exact_u).sum())}, "
+                   f"their max |dt| {d[~exact_u].max() if (~exact_u).any() else 0.0:.3g} s; all units max |dt| {d.max():.3g} s | exact {st['ms_exact']:.0f} ms, {int(st['exact_pops'])} accepts")
+    assert same[exact_u].all()
+    assert d.max() <= TOL

@@ -21,6 +21,7 @@ def H():
     src = os.path.join(HERE, "hostcheck.cpp")
     hdr = [os.path.join(L.ROOT, "dsurftomo_amd", "csrc", n) for n in ("eikonal_core.h", "source_stage.h", "host_geometry.h")]
     hdr.append(os.path.join(HERE, "solve_node_walk_ref.h"))
+    hdr.append(os.path.join(L.ROOT, "dsurftomo_amd", "csrc", "exact_march.h"))
     if L._stale(SO, [src] + hdr):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-msse2",
                                "-mfpmath=sse", "-shared", "-o", SO, src, "-lm"])
@@ -34,6 +35,7 @@ def H():
     h.hc_device_schedule.restype = C.c_long
     h.hc_solve_node_compare.argtypes = [C.c_ulonglong, C.c_long, L.vp]
     h.hc_solve_node_compare.restype = C.c_long
+    h.hc_exact_solve.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.f32, L.f32, L.i32, L.i32] + [L.vp] * 5
     return h
 
 
@@ -153,3 +155,33 @@ def test_dependency_pruning_is_exact(H):
         C.c_int.in_dll(H, "g_prune").value = 1
         assert (bits(res[0][0]) != bits(res[1][0])).sum() == 0 and (bits(res[0][1]) != bits(res[1][1])).sum() == 0
         assert res[1][2] < 0.6 * res[0][2]
+
+
+@pytest.mark.parametrize("nx,kind,gd,lcap", [(18, "homog", 8, 4096), (18, "smooth", 8, 64), (18, "smooth", 5, 4096), (35, "checker4", 8, 256),
+                                             (35, "rough", 8, 100), (35, "homog", 8, 4096)])
+def test_exact_march_is_the_oracle_bit_for_bit(H, nx, kind, gd, lcap):
+    """the exact mode's march (csrc/exact_march.h, what k_exact runs) against the oracle's Fast Marching: refined snapshot, statuses and
+    the whole coarse field, every bit -- exact ties included (homogeneous and checkerboard media), with the tree split between its
+    two storage parts at different depths"""
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+    pv = synth.medium(nx, kind)
+    veln = L.o_gridder(g, pv)
+    N = g.nnx
+    frac = [(0.43 * N + 0.3, 0.61 * N + 0.6), (1.4, N / 2 + 0.2), (N - 2.5, N - 3.3), (N - 1.0, N - 1.0), (0.0, 0.0), (N * 0.7, N * 0.2),
+            (N - 2.483, 0.58 * N + 0.3), (0.5 * N, 0.5 * N), (37.0, 52.0)]
+    for fx, fz in frac:
+        sx = np.float32(g.gox + np.float32(fx) * g.dnx)
+        sz = np.float32(g.goz + np.float32(fz) * g.dnz)
+        o = L.o_solve(g, pv, veln, sx, sz)
+        T = np.zeros((N, N), np.float32); Tr = np.zeros(129 * 129, np.float32); Sr = np.zeros(129 * 129, np.int32)
+        box = np.zeros(6, np.int32); st = np.zeros(4, np.int64)
+        assert H.hc_exact_solve(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd, L.ptr(pv), sx, sz, lcap, 16 * N + 4096,
+                                L.ptr(T), L.ptr(Tr), L.ptr(Sr), L.ptr(box), L.ptr(st)) == 0
+        n = box[4] * box[5]
+        cls_o = np.sign(o["Sr"]).clip(-1, 1)
+        cls_h = Sr[:n].reshape(box[4], box[5])
+        assert (cls_o != cls_h).sum() == 0
+        alive = cls_o == 0
+        assert (bits(Tr[:n].reshape(box[4], box[5])[alive]) != bits(o["Tr"][alive])).sum() == 0
+        assert (bits(T) != bits(o["T"])).sum() == 0, (fx, fz)
+        assert st[1] >= N * N - 300
