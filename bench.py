@@ -165,9 +165,28 @@ def spawn_ranks(args):
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         procs.append(subprocess.Popen(cmd, env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # poll: when one rank dies (build error, bad device, out of memory) the others would sit in the rendezvous or the
+    # collective until the backend's timeout -- end them and fail at once; an overall limit covers a silent hang
+    rc, t0, limit = 0, time.time(), float(os.environ.get("DSA_BENCH_TIMEOUT", "3600"))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(r))
+        if live and (rc != 0 or time.time() - t0 > limit):
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            sys.exit(rc or 124)
+        if live:
+            time.sleep(0.2)
     sys.exit(rc)
 
 

@@ -17,7 +17,7 @@ template <int IFUNC>
 __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__ G, const float* __restrict__ vels, int ncol,
                                                    int npert, int igr, int kmax, const double* __restrict__ t,
                                                    float* __restrict__ ws, size_t nlanes, double* __restrict__ curves, int layers_in_lds,
-                                                   int gshift)
+                                                   int gshift, unsigned long long* __restrict__ diag)
 {
     // gshift > 0 (few curves): 2^gshift neighbouring lanes share one curve -- see Layers::gsize.  A curve is one
     // dependent chain of ~20 000 layer matrices; with one lane per curve a call with 324 columns keeps a quarter of the
@@ -59,12 +59,17 @@ __global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__
         m.stride = nlanes;
     }
     build_layers<IFUNC>(*G, vs, vp, rho, m);
-    dispersion_curve<IFUNC>(m, igr, kmax, t, curves + (size_t)p * kmax * ncol + c, (size_t)ncol);
+    const int kfail = dispersion_curve<IFUNC>(m, igr, kmax, t, curves + (size_t)p * kmax * ncol + c, (size_t)ncol);
+    // diagnostics of the boundary (surfdisp96.f:308-339): how many curves ended without a root, and the first of them (by curve number)
+    if (kfail && diag && (gshift == 0 || (threadIdx.x & ((1u << gshift) - 1u)) == 0u)) {
+        atomicAdd(diag, 1ull);
+        atomicMin(diag + 1, ((unsigned long long)tid << 16) | (unsigned long long)kfail);
+    }
 }
 
 void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
                        const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, int gshift,
-                       hipStream_t stream)
+                       unsigned long long* d_diag, hipStream_t stream)
 {
     const size_t n = ((size_t)ncol * npert) << gshift;
     if (n == 0) return;
@@ -72,8 +77,8 @@ void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, 
     const int per = 64 >> gshift;
     size_t lds = layers_in_lds ? (size_t)4 * rmax * per * sizeof(float) : 0;
     if (gshift > 0) lds += 8 + (size_t)64 * 15 * sizeof(double);
-    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift);
-    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift);
+    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift, d_diag);
+    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift, d_diag);
 }
 
 // pv(c, k) = curve 0; sen_q(c, slot0 + k, i) = (cg(+) - cg(-)) / dble(dln * base_q(i)), CalSurfG.f90:76-150

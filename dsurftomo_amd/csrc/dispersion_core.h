@@ -486,8 +486,11 @@ DSA_HD void build_layers(const LayerGeom& G, const float* vs, const float* vp, c
 
 // One dispersion curve (surfdisp96.f:52-350 with mode = 1): cg[k] for k < kmax, written with `cstride`.
 // igr = 0 phase velocity, 1 group velocity from two roots at T/(1 +- h).
+// Returns 0, or -- when no zero of the secular function was found for a period (the reference's "improper initial value in disper -
+// no zero found" block on unit 66, surfdisp96.f:308-339, after which it zero-fills the rest of the curve, :342-348) -- the 1-based
+// index k of that period.
 template <int IFUNC>
-DSA_HD void dispersion_curve(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
+DSA_HD int dispersion_curve(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
 {
     const int mmax = m.mmax;
     const float ddc = 0.005f, h = 0.005f;
@@ -548,6 +551,7 @@ DSA_HD void dispersion_curve(const Layers& m, int igr, int kmax, const double* t
     }
     if (failed)
         for (int i = k; i <= kmax; ++i) cg[(size_t)(i - 1) * cstride] = 0.0;   // the reference logs a warning and zero-fills
+    return failed ? k : 0;
 }
 
 }  // namespace dsa

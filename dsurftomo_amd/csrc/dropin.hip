@@ -79,7 +79,14 @@ Layout make_layout(int kRc, int kRg, int kLc, int kLg, int kmax, bool clobber)
     return L;
 }
 
+int g_rbint_notes = 0;                // diagnostics of the last dsa_calsurfg call (dsa_dropin_diagnostics)
+long long g_disp_count = 0;
+int g_disp_first[5] = { 0, 0, 0, 0, 0 };
+double g_disp_period = 0.0;
+
 struct Units {
+    std::vector<int> iter;             // (period slot, source) iteration of the reference's loop nest the unit belongs to, 0-based
+    int niter = 0;
     std::vector<int> map, nrec, mode, slot, data;
     std::vector<float> sx, sz, rx, rz;
     int ndata = 0;
@@ -104,6 +111,7 @@ int make_units(const Layout& L, bool rows, int nsrcsurf, int nrcf, const int* wa
             if (per < 1 || mt >= L.nmaps || nr < 0 || nr > nrcf) { g_dropin_error = "period index or receiver count out of range"; return DSA_ERR_ARGUMENT; }
             const int passes = (rows && gr == 1) ? 2 : 1;
             for (int ig = 1; ig <= passes; ++ig) {
+                U.iter.push_back(U.niter);
                 U.map.push_back(ig == 1 ? mt : mp);
                 U.nrec.push_back(nr);
                 U.mode.push_back(!rows ? 1 : (gr == 0 ? 3 : (ig == 1 ? 1 : 2)));
@@ -117,6 +125,7 @@ int make_units(const Layout& L, bool rows, int nsrcsurf, int nrcf, const int* wa
                 }
             }
             count1 += nr;
+            U.niter += 1;
         }
     U.ndata = count1;
     return 0;
@@ -130,11 +139,6 @@ void remember(const Layout& L, int ncol, bool clobbered)
     g_last_count[0] = L.kRc; g_last_count[1] = L.kRg; g_last_count[2] = L.kLc; g_last_count[3] = L.kLg;
     g_last_ncol = ncol;
 }
-
-const char* kBoundaryNote =
-    " Note that at least one two-point ray path\n tracked along the boundary of the model.\n"
-    " This class of path is unlikely to be\n a true path, and it is STRONGLY RECOMMENDED\n"
-    " that you adjust the dimensions of your grid\n to prevent this from occurring.\n";
 
 }  // namespace
 
@@ -182,6 +186,7 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     if (g_capacity > 0) cap = g_capacity;
     else if (const char* s = getenv("DSA_MAXNAR")) cap = atoll(s);
     *nar = 0;
+    g_rbint_notes = 0; g_disp_count = 0;
 
     // Every engine runs the dispersion stage for the whole model (it is small next to the solves) and then
     // its contiguous slice of the unit list; the two units of a group-velocity datum stay together.
@@ -195,7 +200,8 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     }
     std::vector<size_t> ray0(nu + 1, 0);
     for (int u = 0; u < nu; ++u) ray0[u + 1] = ray0[u] + (size_t)U.nrec[u];
-    struct Part { std::vector<float> rw; std::vector<int> iw, col; long long n = 0; int rc = 0; std::string err; double clamped = 0; };
+    struct Part { std::vector<float> rw; std::vector<int> iw, col; long long n = 0; int rc = 0; std::string err; int first_clamped = -1;
+                  long long disp_count = 0; int disp_first[5] = { 0, 0, 0, 0, 0 }; double disp_period = 0.0; };
     std::vector<Part> part(ne);
     auto work = [&](int k) {
         dsa_engine* e = g_pool[k];
@@ -230,8 +236,10 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
             en->grow_rw = nullptr; en->grow_iw = nullptr; en->grow_col = nullptr;
         }
         if (r != 0) return bad(r);
-        double st[DSA_STAT_COUNT + 8];
-        if (dsa_get_stats(e, st) == 0) P.clamped = st[DSA_STAT_RAYS_CLAMPED];
+        long long nclamped = 0;
+        int fu = -1;
+        if (dsa_ray_diagnostics(e, &nclamped, &fu) == 0 && fu >= 0) P.first_clamped = a + fu;       // unit of the whole call
+        dsa_dispersion_diagnostics(e, &P.disp_count, P.disp_first, &P.disp_period);
     };
     if (ne == 1) work(0);
     else {
@@ -240,7 +248,7 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
         for (auto& t : th) t.join();
     }
     long long n = 0;
-    double clamped = 0;
+    int first_clamped = -1;
     for (int k = 0; k < ne; ++k) {
         if (part[k].rc != 0) { g_dropin_error = part[k].err; return part[k].rc; }
         if (ne > 1) {
@@ -250,12 +258,25 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
             std::memcpy(col + n, part[k].col.data(), (size_t)part[k].n * 4);
         }
         n += part[k].n;
-        clamped += part[k].clamped;
+        if (part[k].first_clamped >= 0 && (first_clamped < 0 || part[k].first_clamped < first_clamped)) first_clamped = part[k].first_clamped;
     }
+    // every engine ran the same dispersion stage: engine 0 speaks for all
+    g_disp_count = part[0].disp_count; g_disp_period = part[0].disp_period;
+    for (int q = 0; q < 5; ++q) g_disp_first[q] = part[0].disp_first[q];
+    // the reference tests rbint after every (period, source) iteration and never clears it inside a call (CalSurfG.f90:1088, :1447)
+    g_rbint_notes = first_clamped >= 0 ? U.niter - U.iter[(size_t)first_clamped] : 0;
     if (n > INT_MAX) { g_dropin_error = "dsa_calsurfg: more than 2^31-1 matrix entries"; return DSA_ERR_ARGUMENT; }
     *nar = (int)n;
     remember(L, *nx * *ny, true);
-    if (clamped > 0) fputs(kBoundaryNote, stdout);
+    return 0;
+}
+
+int dsa_dropin_diagnostics(int* rbint_notes, long long* disp_count, int* disp_first, double* disp_period)
+{
+    if (rbint_notes) *rbint_notes = g_rbint_notes;
+    if (disp_count) *disp_count = g_disp_count;
+    if (disp_first) for (int q = 0; q < 5; ++q) disp_first[q] = g_disp_first[q];
+    if (disp_period) *disp_period = g_disp_period;
     return 0;
 }
 

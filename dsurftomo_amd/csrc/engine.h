@@ -61,6 +61,8 @@ struct Engine {
     DevBuf<unsigned long long> exc_c;  // their exception tables
     int exc_log2cap = 0;
     int exc_log2cap_opt = 0;           // option exc_log2cap: initial table size (0 = from the grid); the table grows by itself when it overflows
+    int grown_nnx = 0, grown_nnz = 0;
+    int exc_log2cap_grown = 0;         // ... and the size it grew to is kept for the later plans of this grid (an inversion solves the same geometry every iteration)
     DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists, launch_rank;
     std::vector<int> h_launch_rank;
     size_t lists_stride = 0;
@@ -110,6 +112,13 @@ struct Engine {
     DevBuf<LayerGeom> geom;
     DevBuf<double> pvstore, curves, tper;
     DevBuf<float> disp_ws;
+    DevBuf<unsigned long long> disp_diag;
+    // non-fatal diagnostics of the boundary since dispersion_begin / the last plan (dsa_dispersion_diagnostics, dsa_ray_diagnostics)
+    long long disp_fail_count = 0;     // dispersion curves that ended with "no zero found" (surfdisp96.f:308-339)
+    int disp_fail_first[5] = {};       // first of them in call order: iwave, igr, column (1-based), perturbation (0 = the model itself), period index k
+    double disp_fail_period = 0.0;
+    long long rays_clamped = 0;        // traced rays that were clamped at the model boundary (reference rbint, CalSurfG.f90:2082-2101)
+    int first_clamped_unit = -1;       // planned unit of the first of them
     int disp_group_shift = -1;         // lanes per Rayleigh curve = 2^shift; -1 = by the number of curves, 0 = one lane per curve
     int disp_layers_lds = -1;          // layer tables of k_dispersion: 1 LDS, 0 global scratch, -1 LDS when they fit
 
@@ -126,6 +135,7 @@ struct Engine {
     long long G_nar = 0;
     template <class T> int ensure_keep(DevBuf<T>& b, size_t n, size_t used);
 
+    bool spmv_attr_set = false;        // LDS attribute of the blocked SpmV kernels set on this engine's device
     SpmvState* spmv = nullptr;         // device copy of a COO matrix for dsa_spmv (spmv.hip)
     int lsmr_device_vectors = 0;       // dsa_lsmr: 1 = vectors and ordered reductions on the device, 0 = on the host (lsmr.hip)
 

@@ -88,7 +88,7 @@ Engine::~Engine()
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
-    rel(X_pool); rel(X_heap); rel(x_units); rel(xinfo); rel(tieinfo);
+    rel(disp_diag); rel(X_pool); rel(X_heap); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -152,6 +152,7 @@ int Engine::finish_maps(int nm)
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = false;
     have_maps = true;
+    if (g.nnx != grown_nnx || g.nnz != grown_nnz) { exc_log2cap_grown = 0; grown_nnx = g.nnx; grown_nnz = g.nnz; }
     return 0;
 }
 
@@ -174,6 +175,7 @@ int Engine::dispersion_begin(int nx, int ny, int nz, const float* vels, const fl
     HIP_TRY(this, hipMemsetAsync(sen_rho.p, 0, nsen * 8, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
     disp_ready = true;
+    disp_fail_count = 0;
     have_sens = false;
     stats[DSA_STAT_MS_DISPERSION] = 0.0;
     stats[DSA_STAT_CURVES] = 0.0;
@@ -192,8 +194,10 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
     const int ncol = disp_nx * disp_ny;
     const int npert = with_kernels ? 1 + 6 * disp_nz : 1;
     const size_t nlanes = (size_t)ncol * npert;
-    if (ensure(curves, nlanes * nper) || ensure(disp_ws, (size_t)4 * h_geom.rmax * nlanes) || ensure(tper, kMaxPeriods)) return status;
+    if (ensure(curves, nlanes * nper) || ensure(disp_ws, (size_t)4 * h_geom.rmax * nlanes) || ensure(tper, kMaxPeriods) || ensure(disp_diag, 2)) return status;
     HIP_TRY(this, hipMemcpyAsync(tper.p, t, (size_t)nper * 8, hipMemcpyHostToDevice, stream));
+    const unsigned long long diag0[2] = { 0ull, ~0ull };
+    HIP_TRY(this, hipMemcpyAsync(disp_diag.p, diag0, 16, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipEventRecord(events[1], stream));
     // layer tables in LDS when they fit (64 curves x 4 arrays x rmax layers x 4 B <= 64 KB, i.e. rmax <= 64) -- see k_dispersion
     const int in_lds = disp_layers_lds >= 0 ? disp_layers_lds : ((size_t)h_geom.rmax * 1024 <= (size_t)64 * 1024 ? 1 : 0);
@@ -204,7 +208,7 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
         if (disp_group_shift > 0) gshift = disp_group_shift;
         else gshift = nlanes <= 4096 ? 3 : nlanes <= 32768 ? 2 : 0;      // measured: 324 curves 21.6 -> 7.8 ms, 17 820 curves 22.7 -> 16.9 ms, 944 k curves 166 -> 285 ms
     }
-    launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, h_geom.rmax, in_lds, gshift, stream);
+    launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, h_geom.rmax, in_lds, gshift, disp_diag.p, stream);
     launch_depth_kernels(vels_d.p, ncol, disp_nz, nper, curves.p, with_kernels, pvstore.p + (size_t)map_first * ncol, sen_vs.p, sen_vp.p, sen_rho.p,
                          disp_kmax_total, sen_slot, stream);
     HIP_TRY(this, hipEventRecord(events[2], stream));
@@ -214,6 +218,18 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
     HIP_TRY(this, hipEventElapsedTime(&ms, events[1], events[2]));
     stats[DSA_STAT_MS_DISPERSION] += ms;
     stats[DSA_STAT_CURVES] += (double)nlanes;
+    unsigned long long diag[2];
+    HIP_TRY(this, hipMemcpy(diag, disp_diag.p, 16, hipMemcpyDeviceToHost));
+    if (diag[0]) {
+        if (disp_fail_count == 0) {
+            const unsigned long long curve = diag[1] >> 16;
+            const int k = (int)(diag[1] & 0xffffull);
+            disp_fail_first[0] = iwave; disp_fail_first[1] = igr; disp_fail_first[2] = (int)(curve % (unsigned long long)ncol) + 1;
+            disp_fail_first[3] = (int)(curve / (unsigned long long)ncol); disp_fail_first[4] = k;
+            disp_fail_period = k >= 1 && k <= nper ? t[k - 1] : 0.0;
+        }
+        disp_fail_count += (long long)diag[0];
+    }
     return 0;
 }
 
@@ -332,7 +348,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         shape_c.sorted = shape_c.tile_words * 4 <= 36 * 1024 ? 1 : 0;      // the coarse solve runs on the compact field: ordered variant only
         if (!shape_c.sorted) { fail(DSA_ERR_ARGUMENT, "plan: a %d x %d grid needs %d bytes of LDS tile bitmap (limit 36 KB): the coarse solve has no other variant", g.nnx, g.nnz, shape_c.tile_words * 4); return DSA_ERR_ARGUMENT; }
         shape_c.compact = 1; shape_r.compact = 0;
-        exc_log2cap = exc_log2cap_opt > 0 ? exc_log2cap_opt : exc_log2cap_of(g.nnx, g.nnz);
+        exc_log2cap = std::max(exc_log2cap_opt > 0 ? exc_log2cap_opt : exc_log2cap_of(g.nnx, g.nnz), exc_log2cap_grown);
         const FimLaunch &lc = shape_c, &lr = shape_r;
         lists_stride = std::max((size_t)4 * lc.list_cap + lc.ready_cap, (size_t)4 * lr.list_cap + lr.ready_cap);
         lists_stride = std::max(lists_stride, (size_t)kFimMaskInts * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile records + one list
@@ -381,6 +397,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     const bool grow = grow_rw && grow_iw && grow_col;
     const bool rows = ((rw && iw && col) || grow || rows_on_device) && nar;
     if (rows && !have_sens) { fail(DSA_ERR_STATE, "solve: Frechet rows need the depth kernels (dsa_set_depth_kernels / dsa_depthkernel) first"); return DSA_ERR_STATE; }
+    rays_clamped = 0; first_clamped_unit = -1;
     if (rows) {
         *nar = 0;
         G_nar = 0;
@@ -504,8 +521,29 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         stats[DSA_STAT_LAUNCHES_FIM_COARSE] += 1;
         last_chunk_first = first;
         last_chunk_n = n;
+        for (int u = 0; u < n; ++u) {      // the exception table first: a solve that ran out of table space may also have run out of rounds
+            const int32_t* fi = &h_info[(size_t)u * 16];
+            if (fi[10] != -2) continue;
+            // more nodes off the causal order than the table holds: four times the table and the chunk once more
+            const size_t grown_bytes = (size_t)chunk * (((size_t)8 << (exc_log2cap + 2)) - ((size_t)8 << exc_log2cap));
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+            if (exc_log2cap + 2 > 26 || grown_bytes + ((size_t)chunk << exc_log2cap) * 8 > free_b || ensure(exc_c, (size_t)chunk << (exc_log2cap + 2))) {
+                fail(DSA_ERR_INTERNAL, "unit %d: the exception table of the compact field overflowed (%d entries) and cannot grow", first + u, 1 << exc_log2cap);
+                return DSA_ERR_INTERNAL;
+            }
+            exc_log2cap += 2;
+            exc_log2cap_grown = exc_log2cap;
+            per_unit_bytes += grown_bytes / (size_t)chunk;
+            stats[DSA_STAT_RESCANS] += 1;
+            redo_chunk = true;
+            break;
+        }
+        if (redo_chunk) continue;
         for (int u = 0; u < n; ++u) {
             const int32_t* fi = &h_info[(size_t)u * 16];
+            if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
+            if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
             stats[DSA_STAT_ROUNDS_MAX] = std::max(stats[DSA_STAT_ROUNDS_MAX], (double)fi[8]);
             unsigned long long ev;
             std::memcpy(&ev, fi + 12, 8);
@@ -514,21 +552,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             stats[DSA_STAT_CHANGES_TOTAL] += (double)ev;
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
-            if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
-            if (fi[10] == -2) {
-                // more nodes off the causal order than the table holds: four times the table and the chunk once more
-                if (exc_log2cap + 2 > 26 || ensure(exc_c, (size_t)chunk << (exc_log2cap + 2))) {
-                    fail(DSA_ERR_INTERNAL, "unit %d: the exception table of the compact field overflowed (%d entries) and cannot grow", first + u, 1 << exc_log2cap);
-                    return DSA_ERR_INTERNAL;
-                }
-                exc_log2cap += 2;
-                stats[DSA_STAT_RESCANS] += 1;
-                redo_chunk = true;
-                break;
-            }
-            if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
         }
-        if (redo_chunk) continue;
         last_chunk_first = first;
         last_chunk_n = n;
         if (rows && trace_chunk(first, n, rw, iw, col, cap, nar) != 0) return status;
@@ -716,7 +740,14 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
         HIP_TRY(this, hipEventElapsedTime(&ms, ea, eb)); stats[DSA_STAT_MS_RAYS] += ms;
         HIP_TRY(this, hipEventElapsedTime(&ms, eb, ec)); stats[DSA_STAT_MS_ROWS] += ms;
         stats[DSA_STAT_RAYS] += m;
-        for (int q = 0; q < m; ++q) { stats[DSA_STAT_RAY_STEPS] += h_info[2 * q + 1]; stats[DSA_STAT_RAYS_CLAMPED] += h_info[2 * q] & 1; }
+        for (int q = 0; q < m; ++q) {
+            stats[DSA_STAT_RAY_STEPS] += h_info[2 * q + 1]; stats[DSA_STAT_RAYS_CLAMPED] += h_info[2 * q] & 1;
+            if (h_info[2 * q] & 1) {
+                const int unit = h_rays[(size_t)h_trace[t + (size_t)q]].src;
+                rays_clamped += 1;
+                if (first_clamped_unit < 0 || unit < first_clamped_unit) first_clamped_unit = unit;
+            }
+        }
     }
     stats[DSA_STAT_NAR] = (double)*nar;
     return 0;
@@ -994,6 +1025,25 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out)
     if (which < 2) return en->fetch_compact((int)slot, which, out);
     const dsa::SourceDesc& s = en->h_src[unit];
     return en->fetch_tiled(en->F_r.p + slot * dsa::kRefRecs, s.rnx, s.rnz, which - 2, out);
+}
+
+int dsa_dispersion_diagnostics(const dsa_engine* e, long long* count, int* first, double* period)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    const Engine* en = reinterpret_cast<const Engine*>(e);
+    if (count) *count = en->disp_fail_count;
+    if (first) for (int q = 0; q < 5; ++q) first[q] = en->disp_fail_count ? en->disp_fail_first[q] : 0;
+    if (period) *period = en->disp_fail_count ? en->disp_fail_period : 0.0;
+    return 0;
+}
+
+int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    const Engine* en = reinterpret_cast<const Engine*>(e);
+    if (clamped) *clamped = en->rays_clamped;
+    if (first_unit) *first_unit = en->first_clamped_unit;
+    return 0;
 }
 
 int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence)

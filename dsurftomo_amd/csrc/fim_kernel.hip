@@ -846,7 +846,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     if (COMPACT) {
                         // causal node (the rule): one float.  Else the table entry first, then the flagged value.
                         if (f2u(c) == f2u(k)) *tc(id) = c;
-                        else { if (!exc_upsert(id, k)) p.info[2] = -2; *tc(id) = -c; }
+                        else { if (!exc_upsert(id, k)) { p.info[2] = -2; sc[SC_OVERFLOW] = 1; } *tc(id) = -c; }
                     } else { rec(id)->T = c; rec(id)->tau = k; }
                     ++nchanged;
                 }
@@ -922,7 +922,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         ++rounds;
         DSA_SYNC(3);
         DSA_PHASE(tE, );
-        if (rounds > p.max_rounds) { if (tid == 0) p.info[2] = -1; break; }
+        if (COMPACT && sc[SC_OVERFLOW]) break;          // the exception table is full (info[2] = -2): the host grows it and solves the chunk again
+        if (rounds > p.max_rounds) { if (tid == 0 && p.info[2] != -2) p.info[2] = -1; break; }
     }
     {
         unsigned long long e64 = evals, c64 = nchanged;

@@ -143,7 +143,8 @@ void launch_scan(const int* d_counts, int n, long long* d_offsets, hipStream_t s
 struct LayerGeom;
 // curves: (npert, kmax, ncol) fp64; ws: 4 * rmax * nlanes floats of layer workspace; iwave 1 Love, 2 Rayleigh
 void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
-                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, int gshift, hipStream_t stream);
+                       const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, int gshift,
+                       unsigned long long* d_diag /* [0] curves without a root, [1] min of (curve << 16 | period index) */, hipStream_t stream);
 void launch_depth_kernels(const float* d_vels, int ncol, int nz, int kmax, const double* d_curves, int with_kernels, double* d_pv,
                           double* d_sen_vs, double* d_sen_vp, double* d_sen_rho, int kmax_total, int slot0, hipStream_t stream);
 void launch_to_float(const double* d_in, float* d_out, size_t n, hipStream_t stream);

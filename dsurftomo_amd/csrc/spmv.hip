@@ -380,11 +380,14 @@ int dsa_spmv(dsa_engine* h, int mode, float* x, float* y)
 namespace dsa {
 static void run_ordering(Engine* e, const SpmvState::Ordering& O, bool abs_sums, const float* d_in, float* d_out)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_block<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kSpmvBlock * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_block<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kSpmvBlock * 4);
-        attr_set = true;
+    // the attribute is per device (an engine per GPU in one process: DSA_DEVICES): set it for the device this engine runs on, once per engine
+    if (!e->spmv_attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_block<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kSpmvBlock * 4) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_block<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, kSpmvBlock * 4) != hipSuccess) {
+            e->fail(DSA_ERR_DEVICE, "spmv: the device refuses %d bytes of dynamic LDS per workgroup", kSpmvBlock * 4);
+            return;
+        }
+        e->spmv_attr_set = true;
     }
     for (int b = 0; b <= O.nblocks; ++b) {
         const SpmvState::Sliced& L = O.blocks[b];

@@ -39,6 +39,12 @@ module dsa_bindings
       integer(c_int) :: which
       real(c_double) :: pv(*)
     end function
+    integer(c_int) function dsa_dropin_diagnostics(rbint_notes, disp_count, disp_first, disp_period) bind(C, name='dsa_dropin_diagnostics')
+      import :: c_int, c_long_long, c_double
+      integer(c_int) :: rbint_notes, disp_first(5)
+      integer(c_long_long) :: disp_count
+      real(c_double) :: disp_period
+    end function
     function dsa_dropin_error() bind(C, name='dsa_dropin_error') result(p)
       import :: c_ptr
       type(c_ptr) :: p
@@ -80,6 +86,50 @@ subroutine CalSurfG(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf, &
        kmaxRc,kmaxRg,kmaxLc,kmaxLg,tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk, &
        scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,nar)
   if (rc /= 0) call dsa_stop('CalSurfG')
+  call dsa_report()
+end subroutine
+
+! The reference's non-fatal messages, written where and how it writes them.
+!  * unit 6, CalSurfG.f90:1447-1454: the six-line note about a ray tracked along the model boundary, once after every (period,
+!    source) iteration from the first such ray on -- the count comes from the engine.
+!  * unit 66 (the host program's log file, main.f90:156), surfdisp96.f:308-339: "improper initial value in disper - no zero found".
+!    The reference writes the block once per failing surfdisp96 call together with that call's layer table; here it is written once
+!    per CalSurfG call for the first failing curve, followed by the number of curves that ended this way (the layer tables stay on
+!    the device).
+subroutine dsa_report()
+  use dsa_bindings
+  implicit none
+  integer :: notes, first(5), rc, i
+  integer(c_long_long) :: ndisp
+  real*8 :: period
+  rc = dsa_dropin_diagnostics(notes, ndisp, first, period)
+  if (rc /= 0) return
+  do i = 1, notes
+    WRITE(6,*)'Note that at least one two-point ray path'
+    WRITE(6,*)'tracked along the boundary of the model.'
+    WRITE(6,*)'This class of path is unlikely to be'
+    WRITE(6,*)'a true path, and it is STRONGLY RECOMMENDED'
+    WRITE(6,*)'that you adjust the dimensions of your grid'
+    WRITE(6,*)'to prevent this from occurring.'
+  enddo
+  if (ndisp > 0) then
+    write(66,*)'improper initial value in disper - no zero found'
+    write(66,*)'in fundamental mode '
+    write(66,*)'This may be due to low velocity zone '
+    write(66,*)'causing reverse phase velocity dispersion, '
+    write(66,*)'and mode jumping.'
+    write(66,*)'due to looking for Love waves in a halfspace'
+    write(66,*)'which is OK if there are Rayleigh data.'
+    write(66,*)'If reverse dispersion is the problem,'
+    write(66,*)'Get present model using OPTION 28, edit sobs.d,'
+    write(66,*)'Rerun with onel large than 2'
+    write(66,*)'which is the default '
+    write(66,*)'ifunc = ',first(1) ,' (1=L, 2=R)'
+    write(66,*)'mode  = ',0
+    write(66,*)'period= ',period, ' for k=',first(5)
+    write(66,*)'grid column (jj-1)*nx+ii = ',first(3),' depth-kernel perturbation = ',first(4),' group velocity = ',first(2)
+    write(66,*)'curves of this call that ended this way: ',ndisp
+  endif
 end subroutine
 
 subroutine synthetic(nx,ny,nz,nparpi,vels,obst, &

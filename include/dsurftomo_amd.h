@@ -177,6 +177,16 @@ int dsa_get_refined(dsa_engine* e, int unit, int* rnx, int* rnz, float* ttnr, in
  * tau (sign bit = queued), 2 refined T, 3 refined tau (rnx*rnz floats, leading dimension rnz) */
 int dsa_debug_field(dsa_engine* e, int unit, int which, float* out);
 
+/* Non-fatal diagnostics of the boundary (SURVEY.md 8b "Error convention").
+ * dispersion: curves of the dispersion runs since dsa_dispersion_begin that ended with the reference's "improper initial value in
+ *   disper - no zero found" (surfdisp96.f:308-339; the rest of such a curve is zero, :342-348): their number, the first one in call
+ *   order as first[5] = { iwave (1 Love, 2 Rayleigh), igr, column (1-based, (jj-1)*nx+ii), perturbation (0 = the model itself, else
+ *   1 + 6 depth + 2 parameter + sign of the depth-kernel differences), period index k }, and that period.
+ * rays: traced rays of the last dsa_solve_rows that were clamped at the model boundary (reference rbint, CalSurfG.f90:2082-2101,
+ *   reported by the note of :1447-1454), and the planned unit of the first of them (-1: none). */
+int dsa_dispersion_diagnostics(const dsa_engine* e, long long* count, int* first, double* period);
+int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit);
+
 /* Exact time ties: the fixed-point solve lands on the reference's Fast-Marching travel times except downstream of
  * bit-equal times of two neighbouring narrow-band nodes, where the reference's own answer depends on the layout of its binary
  * tree (CalSurfG.f90:417-485, :768-921).  Option "exact_ties": 0 (default) fixed point only; 1 = the solve kernel detects such
@@ -244,6 +254,14 @@ int dsa_lsmr_dropin(const int* m, const int* n, const int* leniw, const int* len
 /* pv(nx*ny, kmaxXX) of the last drop-in call: which = 0 Rc, 1 Rg, 2 Lc, 3 Lg (what the reference's synthetic
  * writes to velmap2d*.dat, CalSurfG.f90:2559-2617) */
 int dsa_dropin_velocity_maps(const int* which, double* pv);
+
+/* Non-fatal diagnostics of the last dsa_calsurfg call, for the caller to print where the reference prints them:
+ *   rbint_notes: how many times the reference would have written its six-line boundary note to unit 6 -- once after every
+ *     (period, source) iteration from the first one with a clamped ray on (rbint is set once and tested inside the source loop,
+ *     CalSurfG.f90:1088, :1447-1454); 0 = no ray touched the boundary;
+ *   disp_count / disp_first[5] / disp_period: see dsa_dispersion_diagnostics (the reference writes its block to unit 66).
+ * The C level prints nothing itself; dsurftomo_amd/fortran/calsurfg_shim.f90 writes the reference's texts. */
+int dsa_dropin_diagnostics(int* rbint_notes, long long* disp_count, int* disp_first, double* disp_period);
 
 /* text of the last error of the process-wide engine used by the drop-in level */
 const char* dsa_dropin_error(void);

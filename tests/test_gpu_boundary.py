@@ -190,6 +190,73 @@ def test_ray_paths_against_oracle(ray_budget, tmp_path):
     assert sum(1 for l in lines if l.lstrip().startswith("#")) == len(paths)
 
 
+def write_driver_input(c, fin, maxnar):
+    with open(fin, "wb") as f:
+        np.array([c["nx"], c["ny"], c["nz"], c["kRc"], c["kRg"], c["kLc"], c["kLg"], c["kmax"], c["nsrcsurf"], c["nrcf"], c["ndata"], maxnar], np.int32).tofile(f)
+        np.array([c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], c["minthk"]], np.float32).tofile(f)
+        for a in (c["vels"], c["depz"], c["tRc"], c["tRg"], c["tLc"], c["tLg"], c["wavetype"], c["igrt"], c["periods"], c["nrc1"], c["nsrcsurf1"],
+                  c["scxf"], c["sczf"], c["rcxf"], c["rczf"]):
+            f.write(np.asarray(a).tobytes(order="F"))
+
+
+def diagnostics_case():
+    """a call that makes the reference speak: one source / receiver pair hugging the northern edge under a medium that gets faster
+    towards it (the ray leaves the grid and is clamped: rbint, CalSurfG.f90:2082-2101), and one grid column without any velocity
+    contrast (no Love-wave root: surfdisp96.f:308-339)"""
+    c = synth.boundary_case(nx=12, ny=11, nz=5, kRc=2, kRg=1, kLc=1, kLg=0, nsrc=3, nrcf=3, ragged=False)
+    f = np.float32
+    lat = float(c["goxd"]) - 0.004 * float(c["dvxd"])
+    lon0, lon1 = float(c["gozd"]) + 0.4 * float(c["dvzd"]), float(c["gozd"]) + (c["ny"] - 3.4) * float(c["dvzd"])
+    s, k = 1, 1                          # second source of the second period slot: iteration 4 of 12 (0-based)
+    c["scxf"][s, k] = f((90.0 - lat) * np.pi / 180.0); c["sczf"][s, k] = f(lon0 * np.pi / 180.0)
+    c["rcxf"][0, s, k] = f((90.0 - lat) * np.pi / 180.0); c["rczf"][0, s, k] = f(lon1 * np.pi / 180.0)
+    v = np.array(c["vels"])
+    v *= (1.0 + 0.25 * np.exp(-np.arange(c["nx"])[:, None, None] / 2.0)).astype(np.float32)
+    v[6, 5, :] = v[6, 5, 0]
+    c["vels"] = np.asfortranarray(v.astype(np.float32))
+    return c
+
+
+# what the reference itself wrote for diagnostics_case() (its calsurfg_, built by oracle/Makefile, run in the build container by the
+# reference leg of the test below, which repeats the comparison wherever oracle/_ref is present): boundary notes on unit 6, blocks on unit 66
+REF_NOTES, REF_BLOCKS = 8, 3
+
+
+def test_fortran_shim_prints_the_reference_diagnostics(tmp_path):
+    """non-fatal diagnostics of the boundary: the shim writes the reference's boundary note to unit 6 as many times as
+    the reference does, and the 'no zero found' text to unit 66 with the number of dispersion curves that ended that way"""
+    exe = os.path.join(L.ROOT, "tests", "build", "shim_driver")
+    if not os.path.exists(exe):
+        pytest.skip("tests/build/shim_driver was not built (flang missing)")
+    c = diagnostics_case()
+    maxnar = c["ndata"] * c["nparpi"]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_driver_input(c, fin, maxnar)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and os.path.exists(fout), r.stdout + r.stderr
+    notes = r.stdout.count("Note that at least one two-point ray path")
+    log = (tmp_path / "fort.66").read_text() if (tmp_path / "fort.66").exists() else ""
+    ncurves = [int(line.split(":")[1]) for line in log.splitlines() if "curves of this call that ended this way" in line]
+    assert "improper initial value in disper - no zero found" in log and "(1=L, 2=R)" in log and "due to looking for Love waves in a halfspace" in log
+    assert notes == REF_NOTES and ncurves == [REF_BLOCKS], (notes, ncurves, log[-600:])
+    # the numbers still come out as the oracle's (the clamped ray included)
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    with open(fout, "rb") as f:
+        nar = int(np.fromfile(f, np.int32, 1)[0])
+        dsurf = np.fromfile(f, np.float32, c["ndata"]); np.fromfile(f, np.float32, c["ndata"])
+        rw = np.fromfile(f, np.float32, nar); iw = np.fromfile(f, np.int32, nar); col = np.fromfile(f, np.int32, nar)
+    check_rows(o, dict(dsurf=dsurf, rw=rw, iw=iw, col=col, nar=nar), c)
+    if L.ref() is not None:              # the reference's own words, same call, in a process of its own (Fortran units 6 and 66)
+        refdir = tmp_path / "ref"
+        refdir.mkdir()
+        code = ("import sys; sys.path[:0] = [%r, %r]; import _libs as L, test_gpu_boundary as t; "
+                "L.call_boundary(L.ref().calsurfg_, t.diagnostics_case())" % (L.ROOT, os.path.join(L.ROOT, "tests")))
+        rr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(refdir))
+        assert rr.returncode == 0, rr.stderr[-800:]
+        assert rr.stdout.count("Note that at least one two-point ray path") == notes
+        assert (refdir / "fort.66").read_text().count("improper initial value in disper - no zero found") == ncurves[0]
+
+
 def test_fortran_shim(tmp_path):
     """calsurfg_ / synthetic_ through the flang-built shim and a Fortran caller"""
     exe = os.path.join(L.ROOT, "tests", "build", "shim_driver")
@@ -200,12 +267,7 @@ def test_fortran_shim(tmp_path):
     so = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
     maxnar = c["ndata"] * c["nparpi"]
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    with open(fin, "wb") as f:
-        np.array([c["nx"], c["ny"], c["nz"], c["kRc"], c["kRg"], c["kLc"], c["kLg"], c["kmax"], c["nsrcsurf"], c["nrcf"], c["ndata"], maxnar], np.int32).tofile(f)
-        np.array([c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], c["minthk"]], np.float32).tofile(f)
-        for a in (c["vels"], c["depz"], c["tRc"], c["tRg"], c["tLc"], c["tLg"], c["wavetype"], c["igrt"], c["periods"], c["nrc1"], c["nsrcsurf1"],
-                  c["scxf"], c["sczf"], c["rcxf"], c["rczf"]):
-            f.write(np.asarray(a).tobytes(order="F"))
+    write_driver_input(c, fin, maxnar)
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0 and os.path.exists(fout), r.stdout + r.stderr
     with open(fout, "rb") as f:
