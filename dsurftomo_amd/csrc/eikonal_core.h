@@ -383,6 +383,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
 
     float c = kInf;
     bool first = alive != 0u;           // pinned neighbours are alive from the start: one evaluation before the walk
+#ifndef DSA_SOLVE_NO_FIRST_STEP         // (A/B switch of tools/ab_build.sh: without the block the loop below does the same step with its whole body)
     if (!first && key[0] < kInf) {      // no pinned neighbour: the walk's first neighbour alone (c = +inf > its key)
         const int a = idx[0];
         const bool x = a < 2;
@@ -399,6 +400,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
         const float one = sw1 ? div3(fmaf(4.0f, tna, -t2a) + (x ? c2x : c2z)) : tna + (x ? c1x : c1z);
         c = (have && one < kInf) ? one : kInf;
     }
+#endif
     bool probing = false;               // TIE: the trip after a tie
     float c_keep = 0.0f, tnow_keep = 0.0f;
     if (TIE) *tie_out = -1.0f;

@@ -18,8 +18,8 @@ __global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int
     const int s = units[slot];
     const SourceDesc sd = b.src[s];
     DSA_LDS XEntry* const hl = (DSA_LDS XEntry*)x_lds;                         // slots 1..lcap
-    DSA_LDS int* const log = (DSA_LDS int*)(hl + lcap + 1);
-    DSA_LDS int* const stage_st = log + 2 * kXLogCap;
+    DSA_LDS XLog* const log = (DSA_LDS XLog*)(hl + lcap + 1);
+    DSA_LDS int* const stage_st = (DSA_LDS int*)(log + kXLogCap);
     DSA_LDS float* const stage_T = (DSA_LDS float*)(stage_st + kXStage);
     const size_t rr = (size_t)kRefMax * kRefMax;
 
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int
     for (int i = lane; i < kRefRecs; i += 64) Fr[i] = XRec{ 0.0f, -1 };
     __threadfence_block();
     m.F = Fr; m.slow = b.slow_r + (size_t)s * kRefRecs; m.risti = b.risti_r + (size_t)s * kRefMax;
-    m.nbz = sd.nbz_r; m.nnx = sd.rnx; m.nnz = sd.rnz; m.dnx = sd.rdnx; m.dnz = sd.rdnz;
+    x_set_grid(m, sd.nbz_r, sd.rnx, sd.rnz); m.dnx = sd.rdnx; m.dnz = sd.rdnz;
     x_refined_start(m, sd, b.vcorner + (size_t)s * 4);
     x_march<true>(m, sd);
     __threadfence_block();
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int
     for (int i = lane; i < nrec; i += 64) Fc[i] = XRec{ 0.0f, -1 };
     __threadfence_block();
     m.F = Fc; m.slow = slow_all + (size_t)sd.period * field_stride; m.risti = risti_c;
-    m.nbz = g.nbz; m.nnx = g.nnx; m.nnz = g.nnz; m.dnx = g.dnx; m.dnz = g.dnz;
+    x_set_grid(m, g.nbz, g.nnx, g.nnz); m.dnx = g.dnx; m.dnz = g.dnz;
     m.ntr = 0; m.nlog = 0; m.pops = 0u;
     for (int q = lane; q < bxn * bzn; q += 64)
         if (stage_st[q] == 0) {
@@ -93,11 +93,12 @@ __global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int
     __threadfence_block();
     // tree start in the reference's scan order: ix outer, iz inner (:341-347)
     for (int q = 0; q < bxn * bzn; ++q) {
-        if (stage_st[q] <= 0) continue;
+        if (x_uni(stage_st[q]) <= 0) continue;
         const int bx = q / bzn, bz = q - bx * bzn;
-        const int node = ((sd.vnt + bz) << 16) | (sd.vnl + bx);
-        if (lane == 0) Fc[x_id(m, node)].T = stage_T[q];
-        x_add(m, node, stage_T[q]);
+        const int id = rec_index(g.nbz, sd.vnt + bz - 1, sd.vnl + bx - 1);
+        const float tq = x_unif(stage_T[q]);
+        if (lane == 0) Fc[id].T = tq;
+        x_add(m, id, tq);
     }
     x_march<false>(m, sd);
     __threadfence_block();
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int
     if (lane == 0) { xinfo[4 * s + 0] = (int)pops_r; xinfo[4 * s + 1] = (int)m.pops; xinfo[4 * s + 2] = err; xinfo[4 * s + 3] = 0; }
 }
 
-size_t exact_lds_bytes(int lcap) { return (size_t)(lcap + 1) * sizeof(XEntry) + (size_t)2 * kXLogCap * 4 + (size_t)kXStage * 8; }
+size_t exact_lds_bytes(int lcap) { return (size_t)(lcap + 1) * sizeof(XEntry) + (size_t)kXLogCap * sizeof(XLog) + (size_t)kXStage * 8; }
 
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
                   const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, int32_t* d_xinfo,

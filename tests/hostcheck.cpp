@@ -544,13 +544,13 @@ extern "C" int hc_exact_solve(int nx, int ny, float goxd, float gozd, float dvxd
             if ((lx == s.isx_r || lx == s.isx_r + 1) && (kz == s.isz_r || kz == s.isz_r + 1)) vcorner[(lx - s.isx_r) * 2 + (kz - s.isz_r)] = v;
         }
     std::vector<XEntry> hl((size_t)lcap + 1), hg((size_t)gcap + 1);
-    std::vector<int> log(2 * kXLogCap);
+    std::vector<XLog> log(kXLogCap);
     XMarch m;
     m.hl = hl.data(); m.lcap = lcap; m.hg = hg.data(); m.gcap = gcap; m.log = log.data();
     m.ntr = 0; m.error = 0; m.nlog = 0; m.pops = 0u; m.ri = g.earth;
     std::vector<XRec> Fr(kRefRecs, XRec{ 0.0f, -1 });
     m.F = Fr.data(); m.slow = slow_r.data(); m.risti = risti_r.data();
-    m.nbz = s.nbz_r; m.nnx = s.rnx; m.nnz = s.rnz; m.dnx = s.rdnx; m.dnz = s.rdnz;
+    x_set_grid(m, s.nbz_r, s.rnx, s.rnz); m.dnx = s.rdnx; m.dnz = s.rdnz;
     x_refined_start(m, s, vcorner.data());
     x_march<true>(m, s);
     if (m.error) return m.error;
@@ -584,18 +584,24 @@ extern "C" int hc_exact_solve(int nx, int ny, float goxd, float gozd, float dvxd
     for (int q = 0; q < bxn * bzn; ++q) if (pr[q]) st[q] = 1;
     std::vector<XRec> Fc(nrc, XRec{ 0.0f, -1 });
     m.F = Fc.data(); m.slow = slow_c.data(); m.risti = risti_c.data();
-    m.nbz = g.nbz; m.nnx = g.nnx; m.nnz = g.nnz; m.dnx = g.dnx; m.dnz = g.dnz;
+    x_set_grid(m, g.nbz, g.nnx, g.nnz); m.dnx = g.dnx; m.dnz = g.dnz;
     m.ntr = 0; m.nlog = 0; m.pops = 0u;
     for (int q = 0; q < bxn * bzn; ++q)
         if (st[q] == 0) Fc[rec_index(g.nbz, s.vnt + q % bzn - 1, s.vnl + q / bzn - 1)] = XRec{ sT[q], 0 };
     for (int q = 0; q < bxn * bzn; ++q) {
         if (st[q] <= 0) continue;
-        const int node = ((s.vnt + q % bzn) << 16) | (s.vnl + q / bzn);
-        Fc[x_id(m, node)].T = sT[q];
-        x_add(m, node, sT[q]);
+        const int id = rec_index(g.nbz, s.vnt + q % bzn - 1, s.vnl + q / bzn - 1);
+        Fc[id].T = sT[q];
+        x_add(m, id, sT[q]);
     }
     int maxtree = m.ntr;
-    while (m.ntr > 0 && m.error == 0) { x_accept_root(m, xh_get(m, 1)); if (m.ntr > maxtree) maxtree = m.ntr; }
+    while (m.ntr > 0 && m.error == 0) {
+        const XEntry root = xh_get(m, 1);
+        int iz0, ix0;
+        x_coords(m, root.id, &iz0, &ix0);
+        x_accept_root(m, root, iz0, ix0);
+        if (m.ntr > maxtree) maxtree = m.ntr;
+    }
     if (m.error) return m.error;
     if (stat) { stat[1] = (long)m.pops; stat[2] = maxtree; }
     for (int ix = 0; ix < g.nnx; ++ix)
