@@ -255,10 +255,16 @@ def main():
     dev = torch.device("cpu") if shared else torch.device("cuda", device_index)
     counts = sharding.ray_counts(units["nrec"], world)
 
+    mine = torch.empty(eng.ndata, dtype=torch.float32, device=dev) if (world > 1 and not shared) else None
+
     def step():
+        if world > 1 and not shared:
+            # the path's one exchange step, device to device: the rank's receiver times stay in HBM (dsa_solve_device) and the RCCL
+            # all-gather completes the vector on every rank; nothing visits the host before the collective
+            eng.solve_device(mine.data_ptr())
+            return sharding.all_gather_times(dist, mine, counts)
         t = eng.solve()
-        if world > 1:
-            # the path's one exchange step: every rank ends up with the full receiver-time vector
+        if world > 1:                                  # ranks sharing a device (1-GPU rehearsal): gloo, host tensors
             return sharding.all_gather_times(dist, torch.from_numpy(t).to(dev), counts)
         return t
 
@@ -295,7 +301,10 @@ def main():
         achieved = my_units * bps / kernel_s / 1e9 if kernel_s > 0 else 0.0
         pmc = pmc_record()
         traffic = valu = None
+        traffic_source = None
         if pmc:
+            traffic_source = {"file": "profiles/pmc_latest.json", "kernel_source_hash": pmc.get("kernel_source_hash"), "tree_hash": kernel_source_hash(),
+                              "collected_by": "tools/profile_bench.sh (rocprofv3 --pmc passes of this command)"}
             if pmc.get("fabric_bytes_per_solve"):
                 traffic = round(pmc["fabric_bytes_per_solve"] * my_units / launches)
             valu = pmc.get("valu_issue")
@@ -308,7 +317,7 @@ def main():
                        "grid": n, "units_per_step": total_units, "receivers_per_step": total_units * NREC,
                        "parallelism": "units sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_fim_sorted<256, compact> (coarse fixed-point solve)", "bytes_per_solve": bps,
                          "launches": int(acc["launches_fim_coarse"]),
                          "avg_launch_ms": round(acc["ms_fim_coarse"] / launches, 3),
@@ -325,10 +334,17 @@ def main():
             "value_incl_setup": round(solves / (dt + setup_ms / 1000.0), 2),
             "max_abs_err": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            rec, pick, ref_times = cpu_baseline()
-            line["cpu_baseline"] = rec
-            got = np.asarray(last, np.float32).reshape(total_units, NREC)[pick]
+        if not args.no_cpu_baseline:
+            # N = 1: the bounded CPU baseline (its times are the parity reference).  N > 1: no baseline line (contract), but the
+            # gathered vector is still checked against the reference on a smaller sample of units
+            rec, pick, ref_times = cpu_baseline(64 if world == 1 else 16)
+            if world == 1:
+                line["cpu_baseline"] = rec
+                line["vs_baseline"] = round(line["value"] / rec["value"], 1)
+                line["vs_baseline_note"] = "value / cpu_baseline.value: the %s on ONE host core of this box (%d cores present); BASELINE.md holds no published number" % (
+                    "reference's own Fortran" if rec["kind"] == "reference" else "C restatement of the reference", os.cpu_count() or 0)
+            last_host = last.detach().cpu().numpy() if hasattr(last, "detach") else np.asarray(last, np.float32)
+            got = np.asarray(last_host, np.float32).reshape(total_units, NREC)[pick]
             d = np.abs(got.astype(np.float64) - ref_times.astype(np.float64))
             line["max_abs_err"] = float(d.max())
             line["parity"] = {"checked_receiver_times": int(d.size), "units": int(len(pick)), "beyond_1e-4_s": int((d > TOL).sum()),

@@ -970,6 +970,21 @@ int dsa_solve(dsa_engine* e, float* dsurf)
     return reinterpret_cast<Engine*>(e)->solve(dsurf, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
+// the receiver times left on the device: d_dsurf is a device pointer (on the engine's device) to ndata floats; what the N-rank path
+// hands to the RCCL all-gather without a detour through the host (north_star: all-gather of the travel times over xGMI)
+int dsa_solve_device(dsa_engine* e, void* d_dsurf)
+{
+    if (!e || !d_dsurf) return DSA_ERR_ARGUMENT;
+    Engine* en = reinterpret_cast<Engine*>(e);
+    const int rc = en->solve(nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    if (rc != 0) return rc;
+    if (en->ndata == 0) return 0;
+    if (hipSetDevice(en->device) != hipSuccess ||
+        hipMemcpyAsync(d_dsurf, en->out.p, en->ndata * sizeof(float), hipMemcpyDeviceToDevice, en->stream) != hipSuccess ||
+        hipStreamSynchronize(en->stream) != hipSuccess) { en->fail(DSA_ERR_DEVICE, "solve_device: copy into the caller's device buffer failed"); return DSA_ERR_DEVICE; }
+    return 0;
+}
+
 int dsa_solve_rows(dsa_engine* e, float* dsurf, float* rw, int* iw, int* col, long long capacity, long long* nar)
 {
     if (!e || !nar) return DSA_ERR_ARGUMENT;

@@ -44,6 +44,7 @@ def load_library():
     L.dsa_set_maps.argtypes = [_vp, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _i32, _vp]
     L.dsa_plan.argtypes = [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
     L.dsa_solve.argtypes = [_vp, _vp]
+    L.dsa_solve_device.argtypes = [_vp, _vp]
     L.dsa_plan_units.argtypes = [_vp, _i32] + [_vp] * 9
     L.dsa_set_depth_kernels.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
     L.dsa_solve_rows.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_longlong, C.POINTER(C.c_longlong)]
@@ -140,6 +141,14 @@ class Engine:
         out = np.zeros(self._ndata, np.float32) if want_times else None
         self._check(self._L.dsa_solve(self._h, _p(out) if want_times else None))
         return out
+
+    def solve_device(self, device_ptr):
+        """solve; the receiver times (ndata float32) go to `device_ptr`, memory of this engine's GPU (e.g. tensor.data_ptr())"""
+        self._check(self._L.dsa_solve_device(self._h, C.c_void_p(int(device_ptr))))
+
+    @property
+    def ndata(self):
+        return self._ndata
 
     def set_depth_kernels(self, vels, depz, sen_vs, sen_vp, sen_rho):
         """vels: (nz, ny, nx) fp32 [Fortran vels(nx,ny,nz)]; sen_*: (nz, kmax, ny*nx) fp64 [Fortran (nx*ny, kmax, nz)]"""

@@ -117,6 +117,10 @@ int dsa_kernels_from_dispersion(dsa_engine* e);
  * one float per datum, unit-major order == the reference's (knumi, srcnum, istep) order). */
 int dsa_solve(dsa_engine* e, float* dsurf);
 
+/* dsa_solve with the receiver times left on the device: d_dsurf is a DEVICE pointer (memory of the engine's GPU, one float per
+ * datum).  For the multi-GPU path: the rank's slice goes into the RCCL all-gather straight from HBM (bench.py, sharding.py). */
+int dsa_solve_device(dsa_engine* e, void* d_dsurf);
+
 /* dsa_solve plus rays and Frechet rows (reference rpaths + row loop, CalSurfG.f90:1377-1432):
  * COO triplets in the reference's order -- rw[k] value, iw[k] 1-based row (datum), col[k]
  * 1-based column (k-1)*nvx*nvz + (jj-1)*nvx + kk -- *nar entries, at most `capacity`. */

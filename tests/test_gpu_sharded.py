@@ -43,7 +43,13 @@ def _worker(rank, world, port, q):
     pv = np.stack([synth.medium(NX, "smooth", p) for p in range(NPER)])
     e.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     e.plan(u["map_index"][lo:hi], u["scx"][lo:hi], u["scz"][lo:hi], u["nrec"][lo:hi], u["rcx"][lo * NREC:hi * NREC], u["rcz"][lo * NREC:hi * NREC])
-    mine = e.solve()
+    # the rank's slice stays on the device (dsa_solve_device), as on a multi-GPU node where it goes straight into the RCCL all-gather;
+    # here the ranks share GPU 0, RCCL cannot join two ranks of one device, so the collective itself runs over gloo on a host copy
+    buf = torch.empty(e.ndata, dtype=torch.float32, device="cuda:0")
+    e.solve_device(buf.data_ptr())
+    torch.cuda.synchronize()
+    mine = buf.cpu().numpy()
+    assert np.array_equal(mine.view(np.uint32), e.solve().view(np.uint32)), "dsa_solve_device differs from dsa_solve"
     e.close()
     full = sharding.all_gather_times(dist, torch.from_numpy(mine), sharding.ray_counts(u["nrec"], world))
     q.put((rank, full.numpy().copy()))

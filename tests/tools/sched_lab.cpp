@@ -75,7 +75,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     for (int ix = 0; ix < nnx; ++ix) for (int iz = 0; iz < nnz; ++iz)
         if (t_pinned(F[rec_index(nbz, iz, ix)].T)) { act(iz, ix - 1, 0.f); act(iz, ix + 1, 0.f); act(iz - 1, ix, 0.f); act(iz + 1, ix, 0.f); }
     cur.swap(next);
-    float theta = kInf; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, trips256 = 0, trips128 = 0;
+    float theta = kInf; long key_routed = 0; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, trips256 = 0, trips128 = 0;
     float wnow = window;
     float best_tmin = -kInf, freeze = -kInf; int stall = 0; long freezes = 0;
     unsigned hist[4] = { 1u, 2u, 3u, 4u }, hsh = 0u;
@@ -124,6 +124,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             if (tau_value(F[id].tau) < freeze) { queued[id] = 0; continue; }
             int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
             float lb = fminf(fminf(tv(iz0, ix0 - 1), tv(iz0, ix0 + 1)), fminf(tv(iz0 - 1, ix0), tv(iz0 + 1, ix0)));
+            if (!(theta < kInf) || key[id] < theta) ++key_routed;          // statistics: listings that the activator's acceptance time alone routes (no neighbour loads)
             if (mode == 5) lb = fmaxf(lb, fminf(key[id], kInf));            // lazy: route by the activator's acceptance time
             if (mode == 12) lb = key[id] * slot_w;                         // slot lower edge
             float lb2 = lb;
@@ -200,6 +201,6 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     }
     for (int ix = 0; ix < nnx; ++ix)
         for (int iz = 0; iz < nnz; ++iz) { const Rec r = F[rec_index(nbz, iz, ix)]; Tio[(size_t)ix * nnz + iz] = r.T; tauio[(size_t)ix * nnz + iz] = r.tau; }
-    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready; out[8] = trips256; out[9] = trips128;
+    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready; out[8] = trips256; out[9] = trips128; out[10] = key_routed;
     return cur.empty() ? 0 : -1;
 }
