@@ -10,9 +10,9 @@
 // How a serial algorithm is laid on a wavefront:
 //   * the tree lives in LDS (slots 1..lcap; deeper slots, if a front ever needs them, in global memory), each entry carrying
 //     its key and the node's record index, so a sift step is one LDS access and no field access;
-//   * per accept step, lanes 0..3 each own one neighbour of the accepted node: they fetch its nine-point neighbourhood
-//     (ten independent loads per lane, one memory round trip for the step) BEFORE the root is sifted down, and evaluate
-//     the stencil afterwards, so the tree work hides the memory latency;
+//   * per accept step, sixteen lanes own the four quadrants of the four neighbours of the accepted node: they fetch what their
+//     quadrant of the stencil needs (seven independent loads per lane, one memory round trip for the step) BEFORE the root is
+//     sifted down, and evaluate the stencil afterwards, so the tree work hides the memory latency;
 //   * a neighbour's tree slot fetched before the sift is stale when the step itself moved that entry; the slot is checked
 //     against the tree (one LDS read) and, when stale, looked up in the step's log of (node, slot) assignments in LDS by all
 //     lanes at once;
@@ -177,44 +177,153 @@ DSA_HD void x_pop_root(XMarch& m)
     xh_put(m, tpp, e);
 }
 
-// the nine-point neighbourhood of a neighbour (record nid, 1-based coordinates (nz, nx)) of the accepted node, as fetched
-// (before the step changes anything)
-struct XRaw { int in; int nid[8]; XRec own; XRec a[8]; float slown; float risti; };
-DSA_HD XRaw x_fetch(const XMarch& m, int id, int nz, int nx)
+// ---- trial values of the four neighbours, laid on sixteen lanes -----------------------------------------------------------
+// Lane 4 q + 2 j + k owns one quadrant (j: the x- / x+ side, k: the z- / z+ side) of neighbour q of the accepted node.  It fetches
+// the neighbour's own record and slowness and the four stencil records of its quadrant (seven loads instead of eleven, and the
+// sixteen lanes share their instructions), evaluates the candidates reference fouds2 (CalSurfG.f90:587-759) takes from that quadrant
+// -- the one-sided step from j when some z neighbour inside the grid is not alive, the one-sided step from k likewise, the two-sided
+// quadratic when both are alive, each by fouds2's own expression (eikonal_core.h) -- and the minimum over the four lanes of a
+// neighbour is its trial value (the minimum does not depend on the order).  tests/test_hostcheck.py compares the march built on this
+// with the oracle bit for bit; tests/hostcheck.cpp also compares x_trial_of_quads with fouds2 on random neighbourhoods.
+struct XQuad {
+    int in;                    // the neighbour lies inside the grid
+    int idj, idj2, idk, idk2;  // record indices of the quadrant's four stencil nodes (-1: outside the grid)
+    XRec own, rj, rj2, rk, rk2;
+    float slown, risti;
+};
+DSA_HD XQuad x_fetch_quad(const XMarch& m, int id, int nz, int nx, int j, int k)
 {
-    XRaw r;
+    XQuad r;
     r.in = nx >= 1 && nx <= m.nnx && nz >= 1 && nz <= m.nnz;
     r.own = XRec{ 0.0f, 0 }; r.slown = 1.0f; r.risti = 1.0f;
-    for (int q = 0; q < 8; ++q) { r.a[q] = XRec{ kInf, -1 }; r.nid[q] = -1; }
+    r.rj = r.rj2 = r.rk = r.rk2 = XRec{ kInf, -1 };
+    r.idj = r.idj2 = r.idk = r.idk2 = -1;
     if (!r.in) return r;
-    rec_stencil(m.nbz, id, r.nid);
-    const bool inq[8] = { nx > 1, nx < m.nnx, nz > 1, nz < m.nnz, nx > 2, nx + 1 < m.nnx, nz > 2, nz + 1 < m.nnz };
+    int nid[8];
+    rec_stencil(m.nbz, id, nid);
+    const bool inj = j ? nx < m.nnx : nx > 1, inj2 = j ? nx + 1 < m.nnx : nx > 2;
+    const bool ink = k ? nz < m.nnz : nz > 1, ink2 = k ? nz + 1 < m.nnz : nz > 2;
+    r.idj = inj ? (j ? nid[1] : nid[0]) : -1;   r.idj2 = inj2 ? (j ? nid[5] : nid[4]) : -1;
+    r.idk = ink ? (k ? nid[3] : nid[2]) : -1;   r.idk2 = ink2 ? (k ? nid[7] : nid[6]) : -1;
     r.own = m.F[id];
-    for (int q = 0; q < 8; ++q) { if (inq[q]) r.a[q] = m.F[r.nid[q]]; else r.nid[q] = -1; }
+    if (inj) r.rj = m.F[r.idj];
+    if (inj2) r.rj2 = m.F[r.idj2];
+    if (ink) r.rk = m.F[r.idk];
+    if (ink2) r.rk2 = m.F[r.idk2];
     r.slown = m.slow[id];
     r.risti = m.risti[nx - 1];
     return r;
 }
-// its trial value from the alive set, the node being accepted (root) included; reference fouds2 (CalSurfG.f90:587-759)
-DSA_HD float x_trial(const XMarch& m, const XRaw& r, XEntry root)
+// what a quadrant knows after the fetch: who is alive (the node being accepted counts, with its key as value) and the values
+struct XQuadState { bool ej, aj, oj, ek, ak, ok; float tj, tj2, tk, tk2; };
+DSA_HD XQuadState x_quad_state(const XQuad& r, XEntry root)
 {
-    bool al[8];
-    float t[8];
-    for (int q = 0; q < 8; ++q) {
-        const bool is_root = r.nid[q] == root.id;
-        al[q] = r.nid[q] >= 0 && (r.a[q].st == 0 || is_root);
-        t[q] = al[q] ? (is_root ? root.key : r.a[q].T) : kInf;
-    }
-    Stencil s;
-    for (int d = 0; d < 2; ++d) {
-        s.ej[d] = r.nid[d] >= 0;     s.aj[d] = al[d];     s.tj[d] = t[d];
-        s.oj[d] = al[4 + d];         s.tj2[d] = t[4 + d];
-        s.ek[d] = r.nid[2 + d] >= 0; s.ak[d] = al[2 + d]; s.tk[d] = t[2 + d];
-        s.ok[d] = al[6 + d];         s.tk2[d] = t[6 + d];
-    }
-    const NodeGeom g = { m.ri, r.risti, m.dnx, m.dnz };
-    return fouds2(s, r.slown, g);
+    XQuadState q;
+    const bool rj = r.idj == root.id, rj2 = r.idj2 == root.id, rk = r.idk == root.id, rk2 = r.idk2 == root.id;
+    q.ej = r.idj >= 0; q.ek = r.idk >= 0;
+    q.aj = q.ej && (r.rj.st == 0 || rj);           q.tj = q.aj ? (rj ? root.key : r.rj.T) : kInf;
+    q.oj = r.idj2 >= 0 && (r.rj2.st == 0 || rj2);  q.tj2 = q.oj ? (rj2 ? root.key : r.rj2.T) : kInf;
+    q.ak = q.ek && (r.rk.st == 0 || rk);           q.tk = q.ak ? (rk ? root.key : r.rk.T) : kInf;
+    q.ok = r.idk2 >= 0 && (r.rk2.st == 0 || rk2);  q.tk2 = q.ok ? (rk2 ? root.key : r.rk2.T) : kInf;
+    return q;
 }
+// the candidates of one quadrant; k_dead / j_dead: some z / x neighbour of the node inside the grid is not alive (both sides looked at)
+DSA_HD float x_quad_candidates(const XQuadState& s, bool k_dead, bool j_dead, float slown, const NodeGeom& g)
+{
+    const float ri = g.ri, risti = g.risti, dnx = g.dnx, dnz = g.dnz;
+    const float s2 = sq(slown);
+    const bool swj = s.ej && s.aj && s.oj && (s.tj > s.tj2);
+    const bool swk = s.ek && s.ak && s.ok && (s.tk > s.tk2);
+    float best = kInf;
+    if (k_dead && s.ej && s.aj) {
+        float trav;
+        if (swj) { const float u = 2.0f * ri * dnx; trav = div3((4.0f * s.tj - s.tj2) + sqrt_pos(sq(u) * s2)); }
+        else trav = s.tj + sqrt_pos(s2 * sq(ri) * sq(dnx));
+        best = (trav < best) ? trav : best;
+    }
+    if (j_dead && s.ek && s.ak) {
+        float trav;
+        if (swk) { const float u = 2.0f * risti * dnz; trav = div3((4.0f * s.tk - s.tk2) + sqrt_pos(sq(u) * s2)); }
+        else trav = s.tk + sqrt_pos(s2 * sq(risti) * sq(dnz));
+        best = (trav < best) ? trav : best;
+    }
+    if (s.ej && s.aj && s.ek && s.ak) {
+        float a, b, c, tref;
+        bool third = false;
+        if (swj) {
+            if (swk) {
+                const float u = 2.0f * ri * dnx;
+                const float v = 2.0f * risti * dnz;
+                float em = 4.0f * s.tj - s.tj2 - 4.0f * s.tk;
+                em = em + s.tk2;
+                a = sq(v) + sq(u);
+                b = 2.0f * em * sq(u);
+                c = sq(u) * (sq(em) - s2 * sq(v));
+                tref = 4.0f * s.tj - s.tj2;
+                third = true;
+            } else {
+                const float u = risti * dnz;
+                const float v = 2.0f * ri * dnx;
+                const float em = 3.0f * s.tk - 4.0f * s.tj + s.tj2;
+                a = sq(v) + 9.0f * sq(u);
+                b = 6.0f * em * sq(u);
+                c = sq(u) * (sq(em) - s2 * sq(v));
+                tref = s.tk;
+            }
+        } else {
+            if (swk) {
+                const float u = ri * dnx;
+                const float v = 2.0f * risti * dnz;
+                const float em = 3.0f * s.tj - 4.0f * s.tk + s.tk2;
+                a = sq(v) + 9.0f * sq(u);
+                b = 6.0f * em * sq(u);
+                c = sq(u) * (sq(em) - sq(v) * s2);
+                tref = s.tj;
+            } else {
+                const float u = ri * dnx;
+                const float v = risti * dnz;
+                const float em = s.tk - s.tj;
+                a = sq(u) + sq(v);
+                b = -(2.0f * sq(u) * em);
+                c = sq(u) * (sq(em) - sq(v) * s2);
+                tref = s.tj;
+            }
+        }
+        float rd1 = sq(b) - 4.0f * a * c;
+        if (rd1 < 0.0f) rd1 = 0.0f;
+        const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+        float trav = tref + tdsh;
+        if (third) trav = div3(trav);
+        best = (trav < best) ? trav : best;
+    }
+    return best;
+}
+// the trial value of a node from the states of its four quadrants (index 2 j + k); what the sixteen lanes compute, in one place
+// for the host (and for the comparison with fouds2 in tests/hostcheck.cpp)
+DSA_HD float x_trial_of_quads(const XQuadState* q4, float slown, const NodeGeom& g)
+{
+    const bool k_dead = (q4[0].ek && !q4[0].ak) || (q4[1].ek && !q4[1].ak);
+    const bool j_dead = (q4[0].ej && !q4[0].aj) || (q4[2].ej && !q4[2].aj);
+    float best = kInf;
+    for (int i = 0; i < 4; ++i) {
+        const float c = x_quad_candidates(q4[i], k_dead, j_dead, slown, g);
+        best = (c < best) ? c : best;
+    }
+    return best;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// exchange inside a group of four lanes: quad_perm [1,0,3,2] (the other k) and [2,3,0,1] (the other j)
+DSA_HD int x_dpp_other_k(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
+DSA_HD int x_dpp_other_j(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }
+DSA_HD float x_dpp_min4(float v)
+{
+    float o = __int_as_float(x_dpp_other_k(__float_as_int(v)));
+    v = (o < v) ? o : v;
+    o = __int_as_float(x_dpp_other_j(__float_as_int(v)));
+    return (o < v) ? o : v;
+}
+#endif
 
 // One accept step of reference travel (CalSurfG.f90:417-485): the root becomes alive, leaves the tree, and its four neighbours
 // x-, x+, z-, z+ (in that order) get a new trial value and enter the tree / move in it.
@@ -228,16 +337,16 @@ DSA_HD void x_accept_root(XMarch& m, XEntry root, int iz0, int ix0)
     float nb_trial[4];
 #if defined(__HIP_DEVICE_COMPILE__)
     const int lane = x_lane();
-    const int ql = lane & 3;
+    const int ql = (lane >> 2) & 3, jl = (lane >> 1) & 1, kl = lane & 1;
     const int mz = ql == 0 ? nzq[0] : ql == 1 ? nzq[1] : ql == 2 ? nzq[2] : nzq[3];
     const int mx = ql == 0 ? nxq[0] : ql == 1 ? nxq[1] : ql == 2 ? nxq[2] : nxq[3];
     const int mid = ql == 0 ? rid[0] : ql == 1 ? rid[1] : ql == 2 ? rid[2] : rid[3];
-    XRaw raw;
+    XQuad raw;
     raw.in = 0;
-    if (lane < 4) raw = x_fetch(m, mid, mz, mx);               // ten loads per lane in flight
+    if (lane < 16) raw = x_fetch_quad(m, mid, mz, mx, jl, kl);   // seven loads per lane in flight
 #else
-    XRaw raws[4];
-    for (int q = 0; q < 4; ++q) raws[q] = x_fetch(m, rid[q], nzq[q], nxq[q]);
+    XQuad raws[16];
+    for (int l = 0; l < 16; ++l) raws[l] = x_fetch_quad(m, rid[l >> 2], nzq[l >> 2], nxq[l >> 2], (l >> 1) & 1, l & 1);
 #endif
     m.nlog = 0;
     if (x_lane() == 0) m.F[root.id].st = 0;
@@ -245,19 +354,31 @@ DSA_HD void x_accept_root(XMarch& m, XEntry root, int iz0, int ix0)
 #if defined(__HIP_DEVICE_COMPILE__)
     float trial = kInf;
     int st = 0, in = 0;
-    if (lane < 4) {
+    if (lane < 16) {
         in = raw.in; st = raw.own.st;
-        if (in && st != 0) trial = x_trial(m, raw, root);
+        const XQuadState s = x_quad_state(raw, root);
+        // the other k of my j, the other j of my k: who is inside the grid and not alive
+        const int dk = (s.ek && !s.ak) ? 1 : 0, dj = (s.ej && !s.aj) ? 1 : 0;
+        const bool k_dead = dk || x_dpp_other_k(dk), j_dead = dj || x_dpp_other_j(dj);
+        const NodeGeom g = { m.ri, raw.risti, m.dnx, m.dnz };
+        float c = kInf;
+        if (in && st != 0) c = x_quad_candidates(s, k_dead, j_dead, raw.slown, g);
+        trial = x_dpp_min4(c);
     }
     for (int q = 0; q < 4; ++q) {
-        nb_in[q] = __builtin_amdgcn_readlane(in, q);
-        nb_st[q] = __builtin_amdgcn_readlane(st, q);
-        nb_trial[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(trial), q));
+        nb_in[q] = __builtin_amdgcn_readlane(in, 4 * q);
+        nb_st[q] = __builtin_amdgcn_readlane(st, 4 * q);
+        nb_trial[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(trial), 4 * q));
     }
 #else
     for (int q = 0; q < 4; ++q) {
-        nb_in[q] = raws[q].in; nb_st[q] = raws[q].own.st; nb_trial[q] = kInf;
-        if (nb_in[q] && nb_st[q] != 0) nb_trial[q] = x_trial(m, raws[q], root);
+        nb_in[q] = raws[4 * q].in; nb_st[q] = raws[4 * q].own.st; nb_trial[q] = kInf;
+        if (nb_in[q] && nb_st[q] != 0) {
+            XQuadState s4[4];
+            for (int i = 0; i < 4; ++i) s4[i] = x_quad_state(raws[4 * q + i], root);
+            const NodeGeom g = { m.ri, raws[4 * q].risti, m.dnx, m.dnz };
+            nb_trial[q] = x_trial_of_quads(s4, raws[4 * q].slown, g);
+        }
     }
 #endif
     for (int q = 0; q < 4; ++q) {

@@ -611,3 +611,47 @@ extern "C" int hc_exact_solve(int nx, int ny, float goxd, float gozd, float dvxd
         }
     return 0;
 }
+
+
+// the quadrant form of the stencil (exact_march.h: x_trial_of_quads, what the sixteen lanes of k_exact evaluate) against fouds2 on n
+// random neighbourhoods; returns the number of results whose bits differ
+extern "C" long hc_quads_compare(unsigned long long seed, long n)
+{
+    unsigned long long st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(st >> 33); };
+    auto uni = [&]() { return (float)(rnd() & 0xffffff) / 16777216.0f; };
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        NodeGeom g;
+        g.ri = 6371.0f - 40.0f * uni();
+        g.risti = g.ri * sinf(0.3f + 1.2f * uni());
+        g.dnx = 5e-5f + 6e-4f * uni();
+        g.dnz = (rnd() & 3) ? g.dnx * (0.7f + 0.6f * uni()) : g.dnx;
+        const float slown = 1.0f / (1.5f + 3.5f * uni());
+        const float hx = g.ri * g.dnx * slown, hz = g.risti * g.dnz * slown;
+        const float t0 = (rnd() & 7) ? 300.0f * uni() : 2.0f * uni();
+        Stencil s;
+        for (int d = 0; d < 2; ++d) {
+            const unsigned r = rnd();
+            s.ej[d] = (r & 15) != 0; s.ek[d] = ((r >> 4) & 15) != 0;
+            s.aj[d] = s.ej[d] && ((r >> 8) & 3) != 0; s.ak[d] = s.ek[d] && ((r >> 10) & 3) != 0;
+            s.oj[d] = s.aj[d] && ((r >> 12) & 3) != 0; s.ok[d] = s.ak[d] && ((r >> 14) & 3) != 0;
+            s.tj[d] = s.aj[d] ? t0 + hx * (2.4f * uni() - 1.2f) : kInf;
+            s.tk[d] = s.ak[d] ? t0 + hz * (2.4f * uni() - 1.2f) : kInf;
+            if ((r >> 16) & 1) { if (s.aj[d] && s.ak[d]) s.tk[d] = s.tj[d]; }          // ties
+            s.tj2[d] = s.oj[d] ? s.tj[d] + hx * (1.6f * uni() - 1.1f) : kInf;
+            s.tk2[d] = s.ok[d] ? s.tk[d] + hz * (1.6f * uni() - 1.1f) : kInf;
+            if (((r >> 17) & 7) == 0 && s.oj[d]) s.tj2[d] = s.tj[d];
+        }
+        XQuadState q4[4];
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+                XQuadState& q = q4[2 * j + k];
+                q.ej = s.ej[j]; q.aj = s.aj[j]; q.oj = s.oj[j]; q.tj = s.tj[j]; q.tj2 = s.tj2[j];
+                q.ek = s.ek[k]; q.ak = s.ak[k]; q.ok = s.ok[k]; q.tk = s.tk[k]; q.tk2 = s.tk2[k];
+            }
+        const float a = fouds2(s, slown, g), b = x_trial_of_quads(q4, slown, g);
+        if (std::memcmp(&a, &b, 4) != 0) { if (bad < 5) std::fprintf(stderr, "quadrant form differs at case %ld: %.9g vs %.9g\n", i, (double)a, (double)b); ++bad; }
+    }
+    return bad;
+}

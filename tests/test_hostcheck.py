@@ -35,6 +35,8 @@ def H():
     h.hc_device_schedule.restype = C.c_long
     h.hc_solve_node_compare.argtypes = [C.c_ulonglong, C.c_long, L.vp]
     h.hc_solve_node_compare.restype = C.c_long
+    h.hc_quads_compare.argtypes = [C.c_ulonglong, C.c_long]
+    h.hc_quads_compare.restype = C.c_long
     h.hc_exact_solve.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.f32, L.f32, L.i32, L.i32] + [L.vp] * 5
     return h
 
@@ -185,3 +187,8 @@ def test_exact_march_is_the_oracle_bit_for_bit(H, nx, kind, gd, lcap):
         assert (bits(Tr[:n].reshape(box[4], box[5])[alive]) != bits(o["Tr"][alive])).sum() == 0
         assert (bits(T) != bits(o["T"])).sum() == 0, (fx, fz)
         assert st[1] >= N * N - 300
+
+
+def test_quadrant_form_of_the_stencil_equals_fouds2(H):
+    """what the sixteen lanes of the exact mode evaluate (one quadrant each, minimum over four) == fouds2, bit for bit, on 5e6 random neighbourhoods"""
+    assert H.hc_quads_compare(20261003, 5_000_000) == 0
