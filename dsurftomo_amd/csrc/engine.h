@@ -64,6 +64,14 @@ struct Engine {
     int grown_nnx = 0, grown_nnz = 0;
     int exc_log2cap_grown = 0;         // ... and the size it grew to is kept for the later plans of this grid (an inversion solves the same geometry every iteration)
     DevBuf<int> seed_r, nseed_r, seed_c, nseed_c, lists, launch_rank;
+    // field slots of the coarse solve (kernels.h: FimEnds): T_c, exc_c and lists_c hold `pool_slots` slots; a launch with more units than
+    // slots recycles them (only when nobody needs the fields afterwards: no rows, no exact mode, no keep_fields)
+    DevBuf<int> lists_c, pool_gen;
+    DevBuf<FimEnds> ends_c;
+    size_t lists_c_stride = 0;
+    int pool_slots = 0;
+    int field_pool_opt = 0;            // option field_pool: 0 = automatic (four times the workgroups the chip holds), -1 = one slot per unit, > 0 = that many slots
+    size_t per_slot_bytes = 0;
     std::vector<int> h_launch_rank;
     size_t lists_stride = 0;
     int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)

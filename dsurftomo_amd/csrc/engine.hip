@@ -88,7 +88,7 @@ Engine::~Engine()
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
-    rel(disp_diag); rel(X_pool); rel(X_heap); rel(x_units); rel(xinfo); rel(tieinfo);
+    rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(X_pool); rel(X_heap); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -349,25 +349,40 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         if (!shape_c.sorted) { fail(DSA_ERR_ARGUMENT, "plan: a %d x %d grid needs %d bytes of LDS tile bitmap (limit 36 KB): the coarse solve has no other variant", g.nnx, g.nnz, shape_c.tile_words * 4); return DSA_ERR_ARGUMENT; }
         shape_c.compact = 1; shape_r.compact = 0;
         exc_log2cap = std::max(exc_log2cap_opt > 0 ? exc_log2cap_opt : exc_log2cap_of(g.nnx, g.nnz), exc_log2cap_grown);
-        const FimLaunch &lc = shape_c, &lr = shape_r;
-        lists_stride = std::max((size_t)4 * lc.list_cap + lc.ready_cap, (size_t)4 * lr.list_cap + lr.ready_cap);
-        lists_stride = std::max(lists_stride, (size_t)kFimMaskInts * g.nbx * g.nbz + lc.list_cap + lc.ready_cap + 2);   // ordered variant: tile records + one list
-        lists_stride = std::max(lists_stride, (size_t)kFimMaskInts * kRefTiles * kRefTiles + 2);
+        const FimLaunch &lr = shape_r;
+        lists_stride = std::max((size_t)4 * lr.list_cap + lr.ready_cap, (size_t)kFimMaskInts * kRefTiles * kRefTiles + 2);      // refined solve, per unit: list or tile-record variant
         lists_stride = (lists_stride + 1) & ~(size_t)1;      // the masks are 8-byte words
+        lists_c_stride = ((size_t)kFimMaskInts * g.nbx * g.nbz + 2 + 1) & ~(size_t)1;                                             // coarse solve, per field slot: tile records
     }
-    per_unit_bytes = nrec_c * 4 + ((size_t)8 << exc_log2cap) + (size_t)kCWinMax * kCWinMax * 8 + lists_stride * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
-                     (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(SourceDesc);
-    size_t c = budget / per_unit_bytes;
-    if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B)", budget, per_unit_bytes); return DSA_ERR_DEVICE; }
+    // what lives per field slot (the coarse field, its exception table, its tile records) and what lives per unit of a launch
+    per_slot_bytes = nrec_c * 4 + ((size_t)8 << exc_log2cap) + lists_c_stride * 4;
+    per_unit_bytes = (size_t)kCWinMax * kCWinMax * 8 + lists_stride * 4 + (size_t)kRefRecs * 12 + rr * 5 + kRefMax * 4 + (size_t)kSeedR * 4 + (size_t)kSeedC * 4 + kRWin * kRWin * 2 +
+                     (size_t)kCWinMax * kCWinMax * 3 + kHeapCap * 4 + 256 + sizeof(FimProblem) * 2 + sizeof(FimEnds) + sizeof(SourceDesc);
+    {
+        // field slots: by default four times the workgroups the chip holds at once (256 CUs, up to four workgroups each), never more than the units,
+        // within 70 % of the budget; keep_fields or option field_pool = -1: a slot per unit
+        const int resident = 256 * std::max(1, std::min(4, 1024 / std::max(shape_c.threads, 1)));
+        size_t P = field_pool_opt > 0 ? (size_t)field_pool_opt : (size_t)4 * resident;
+        if (field_pool_opt < 0 || keep_fields) P = (size_t)std::max(nunits, 1);
+        P = std::min<size_t>(P, (size_t)std::max(nunits, 1));
+        if (max_chunk > 0) P = std::min<size_t>(P, (size_t)max_chunk);
+        const size_t fit = (size_t)(0.7 * (double)budget) / per_slot_bytes;
+        if (fit < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one coarse field slot (%zu B)", budget, per_slot_bytes); return DSA_ERR_DEVICE; }
+        if (keep_fields && fit < P) { fail(DSA_ERR_CAPACITY, "plan: keep_fields is set but only %zu of the %d units' fields fit the memory budget", fit, nunits); return DSA_ERR_CAPACITY; }
+        pool_slots = (int)std::min(P, fit);
+    }
+    size_t c = (budget - (size_t)pool_slots * per_slot_bytes) / per_unit_bytes;
+    if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B per unit + %zu B per field slot)", budget, per_unit_bytes, per_slot_bytes); return DSA_ERR_DEVICE; }
     chunk = (int)std::min<size_t>(c, (size_t)std::max(nunits, 1));
     if (max_chunk > 0) chunk = std::min(chunk, max_chunk);
-    if (keep_fields && chunk < nunits) { fail(DSA_ERR_CAPACITY, "plan: keep_fields is set but only %d of the %d units fit one resident chunk (memory budget / max_chunk)", chunk, nunits); return DSA_ERR_CAPACITY; }
+    if (keep_fields && (chunk < nunits || pool_slots < nunits)) { fail(DSA_ERR_CAPACITY, "plan: keep_fields is set but only %d of the %d units fit one resident chunk (memory budget / max_chunk)", std::min(chunk, pool_slots), nunits); return DSA_ERR_CAPACITY; }
     const size_t C = (size_t)chunk;
-    if (ensure(lists, C * lists_stride) || ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(ndata, 1)) || ensure(trace_ids, std::max<size_t>(h_trace.size(), 1)) || ensure(err, 4) ||
+    const size_t PS = (size_t)pool_slots;
+    if (ensure(lists, C * lists_stride) || ensure(lists_c, PS * lists_c_stride) || ensure(pool_gen, PS) || ensure(ends_c, C) || ensure(src, C) || ensure(rays, std::max<size_t>(nr, 1)) || ensure(out, std::max<size_t>(ndata, 1)) || ensure(trace_ids, std::max<size_t>(h_trace.size(), 1)) || ensure(err, 4) ||
         ensure(slow_r, C * kRefRecs) || ensure(F_r, C * kRefRecs) || ensure(Tfin_r, C * rr) || ensure(S_r, C * rr) ||
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
-        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, C * nrec_c) || ensure(exc_c, C << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
+        ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, PS * nrec_c) || ensure(exc_c, PS << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
         ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8) ||
         ensure(tieinfo, C * 4) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
     h_unit_flags.assign((size_t)nunits, 0);
@@ -388,6 +403,7 @@ BatchPtrs Engine::batch() const
     b.vcorner = vcorner.p; b.seed_r = seed_r.p; b.nseed_r = nseed_r.p; b.rst = rst.p; b.cst = cst.p; b.cinit = cinit.p;
     b.heap = heap.p; b.flags = flags.p; b.T_c = T_c.p; b.exc_c = exc_c.p; b.exc_log2cap = exc_log2cap; b.W_c = W_c.p; b.seed_c = seed_c.p; b.nseed_c = nseed_c.p;
     b.lists = lists.p; b.lists_stride = lists_stride;
+    b.lists_c = lists_c.p; b.lists_c_stride = lists_c_stride; b.pool = pool_slots; b.pool_gen = pool_gen.p;
     return b;
 }
 
@@ -410,8 +426,15 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
       std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
       stats[DSA_STAT_MS_DISPERSION] = keep_ms; stats[DSA_STAT_CURVES] = keep_n; }
     std::fill(phase_ticks, phase_ticks + 8, 0.0);
+    // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
+    // the solve (rays and rows, the exact mode, keep_fields) a launch takes one unit per slot
+    const bool may_recycle = !rows && exact_ties == 0 && !keep_fields;
+    const int step = may_recycle ? chunk : std::min(chunk, pool_slots);
+    const bool fused_times = exact_ties == 0;          // the coarse solve writes its unit's receiver times itself
     stats[DSA_STAT_UNITS] = nunits;
-    stats[DSA_STAT_CHUNK] = chunk;
+    stats[DSA_STAT_CHUNK] = step;
+    stats[DSA_STAT_FIELD_SLOTS] = pool_slots;
+    stats[DSA_STAT_FOOTPRINT_MB] = ((double)pool_slots * (double)per_slot_bytes + (double)chunk * (double)per_unit_bytes) / 1.0e6;
     // causal window: a few cells' worth of travel time (narrowest cell, fastest velocity of the model)
     const float cell_c = dpl * hmin_slow;
     const float window_c = window_cells * cell_c;
@@ -420,8 +443,8 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     HIP_TRY(this, hipMemsetAsync(err.p, 0, 4 * sizeof(int32_t), stream));
     HIP_TRY(this, hipEventRecord(events[0], stream));
     std::vector<int32_t> h_info, h_flags;
-    for (int first = 0; first < nunits; first += chunk) {
-        const int n = std::min(chunk, nunits - first);
+    for (int first = 0; first < nunits; first += step) {
+        const int n = std::min(step, nunits - first);
         bool redo_chunk = false;
       do {
         redo_chunk = false;
@@ -429,8 +452,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipMemcpyAsync(src.p, h_src.data() + first, (size_t)n * sizeof(SourceDesc), hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipMemcpyAsync(risti_r.p, h_risti_r.data() + (size_t)first * kRefMax, (size_t)n * kRefMax * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(this, hipEventRecord(events[1], stream));
-        launch_fill(T_c.p, (size_t)n * nrec_c, kInf, stream);                                   // every node unreached
-        launch_fill64(exc_c.p, (size_t)n << exc_log2cap, kExcEmpty, stream);                      // exception tables empty
+        HIP_TRY(this, hipMemsetAsync(pool_gen.p, 0, (size_t)pool_slots * sizeof(int), stream));       // (the coarse solve itself resets its field slot: FimEnds)
         {   // Launch order of the coarse solves: a launch ends with its slowest workgroups, and the rounds of a solve grow with the
             // distance from the source to the farthest corner of the grid, so the units with the longest fronts get the lowest
             // workgroup numbers (dispatched first) and the short ones fill the tail.
@@ -448,7 +470,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         }
         const bool detect = exact_ties == 1;
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
-                             detect ? tieinfo.p : nullptr, tie_threshold, stream);
+                             detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         FimLaunch sr = shape_r, sc = shape_c;
         sr.tie = sc.tie = detect ? 1 : 0;
@@ -461,7 +483,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
         }
         HIP_TRY(this, hipEventRecord(events[4], stream));
-        if (exact_ties != 2) launch_fim(prob_c.p, n, sc, stream);
+        if (exact_ties != 2) launch_fim(prob_c.p, n, sc, stream, ends_c.p);
         HIP_TRY(this, hipEventRecord(events[5], stream));
         if (exact_ties) {
             // which units go through the literal march: all (2), or those whose fixed point met a tie / froze a cycle (1)
@@ -491,7 +513,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         // receivers of this chunk
         const int r0 = h_src[first].first_ray;
         const int r1 = h_src[first + n - 1].first_ray + h_src[first + n - 1].nrec;
-        if (r1 > r0) launch_srtimes_chunk(r0, r1 - r0, first);
+        if (!fused_times && r1 > r0) launch_srtimes_chunk(r0, r1 - r0, first);
         HIP_TRY(this, hipEventRecord(events[6], stream));
         HIP_TRY(this, hipGetLastError());
         h_info.resize((size_t)n * 16);
@@ -519,22 +541,20 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipEventElapsedTime(&d, events[5], events[6]));
         stats[DSA_STAT_MS_STAGES] += a + c2 + d;
         stats[DSA_STAT_LAUNCHES_FIM_COARSE] += 1;
-        last_chunk_first = first;
-        last_chunk_n = n;
         for (int u = 0; u < n; ++u) {      // the exception table first: a solve that ran out of table space may also have run out of rounds
             const int32_t* fi = &h_info[(size_t)u * 16];
             if (fi[10] != -2) continue;
             // more nodes off the causal order than the table holds: four times the table and the chunk once more
-            const size_t grown_bytes = (size_t)chunk * (((size_t)8 << (exc_log2cap + 2)) - ((size_t)8 << exc_log2cap));
+            const size_t grown_bytes = (size_t)pool_slots * (((size_t)8 << (exc_log2cap + 2)) - ((size_t)8 << exc_log2cap));
             size_t free_b = 0, total_b = 0;
             HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
-            if (exc_log2cap + 2 > 26 || grown_bytes + ((size_t)chunk << exc_log2cap) * 8 > free_b || ensure(exc_c, (size_t)chunk << (exc_log2cap + 2))) {
+            if (exc_log2cap + 2 > 26 || grown_bytes + ((size_t)pool_slots << exc_log2cap) * 8 > free_b || ensure(exc_c, (size_t)pool_slots << (exc_log2cap + 2))) {
                 fail(DSA_ERR_INTERNAL, "unit %d: the exception table of the compact field overflowed (%d entries) and cannot grow", first + u, 1 << exc_log2cap);
                 return DSA_ERR_INTERNAL;
             }
             exc_log2cap += 2;
             exc_log2cap_grown = exc_log2cap;
-            per_unit_bytes += grown_bytes / (size_t)chunk;
+            per_slot_bytes += grown_bytes / (size_t)pool_slots;
             stats[DSA_STAT_RESCANS] += 1;
             redo_chunk = true;
             break;
@@ -553,7 +573,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
         }
-        last_chunk_first = first;
+        last_chunk_first = n <= pool_slots ? first : -1;       // (recycled slots: the fields are gone)
         last_chunk_n = n;
         if (rows && trace_chunk(first, n, rw, iw, col, cap, nar) != 0) return status;
       } while (redo_chunk);
@@ -869,6 +889,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "exc_log2cap" && (value == 0 || (value >= 6 && value <= 24))) { en->planned = false; en->exc_log2cap_opt = (int)value; return 0; }
     if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
+    if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
     if (n == "exact_lds_slots" && value >= 64 && value <= 8000) { en->exact_lds_slots = (int)value; return 0; }

@@ -25,6 +25,7 @@
 //     read a torn or stale state this round has its bit clear and is therefore re-queued;
 //   * the fixed point is schedule independent, so races only cost re-evaluations.
 #include "kernels.h"
+#include "receiver_core.h"
 
 namespace dsa {
 
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 typedef __attribute__((address_space(1))) unsigned long long GU64;
 
 template <int NT, bool COMPACT, bool TIE>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVES, DSA_FIM_WAVES))) void k_fim_sorted(const FimProblem* __restrict__ problems, int cap, int rcap)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVES, DSA_FIM_WAVES))) void k_fim_sorted(const FimProblem* __restrict__ problems, int cap, int rcap, const FimEnds* __restrict__ ends)
 {
     extern __shared__ unsigned dyn_lds[];
     __shared__ int smem[SC_COUNT];
@@ -471,6 +472,43 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         *iz0 = (int)(bz << kTileShift) + rec_iz_in_tile(id);
     };
 
+    bool dead = false;                                       // an error before the first round: skip the rounds, still hand the slot on
+    if (COMPACT && ends) {
+        // The field slot (FimEnds): wait for its previous user, then every node unreached, the exception table empty, and the nodes the
+        // serial prologue pinned (window records) into both.  All by this workgroup, in this order.
+        const FimEnds* const E = ends + blockIdx.x;
+        int* const pg = E->pool_gen;
+        if (pg) {
+            if (tid == 0) { const int want = E->gen; while (__hip_atomic_load(pg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(64); }
+            __syncthreads();
+        }
+        typedef float __attribute__((ext_vector_type(4))) V4;
+        typedef __attribute__((address_space(1))) V4 GV4;
+        const V4 inf4 = { kInf, kInf, kInf, kInf };
+        for (int i = tid; i < ntile * (kTileRecs / 4); i += NT) ((GV4*)Fb)[i] = inf4;
+        for (int i = tid; i < (1 << xlog); i += NT) *exc_at((unsigned)i) = kExcEmpty;
+        __threadfence_block();
+        __syncthreads();
+        typedef __attribute__((address_space(1))) const Rec GCRec;
+        GCRec* const W = (GCRec*)E->W;
+        const int cwz0 = E->cwz0, cwx0 = E->cwx0, cwnz = E->cwnz, nw = E->cwnx * cwnz;
+        for (int q = tid; q < nw; q += NT) {
+            const float wt = W[q].T, wk = W[q].tau;
+            if (!t_pinned(wt)) continue;
+            const int lx = q / cwnz, lz = q - lx * cwnz;
+            const int id = rec_index(nbz, cwz0 + lz, cwx0 + lx);
+            const unsigned long long mine = exc_pack(id | kExcPinned, wk);
+            const unsigned mask = (1u << xlog) - 1u;
+            unsigned h = exc_hash(id, xlog);
+            bool placed = false;
+            for (unsigned n = 0; n <= mask && !placed; ++n, h = (h + 1u) & mask)
+                placed = atomicCAS((unsigned long long*)exc_at(h), kExcEmpty, mine) == kExcEmpty;      // (every node is inserted once: no key to match)
+            if (!placed) { p.info[2] = -2; }
+            *tc(id) = wt;                                   // -T: the sign bit marks the exceptional node
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int i = tid; i < (ntile << (kMaskShift - 3)); i += NT) *(GU64*)(maskb + ((size_t)i << 3)) = 0ull;
     for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
     if (tid == 0) {
@@ -479,8 +517,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     }
     __syncthreads();
     const int nseed = *p.seed_count;
-    if (COMPACT && nseed > p.seed_cap) { if (tid == 0) p.info[2] = -1; return; }        // (cannot happen: kSeedC covers the march window)
-    if (nseed <= p.seed_cap) {
+    if (COMPACT && nseed > p.seed_cap) { if (tid == 0) p.info[2] = -1; dead = true; }   // (cannot happen: kSeedC covers the march window)
+    else if (nseed <= p.seed_cap) {
         for (int i = tid; i < nseed; i += NT) {
             const int id = p.seed[i];
             if (!COMPACT) atomicAnd((unsigned*)&rec(id)->tau, ~kQueuedBit);
@@ -546,7 +584,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #define DSA_PRIO_S 0     // pass B: solve_node
 #define DSA_PRIO_W 1     // pass B: store, activation
 #endif
-    for (;;) {
+    for (; !dead;) {
         const float theta = u2f((unsigned)sc[SC_THETA]);
         const bool open = !(theta < kInf);
         const float freeze = u2f((unsigned)sc[SC_FREEZE]);
@@ -941,6 +979,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         if (tid == 0) p.clocks[4] = wall_clock64() - bstart;
     }
 #endif
+    if (COMPACT && ends) {
+        // the unit's receiver times from its own field (reference srtimes), then the slot goes to the next unit
+        const FimEnds* const E = ends + blockIdx.x;
+        if (E->rays) {
+            __threadfence_block();
+            __syncthreads();
+            const GridDesc g = E->g;
+            for (int r = tid; r < E->nrays; r += NT) {
+                const RayDesc rd = E->rays[r];
+                if (!(rd.flags & kRayTime)) continue;
+                float t;
+                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)p.Tc, E->veln, E->dpl, &t)) atomicExch(E->err, E->ray0 + r + 1);
+                E->out[rd.data] = t;
+            }
+        }
+        if (E->pool_gen) {
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(E->pool_gen, E->gen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (tid == 0) {
         p.info[0] = rounds; p.info[1] = 0; p.info[3] = freezes;
 #ifdef DSA_PHASE_CLOCKS
@@ -955,12 +1014,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 size_t fim_lds_bytes(const FimLaunch& l) { return (l.sorted ? (size_t)l.tile_words * 4 : 0) + (size_t)l.lds_pad; }
 
 
-void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream)
+void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream, const FimEnds* d_ends)
 {
     if (nproblems <= 0) return;
     if (l.sorted) {
         const size_t lds = fim_lds_bytes(l);
-#define DSA_LAUNCH_SORTED_T(NT, C, T) hipLaunchKernelGGL((k_fim_sorted<NT, C, T>), dim3(nproblems), dim3(NT), lds, stream, d_problems, l.list_cap, l.ready_cap)
+#define DSA_LAUNCH_SORTED_T(NT, C, T) hipLaunchKernelGGL((k_fim_sorted<NT, C, T>), dim3(nproblems), dim3(NT), lds, stream, d_problems, l.list_cap, l.ready_cap, d_ends)
 #define DSA_LAUNCH_SORTED(NT, C) do { if (l.tie) DSA_LAUNCH_SORTED_T(NT, C, true); else DSA_LAUNCH_SORTED_T(NT, C, false); } while (0)
         if (l.compact) {
             if (l.threads == 128) DSA_LAUNCH_SORTED(128, true); else if (l.threads == 256) DSA_LAUNCH_SORTED(256, true);

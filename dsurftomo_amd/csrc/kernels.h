@@ -8,6 +8,11 @@
 
 namespace dsa {
 
+// data = 0-based index of the datum (travel time / Frechet row) a ray belongs to;
+// flags: kRayTime = write the receiver time, kRayPath = trace the ray and emit its row
+struct RayDesc { int src; float rx, rz; float sin_rx; int data; int flags; };   // sin_rx = libm sinf(rx), made on the host
+constexpr int kRayTime = 1, kRayPath = 2;
+
 // One fixed-point problem: a travel-time field on an (nnz, nnx) grid stored as tiled (T, tau)
 // records (eikonal_core.h).  The records carry the boundary condition: pinned nodes (sign bit of T)
 // are never recomputed, every other node starts at +inf.  `seed` lists the record indices to
@@ -33,6 +38,27 @@ struct FimProblem {
     float tie_threshold;
 };
 
+// What the COARSE solve does around its fixed point: the workgroup owns its unit's field slot from the first store to the last read.
+//   start: (recycled slots) wait until the previous user of the slot is done; every node unreached (+inf), exception table empty, the
+//          serial prologue's pinned nodes (records of the coarse march window, k_coarse_march) into the field and the table;
+//   end:   the unit's receiver times (reference srtimes) when `rays` is set -- the field is then not needed by anyone else -- and the
+//          slot is handed on.
+// Round 3: this replaces the global fill of all fields before the launch (67 GB per step at the headline size) and lets a launch
+// of 16 000 units run on a pool of a few thousand field slots.
+struct FimEnds {
+    const Rec* W;            // window records, (cwnz, cwnx) column-major
+    int cwz0, cwx0, cwnz, cwnx;
+    int* pool_gen;           // the slot's use counter; null: the slot is this unit's alone
+    int gen;                 // the slot is free for this unit when *pool_gen == gen; gen + 1 is stored when the unit is done
+    const RayDesc* rays;     // the unit's receivers; null: the receiver kernel (k_srtimes) runs after the launch
+    int nrays, ray0;         // ray0: index of the first of them in the plan (error reporting)
+    const float* veln;       // row-major velocity grid of the unit's period
+    float scx, scz, dpl;
+    float* out;
+    int32_t* err;
+    GridDesc g;
+};
+
 #ifndef DSA_ODD_CLEAR
 #define DSA_ODD_CLEAR 1            // fim_kernel.hip: 1 = tile records {E, O, R, round} (default), 0 = one mask per tile (see there)
 #endif
@@ -50,7 +76,7 @@ struct FimLaunch {
 };
 
 size_t fim_lds_bytes(const FimLaunch& l);
-void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream);
+void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream, const FimEnds* d_ends = nullptr);
 
 // period-level tables ---------------------------------------------------------------------------
 // velv: fp32 vertex values (ny, nx); basis: (gd+1) x 4; outputs veln (nnz, nnx row-major, for the
@@ -76,7 +102,12 @@ struct BatchPtrs {
     int exc_log2cap;
     Rec* W_c;                    // (T, tau) records of the coarse march window, stride kCWinMax*kCWinMax
     int* seed_c; int* nseed_c;   // stride kSeedC / 1
-    int* lists; size_t lists_stride;   // active-list scratch, shared by the refined and the coarse solve
+    int* lists; size_t lists_stride;   // active-list scratch of the refined solve, per unit
+    int* lists_c; size_t lists_c_stride;   // tile records of the coarse solve, per field slot
+    // field slots of the coarse solve: T_c / exc_c / lists_c hold `pool` slots; pool >= units of the launch: unit s owns slot s for the whole
+    // chunk; fewer: workgroup r of the launch takes slot r % pool after workgroup r - pool has finished (slot counters pool_gen)
+    int pool;
+    int* pool_gen;
 };
 constexpr int kSeedR = kRWin * kRWin;              // the start-up march cannot pin more than its window
 constexpr int kSeedC = kCWinMax * kCWinMax + 4 * kCWinMax;    // every node of the window at most once, plus its outer rim
@@ -92,7 +123,8 @@ void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
-                          const int* d_launch_rank, int32_t* d_tie, float tie_threshold, hipStream_t stream);
+                          const int* d_launch_rank, int32_t* d_tie, float tie_threshold, FimEnds* d_ends_c, const RayDesc* d_rays /* null: no receiver times inside the solve */,
+                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, hipStream_t stream);
 
 // exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), one wavefront each,
 // workgroup j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per slot beyond the lcap in LDS);
@@ -103,10 +135,6 @@ void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int
                   hipStream_t stream);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
-// data = 0-based index of the datum (travel time / Frechet row) this ray belongs to;
-// flags: kRayTime = write the receiver time, kRayPath = trace the ray and emit its row
-struct RayDesc { int src; float rx, rz; float sin_rx; int data; int flags; };   // sin_rx = libm sinf(rx), made on the host
-constexpr int kRayTime = 1, kRayPath = 2;
 // RayDesc::src is a global unit index; unit_base is the first unit held by the batch arrays
 void launch_srtimes(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, int nrays,
                     const float* d_veln_all, size_t field_stride, float dpl, float* d_out, int32_t* d_err,

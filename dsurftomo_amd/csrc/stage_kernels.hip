@@ -1,6 +1,7 @@
 // Kernels around the fixed-point solve: period-level velocity tables, the per-source stages of
 // source_stage.h, and the receiver gather.  See kernels.h for the data layout.
 #include "kernels.h"
+#include "receiver_core.h"
 
 namespace dsa {
 
@@ -253,8 +254,6 @@ __global__ __launch_bounds__(64) void k_coarse_march(GridDesc g, BatchPtrs b, in
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
     Rec* W = b.W_c + (size_t)s * kCWinMax * kCWinMax;
-    float* T_c = b.T_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
-    unsigned long long* exc = b.exc_c + ((size_t)s << b.exc_log2cap);
     const float* slow_c = slow_all + (size_t)sd.period * field_stride;      // tiled slowness of this period
     const int nw = sd.cwnx * sd.cwnz;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -283,24 +282,8 @@ __global__ __launch_bounds__(64) void k_coarse_march(GridDesc g, BatchPtrs b, in
     __threadfence_block();
     if (lane == 0) band_march_run(m, sd, w, ninit);
     __threadfence_block();
-    // pinning and export: the window's alive nodes into the compact field (+inf everywhere on entry) and its exception table
-    bool ok = true;
-    for (int q = lane; q < nw; q += 64) {
-        band_march_finish_node(w, W, q);
-        const Rec r = W[q];
-        if (!t_pinned(r.T)) continue;
-        const int lx = q / sd.cwnz, lz = q - lx * sd.cwnz;
-        const int id = rec_index(g.nbz, sd.cwz0 + lz, sd.cwx0 + lx);
-        const unsigned long long mine = exc_pack(id | kExcPinned, r.tau);
-        const unsigned mask = (1u << b.exc_log2cap) - 1u;
-        unsigned h = exc_hash(id, b.exc_log2cap);
-        bool placed = false;
-        for (unsigned n = 0; n <= mask && !placed; ++n, h = (h + 1u) & mask)
-            placed = atomicCAS(exc + h, kExcEmpty, mine) == kExcEmpty;      // (every node is inserted once: no key to match)
-        ok = ok && placed;
-        T_c[id] = r.T;                                      // -T: the sign bit marks the exceptional node
-    }
-    if (!ok) w.flags[1] = 32;
+    // pinning: the window's alive nodes get their sign bit; the coarse solve carries them into its field slot and exception table (FimEnds)
+    for (int q = lane; q < nw; q += 64) band_march_finish_node(w, W, q);
     // seeds of the fixed-point solve: every node of the grid that is not itself pinned and has a pinned neighbour; they lie in the
     // window or in the ring around it, so each candidate is looked at by one lane and listed once
     int* seed = b.seed_c + (size_t)s * kSeedC;
@@ -339,7 +322,8 @@ void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const 
 __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* slow_all, size_t field_stride,
                                 const float* risti_c, float window_r, float window_c, FimProblem* prob_r,
                                 FimProblem* prob_c, int32_t* info, unsigned long long* clocks, const int* __restrict__ launch_rank,
-                                int32_t* tie, float tie_threshold)
+                                int32_t* tie, float tie_threshold, FimEnds* ends_c, const RayDesc* __restrict__ rays, const float* __restrict__ veln_all,
+                                size_t veln_stride, float dpl, float* out, int32_t* err)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -355,18 +339,30 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     r.info = info + (size_t)s * 16;
     r.tie = tie ? tie + (size_t)s * 4 : nullptr; r.tie_threshold = tie_threshold;
     prob_r[s] = r;
+    // field slot: the unit's own, or (a pool smaller than the launch) the one its workgroup number selects
+    const int rank = launch_rank ? launch_rank[s] : s;
+    const bool recycled = b.pool < nsrc;
+    const int slot = recycled ? rank % b.pool : s;
     FimProblem c;
     c.F = nullptr;
-    c.Tc = b.T_c + (size_t)s * g.nbx * g.nbz * kTileRecs; c.exc = b.exc_c + ((size_t)s << b.exc_log2cap); c.exc_log2cap = b.exc_log2cap;
+    c.Tc = b.T_c + (size_t)slot * g.nbx * g.nbz * kTileRecs; c.exc = b.exc_c + ((size_t)slot << b.exc_log2cap); c.exc_log2cap = b.exc_log2cap;
     c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
-    c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.seed_cap = kSeedC; c.lists = b.lists + (size_t)s * b.lists_stride;
+    c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.seed_cap = kSeedC; c.lists = b.lists_c + (size_t)slot * b.lists_c_stride;
     c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
     c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = window_c;
     c.max_rounds = 64 * (g.nnx + g.nnz) + 4096;
     c.clocks = clocks ? clocks + (size_t)s * 8 : nullptr;
     c.info = info + (size_t)s * 16 + 8;
     c.tie = tie ? tie + (size_t)s * 4 + 2 : nullptr; c.tie_threshold = tie_threshold;
-    prob_c[launch_rank ? launch_rank[s] : s] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
+    prob_c[rank] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
+    if (ends_c) {
+        FimEnds e;
+        e.W = b.W_c + (size_t)s * kCWinMax * kCWinMax; e.cwz0 = sd.cwz0; e.cwx0 = sd.cwx0; e.cwnz = sd.cwnz; e.cwnx = sd.cwnx;
+        e.pool_gen = recycled ? b.pool_gen + slot : nullptr; e.gen = recycled ? rank / b.pool : 0;
+        e.rays = rays ? rays + sd.first_ray : nullptr; e.nrays = sd.nrec; e.ray0 = sd.first_ray;
+        e.veln = veln_all + (size_t)sd.period * veln_stride; e.scx = sd.scx; e.scz = sd.scz; e.dpl = dpl; e.out = out; e.err = err; e.g = g;
+        ends_c[rank] = e;
+    }
     for (int q = 0; q < 16; ++q) info[(size_t)s * 16 + q] = 0;
     if (tie) for (int q = 0; q < 4; ++q) tie[(size_t)s * 4 + q] = 0;
     if (clocks) for (int q = 0; q < 8; ++q) clocks[(size_t)s * 8 + q] = 0ull;      // probe builds accumulate into them
@@ -375,11 +371,13 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
-                          const int* d_launch_rank, int32_t* d_tie, float tie_threshold, hipStream_t stream)
+                          const int* d_launch_rank, int32_t* d_tie, float tie_threshold, FimEnds* d_ends_c, const RayDesc* d_rays,
+                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, hipStream_t stream)
 {
     if (nsrc <= 0) return;
     hipLaunchKernelGGL(k_make_problems, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all,
-                       field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks, d_launch_rank, d_tie, tie_threshold);
+                       field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks, d_launch_rank, d_tie, tie_threshold,
+                       d_ends_c, d_rays, d_veln_all, veln_stride, dpl, d_out, d_err);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,55 +394,8 @@ __global__ void k_srtimes(GridDesc g, BatchPtrs b, int unit_base, const RayDesc*
     const SourceDesc sd = b.src[slot];
     const float* Tc = b.T_c + (size_t)slot * g.nbx * g.nbz * kTileRecs;
     const float* veln = veln_all + (size_t)sd.period * field_stride;
-    const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, earth = g.earth;
-    const float rcx1 = rd.rx, rcz1 = rd.rz, scx = sd.scx, scz = sd.scz;
-    int irx = (int)((rcx1 - gox) / dnx) + 1;
-    int irz = (int)((rcz1 - goz) / dnz) + 1;
-    if (irx < 1 || irx > g.nnx || irz < 1 || irz > g.nnz) { atomicExch(err, r + 1); out[rd.data] = 0.0f; return; }
-    if (irx == g.nnx) irx -= 1;
-    if (irz == g.nnz) irz -= 1;
-    const int isx = (int)((scx - gox) / dnx) + 1;
-    const int isz = (int)((scz - goz) / dnz) + 1;
-    float sred = sq((scx - rcx1) * earth);
-    sred = sred + sq((scz - rcz1) * earth * rd.sin_rx);
-    sred = sqrtf(sred);
-    bool nearsrc = sred < dpl;
-    if (isx == irx && isz == irz) nearsrc = true;
     float trr;
-    const size_t ld = g.nnz;
-    if (nearsrc) {
-        // The reference does not clamp the source cell here (CalSurfG.f90:1703-1704), so a source on
-        // the last node row/column makes it read one node past the grid.  Clamp the read instead.
-        float vss[2][2];
-        for (int k = 1; k <= 2; ++k)
-            for (int l = 1; l <= 2; ++l) {
-                const int cx = min(isx - 1 + k - 1, g.nnx - 1), cz = min(isz - 1 + l - 1, g.nnz - 1);
-                vss[k - 1][l - 1] = veln[(size_t)cx * ld + cz];
-            }
-        float drx = (scx - gox) - (float)(isx - 1) * dnx;
-        float drz = (scz - goz) - (float)(isz - 1) * dnz;
-        const float vels = bilinear4(vss, dnx, dnz, drx, drz);
-        for (int k = 1; k <= 2; ++k)
-            for (int l = 1; l <= 2; ++l) vss[k - 1][l - 1] = veln[(size_t)(irx - 1 + k - 1) * ld + (irz - 1 + l - 1)];
-        drx = (rcx1 - gox) - (float)(irx - 1) * dnx;
-        drz = (rcz1 - goz) - (float)(irz - 1) * dnz;
-        const float velr = bilinear4(vss, dnx, dnz, drx, drz);
-        trr = 2.0f * sred / (vels + velr);
-    } else {
-        const float drx = (rcx1 - gox) - (float)(irx - 1) * dnx;
-        const float drz = (rcz1 - goz) - (float)(irz - 1) * dnz;
-        trr = 0.0f;
-        for (int k = 1; k <= 2; ++k)
-            for (int l = 1; l <= 2; ++l) {
-                const float produ = (1.0f - fabsf(((float)(l - 1) * dnz - drz) / dnz)) *
-                                    (1.0f - fabsf(((float)(k - 1) * dnx - drx) / dnx));
-                trr = trr + t_value(Tc[rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1)]) * produ;
-            }
-    }
-    // A source inside the last cell next to a high model edge ends the reference's refined stage at once and
-    // leaves its whole field at the initial 0 (the literal open-edge test, CalSurfG.f90:396-407); here such a
-    // field is +inf (never reached).  Report the reference's 0 rather than a non-finite time.
-    if (!(trr < kInf)) trr = 0.0f;
+    if (!receiver_time(g, sd.scx, sd.scz, rd, Tc, veln, dpl, &trr)) { atomicExch(err, r + 1); out[rd.data] = 0.0f; return; }
     out[rd.data] = trr;
 }
 

@@ -179,3 +179,32 @@ def test_wild_medium_keeps_the_exception_table_small(engine):
         engine.set_option("exc_log2cap", 0)
     assert grown >= 1
     assert np.array_equal(bits(t2), bits(t)) and np.array_equal(bits(T2), bits(T))
+
+
+def test_recycled_field_slots_give_the_same_times(engine):
+    """option field_pool: a launch with more units than coarse field slots hands the slots from workgroup to workgroup (each resets
+    its slot, solves, writes its unit's receiver times itself, then releases the slot).  Same bits as one slot per unit; and the
+    fields of a recycled solve are reported as gone instead of being read from a slot another unit has reused."""
+    from dsurftomo_amd.engine import EngineError
+    nx, nsrc, nper, nrec = 35, 300, 2, 6
+    u = synth.units(nx, nsrc, nper, nrec)
+    pv = np.stack([synth.medium(nx, k, p) for p, k in enumerate(("checker4", "rough"))])
+    out = {}
+    try:
+        for pool in (-1, 16, 97, 0):
+            engine.set_option("field_pool", pool)
+            engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+            out[pool] = engine.traveltimes(**u)
+            st = engine.stats()
+            assert st["field_slots"] == (600 if pool <= 0 else pool)
+            if pool > 0:
+                with pytest.raises(EngineError):
+                    engine.field(0)
+            else:
+                engine.field(599)
+    finally:
+        engine.set_option("field_pool", 0)
+    assert np.isfinite(out[-1]).all() and (out[-1] > 0).sum() > 0.95 * out[-1].size
+    for pool in (16, 97, 0):
+        assert np.array_equal(bits(out[pool]), bits(out[-1])), pool
+    parity_log.add(f"field slots: 600 units at N=257 through 16 / 97 / 600 slots: receiver times bit-identical")
