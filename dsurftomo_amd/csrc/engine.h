@@ -81,7 +81,7 @@ struct Engine {
     // again by the literal Fast Marching; 2 = every unit by the literal Fast Marching only
     int exact_ties = 0;
     float tie_threshold = 0.0f;        // a tie counts when taking the tied neighbour in moves the node's value by more than this (s)
-    int exact_lds_slots = 2048;        // tree slots kept in LDS per marching unit (8 bytes each)
+    int exact_lds_slots = 768;         // tree slots kept in LDS per marching unit (8 bytes each)
     int exact_pool = 0;                // units marching at a time (0 = by free memory, at most 4096)
     DevBuf<unsigned long long> X_pool, X_heap;   // per marching unit: (T, status) records of the whole grid; tree slots beyond the LDS part
     DevBuf<int> x_units;

@@ -27,6 +27,8 @@
 #include "kernels.h"
 #include "receiver_core.h"
 
+#include <type_traits>
+
 namespace dsa {
 
 namespace {
@@ -423,7 +425,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     auto rec = [&](int id) -> GRec* { return (GRec*)(Fb + ((unsigned)id << 3)); };
     auto slow_at = [&](int id) -> float { return *(GCF32*)(slowb + ((unsigned)id << 2)); };
     constexpr bool kOddR = DSA_ODD_CLEAR != 0;
-    constexpr int kMaskShift = kOddR ? 5 : 3, kClrWords = kOddR ? 4 : 2;
+    constexpr bool kKeyMasks = DSA_KEY_MASKS != 0;          // (implies the tile records of DSA_ODD_CLEAR)
+    static_assert(!kKeyMasks || kOddR, "DSA_KEY_MASKS needs DSA_ODD_CLEAR");
+    constexpr int kMaskShift = kKeyMasks ? 6 : (kOddR ? 5 : 3), kClrWords = kOddR ? 4 : 2;
     auto mask_at = [&](int tile) -> GU64* { return (GU64*)(maskb + ((size_t)(unsigned)tile << kMaskShift)); };
     constexpr int rhalf = NT * 4;                            // ready nodes of one colour a round can take (8 per thread: no gain)
     __shared__ int ready[2 * rhalf];                         // (the rest stay in their masks for the next round)
@@ -605,6 +609,158 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         unsigned* const clr = wclr + wave * kTileBuf * kClrWords;
         constexpr int NW = NT / 64;
         constexpr int kQ = kTileBuf / 64, kI = kWaveBuf / 64;
+#if DSA_KEY_MASKS
+        // Tile record {E, O, R, DE, DO, round}: E / O = nodes activated by the even / odd half of the last round from a node whose new
+        // acceptance time lay below that round's theta -- their lower bound is below this round's theta as well (theta does not go back),
+        // so they are ready as they are: no coordinates, no neighbour loads; DE / DO = activated from a later node, or carried over: lower
+        // bound from the four near neighbours, as before.  R filters what the even half activated at nodes the odd half of the same
+        // round evaluated (both kinds).  Same ready sets as with one kind of mask, i.e. the same schedule; pass A only does less.
+        auto sweep_tiles = [&](int ntiles) {
+            DSA_TICK(0);
+            DSA_PRIO(DSA_PRIO_A);
+            int tl[kQ];
+            unsigned long long mN[kQ], mL[kQ];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                tl[q] = q * 64 + lane < ntiles ? tbuf[q * 64 + lane] : -1;
+                mN[q] = 0ull; mL[q] = 0ull;
+                if (tl[q] >= 0) {
+                    GU64* const r8 = mask_at(tl[q]);
+                    const unsigned long long E = r8[0], O = r8[1], R = r8[2], DE = r8[3], DO = r8[4];
+                    const unsigned stamp = (unsigned)r8[5];
+                    const unsigned long long Rf = stamp == (unsigned)rounds ? R : 0ull;
+                    mN[q] = (E & ~Rf) | O;
+                    mL[q] = ((DE & ~Rf) | DO) & ~mN[q];
+                    if (frozen_any) { mL[q] |= mN[q]; mN[q] = 0ull; }      // a freeze horizon is up: every node shows its own acceptance time
+                }
+                if (q * 64 < ntiles)
+                    for (int w4 = 0; w4 < kClrWords; ++w4) clr[kClrWords * (q * 64 + lane) + w4] = 0u;
+                if (q * 64 < ntiles && tl[q] >= 0 && (mN[q] | mL[q]) == 0ull) atomicAnd(&tb[tl[q] >> 5], ~(1u << (tl[q] & 31)));      // the tile has drained
+            }
+            DSA_TICK(1);
+            auto process = [&](const unsigned long long* m, auto tag) {
+                constexpr bool LB = decltype(tag)::value;       // true: lower bounds from the neighbourhood; false: ready as they are
+                int off[kQ], total = 0;
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) {
+                    off[q] = total;
+                    if (q * 64 >= ntiles) continue;                           // wave-uniform: no tiles in this group
+                    const int n = __popcll(m[q]);
+                    const int incl = wave_scan_incl(n);
+                    off[q] = total + incl - n;
+                    total += wave_last(incl);
+                }
+                seen += total;
+                for (int base = 0; base < total; base += kWaveBuf) {
+#pragma unroll
+                    for (int q = 0; q < kQ; ++q) {
+                        unsigned long long mm = m[q];
+                        int idx = off[q];
+                        while (mm) {
+                            const int nb = __ffsll((long long)mm) - 1;
+                            mm &= mm - 1ull;
+                            if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = ((q * 64 + lane) << 6) + nb;     // (tile slot, node)
+                            ++idx;
+                        }
+                    }
+                    const int nn = min(total - base, kWaveBuf);
+                    DSA_TICK(2);
+                    DSA_PRIO(DSA_PRIO_A);
+                    int id[kI], par[kI], slot[kI];
+                    float lb[kI], own[kI];
+#pragma unroll
+                    for (int i = 0; i < kI; ++i) {
+                        id[i] = -1; par[i] = 0; slot[i] = 0; lb[i] = kInf; own[i] = kInf;
+                        if (i * 64 >= nn) continue;                           // wave-uniform: this group of 64 is empty
+                        const bool have = i * 64 + lane < nn;
+                        const int e = have ? nbuf[i * 64 + lane] : 0;
+                        slot[i] = e >> 6;
+                        id[i] = have ? (tbuf[slot[i]] << 6) + (e & 63) : -1;
+                        par[i] = ((e >> 3) ^ e) & 1;                           // tiles start at even coordinates: the parity of (ix + iz) is that of the node inside its tile
+                        if (!LB) { lb[i] = -kInf; continue; }
+                        if (have) {
+                            int iz, ix;
+                            coords(id[i], &iz, &ix);
+                            int nid[8];
+                            rec_stencil(nbz, id[i], nid);
+                            float a, b2, c2, d2;
+                            if (COMPACT) {
+                                a = ix > 0 ? *tc(nid[0]) : kInf; b2 = ix + 1 < nnx ? *tc(nid[1]) : kInf;
+                                c2 = iz > 0 ? *tc(nid[2]) : kInf; d2 = iz + 1 < nnz ? *tc(nid[3]) : kInf;
+                                if (frozen_any) own[i] = *tc(id[i]);
+                            } else {
+                                a = ix > 0 ? rec(nid[0])->tau : kInf; b2 = ix + 1 < nnx ? rec(nid[1])->tau : kInf;
+                                c2 = iz > 0 ? rec(nid[2])->tau : kInf; d2 = iz + 1 < nnz ? rec(nid[3])->tau : kInf;
+                                if (frozen_any) own[i] = rec(id[i])->tau;
+                            }
+                            if (COMPACT && (__builtin_signbit(a) || __builtin_signbit(b2) || __builtin_signbit(c2) || __builtin_signbit(d2) || __builtin_signbit(own[i]))) {
+                                bool pin;
+                                if (__builtin_signbit(a)) a = exc_lookup(nid[0], &pin);
+                                if (__builtin_signbit(b2)) b2 = exc_lookup(nid[1], &pin);
+                                if (__builtin_signbit(c2)) c2 = exc_lookup(nid[2], &pin);
+                                if (__builtin_signbit(d2)) d2 = exc_lookup(nid[3], &pin);
+                                if (__builtin_signbit(own[i])) own[i] = exc_lookup(id[i], &pin);
+                            }
+                            lb[i] = fminf(fminf(a, b2), fminf(c2, d2));
+                        }
+                    }
+                    DSA_TICK(3);
+                    DSA_PRIO(DSA_PRIO_R);
+                    // routing: one slot allocation per colour for the whole window
+                    unsigned long long be[kI], bo[kI];
+                    bool frozen[kI];
+                    int ne = 0, no = 0;
+#pragma unroll
+                    for (int i = 0; i < kI; ++i) {
+                        be[i] = 0ull; bo[i] = 0ull; frozen[i] = false;
+                        if (i * 64 >= nn) continue;
+                        const bool have = id[i] >= 0;
+                        frozen[i] = LB && have && frozen_any && own[i] < freeze;
+                        const bool want = have && !frozen[i] && (!LB || open || lb[i] < theta);
+                        be[i] = __ballot(want && par[i] == 0);
+                        bo[i] = __ballot(want && par[i] != 0);
+                        ne += __popcll(be[i]); no += __popcll(bo[i]);
+                    }
+                    int base_e = 0, base_o = 0;
+                    if (lane == 0) {
+                        if (ne) base_e = atomicAdd(&sc[SC_READY], ne);
+                        if (no) base_o = atomicAdd(&sc[SC_READY_ODD], no);
+                    }
+                    base_e = __builtin_amdgcn_readfirstlane(base_e);
+                    base_o = __builtin_amdgcn_readfirstlane(base_o);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                    for (int i = 0; i < kI; ++i) {
+                        if (i * 64 >= nn) continue;
+                        const bool have = id[i] >= 0;
+                        const bool want_e = (be[i] >> lane) & 1ull, want_o = (bo[i] >> lane) & 1ull;
+                        const int pe = base_e + __popcll(be[i] & below), po = base_o + __popcll(bo[i] & below);
+                        base_e += __popcll(be[i]); base_o += __popcll(bo[i]);
+                        const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
+                        if (got) ready[want_o ? rhalf + po : pe] = id[i];
+                        if ((got && !want_o) || frozen[i]) atomicOr(&clr[kClrWords * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
+                        if (got && want_o) atomicOr(&clr[kClrWords * slot[i] + 2 + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));     // evaluated by this round's odd half
+                        // what stays behind bounds the next theta from below: its lower bound -- or, for a ready node the lists had no room for, theta itself
+                        if (have && !frozen[i] && !got) tmin_lane = fminf(tmin_lane, LB ? lb[i] : theta);
+                    }
+                    DSA_TICK(4);
+                }
+            };
+            process(mN, std::false_type{});
+            process(mL, std::true_type{});
+            // the tile's record for the next round: what stays queued needs its lower bound again (DO), nothing new yet, and who is evaluated by
+            // this round's odd half; plain stores -- a tile has one owner in pass A and nobody activates then
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+                if (tl[q] >= 0) {
+                    const unsigned* const cw = clr + kClrWords * (q * 64 + lane);
+                    const unsigned long long c = (unsigned long long)cw[0] | ((unsigned long long)cw[1] << 32);
+                    const unsigned long long ro = (unsigned long long)cw[2] | ((unsigned long long)cw[3] << 32);
+                    GU64* const r8 = mask_at(tl[q]);
+                    r8[0] = 0ull; r8[1] = 0ull; r8[2] = ro; r8[3] = 0ull; r8[4] = (mN[q] | mL[q]) & ~c & ~ro; r8[5] = (unsigned long long)(unsigned)(rounds + 1);
+                }
+        };
+#else
         auto sweep_tiles = [&](int ntiles) {
             DSA_TICK(0);
             DSA_PRIO(DSA_PRIO_A);
@@ -746,6 +902,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     } else if (c) atomicAnd((unsigned long long*)mask_at(tl[q]), ~c);
                 }
         };
+#endif
         int ntw = 0;                                                               // tiles collected, wave-uniform
         // 64 bitmap words of this wave per trip: groups of 2^gs consecutive words dealt round-robin to the waves,
         // ascending (16-word groups on large grids: -2.5 % against single words at 1025^2; single words on the small
@@ -915,9 +1072,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 fxp = sel(want[1], b >> 56) | sel(want[5], b >> 48);
                 fzm = sel(want[2], (b << 7) & 0x8080808080808080ull) | sel(want[6], (b << 6) & 0xc0c0c0c0c0c0c0c0ull);
                 fzp = sel(want[3], (b >> 7) & 0x0101010101010101ull) | sel(want[7], (b >> 6) & 0x0303030303030303ull);
+                // which mask: activated from a node accepted inside this round's window (ready without a lower bound) or from a later one
+                const int mword = kKeyMasks ? ((k < theta) ? half : 3 + half) : (kOddR ? half : 0);
                 auto activate = [&](int tile, unsigned long long bits) {
                     if (bits) {
-                        atomicOr((unsigned long long*)(mask_at(tile) + (kOddR ? half : 0)), bits);
+                        atomicOr((unsigned long long*)(mask_at(tile) + mword), bits);
                         atomicOr(&tb[tile >> 5], 1u << (tile & 31));
                     }
                 };

@@ -62,7 +62,13 @@ struct FimEnds {
 #ifndef DSA_ODD_CLEAR
 #define DSA_ODD_CLEAR 1            // fim_kernel.hip: 1 = tile records {E, O, R, round} (default), 0 = one mask per tile (see there)
 #endif
-constexpr int kFimMaskInts = DSA_ODD_CLEAR ? 8 : 2;     // ints of active-set record per tile in the per-problem scratch
+// DSA_KEY_MASKS (round 3): the tile record also says HOW a node was activated -- by a neighbour whose acceptance time already lay inside
+// the causal window (the node's lower bound is then inside it too: it goes to the ready list without a look at its neighbourhood) or by a
+// later one (lower bound from four loads, as before).  Record {E, O, R, DE, DO, round} in 64 bytes; the schedule itself is unchanged.
+#ifndef DSA_KEY_MASKS
+#define DSA_KEY_MASKS 1
+#endif
+constexpr int kFimMaskInts = DSA_KEY_MASKS ? 16 : (DSA_ODD_CLEAR ? 8 : 2);     // ints of active-set record per tile in the per-problem scratch
 
 struct FimLaunch {
     int list_cap;          // entries per active list

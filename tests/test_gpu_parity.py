@@ -88,7 +88,7 @@ def test_fields_match_oracle(engine, nx, kind, gd):
         nbad_nodes += int((bits(T) != bits(o["T"])).sum())
         bound, nbound = TIE_CASES.get((nx, kind, gd, u), (TOL, 0))
         if d > 0:
-            parity_log.add(f"fixture nx={nx} {kind} gd={gd} source {u} {FRAC[u]}: field max |dT| {d:.3g} s, nodes beyond 1e-4 s {over}"
+            parity_log.add(f"fixture nx={nx} {kind} gd={gd} source {u} {FRAC[u]}: field max |dT| {d:.9g} s, nodes beyond 1e-4 s {over}"
                            + (" [named tie case]" if (nx, kind, gd, u) in TIE_CASES else ""))
         assert d <= bound, (nx, kind, gd, u, d)
         assert over <= nbound, (nx, kind, gd, u, over)

@@ -15,6 +15,8 @@
 //   11 like 6 with a window steered towards `param` ready nodes per round (proportional control, 0.25 .. 4 x the given window)
 //   12 key slots (no lower bounds at all): a node is due when the time slot (width window / param%100 ... see code) of the smallest acceptance
 //      time among the neighbours that activated it since its last evaluation lies inside the window; odd rule as in 6
+//   13 like 6, but an activation whose key (the activator's acceptance time) is not below theta is never dropped: it re-queues an odd node
+//      that the same round's odd half is about to evaluate (what a separate "needs a lower bound" mask per tile would do)
 //   5  lazy: a node waits for the acceptance time of the neighbour that activated it to enter the window (key routing), parity sub-passes
 // build: g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -msse2 -mfpmath=sse -o tests/tools/libsched_lab.so tests/tools/sched_lab.cpp
 #include <algorithm>
@@ -63,19 +65,21 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     std::vector<float> curkey, nextkey;
     std::vector<unsigned char> queued(n, 0);
     std::vector<float> key(n, kInf);
+    std::vector<unsigned char> pending_odd(n, 0), requeue(n, 0);
+    float theta = kInf;
     float slot_w = 0.0f; long slotB = 0; int ring = 1 << 30, Wslots = 2;
     auto act = [&](int iz0, int ix0, float k) {
         if (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) return;
         if (slot_w > 0.0f) { long a = (long)floorf(k / slot_w); if (a < slotB) a = slotB; if (a > slotB + ring - 1) a = slotB + ring - 1; k = (float)a; }   // the key becomes a slot number
         const int id = rec_index(nbz, iz0, ix0);
         if (t_pinned(F[id].T)) return;
-        if (queued[id]) { if (k < key[id]) key[id] = k; return; }
+        if (queued[id]) { if (k < key[id]) key[id] = k; if (mode == 13 && pending_odd[id] && !(k < theta)) requeue[id] = 1; return; }
         queued[id] = 1; key[id] = k; next.push_back(id);
     };
     for (int ix = 0; ix < nnx; ++ix) for (int iz = 0; iz < nnz; ++iz)
         if (t_pinned(F[rec_index(nbz, iz, ix)].T)) { act(iz, ix - 1, 0.f); act(iz, ix + 1, 0.f); act(iz - 1, ix, 0.f); act(iz + 1, ix, 0.f); }
     cur.swap(next);
-    float theta = kInf; long key_routed = 0; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, trips256 = 0, trips128 = 0;
+    long key_routed = 0; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, trips256 = 0, trips128 = 0;
     float wnow = window;
     float best_tmin = -kInf, freeze = -kInf; int stall = 0; long freezes = 0;
     unsigned hist[4] = { 1u, 2u, 3u, 4u }, hsh = 0u;
@@ -143,6 +147,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             if (rdy) {
                 ready.push_back(R{ id, lb });
                 if (!(mode >= 6 && par) && mode != 10) queued[id] = 0;
+                if (mode == 13 && par) pending_odd[id] = 1;
                 key[id] = kInf;
             }
             else { next.push_back(id); tmin = fminf(tmin, lb); }
@@ -165,7 +170,10 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
                 { long cnt = 0; for (auto& r : ready) if (parity(r.id) == p) ++cnt; trips256 += (cnt + 255) / 256; trips128 += (cnt + 127) / 128; }
                 const int want = (mode == 8 && (rounds & 1)) ? p ^ 1 : p;
                 sub.clear(); for (auto& r : ready) if (parity(r.id) == want) sub.push_back(r.id);
-                if (mode >= 6 && p == 1) for (int id : sub) queued[id] = 0;
+                if (mode >= 6 && p == 1) for (int id : sub) {
+                    queued[id] = 0;
+                    if (mode == 13) { pending_odd[id] = 0; if (requeue[id]) { requeue[id] = 0; queued[id] = 1; next.push_back(id); } }
+                }
                 eval_batch(sub);
             }
         } else if (mode == 2 || mode == 3) {
