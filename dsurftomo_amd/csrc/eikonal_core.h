@@ -342,9 +342,16 @@ struct Hood {
 // layout of the reference's heap.  The detector takes the tied neighbour in for one more trip of the same body and
 // reports |c' - c| in *tie_out (>= 0; -1 when the walk did not end on a tie); the returned (T, tau) are those of the walk that
 // stopped at the tie, as before.
+// (DSA_LEDGER builds of fim_kernel.hip count the trips of the solver's parts: tools/isa_ledger.py)
+#ifndef DSA_LEDGER_PARAM
+#define DSA_LEDGER_PARAM
+#define DSA_LEDGER_PASS
+#define DSA_LEDGER_COUNT(k, name) do { } while (0)
+#endif
 template <bool TIE>
-DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* tau_out, float* tie_out)
+DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* tau_out, float* tie_out DSA_LEDGER_PARAM)
 {
+    DSA_LEDGER_COUNT(10, "solve_prologue");
     float tn[4], t2[4], ko[4], key[4];
     int idx[4] = { 0, 1, 2, 3 };
     unsigned alive = 0u, inside = 0u;   // bit q: near neighbour q is alive / inside the grid
@@ -384,7 +391,9 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
     float c = kInf;
     bool first = alive != 0u;           // pinned neighbours are alive from the start: one evaluation before the walk
 #ifndef DSA_SOLVE_NO_FIRST_STEP         // (A/B switch of tools/ab_build.sh: without the block the loop below does the same step with its whole body)
+    DSA_LEDGER_COUNT(11, "solve_consts");
     if (!first && key[0] < kInf) {      // no pinned neighbour: the walk's first neighbour alone (c = +inf > its key)
+        DSA_LEDGER_COUNT(12, "walk_first");
         const int a = idx[0];
         const bool x = a < 2;
         const float tna = a == 0 ? tn[0] : a == 1 ? tn[1] : a == 2 ? tn[2] : tn[3];
@@ -417,6 +426,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
             idx[0] = idx[1]; idx[1] = idx[2]; idx[2] = idx[3];
         }
         first = false;
+        DSA_LEDGER_COUNT(13, "walk_body");
 
         bool sw[4];
         float P[4];
@@ -437,6 +447,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
         }
         unsigned pm = ((aj & 1u) ? ak : 0u) | ((aj & 2u) ? (ak << 2) : 0u);   // bit 2 j + k: quadrant with both neighbours alive
         while (pm) {
+            DSA_LEDGER_COUNT(14, "walk_quadrant");
             const bool j1 = (pm & 3u) == 0u;                             // lowest set bit: quadrant (j, k)
             const unsigned pj = j1 ? (pm >> 2) : pm;
             const bool k1 = (pj & 1u) == 0u;
@@ -473,12 +484,16 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
         c = best;
         if (TIE && probing) { *tie_out = fabsf(c - c_keep); c = c_keep; tnow = tnow_keep; break; }
     }
+    DSA_LEDGER_COUNT(15, "solve_epilogue");
     *tau_out = (c > tnow) ? c : tnow;
     return c;
 }
 DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* tau_out)
 {
-    return solve_node_t<false>(h, slown, g, tau_out, nullptr);
+#ifdef DSA_LEDGER
+    unsigned dsa_lc[24] = {};       // (callers outside the ledger's kernel: counted into nothing)
+#endif
+    return solve_node_t<false>(h, slown, g, tau_out, nullptr DSA_LEDGER_PASS);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -94,7 +94,7 @@ struct Engine {
     DevBuf<int32_t> heap, flags, info;
     DevBuf<FimProblem> prob_r, prob_c;
     DevBuf<unsigned long long> clocks;
-    double phase_ticks[8] = {};
+    double phase_ticks[kClockSlots] = {};
 
     // Frechet rows: depth-kernel factor S (ray_kernels.hip) and per-launch ray scratch
     bool have_sens = false;

@@ -383,7 +383,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(risti_r, C * kRefMax) || ensure(vcorner, C * 4) || ensure(seed_r, C * kSeedR) || ensure(nseed_r, C) ||
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, PS * nrec_c) || ensure(exc_c, PS << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
-        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * 8) ||
+        ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * kClockSlots) ||
         ensure(tieinfo, C * 4) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
     h_unit_flags.assign((size_t)nunits, 0);
     h_unit_tie.assign((size_t)nunits, 0.0f);
@@ -425,7 +425,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     { const double keep_ms = stats[DSA_STAT_MS_DISPERSION], keep_n = stats[DSA_STAT_CURVES];
       std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
       stats[DSA_STAT_MS_DISPERSION] = keep_ms; stats[DSA_STAT_CURVES] = keep_n; }
-    std::fill(phase_ticks, phase_ticks + 8, 0.0);
+    std::fill(phase_ticks, phase_ticks + kClockSlots, 0.0);
     // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
     // the solve (rays and rows, the exact mode, keep_fields) a launch takes one unit per slot
     const bool may_recycle = !rows && exact_ties == 0 && !keep_fields;
@@ -524,13 +524,14 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             const int d0 = h_rays[r0].data, d1 = h_rays[r1 - 1].data + 1;
             HIP_TRY(this, hipMemcpyAsync(dsurf + d0, out.p + d0, (size_t)(d1 - d0) * 4, hipMemcpyDeviceToHost, stream));
         }
-        std::vector<unsigned long long> h_clk((size_t)n * 8);
-        HIP_TRY(this, hipMemcpyAsync(h_clk.data(), clocks.p, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
+        std::vector<unsigned long long> h_clk((size_t)n * kClockSlots);
+        HIP_TRY(this, hipMemcpyAsync(h_clk.data(), clocks.p, (size_t)n * kClockSlots * 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipStreamSynchronize(stream));
         for (int u = 0; u < n; ++u) {
-            for (int q = 0; q < 6; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * 8 + q];
-            phase_ticks[7] += (double)h_clk[(size_t)u * 8 + 7];
-            phase_ticks[6] = std::max(phase_ticks[6], (double)h_clk[(size_t)u * 8 + 6]);
+            for (int q = 0; q < 6; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * kClockSlots + q];
+            phase_ticks[7] += (double)h_clk[(size_t)u * kClockSlots + 7];
+            phase_ticks[6] = std::max(phase_ticks[6], (double)h_clk[(size_t)u * kClockSlots + 6]);
+            for (int q = 8; q < kClockSlots; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * kClockSlots + q];
         }
         float ms = 0;
         HIP_TRY(this, hipEventElapsedTime(&ms, events[2], events[3])); stats[DSA_STAT_MS_FIM_REFINED] += ms;
@@ -1061,6 +1062,14 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out)
     if (which < 2) return en->fetch_compact((int)slot, which, out);
     const dsa::SourceDesc& s = en->h_src[unit];
     return en->fetch_tiled(en->F_r.p + slot * dsa::kRefRecs, s.rnx, s.rnz, which - 2, out);
+}
+
+// probe builds: the 24 trip counters of a DSA_LEDGER build (tools/isa_ledger.py), summed over the units of the last solve
+int dsa_debug_counters(const dsa_engine* e, double* out24)
+{
+    if (!e || !out24) return DSA_ERR_ARGUMENT;
+    for (int q = 0; q < 24; ++q) out24[q] = reinterpret_cast<const Engine*>(e)->phase_ticks[8 + q];
+    return 0;
 }
 
 int dsa_dispersion_diagnostics(const dsa_engine* e, long long* count, int* first, double* period)

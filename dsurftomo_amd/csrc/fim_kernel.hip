@@ -24,6 +24,16 @@
 //   * a changed node stores (T, tau) first and activates dependents afterwards; a dependent that
 //     read a torn or stale state this round has its bit clear and is therefore re-queued;
 //   * the fixed point is schedule independent, so races only cost re-evaluations.
+#ifdef DSA_LEDGER      // probe build of tools/isa_ledger.py: named markers in the assembly and one wave-trip counter per marker
+#define DSA_LEDGER_PARAM , unsigned* dsa_lc
+#define DSA_LEDGER_PASS , dsa_lc
+#define DSA_LEDGER_COUNT(k, name)                                                                                              \
+    do {                                                                                                                       \
+        asm volatile("; LEDGER " #k " " name);                                                                                 \
+        const unsigned long long ex_ = __builtin_amdgcn_read_exec();                                                           \
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)ex_) - 1) dsa_lc[k] += 1u;                                          \
+    } while (0)
+#endif
 #include "kernels.h"
 #include "receiver_core.h"
 
@@ -555,6 +565,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #endif
     float best_tmin = -kInf;
     unsigned evals = 0, nchanged = 0;                        // per lane (a lane evaluates < 2^32 nodes)
+#ifdef DSA_LEDGER
+    unsigned dsa_lc[24] = {};                                // wave trips per marker (held by the lowest active lane of each trip)
+#endif
     unsigned tie_n = 0;                                      // TIE: evaluations that ended on an exact tie with influence, and the largest influence
     float tie_max = 0.0f;
 #ifdef DSA_PASSA_CLOCKS
@@ -589,6 +602,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #define DSA_PRIO_W 1     // pass B: store, activation
 #endif
     for (; !dead;) {
+        DSA_LEDGER_COUNT(0, "round_head");
         const float theta = u2f((unsigned)sc[SC_THETA]);
         const bool open = !(theta < kInf);
         const float freeze = u2f((unsigned)sc[SC_FREEZE]);
@@ -618,6 +632,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         auto sweep_tiles = [&](int ntiles) {
             DSA_TICK(0);
             DSA_PRIO(DSA_PRIO_A);
+            DSA_LEDGER_COUNT(2, "tile_records");
             int tl[kQ];
             unsigned long long mN[kQ], mL[kQ];
 #pragma unroll
@@ -640,6 +655,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
             DSA_TICK(1);
             auto process = [&](const unsigned long long* m, auto tag) {
                 constexpr bool LB = decltype(tag)::value;       // true: lower bounds from the neighbourhood; false: ready as they are
+                if (LB) DSA_LEDGER_COUNT(4, "scan_L"); else DSA_LEDGER_COUNT(3, "scan_N");
                 int off[kQ], total = 0;
 #pragma unroll
                 for (int q = 0; q < kQ; ++q) {
@@ -657,6 +673,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                         unsigned long long mm = m[q];
                         int idx = off[q];
                         while (mm) {
+                            DSA_LEDGER_COUNT(5, "expand_bit");
                             const int nb = __ffsll((long long)mm) - 1;
                             mm &= mm - 1ull;
                             if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = ((q * 64 + lane) << 6) + nb;     // (tile slot, node)
@@ -666,6 +683,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     const int nn = min(total - base, kWaveBuf);
                     DSA_TICK(2);
                     DSA_PRIO(DSA_PRIO_A);
+                    if (LB) DSA_LEDGER_COUNT(7, "nodes_L_window"); else DSA_LEDGER_COUNT(6, "nodes_N_window");
                     int id[kI], par[kI], slot[kI];
                     float lb[kI], own[kI];
 #pragma unroll
@@ -678,6 +696,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                         id[i] = have ? (tbuf[slot[i]] << 6) + (e & 63) : -1;
                         par[i] = ((e >> 3) ^ e) & 1;                           // tiles start at even coordinates: the parity of (ix + iz) is that of the node inside its tile
                         if (!LB) { lb[i] = -kInf; continue; }
+                        DSA_LEDGER_COUNT(8, "nodes_L_group64");
                         if (have) {
                             int iz, ix;
                             coords(id[i], &iz, &ix);
@@ -706,6 +725,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     }
                     DSA_TICK(3);
                     DSA_PRIO(DSA_PRIO_R);
+                    DSA_LEDGER_COUNT(9, "routing_window");
                     // routing: one slot allocation per colour for the whole window
                     unsigned long long be[kI], bo[kI];
                     bool frozen[kI];
@@ -748,6 +768,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
             };
             process(mN, std::false_type{});
             process(mL, std::true_type{});
+            DSA_LEDGER_COUNT(16, "record_rewrite");
             // the tile's record for the next round: what stays queued needs its lower bound again (DO), nothing new yet, and who is evaluated by
             // this round's odd half; plain stores -- a tile has one owner in pass A and nobody activates then
 #pragma unroll
@@ -764,6 +785,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         auto sweep_tiles = [&](int ntiles) {
             DSA_TICK(0);
             DSA_PRIO(DSA_PRIO_A);
+            DSA_LEDGER_COUNT(2, "tile_records");
             int tl[kQ];
             unsigned long long m[kQ];
 #pragma unroll
@@ -782,6 +804,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     for (int w4 = 0; w4 < kClrWords; ++w4) clr[kClrWords * (q * 64 + lane) + w4] = 0u;
             }
             DSA_TICK(1);
+            DSA_LEDGER_COUNT(3, "scan");
             int off[kQ], total = 0;
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
@@ -800,6 +823,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     unsigned long long mm = m[q];
                     int idx = off[q];
                     while (mm) {
+                        DSA_LEDGER_COUNT(5, "expand_bit");
                         const int nb = __ffsll((long long)mm) - 1;
                         mm &= mm - 1ull;
                         if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = ((q * 64 + lane) << 6) + nb;     // (tile slot, node)
@@ -809,12 +833,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 const int nn = min(total - base, kWaveBuf);
                 DSA_TICK(2);
                 DSA_PRIO(DSA_PRIO_A);
+                DSA_LEDGER_COUNT(7, "nodes_window");
                 int id[kI], par[kI], slot[kI];
                 float lb[kI], own[kI];
 #pragma unroll
                 for (int i = 0; i < kI; ++i) {
                     id[i] = -1; par[i] = 0; slot[i] = 0; lb[i] = kInf; own[i] = kInf;
                     if (i * 64 >= nn) continue;                           // wave-uniform: this group of 64 is empty
+                    DSA_LEDGER_COUNT(8, "nodes_group64");
                     const bool have = i * 64 + lane < nn;
                     const int e = have ? nbuf[i * 64 + lane] : 0;
                     slot[i] = e >> 6;
@@ -849,6 +875,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 }
                 DSA_TICK(3);
                 DSA_PRIO(DSA_PRIO_R);
+                DSA_LEDGER_COUNT(9, "routing_window");
                 // routing: one slot allocation per colour for the whole window
                 unsigned long long be[kI], bo[kI];
                 bool frozen[kI];
@@ -889,6 +916,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
             }
             // leaving the active set, one atomic per tile; it happens before the barrier, so a change that lands
             // while a node is being evaluated sets its bit again
+            DSA_LEDGER_COUNT(16, "record_rewrite");
 #pragma unroll
             for (int q = 0; q < kQ; ++q)
                 if (tl[q] >= 0) {
@@ -913,28 +941,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         const int colw = nbz >> 5;
         const int gs_col = colw >= 16 ? 4 : colw >= 8 ? 3 : colw >= 4 ? 2 : colw >= 2 ? 1 : 0;
         const int gs = nwords >= 64 * NW ? (DSA_FIM_GROUP_SHIFT >= 0 ? DSA_FIM_GROUP_SHIFT : gs_col) : 0;
-        for (int wb = 0; ((wb * (64 >> gs) * NW + wave) << gs) < nwords; ++wb) {
-            const int w = (((wb * (64 >> gs) + (lane >> gs)) * NW + wave) << gs) + (lane & ((1 << gs) - 1));
-            const unsigned bits = w < nwords ? tb[w] : 0u;
-            const int nt_lane = __popc(bits);
-            const int tincl = wave_scan_incl(nt_lane);
-            const int ttotal = wave_last(tincl);
-            const int toff = tincl - nt_lane;
-            for (int tbase = 0; tbase < ttotal;) {                                 // wave-uniform
-                const int take = min(kTileBuf - ntw, ttotal - tbase);
-                unsigned bb = bits;
-                int idx = toff;
-                while (bb) {
-                    const int b2 = __ffs((int)bb) - 1;
-                    bb &= bb - 1u;
-                    if (idx >= tbase && idx < tbase + take) tbuf[ntw + idx - tbase] = (w << 5) + b2;
-                    ++idx;
+        // (one call site of sweep_tiles: its body is three thousand instructions, and two inlined copies were what the loop used to hold)
+        {
+            int wb = 0, tbase = 0, ttotal = 0, toff = 0, w = 0;
+            unsigned bits = 0u;
+            bool words_left = true;
+            while (words_left || ntw) {
+                while (words_left && ntw < kTileBuf) {
+                    if (tbase >= ttotal) {                                         // next 64 words of this wave
+                        if (!(((wb * (64 >> gs) * NW + wave) << gs) < nwords)) { words_left = false; break; }
+                        DSA_LEDGER_COUNT(1, "bitmap_words");
+                        w = (((wb * (64 >> gs) + (lane >> gs)) * NW + wave) << gs) + (lane & ((1 << gs) - 1));
+                        bits = w < nwords ? tb[w] : 0u;
+                        const int nt_lane = __popc(bits);
+                        const int tincl = wave_scan_incl(nt_lane);
+                        ttotal = wave_last(tincl);
+                        toff = tincl - nt_lane;
+                        tbase = 0;
+                        ++wb;
+                        if (ttotal == 0) continue;
+                    }
+                    const int take = min(kTileBuf - ntw, ttotal - tbase);
+                    unsigned bb = bits;
+                    int idx = toff;
+                    while (bb) {
+                        const int b2 = __ffs((int)bb) - 1;
+                        bb &= bb - 1u;
+                        if (idx >= tbase && idx < tbase + take) tbuf[ntw + idx - tbase] = (w << 5) + b2;
+                        ++idx;
+                    }
+                    ntw += take; tbase += take;
                 }
-                ntw += take; tbase += take;
-                if (ntw == kTileBuf) { sweep_tiles(ntw); ntw = 0; }
+                if (ntw) { sweep_tiles(ntw); ntw = 0; }
             }
         }
-        if (ntw) sweep_tiles(ntw);
         DSA_TICK(0);
         tmin_lane = wave_min(tmin_lane);
         if (lane == 0) {
@@ -963,6 +1003,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 const int id = act ? ready[half ? rhalf + j : j] : 0;
                 int iz, ix;
                 DSA_PRIO(DSA_PRIO_BL);
+                DSA_LEDGER_COUNT(17, "passB_loads");
                 coords(id, &iz, &ix);
                 Hood h;
                 h.in[0] = act && ix > 0;          h.in_outer[0] = act && ix > 1;
@@ -1014,9 +1055,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                     const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
                     if (TIE) {
                         float tie;
-                        c = solve_node_t<true>(h, slow_at(id), geom, &k, &tie);
+                        c = solve_node_t<true>(h, slow_at(id), geom, &k, &tie DSA_LEDGER_PASS);
                         if (tie > p.tie_threshold) { ++tie_n; tie_max = fmaxf(tie_max, tie); }
-                    } else c = solve_node(h, slow_at(id), geom, &k);
+                    } else c = solve_node_t<false>(h, slow_at(id), geom, &k, nullptr DSA_LEDGER_PASS);
 #ifdef DSA_PROBE_EXTRA_READ
                     if (COMPACT) {   // bandwidth probe: one more cold line per evaluated node group (the slowness half a grid away); result unused
                         const float extra = slow_at(id < 524288 ? id + 524288 : id - 524288);
@@ -1037,6 +1078,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 }
                 DSA_TICK(6);
                 DSA_PRIO(DSA_PRIO_W);
+                DSA_LEDGER_COUNT(18, "store_activate");
                 if (changed) {
                     if (COMPACT) {
                         // causal node (the rule): one float.  Else the table entry first, then the flagged value.
@@ -1103,6 +1145,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #ifdef DSA_PHASE_CLOCKS
         sum_ready += nready_even + nready_odd;
 #endif
+        DSA_LEDGER_COUNT(19, "round_end");
         if (tid == 0) {
             sc[SC_READY] = 0; sc[SC_READY_ODD] = 0; sc[SC_CUR] = 0;
             const float tmin = u2f((unsigned)sc[SC_TMIN]);
@@ -1122,11 +1165,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         if (COMPACT && sc[SC_OVERFLOW]) break;          // the exception table is full (info[2] = -2): the host grows it and solves the chunk again
         if (rounds > p.max_rounds) { if (tid == 0 && p.info[2] != -2) p.info[2] = -1; break; }
     }
+    DSA_LEDGER_COUNT(20, "kernel_tail");
     {
         unsigned long long e64 = evals, c64 = nchanged;
         for (int o = 32; o > 0; o >>= 1) { e64 += __shfl_xor(e64, o); c64 += __shfl_xor(c64, o); }
         if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), e64); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), c64); }
     }
+#ifdef DSA_LEDGER
+    if (p.clocks) {
+#pragma unroll
+        for (int q = 0; q < 24; ++q) { const unsigned v = wave_sum(dsa_lc[q]); if (lane == 0 && v) atomicAdd(p.clocks + 8 + q, (unsigned long long)v); }
+    }
+#endif
     if (TIE && p.tie) {
         const unsigned tn = wave_sum(tie_n);
         const float tm = -wave_min(-tie_max);

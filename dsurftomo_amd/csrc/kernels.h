@@ -13,6 +13,8 @@ namespace dsa {
 struct RayDesc { int src; float rx, rz; float sin_rx; int data; int flags; };   // sin_rx = libm sinf(rx), made on the host
 constexpr int kRayTime = 1, kRayPath = 2;
 
+constexpr int kClockSlots = 32;     // probe counters per unit (FimProblem::clocks)
+
 // One fixed-point problem: a travel-time field on an (nnz, nnx) grid stored as tiled (T, tau)
 // records (eikonal_core.h).  The records carry the boundary condition: pinned nodes (sign bit of T)
 // are never recomputed, every other node starts at +inf.  `seed` lists the record indices to
@@ -32,7 +34,7 @@ struct FimProblem {
     float ri, dnx, dnz;
     float window;          // causal window (seconds of travel time) evaluated per round
     int max_rounds;
-    unsigned long long* clocks;   // optional, 8 u64: phase clocks of thread 0 (wall_clock64 ticks) + list sizes
+    unsigned long long* clocks;   // optional, kClockSlots u64: [0..7] phase clocks of thread 0 (wall_clock64 ticks) + list sizes; [8..31] trip counters of DSA_LEDGER builds
     int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [3] stall freezes, [4..5] evaluations (u64)
     int32_t* tie;          // tie detector (kernels launched with FimLaunch::tie): [0] evaluations that ended on an exact tie whose influence exceeds tie_threshold, [1] largest influence (float bits)
     float tie_threshold;
@@ -65,8 +67,11 @@ struct FimEnds {
 // DSA_KEY_MASKS (round 3): the tile record also says HOW a node was activated -- by a neighbour whose acceptance time already lay inside
 // the causal window (the node's lower bound is then inside it too: it goes to the ready list without a look at its neighbourhood) or by a
 // later one (lower bound from four loads, as before).  Record {E, O, R, DE, DO, round} in 64 bytes; the schedule itself is unchanged.
+// MEASURED AND SWITCHED OFF (profiles/r03_ab_key_masks.txt): -7 % solves/s at 16 384 units (smooth), -9 % (checkerboard).  55 % of the listed
+// nodes skip their loads, but pass A then expands two masks per tile and routes in two passes, the record doubles (64 B), and the kernel
+// spills more (10 VGPRs / 51 SGPRs against 4 / 32).  Kept as a build variant for the record.
 #ifndef DSA_KEY_MASKS
-#define DSA_KEY_MASKS 1
+#define DSA_KEY_MASKS 0
 #endif
 constexpr int kFimMaskInts = DSA_KEY_MASKS ? 16 : (DSA_ODD_CLEAR ? 8 : 2);     // ints of active-set record per tile in the per-problem scratch
 

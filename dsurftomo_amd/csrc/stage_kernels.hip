@@ -351,7 +351,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
     c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = window_c;
     c.max_rounds = 64 * (g.nnx + g.nnz) + 4096;
-    c.clocks = clocks ? clocks + (size_t)s * 8 : nullptr;
+    c.clocks = clocks ? clocks + (size_t)s * kClockSlots : nullptr;
     c.info = info + (size_t)s * 16 + 8;
     c.tie = tie ? tie + (size_t)s * 4 + 2 : nullptr; c.tie_threshold = tie_threshold;
     prob_c[rank] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
@@ -365,7 +365,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     }
     for (int q = 0; q < 16; ++q) info[(size_t)s * 16 + q] = 0;
     if (tie) for (int q = 0; q < 4; ++q) tie[(size_t)s * 4 + q] = 0;
-    if (clocks) for (int q = 0; q < 8; ++q) clocks[(size_t)s * 8 + q] = 0ull;      // probe builds accumulate into them
+    if (clocks) for (int q = 0; q < kClockSlots; ++q) clocks[(size_t)s * kClockSlots + q] = 0ull;      // probe builds accumulate into them
 }
 
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,

@@ -61,6 +61,7 @@ def load_library():
     L.dsa_get_refined.argtypes = [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]
     L.dsa_get_stats.argtypes = [_vp, _vp]
     L.dsa_unit_ties.argtypes = [_vp, _i32, _vp, _vp]
+    L.dsa_debug_counters.argtypes = [_vp, _vp]
     L.dsa_ray_paths.argtypes = [_vp, _vp, _vp, _vp]
     L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]
     L.dsa_spmv.argtypes = [_vp, _i32, _vp, _vp]
@@ -267,6 +268,11 @@ class Engine:
         """raw device state of a resident unit (see dsa_debug_field); coarse fields come back [ix, iz]"""
         out = np.zeros((self.nnx, self.nnz) if which < 2 else (129 * 129,), np.float32)
         self._check(self._L.dsa_debug_field(self._h, int(unit), int(which), _p(out)))
+        return out
+
+    def debug_counters(self):
+        out = np.zeros(24, np.float64)
+        self._check(self._L.dsa_debug_counters(self._h, _p(out)))
         return out
 
     def unit_ties(self):

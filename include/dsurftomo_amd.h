@@ -208,6 +208,9 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  * tie influence in seconds (either array may be NULL). */
 int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence);
 
+/* probe builds only (-DDSA_LEDGER, tools/isa_ledger.py): trip counters of the coarse solve's phases, summed over the units of the last solve */
+int dsa_debug_counters(const dsa_engine* e, double* out24);
+
 /* counters of the last dsa_solve: see DSA_STAT_* */
 enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, DSA_STAT_MS_STAGES,
        DSA_STAT_LAUNCHES_FIM_COARSE, DSA_STAT_UNITS, DSA_STAT_ROUNDS_MAX, DSA_STAT_EVALS_TOTAL,

@@ -15,14 +15,14 @@ import synth
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
-# The only fields of this file that leave the 1e-4 s bar, by (nx, medium, dicing, source index): (bound on the field's
-# max |dT| = 1.5 x measured, bound on the nodes beyond 1e-4 s = 1.5 x measured).  Each is an exact-tie case: two
+# The only field of this file that leaves the 1e-4 s bar, by (nx, medium, dicing, source index): (largest |dT| as printed with 9 digits,
+# nodes beyond 1e-4 s) -- the MEASURED figures, asserted exactly (the solve is deterministic).  It is an exact-tie case: two
 # neighbouring narrow-band nodes carry bit-equal times, the reference pops one of them first (which one is decided by
 # its heap layout, CalSurfG.f90:417-424 / :768-921) and re-evaluates the other against it at the double root of the
-# two-sided quadratic; this engine accepts both without using either in the other's stencil.  Measured with
-# tests/tools/parity_table.py (profiles/r02_parity_table.log).  Every other (case, source) asserts 1e-4 s over the field.
+# two-sided quadratic; the fixed-point solve accepts both without using either in the other's stencil.  The exact mode
+# (tests/test_gpu_exact.py) reproduces the reference on this case bit for bit.  Every other (case, source) asserts 1e-4 s over the field.
 TIE_CASES = {
-    (35, "checker4", 8, 3): (6.2e-4, 62),     # source on the node (5, 7) of a +-13 % checkerboard: measured 4.13e-4 s, 41 of 66 049 nodes
+    (35, "checker4", 8, 3): ("0.000412940979", 41),     # source on the node (5, 7) of a +-13 % checkerboard: 41 of 66 049 nodes
 }
 
 
@@ -86,12 +86,14 @@ def test_fields_match_oracle(engine, nx, kind, gd):
         over = int((dT > TOL).sum())
         worst = max(worst, d)
         nbad_nodes += int((bits(T) != bits(o["T"])).sum())
-        bound, nbound = TIE_CASES.get((nx, kind, gd, u), (TOL, 0))
+        named = TIE_CASES.get((nx, kind, gd, u))
         if d > 0:
             parity_log.add(f"fixture nx={nx} {kind} gd={gd} source {u} {FRAC[u]}: field max |dT| {d:.9g} s, nodes beyond 1e-4 s {over}"
                            + (" [named tie case]" if (nx, kind, gd, u) in TIE_CASES else ""))
-        assert d <= bound, (nx, kind, gd, u, d)
-        assert over <= nbound, (nx, kind, gd, u, over)
+        if named is not None:
+            assert ("%.9g" % d, over) == named, (nx, kind, gd, u, d, over)
+        else:
+            assert d <= TOL and over == 0, (nx, kind, gd, u, d, over)
         Tr, Sr = engine.refined(u)
         cls_o = np.sign(o["Sr"]).clip(-1, 1)
         # status classes may differ only at exact time ties (symmetric media); values where both alive agree
