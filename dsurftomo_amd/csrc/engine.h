@@ -80,7 +80,7 @@ struct Engine {
     // exact mode (exact_kernel.hip): 0 off; 1 = units whose fixed-point solve met an exact time tie (or froze a cycle) are solved
     // again by the literal Fast Marching; 2 = every unit by the literal Fast Marching only
     int exact_ties = 0;
-    float tie_threshold = 0.0f;        // a tie counts when taking the tied neighbour in moves the node's value by more than this (s)
+    float tie_threshold = 2.0e-5f;     // a tie counts when taking the tied neighbour in moves the node's value by more than this (s); 0 = any tie
     int exact_lds_slots = 768;         // tree slots kept in LDS per marching unit (8 bytes each)
     int exact_pool = 0;                // units marching at a time (0 = by free memory, at most 4096)
     DevBuf<unsigned long long> X_pool, X_heap;   // per marching unit: (T, status) records of the whole grid; tree slots beyond the LDS part

@@ -24,7 +24,7 @@
 //   * a changed node stores (T, tau) first and activates dependents afterwards; a dependent that
 //     read a torn or stale state this round has its bit clear and is therefore re-queued;
 //   * the fixed point is schedule independent, so races only cost re-evaluations.
-#ifdef DSA_LEDGER      // probe build of tools/isa_ledger.py: named markers in the assembly and one wave-trip counter per marker
+#if defined(DSA_LEDGER)      // probe build of tools/isa_ledger.py, run on the GPU: named markers in the assembly and one wave-trip counter per marker
 #define DSA_LEDGER_PARAM , unsigned* dsa_lc
 #define DSA_LEDGER_PASS , dsa_lc
 #define DSA_LEDGER_COUNT(k, name)                                                                                              \
@@ -33,6 +33,10 @@
         const unsigned long long ex_ = __builtin_amdgcn_read_exec();                                                           \
         if ((int)(threadIdx.x & 63u) == __ffsll((long long)ex_) - 1) dsa_lc[k] += 1u;                                          \
     } while (0)
+#elif defined(DSA_LEDGER_MARKS)   // the markers alone (assembly comments: no instructions): what tools/isa_ledger.py counts the static mix on
+#define DSA_LEDGER_PARAM
+#define DSA_LEDGER_PASS
+#define DSA_LEDGER_COUNT(k, name) asm volatile("; LEDGER " #k " " name)
 #endif
 #include "kernels.h"
 #include "receiver_core.h"

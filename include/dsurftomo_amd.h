@@ -200,7 +200,7 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
 /* Exact time ties: the fixed-point solve lands on the reference's Fast-Marching travel times except downstream of
  * bit-equal times of two neighbouring narrow-band nodes, where the reference's own answer depends on the layout of its binary
  * tree (CalSurfG.f90:417-485, :768-921).  Option "exact_ties": 0 (default) fixed point only; 1 = the solve kernel detects such
- * ties (option "tie_threshold", seconds: the influence on the node's value a tie must have to count; default 0 = any) and the
+ * ties (option "tie_threshold", seconds: the influence on the node's value a tie must have to count; default 2e-5, 0 = any tie) and the
  * units that met one are solved again by the reference's march itself, replayed on the device one wavefront per unit -- their
  * fields are then bit-identical to the reference's; 2 = every unit by the literal march.  Options "exact_lds_slots" (tree slots
  * in LDS per marching unit, default 768) and "exact_pool" (units marching at a time, 0 = by free memory).

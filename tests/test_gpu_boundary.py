@@ -20,7 +20,7 @@ import pytest
 import _libs as L
 import parity_log
 import synth
-import taipei
+from dsurftomo_amd import io as taipei      # the reference's Taipei example (tests/golden/taipei/) through the package's format readers
 
 pytestmark = pytest.mark.gpu
 

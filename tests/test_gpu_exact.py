@@ -29,7 +29,7 @@ def bits(a):
 def exact(engine):
     yield engine
     engine.set_option("exact_ties", 0)
-    engine.set_option("tie_threshold", 0)
+    engine.set_option("tie_threshold", 2e-5)
     engine.set_option("exact_lds_slots", 768)
 
 
@@ -104,7 +104,7 @@ def test_tie_detector_and_exact_redo_at_headline_size(exact, kind, nsrc):
     nx, nrec = 131, 32
     u = synth.units(nx, nsrc, 1, nrec, seed=synth.SEED + 5)
     pv = synth.medium(nx, kind, 0)[None, :]
-    e.set_option("exact_ties", 1)
+    e.set_option("exact_ties", 1)               # (default tie_threshold: 2e-5 s)
     e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     t = e.traveltimes(**u).reshape(nsrc, nrec)
     st = e.stats()

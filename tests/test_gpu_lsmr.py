@@ -9,7 +9,7 @@ import pytest
 import _libs as L
 import inversion as inv
 import synth
-import taipei
+from dsurftomo_amd import io as taipei      # the reference's Taipei example (tests/golden/taipei/) through the package's format readers
 from dsurftomo_amd.engine import Engine, load_library
 
 pytestmark = pytest.mark.gpu

@@ -53,7 +53,7 @@ if "full" in what:
 e.close()
 if "boundary" in what:
     lib = E.load_library()
-    import taipei
+    from dsurftomo_amd import io as taipei
     cases = [(n, synth.boundary_case(**B.CASES[n])) for n in sorted(B.CASES)] + [("taipei", taipei.load())]
     for name, c in cases:
         o = L.call_boundary(L.oracle().dso_calsurfg, c)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _libs as L      # noqa: E402
-import taipei          # noqa: E402  (tests/taipei.py -> dsurftomo_amd.io)
+from dsurftomo_amd import io as taipei          # noqa: E402
 from dsurftomo_amd import engine as E   # noqa: E402
 
 

@@ -24,10 +24,19 @@ st = e.stats(); fl, inf = e.unit_ties()
 print(f'  exact_ties=1: {n/dt:8.1f} solves/s | flagged {int(st["tie_units"])} of {n} units ({100.0*st["tie_units"]/n:.1f} %), largest influence {inf.max():.3g} s, '
       f'median of flagged {np.median(inf[fl & 1 > 0]) if (fl & 1).any() else 0:.3g} s | exact part {st["ms_exact"]:.0f} ms | receivers differing from the fixed point: '
       f'{int((t1.view(np.uint32) != tf.view(np.uint32)).sum())} of {t1.size}, max {np.abs(t1 - tf).max():.3g} s', flush=True)
-for thr in (1e-6, 1e-5, 2e-5, 5e-5):
-    e.set_option('tie_threshold', thr); e.plan(**u); e.solve(); st = e.stats()
-    print(f'  tie_threshold {thr:g}: flagged {int(st["tie_units"])} of {n}', flush=True)
-e.set_option('tie_threshold', 0)
+e.set_option('exact_ties', 2); e.set_option('exact_lds_slots', lds[0]); e.plan(**u)
+tx = e.solve()                      # the literal march for every unit: the reference to judge the thresholds by
+nrec = 32
+dfix = np.abs(tf.astype(np.float64) - tx.astype(np.float64)).reshape(n, nrec).max(axis=1)
+print(f'  fixed point vs literal march: units with a receiver beyond 1e-4 s: {int((dfix > 1e-4).sum())} of {n}, worst {dfix.max():.3g} s', flush=True)
+e.set_option('exact_ties', 1)
+for thr in (1e-6, 5e-6, 1e-5, 2e-5, 3e-5, 5e-5, 1e-4):
+    e.set_option('tie_threshold', thr); e.plan(**u); tt = e.solve(); st = e.stats(); fl, inf = e.unit_ties()
+    left = (fl & 2) == 0
+    d = np.abs(tt.astype(np.float64) - tx.astype(np.float64)).reshape(n, nrec).max(axis=1)
+    print(f'  tie_threshold {thr:g}: flagged {int(st["tie_units"])} of {n} ({100.0*st["tie_units"]/n:.1f} %) | units left to the fixed point: worst receiver |dt| {d[left].max() if left.any() else 0:.3g} s, '
+          f'{int((d[left] > 1e-4).sum())} beyond 1e-4 s | flagged units identical to the march: {bool((d[~left] == 0).all())} | {n/ (st["ms_total"]/1e3 + 1e-9):.0f} solves/s (device time)', flush=True)
+e.set_option('tie_threshold', 2e-5)
 e.set_option('exact_ties', 2)
 ref = None
 for l in lds:

@@ -12,7 +12,7 @@ with the SQ_INSTS_* counters of profiles/pmc_latest.json where that file matches
 import json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DDSA_LEDGER", "-S", "--cuda-device-only"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DDSA_LEDGER_MARKS", "-S", "--cuda-device-only"]
 KERNEL = "_ZN3dsa12k_fim_sortedILi256ELb1ELb0EEE"
 FP32 = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_div_scale_f32", "v_div_fmas_f32",
         "v_div_fixup_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_min_f32", "v_max_f32", "v_mad_f32")
@@ -54,13 +54,14 @@ def main():
                 m = re.match(r"\s*\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|group_segment_fixed_size):\s*(\d+)", l2)
                 if m:
                     meta[m.group(1)] = int(m.group(2))
-    seg_order, segs = [], {}
+    seg_order, segs, copies = [], {}, {}
     cur = ("-", "prologue (before the first round)")
     for l in lines[start:end]:
         t = l.strip()
         m = re.match(r";\s*LEDGER (\d+) (\S+)", t)
         if m:
             cur = (m.group(1), m.group(2))
+            copies[cur] = copies.get(cur, 0) + 1
             continue
         if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
             continue
@@ -80,10 +81,10 @@ def main():
         if op.startswith("scratch_"):
             d["scratch"] = d.get("scratch", 0) + 1
     cols = ["valu", "salu", "vmem", "lds", "smem", "branch", "sync", "cndmask", "lane_moves", "fp32_arith", "scratch"]
-    print("ISA ledger of k_fim_sorted<256, compact> (gfx950, the tree's flags + -DDSA_LEDGER); static = instructions in the piece of code that follows the marker, in text order")
+    print("ISA ledger of k_fim_sorted<256, compact> (gfx950, the tree's flags + -DDSA_LEDGER_MARKS: assembly comments only); static = instructions in the piece of code that follows the marker, in text order")
     print("kernel metadata: " + ", ".join("%s %s" % kv for kv in sorted(meta.items())))
     trips = counters["wave_trips_per_solve"] if counters else {}
-    hdr = "%-4s %-22s " % ("id", "piece") + " ".join("%8s" % c for c in cols) + "   %12s %12s %12s" % ("trips/solve", "VALU/solve", "SALU/solve")
+    hdr = "%-4s %-22s %6s " % ("id", "piece", "copies") + " ".join("%8s" % c for c in cols) + "   %12s %12s %12s" % ("trips/solve", "VALU/solve", "SALU/solve")
     print(hdr)
     tot = {c: 0 for c in cols}
     dyn_v = dyn_s = dyn_m = dyn_l = 0.0
@@ -93,14 +94,15 @@ def main():
         for c in cols:
             tot[c] += d.get(c, 0)
         tr = trips.get(k[0]) if k[0] != "-" else None
-        dv = d.get("valu", 0) * tr if tr is not None else None
-        ds_ = d.get("salu", 0) * tr if tr is not None else None
+        nc = max(copies.get(k, 1), 1)          # an unrolled loop holds several copies of the piece: a trip runs one of them
+        dv = d.get("valu", 0) / nc * tr if tr is not None else None
+        ds_ = d.get("salu", 0) / nc * tr if tr is not None else None
         if tr is not None:
-            dyn_v += dv; dyn_s += ds_; dyn_m += d.get("vmem", 0) * tr; dyn_l += d.get("lds", 0) * tr
+            dyn_v += dv; dyn_s += ds_; dyn_m += d.get("vmem", 0) / nc * tr; dyn_l += d.get("lds", 0) / nc * tr
         rows.append((k, d, tr, dv, ds_))
     for k, d, tr, dv, ds_ in rows:
-        print("%-4s %-22s " % k + " ".join("%8d" % d.get(c, 0) for c in cols) + ("   %12.0f %12.0f %12.0f" % (tr, dv, ds_) if tr is not None else "   %12s %12s %12s" % ("-", "-", "-")))
-    print("%-4s %-22s " % ("", "total (static)") + " ".join("%8d" % tot[c] for c in cols))
+        print("%-4s %-22s %6d " % (k[0], k[1], copies.get(k, 1)) + " ".join("%8d" % d.get(c, 0) for c in cols) + ("   %12.0f %12.0f %12.0f" % (tr, dv, ds_) if tr is not None else "   %12s %12s %12s" % ("-", "-", "-")))
+    print("%-4s %-22s %6s " % ("", "total (static)", "") + " ".join("%8d" % tot[c] for c in cols))
     if counters:
         print()
         print("dynamic, per solve (%d units at N = %d, %s medium; %.0f evaluations, rounds <= %.0f): wave instructions = static x wave trips" %
@@ -108,7 +110,9 @@ def main():
         print("  VALU %.2f M   SALU %.2f M   VMEM %.2f M   LDS %.2f M" % (dyn_v / 1e6, dyn_s / 1e6, dyn_m / 1e6, dyn_l / 1e6))
         print("  share of the VALU wave instructions by piece:")
         for k, d, tr, dv, ds_ in sorted([r for r in rows if r[3]], key=lambda r: -r[3]):
-            print("    %-22s %5.1f %%   (%d static x %.0f trips; fp32 arithmetic %d, selects %d of them)" % (k[1], 100.0 * dv / dyn_v, d.get("valu", 0), tr, d.get("fp32_arith", 0), d.get("cndmask", 0)))
+            nc = max(copies.get(k, 1), 1)
+            print("    %-22s %5.1f %%   (%.0f VALU per trip x %.0f trips; of the static %d: fp32 arithmetic %d, selects %d, lane moves %d)" %
+                  (k[1], 100.0 * dv / dyn_v, d.get("valu", 0) / nc, tr, d.get("valu", 0), d.get("fp32_arith", 0), d.get("cndmask", 0), d.get("lane_moves", 0)))
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
