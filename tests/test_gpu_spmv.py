@@ -7,7 +7,7 @@ import pytest
 
 import _libs as L
 import synth
-import taipei
+from dsurftomo_amd import io as taipei
 from dsurftomo_amd.engine import Engine, load_library
 
 pytestmark = pytest.mark.gpu
