@@ -96,7 +96,7 @@ def main_taipei():
     """b_taipei.npz: the reference's CalSurfG on its own Taipei example (inputs under taipei/): travel
     times and the matrix reduced to row sums / column absolute sums / entry count (the full COO
     list is 565 k entries)"""
-    import taipei
+    from dsurftomo_amd import io as taipei
     c = taipei.load()
     a = L.call_boundary(L.ref().calsurfg_, c)
     G = np.zeros((c["ndata"], c["nparpi"]), np.float32)

@@ -77,7 +77,7 @@ def test_boundary_golden():
 
 def test_taipei_golden():
     """the oracle on the reference's Taipei example against the reference's own output"""
-    import taipei
+    from dsurftomo_amd import io as taipei
     z = np.load(os.path.join(GDIR, "b_taipei.npz"))
     c = taipei.load()
     assert c["ndata"] == z["dsurf"].size == 2061 and c["kmax"] == 26
