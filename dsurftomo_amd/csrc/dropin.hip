@@ -48,6 +48,8 @@ int engine()
         }
         if (const char* s = getenv("DSA_MAX_CHUNK")) dsa_set_option(e, "max_chunk", atof(s));
         if (const char* s = getenv("DSA_WINDOW_CELLS")) dsa_set_option(e, "window_cells", atof(s));
+        if (const char* s = getenv("DSA_EXACT_TIES")) dsa_set_option(e, "exact_ties", atof(s));       // exact mode for an unchanged Fortran host
+        if (const char* s = getenv("DSA_TIE_THRESHOLD")) dsa_set_option(e, "tie_threshold", atof(s));
         g_pool.push_back(e);
     }
     g_engine = g_pool[0];

@@ -335,6 +335,37 @@ print("sharded ok")
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_dropin_exact_mode_from_the_environment():
+    """DSA_EXACT_TIES=2: an unchanged host gets the reference's march itself behind calsurfg_; travel times,
+    rays and rows of whole boundary calls -- a homogeneous model too, where every front is full of exact ties -- bit-identical"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _libs as L, synth
+from dsurftomo_amd import engine
+lib = engine.load_library()
+for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, nsrc=8, nrcf=7, kRc=3, kRg=1, kLc=1, kLg=1), dict(flat=True)):
+    flat = kw.pop("flat", False)
+    c = synth.boundary_case(**kw)
+    if flat:
+        v = np.array(c["vels"]); v[:, :, :] = v[:1, :1, :]; c["vels"] = np.asfortranarray(v)      # no lateral variation: symmetric fronts
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    d = L.call_boundary(lib.dsa_calsurfg, c)
+    assert o["nar"] == d["nar"], (o["nar"], d["nar"])
+    assert (o["dsurf"].view(np.uint32) == d["dsurf"].view(np.uint32)).all()
+    assert (o["iw"] == d["iw"]).all() and (o["col"] == d["col"]).all()
+    assert (o["rw"].view(np.uint32) == d["rw"].view(np.uint32)).all()
+import ctypes as C
+st = np.zeros(40); lib.dsa_dropin_engine.restype = C.c_void_p
+assert lib.dsa_get_stats(C.c_void_p(lib.dsa_dropin_engine()), st.ctypes.data_as(C.c_void_p)) == 0
+assert st[21] > 0, st[:26]          # DSA_STAT_EXACT_UNITS: the last call went through the literal march
+print("exact ok")
+''' % (L.ROOT, os.path.join(L.ROOT, "tests"))
+    env = dict(os.environ, DSA_EXACT_TIES="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "exact ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_synthetic_noise_statistics(lib):
     """dsa_synthetic called directly with a noise level (the Fortran shim passes 0 and adds the host program's
     gaussian() itself): obst = t (1 + level * g), g ~ N(0, 1) from the engine's own generator"""
