@@ -426,6 +426,224 @@ DSA_HD int getsol(const Layers& m, double t1, double* c1io, double clow, double 
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The root search as a STATE MACHINE (round 3).  The reference nests its loops: per period the bracketing walk `getsol`
+// (surfdisp96.f:384-476), inside it the hybrid halving / Neville refinement `nevill` (:551-668), and the secular function is called
+// from seven places.  Sixty-four lanes running that nest re-converge at every loop exit, so a wavefront takes, per period, the
+// LONGEST search among its lanes: measured lane fill 0.76 (profiles/r02_pmc_dispersion.txt).  Here the nest is unrolled into states:
+// the only loop is "evaluate the secular function at my trial wavenumber, then advance my own search to its next trial", so every
+// trip of that loop does useful work on every lane that still has a period to do, whatever stage its search is in.  The sequence of
+// evaluations of a curve -- and therefore every bit of its result -- is the reference's.
+struct RootSearch {
+    // curve level (dispersion_curve)
+    int k, kmax, igr, failed_k;
+    int pass;                 // 1: the root at t1 (phase) / t1a (group), 2: the second root at t1b
+    float t1a, t1b;
+    double cc, cm, dc, c1, cprev, ck, del1st, clow;
+    float betmx;
+    // getsol
+    int st;                   // what the pending evaluation is for (RS_*)
+    int ifirst, idir, guard;
+    double t1, omega, c2, del1, del2;
+    // nevill
+    int nev, nctrl, mm;
+    double c3, del3, x[12], y[12];
+    // the pending evaluation
+    double wvno;
+};
+enum { RS_DONE = 0, RS_G1, RS_G2, RS_NA, RS_NB, RS_NCD };
+
+// what follows a finished getsol (iret, root in r.c1): the curve's bookkeeping, then the next search; false when the curve is done
+template <int IFUNC>
+DSA_HD bool rs_after_getsol(RootSearch& r, int iret, const double* t, double* cg, size_t cstride);
+
+// start a getsol at period r.t1 from r.c1 (surfdisp96.f:384-400)
+DSA_HD void rs_getsol_start(RootSearch& r)
+{
+    const double twopi = 2.0 * 3.141592653589793;
+    r.omega = twopi / r.t1;
+    r.wvno = r.omega / r.c1;
+    r.guard = 0;
+    r.st = RS_G1;
+}
+// the bracketing walk up to its next evaluation; returns false when the search fails here (iret = -1)
+DSA_HD bool rs_bracket_step(RootSearch& r)
+{
+    const double twopi = 2.0 * 3.141592653589793;
+    for (;;) {
+        // (bounded: with NaN in the model no comparison ever ends the reference's loop; a device lane must not spin)
+        if (r.guard > 100000) return false;
+        r.guard += 1;
+        if (r.idir > 0) r.c2 = r.c1 + r.dc; else r.c2 = r.c1 - r.dc;
+        if (r.c2 <= r.clow) { r.idir = +1; r.c1 = r.clow; continue; }
+        r.omega = twopi / r.t1;
+        r.wvno = r.omega / r.c2;
+        r.st = RS_G2;
+        return true;
+    }
+}
+// nevill's loop body (surfdisp96.f:575-668) from the bracket update to its next evaluation; false: the refinement has ended (root r.c3)
+DSA_HD bool rs_nevill_mid(RootSearch& r)
+{
+    const double s13 = r.del1 - r.del3;
+    const double s32 = r.del3 - r.del2;
+    if (sign1(r.del3) * sign1(r.del1) < 0.0) { r.c2 = r.c3; r.del2 = r.del3; }
+    else { r.c1 = r.c3; r.del1 = r.del3; }
+    if (fabs(r.c1 - r.c2) <= 1.e-6 * r.c1) return false;
+    if (sign1(s13) != sign1(s32)) r.nev = 0;
+    const double ss1 = fabs(r.del1);
+    const double s1 = (double)0.01f * ss1;          // single-precision literal in the reference
+    const double ss2 = fabs(r.del2);
+    const double s2 = (double)0.01f * ss2;
+    bool halve = (s1 > ss2 || s2 > ss1 || r.nev == 0);
+    if (!halve) {
+        if (r.nev == 2) { r.x[r.mm + 1] = r.c3; r.y[r.mm + 1] = r.del3; }
+        else { r.x[1] = r.c1; r.y[1] = r.del1; r.x[2] = r.c2; r.y[2] = r.del2; r.mm = 1; }
+        for (int kk = 1; kk <= r.mm; ++kk) {
+            const int j = r.mm - kk + 1;
+            const double denom = r.y[r.mm + 1] - r.y[j];
+            if (fabs(denom) < 1.0e-10 * fabs(r.y[r.mm + 1])) { halve = true; break; }
+            r.x[j] = (-r.y[j] * r.x[j + 1] + r.y[r.mm + 1] * r.x[j]) / denom;
+        }
+        if (!halve) {
+            r.c3 = r.x[1];
+            r.nev = 2;
+            r.mm = r.mm + 1;
+            if (r.mm > 10) r.mm = 10;
+        }
+    }
+    if (halve) {
+        r.c3 = 0.5 * (r.c1 + r.c2);
+        r.nev = 1;
+        r.mm = 1;
+    }
+    r.wvno = r.omega / r.c3;
+    r.st = RS_NCD;
+    return true;
+}
+
+// `del` = the secular function at the trial the search asked for: advance to the next trial.  Returns false when the curve is done.
+template <int IFUNC>
+DSA_HD bool rs_advance(RootSearch& r, double del, const double* t, double* cg, size_t cstride)
+{
+    bool in_nevill_top = false, in_nevill_mid = false;
+    switch (r.st) {
+    case RS_G1: {
+        r.del1 = del;
+        if (r.ifirst == 1) r.del1st = r.del1;
+        const double plmn = sign1(r.del1st) * sign1(r.del1);
+        r.idir = +1;
+        if (r.ifirst != 1 && plmn < 0.0) r.idir = -1;
+        if (!rs_bracket_step(r)) return rs_after_getsol<IFUNC>(r, -1, t, cg, cstride);
+        return true;
+    }
+    case RS_G2: {
+        r.del2 = del;
+        if (sign1(r.del1) != sign1(r.del2)) {
+            // nevill (surfdisp96.f:551-574): the midpoint first
+            r.nctrl = 1; r.mm = 1;
+            r.c3 = 0.5 * (r.c1 + r.c2);
+            r.wvno = r.omega / r.c3;
+            r.st = RS_NA;
+            return true;
+        }
+        r.c1 = r.c2;
+        r.del1 = r.del2;
+        if (r.c1 < r.cm) return rs_after_getsol<IFUNC>(r, -1, t, cg, cstride);
+        if (r.c1 >= ((double)r.betmx + r.dc)) return rs_after_getsol<IFUNC>(r, -1, t, cg, cstride);
+        if (!rs_bracket_step(r)) return rs_after_getsol<IFUNC>(r, -1, t, cg, cstride);
+        return true;
+    }
+    case RS_NA: r.del3 = del; r.nev = 1; in_nevill_top = true; break;
+    case RS_NB: r.del3 = del; in_nevill_mid = true; break;
+    case RS_NCD: r.del3 = del; in_nevill_top = true; break;
+    default: return false;
+    }
+    for (;;) {
+        if (in_nevill_top) {
+            r.nctrl = r.nctrl + 1;
+            if (r.nctrl >= 100) break;
+            if (r.c3 < fmin(r.c1, r.c2) || r.c3 > fmax(r.c1, r.c2)) {
+                r.nev = 0;
+                r.c3 = 0.5 * (r.c1 + r.c2);
+                r.wvno = r.omega / r.c3;
+                r.st = RS_NB;
+                return true;
+            }
+            in_nevill_mid = true;
+        }
+        if (in_nevill_mid) {
+            if (!rs_nevill_mid(r)) break;
+            return true;
+        }
+    }
+    // the refinement has ended: getsol's tail (surfdisp96.f:470-476)
+    r.c1 = r.c3;
+    return rs_after_getsol<IFUNC>(r, r.c1 > (double)r.betmx ? -1 : 1, t, cg, cstride);
+}
+
+// set up period r.k (surfdisp96.f:223-262) and start its first search
+DSA_HD void rs_period_start(RootSearch& r, const double* t)
+{
+    const float h = 0.005f;
+    const double onea = (double)1.500f;
+    double t1 = t[r.k - 1];
+    r.t1b = 0.0f;
+    if (r.igr > 0) {
+        r.t1a = (float)(t1 / (double)(1.f + h));
+        r.t1b = (float)(t1 / (double)(1.f - h));
+        t1 = (double)r.t1a;
+    } else {
+        r.t1a = (float)t1;
+    }
+    if (r.k == 1) { r.c1 = r.cc; r.clow = r.cc; r.ifirst = 1; }
+    else { r.ifirst = 0; r.c1 = r.cprev - onea * r.dc; r.clow = r.cm; }
+    r.t1 = t1;
+    r.pass = 1;
+    rs_getsol_start(r);
+}
+
+template <int IFUNC>
+DSA_HD bool rs_after_getsol(RootSearch& r, int iret, const double* t, double* cg, size_t cstride)
+{
+    const double one = 1.0e-2;
+    const double onea = (double)1.500f;
+    if (r.pass == 1) {
+        if (iret == -1) {
+            // the reference logs "improper initial value in disper - no zero found" and zero-fills the rest of the curve (:308-348)
+            r.failed_k = r.k;
+            for (int i = r.k; i <= r.kmax; ++i) cg[(size_t)(i - 1) * cstride] = 0.0;
+            r.st = RS_DONE;
+            return false;
+        }
+        r.ck = r.c1;
+        r.cprev = r.ck;
+        if (r.igr > 0) {
+            r.t1 = (double)r.t1b;
+            r.clow = 0.0 + one * r.dc;               // cb(k) is still zero here
+            r.c1 = r.c1 - onea * r.dc;
+            r.ifirst = 0;
+            r.pass = 2;
+            rs_getsol_start(r);
+            return true;
+        }
+        r.c1 = 0.0;
+    } else {
+        if (iret == -1) r.c1 = r.ck;
+    }
+    const float cc0 = (float)r.ck;
+    const float cc1b = (float)r.c1;
+    if (r.igr == 0) cg[(size_t)(r.k - 1) * cstride] = (double)cc0;
+    else {
+        const float gvel = (1 / r.t1a - 1 / r.t1b) / (1 / (r.t1a * cc0) - 1 / (r.t1b * cc1b));
+        cg[(size_t)(r.k - 1) * cstride] = (double)gvel;
+    }
+    r.k += 1;
+    if (r.k > r.kmax) { r.st = RS_DONE; return false; }
+    rs_period_start(r, t);
+    return true;
+}
+
 // starting phase velocity from the half-space Rayleigh equation, all REAL*4; surfdisp96.f:361-382
 DSA_HD float gtsolh(float a, float b)
 {
@@ -486,11 +704,54 @@ DSA_HD void build_layers(const LayerGeom& G, const float* vs, const float* vp, c
 
 // One dispersion curve (surfdisp96.f:52-350 with mode = 1): cg[k] for k < kmax, written with `cstride`.
 // igr = 0 phase velocity, 1 group velocity from two roots at T/(1 +- h).
+// One dispersion curve (surfdisp96.f:52-350 with mode = 1): cg[k] for k < kmax, written with `cstride`.
+// igr = 0 phase velocity, 1 group velocity from two roots at T/(1 +- h).
 // Returns 0, or -- when no zero of the secular function was found for a period (the reference's "improper initial value in disper -
 // no zero found" block on unit 66, surfdisp96.f:308-339, after which it zero-fills the rest of the curve, :342-348) -- the 1-based
 // index k of that period.
 template <int IFUNC>
-DSA_HD int dispersion_curve(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
+DSA_HD int dispersion_curve_states(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
+{
+    const int mmax = m.mmax;
+    const float ddc = 0.005f;
+    int jmn = 1, jsol = 1;
+    float betmx = -1.e20f, betmn = 1.e20f;
+    for (int i = 0; i < mmax; ++i) {
+        const float bi = m.B(i), ai = m.A(i);
+        if (bi > 0.01f && bi < betmn) { betmn = bi; jmn = i + 1; jsol = 1; }
+        else if (bi <= 0.01f && ai < betmn) { betmn = ai; jmn = i + 1; jsol = 0; }
+        if (bi > betmx) betmx = bi;
+    }
+    float cc1;
+    if (jsol == 0) cc1 = betmn;
+    else cc1 = gtsolh(m.A(jmn - 1), m.B(jmn - 1));
+    cc1 = .95f * cc1;
+    cc1 = .90f * cc1;
+    RootSearch r;
+    r.k = 1; r.kmax = kmax; r.igr = igr; r.failed_k = 0;
+    r.cc = (double)cc1;
+    r.dc = fabs((double)ddc);
+    r.cm = r.cc;
+    r.c1 = r.cc; r.cprev = 0.0; r.del1st = 0.0; r.ck = 0.0; r.clow = r.cc;
+    r.betmx = betmx;
+    r.c2 = 0.0; r.del1 = 0.0; r.del2 = 0.0; r.c3 = 0.0; r.del3 = 0.0; r.nev = 0; r.nctrl = 0; r.mm = 1; r.idir = 1; r.guard = 0; r.ifirst = 1;
+    for (int i = 0; i < 12; ++i) { r.x[i] = 0.0; r.y[i] = 0.0; }
+    if (kmax < 1) return 0;
+    rs_period_start(r, t);
+    // the one loop: every trip evaluates the secular function once per lane, wherever the lane's search stands
+    bool live = true;
+    while (live) {
+        const double del = secular<IFUNC>(m, r.wvno, r.omega);
+        live = rs_advance<IFUNC>(r, del, t, cg, cstride);
+    }
+    return r.failed_k;
+}
+
+// The reference's own loop nest (kept for Love waves, see dispersion_curve).  Returns 0, or -- when no zero of the secular function was found for a period (the reference's "improper initial value in disper -
+// no zero found" block on unit 66, surfdisp96.f:308-339, after which it zero-fills the rest of the curve, :342-348) -- the 1-based
+// index k of that period.
+template <int IFUNC>
+DSA_HD int dispersion_curve_nested(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
 {
     const int mmax = m.mmax;
     const float ddc = 0.005f, h = 0.005f;
@@ -552,6 +813,16 @@ DSA_HD int dispersion_curve(const Layers& m, int igr, int kmax, const double* t,
     if (failed)
         for (int i = k; i <= kmax; ++i) cg[(size_t)(i - 1) * cstride] = 0.0;   // the reference logs a warning and zero-fills
     return failed ? k : 0;
+}
+
+// Which form runs where (measured, profiles/r03_ab_dispersion_states.txt; both give the reference's bits): the state machine for Rayleigh
+// waves, whose secular function (Dunkin's compound matrices: ~700 instructions per layer) is what the lanes should spend their time in
+// -- +16 % roots/s at the headline size (lane fill 0.76 -> 0.9), +18 % for group velocities; the loop nest for Love waves, whose
+// Thomson-Haskell function is so cheap that the state bookkeeping costs more than the idle lanes did (-9 %).
+template <int IFUNC>
+DSA_HD int dispersion_curve(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
+{
+    return IFUNC == 2 ? dispersion_curve_states<IFUNC>(m, igr, kmax, t, cg, cstride) : dispersion_curve_nested<IFUNC>(m, igr, kmax, t, cg, cstride);
 }
 
 }  // namespace dsa

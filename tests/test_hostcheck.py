@@ -22,6 +22,7 @@ def H():
     hdr = [os.path.join(L.ROOT, "dsurftomo_amd", "csrc", n) for n in ("eikonal_core.h", "source_stage.h", "host_geometry.h")]
     hdr.append(os.path.join(HERE, "solve_node_walk_ref.h"))
     hdr.append(os.path.join(L.ROOT, "dsurftomo_amd", "csrc", "exact_march.h"))
+    hdr.append(os.path.join(L.ROOT, "dsurftomo_amd", "csrc", "dispersion_core.h"))
     if L._stale(SO, [src] + hdr):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-msse2",
                                "-mfpmath=sse", "-shared", "-o", SO, src, "-lm"])
@@ -35,6 +36,7 @@ def H():
     h.hc_device_schedule.restype = C.c_long
     h.hc_solve_node_compare.argtypes = [C.c_ulonglong, C.c_long, L.vp]
     h.hc_solve_node_compare.restype = C.c_long
+    h.hc_depthkernel.argtypes = [L.i32, L.i32, L.vp, L.vp, L.f32, L.i32, L.i32, L.i32, L.vp, L.i32, L.vp, L.vp, L.vp, L.vp]
     h.hc_quads_compare.argtypes = [C.c_ulonglong, C.c_long]
     h.hc_quads_compare.restype = C.c_long
     h.hc_exact_solve.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.f32, L.f32, L.i32, L.i32] + [L.vp] * 5
@@ -192,3 +194,26 @@ def test_exact_march_is_the_oracle_bit_for_bit(H, nx, kind, gd, lcap):
 def test_quadrant_form_of_the_stencil_equals_fouds2(H):
     """what the sixteen lanes of the exact mode evaluate (one quadrant each, minimum over four) == fouds2, bit for bit, on 5e6 random neighbourhoods"""
     assert H.hc_quads_compare(20261003, 5_000_000) == 0
+
+
+@pytest.mark.parametrize("iwave,igr", [(2, 0), (2, 1), (1, 0), (1, 1)])
+def test_dispersion_state_machine_equals_the_oracle(H, iwave, igr):
+    """the product's dispersion code (csrc/dispersion_core.h: the root search unrolled into a state machine, what k_dispersion runs) on
+    the CPU against the oracle's nested loops: phase / group velocities and all three depth kernels, every bit -- including a column
+    with a low-velocity zone and one without any contrast"""
+    c = synth.boundary_case(nx=7, ny=6, nz=7, kRc=4, kRg=3, kLc=3, kLg=2, nsrc=2, nrcf=2)
+    v = np.array(c["vels"])
+    v[2, 3, 2] *= 0.8; v[2, 3, 3] *= 0.75          # a low-velocity zone
+    v[4, 1, :] = v[4, 1, 0]                          # a half space in disguise
+    vel = np.ascontiguousarray(np.asfortranarray(v.astype(np.float32)).T)       # (nz, ny, nx)
+    t = {(2, 0): c["tRc"], (2, 1): c["tRg"], (1, 0): c["tLc"], (1, 1): c["tLg"]}[(iwave, igr)]
+    want = L.depthkernel("oracle", vel, c["depz"], float(c["minthk"]), iwave, igr, t)
+    nz, ny, nx = vel.shape
+    ncol, kmax = nx * ny, len(t)
+    pv = np.zeros((kmax, ncol)); sen = [np.zeros((nz, kmax, ncol)) for _ in range(3)]
+    tt = np.ascontiguousarray(t, np.float64)
+    assert H.hc_depthkernel(ncol, nz, L.ptr(vel.reshape(nz, ncol)), L.ptr(np.ascontiguousarray(c["depz"], np.float32)), float(c["minthk"]), iwave, igr, kmax,
+                            L.ptr(tt), 1, L.ptr(pv), L.ptr(sen[0]), L.ptr(sen[1]), L.ptr(sen[2])) == 0
+    got = (pv, *sen)
+    for a, b in zip(got, want):
+        assert (np.ascontiguousarray(a).view(np.uint64) != np.ascontiguousarray(b).view(np.uint64)).sum() == 0

@@ -117,9 +117,13 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            for key in ("valu_insts_per_solve", "salu_insts_per_solve"):
-                if key in pmc:
-                    print("  counters of profiles/pmc_latest.json (rocprofv3 --pmc, production build, kernel source hash %s): %s = %.2f M" % (pmc.get("kernel_source_hash"), key, pmc[key] / 1e6))
+            if pmc.get("sq_insts_valu_per_solve"):
+                print("  measured by the counters (profiles/pmc_latest.json: rocprofv3 --pmc of the bench command, production build, kernel source hash %s):" % pmc.get("kernel_source_hash"))
+                print("    SQ_INSTS_VALU %.2f M   SQ_INSTS_SALU %.2f M per solve -> the straight-line estimate above is %.2f x / %.2f x the measured counts" %
+                      (pmc["sq_insts_valu_per_solve"] / 1e6, pmc.get("sq_insts_salu_per_solve", 0) / 1e6, dyn_v / pmc["sq_insts_valu_per_solve"],
+                       dyn_s / max(pmc.get("sq_insts_salu_per_solve", 1), 1)))
+                print("    (pieces with wave-uniform skips inside -- the exception-table lookups of nodes_group64 / passB_loads / store_activate, the unrolled 64-lane")
+                print("     groups of routing_window -- count their whole static body per trip: upper bounds)")
 
 
 if __name__ == "__main__":
