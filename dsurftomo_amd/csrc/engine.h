@@ -72,6 +72,7 @@ struct Engine {
     int pool_slots = 0;
     int field_pool_opt = 0;            // option field_pool: 0 = automatic (four times the workgroups the chip holds), -1 = one slot per unit, > 0 = that many slots
     size_t per_slot_bytes = 0;
+    size_t plan_budget = 0;            // bytes plan() worked with (solve() grows the slot pool inside it when a call needs every field afterwards)
     std::vector<int> h_launch_rank;
     size_t lists_stride = 0;
     int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)

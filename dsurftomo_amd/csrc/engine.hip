@@ -371,6 +371,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         if (keep_fields && fit < P) { fail(DSA_ERR_CAPACITY, "plan: keep_fields is set but only %zu of the %d units' fields fit the memory budget", fit, nunits); return DSA_ERR_CAPACITY; }
         pool_slots = (int)std::min(P, fit);
     }
+    plan_budget = budget;
     size_t c = (budget - (size_t)pool_slots * per_slot_bytes) / per_unit_bytes;
     if (c < 1) { fail(DSA_ERR_DEVICE, "memory budget %zu B cannot hold one source (%zu B per unit + %zu B per field slot)", budget, per_unit_bytes, per_slot_bytes); return DSA_ERR_DEVICE; }
     chunk = (int)std::min<size_t>(c, (size_t)std::max(nunits, 1));
@@ -429,6 +430,17 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
     // the solve (rays and rows, the exact mode, keep_fields) a launch takes one unit per slot
     const bool may_recycle = !rows && exact_ties == 0 && !keep_fields;
+    if (!may_recycle && field_pool_opt == 0 && pool_slots < std::min(chunk, nunits)) {
+        // every field of a launch is needed after it (rays and rows, the literal march): a slot per unit for as many units as the
+        // budget holds, so that the call is one launch if it can be (four launches of 4096 have four tails: +4 % on the headline call)
+        const size_t units_b = (size_t)chunk * per_unit_bytes;
+        const size_t fit = plan_budget > units_b ? (plan_budget - units_b) / per_slot_bytes : 0;
+        const size_t want = std::min<size_t>((size_t)std::min(chunk, nunits), fit);
+        if (want > (size_t)pool_slots) {
+            if (ensure(T_c, want * nrec_c) || ensure(exc_c, want << exc_log2cap) || ensure(lists_c, want * lists_c_stride) || ensure(pool_gen, want)) return status;
+            pool_slots = (int)want;
+        }
+    }
     const int step = may_recycle ? chunk : std::min(chunk, pool_slots);
     const bool fused_times = exact_ties == 0;          // the coarse solve writes its unit's receiver times itself
     stats[DSA_STAT_UNITS] = nunits;

@@ -101,13 +101,14 @@ DSA_HD XEntry xh_get(const XMarch& m, int s)
     const XEntry e = s <= m.lcap ? m.hl[s] : m.hg[s - m.lcap - 1];
     return XEntry{ x_unif(e.key), x_uni(e.id) };
 }
-// entry into slot s: the tree, the node's status, the step's log
+// entry into slot s: the tree, the node's status, the step's log.  LDS_ONLY: the caller knows s <= lcap
+template <bool LDS_ONLY = false>
 DSA_HD void xh_put(XMarch& m, int s, XEntry e)
 {
     m.nlog = x_uni(m.nlog);
     if (m.nlog >= kXLogCap) { m.error = 2; return; }
     if (x_lane() == 0) {
-        if (s <= m.lcap) m.hl[s] = e; else m.hg[s - m.lcap - 1] = e;
+        if (LDS_ONLY || s <= m.lcap) m.hl[s] = e; else m.hg[s - m.lcap - 1] = e;
         m.F[e.id].st = s;
         m.log[m.nlog] = XLog{ e.id, s };
     }
@@ -160,9 +161,19 @@ DSA_HD void x_pop_root(XMarch& m)
     const XEntry e = xh_get(m, m.ntr);
     m.ntr -= 1;
     int tpp = 1, tpc = 2;
+    // the levels that lie in LDS altogether (children tpc, tpc + 1 <= lcap, hence the parent too): no look at where a slot lives
+    const int lim = m.ntr < m.lcap ? m.ntr : m.lcap;
+    while (tpc < lim) {
+        const XEntry a0 = m.hl[tpc], b0 = m.hl[tpc + 1];              // the two children sit side by side (one 16-byte read)
+        XEntry a = XEntry{ x_unif(a0.key), x_uni(a0.id) };
+        const XEntry b = XEntry{ x_unif(b0.key), x_uni(b0.id) };
+        if (a.key > b.key) { a = b; tpc += 1; }
+        if (a.key < e.key) { xh_put<true>(m, tpp, a); tpp = tpc; tpc = 2 * tpp; }
+        else { tpc = m.ntr + 1; break; }
+    }
     while (tpc < m.ntr) {
         XEntry a, b;
-        if (tpc + 1 <= m.lcap) {                                              // the two children sit side by side (one 16-byte read)
+        if (tpc + 1 <= m.lcap) {
             const XEntry a0 = m.hl[tpc], b0 = m.hl[tpc + 1];
             a = XEntry{ x_unif(a0.key), x_uni(a0.id) }; b = XEntry{ x_unif(b0.key), x_uni(b0.id) };
         } else { a = xh_get(m, tpc); b = xh_get(m, tpc + 1); }

@@ -655,3 +655,75 @@ extern "C" long hc_quads_compare(unsigned long long seed, long n)
     }
     return bad;
 }
+
+// Tie detector study (tools only): the device schedule emulated as in hc_device_schedule with the detector on -- the largest tie
+// influence met by ANY evaluation (what the kernel's inline detector reports) against the largest one a scan of the CONVERGED field
+// finds (final-state ties only).  out[0] = inline maximum, out[1] = final-state maximum, out[2] / out[3] = evaluations / nodes with a tie
+// above `thr`.
+extern "C" int hc_tie_study(int nnx, int nnz, float* Tio, float* tauio, const float* slow_rm, const float* risti, float ri, float dnx, float dnz,
+                            float window, float thr, double* out)
+{
+    const int nbz = tiles_of(nnz);
+    std::vector<Rec> F = tile_fill(nnx, nnz);
+    std::vector<float> slow(F.size(), 1.0f);
+    for (int ix = 0; ix < nnx; ++ix)
+        for (int iz = 0; iz < nnz; ++iz) {
+            const int id = rec_index(nbz, iz, ix);
+            F[id] = Rec{ Tio[(size_t)ix * nnz + iz], tauio[(size_t)ix * nnz + iz] };
+            slow[id] = slow_rm[(size_t)ix * nnz + iz];
+        }
+    Field f = { nnx, nnz, nbz, F.data(), slow.data(), risti, ri, dnx, dnz };
+    const size_t n = F.size();
+    std::vector<int> cur, next, ready;
+    std::vector<unsigned char> queued(n, 0);
+    auto act = [&](int iz0, int ix0) {
+        if (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) return;
+        const int id = rec_index(nbz, iz0, ix0);
+        if (t_pinned(F[id].T) || queued[id]) return;
+        queued[id] = 1; next.push_back(id);
+    };
+    for (int ix = 0; ix < nnx; ++ix) for (int iz = 0; iz < nnz; ++iz)
+        if (t_pinned(F[rec_index(nbz, iz, ix)].T)) { act(iz, ix - 1); act(iz, ix + 1); act(iz - 1, ix); act(iz + 1, ix); }
+    cur.swap(next);
+    float theta = kInf;
+    double inline_max = 0.0; long inline_n = 0;
+    auto tv = [&](int iz0, int ix0) { return (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) ? kInf : tau_value(F[rec_index(nbz, iz0, ix0)].tau); };
+    long rounds = 0;
+    while (!cur.empty() && rounds < 200000) {
+        float tmin = kInf; ready.clear();
+        for (int id : cur) {
+            int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
+            const float lb = fminf(fminf(tv(iz0, ix0 - 1), tv(iz0, ix0 + 1)), fminf(tv(iz0 - 1, ix0), tv(iz0 + 1, ix0)));
+            if (!(theta < kInf) || lb < theta) { ready.push_back(id); queued[id] = 0; }
+            else { next.push_back(id); tmin = fminf(tmin, lb); }
+        }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int id : ready) {
+                int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
+                if (((ix0 + iz0) & 1) != pass) continue;
+                const Hood h = load_hood(f, iz0 + 1, ix0 + 1); const NodeGeom g = { ri, risti[ix0], dnx, dnz };
+                float k, tie;
+                const float c = solve_node_t<true>(h, slow[id], g, &k, &tie);
+                if (tie > thr) { ++inline_n; if (tie > inline_max) inline_max = tie; }
+                if (std::memcmp(&c, &F[id].T, 4) || std::memcmp(&k, &F[id].tau, 4)) {
+                    F[id].T = c; F[id].tau = k;
+                    const int dz[4] = { 0, 0, -1, 1 }, dx[4] = { -1, 1, 0, 0 };
+                    for (int q = 0; q < 4; ++q) { act(iz0 + dz[q], ix0 + dx[q]); act(iz0 + 2 * dz[q], ix0 + 2 * dx[q]); }
+                    tmin = fminf(tmin, k);
+                }
+            }
+        cur.swap(next); next.clear(); theta = tmin + window; ++rounds;
+    }
+    double final_max = 0.0; long final_n = 0;
+    for (int ix = 0; ix < nnx; ++ix)
+        for (int iz = 0; iz < nnz; ++iz) {
+            const int id = rec_index(nbz, iz, ix);
+            if (t_pinned(F[id].T)) continue;
+            const Hood h = load_hood(f, iz + 1, ix + 1); const NodeGeom g = { ri, risti[ix], dnx, dnz };
+            float k, tie;
+            solve_node_t<true>(h, slow[id], g, &k, &tie);
+            if (tie > thr) { ++final_n; if (tie > final_max) final_max = tie; }
+        }
+    out[0] = inline_max; out[1] = final_max; out[2] = (double)inline_n; out[3] = (double)final_n;
+    return cur.empty() ? 0 : -1;
+}
