@@ -1,5 +1,5 @@
 """Fuzz the solve against the oracle: many random sources (incl. near edges / on nodes) on small grids,
-full-field comparison.  python tests/tools/fuzz_parity.py [nsrc] [seed]"""
+full-field comparison.  python tests/tools/fuzz_parity.py [nsrc] [seed] [nx:medium:dicing ...]      (DSA_EXACT=2: the literal march of the exact mode)"""
 import sys, os, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -26,6 +26,7 @@ for nx, kind, gd in GRIDS:
     e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv, dicing=gd)
     e.set_option("max_chunk", nsrc)
     if os.environ.get("DSA_WINDOW_CELLS"): e.set_option("window_cells", float(os.environ["DSA_WINDOW_CELLS"]))
+    if os.environ.get("DSA_EXACT"): e.set_option("exact_ties", int(os.environ["DSA_EXACT"]))
     e.traveltimes(np.zeros(nsrc, np.int32), sx, sz, np.zeros(nsrc, np.int32), np.zeros(0, np.float32), np.zeros(0, np.float32))
     nbad = 0; mx = 0.0; ndiff = 0; ndeg = 0; nexact = 0; nover = 0
     for k in range(nsrc):
