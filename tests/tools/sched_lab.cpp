@@ -17,6 +17,9 @@
 //      time among the neighbours that activated it since its last evaluation lies inside the window; odd rule as in 6
 //   13 like 6, but an activation whose key (the activator's acceptance time) is not below theta is never dropped: it re-queues an odd node
 //      that the same round's odd half is about to evaluate (what a separate "needs a lower bound" mask per tile would do)
+//   14 like 6, plus `param` extra evaluation passes per round WITHOUT a listing pass: the nodes activated during the round by a node whose
+//      acceptance time lies below the round's theta (their lower bound is below it too) are evaluated right away, even then odd, from a
+//      list filled at activation time; the rest waits for the next listing pass.  "rounds" counts listing passes.
 //   5  lazy: a node waits for the acceptance time of the neighbour that activated it to enter the window (key routing), parity sub-passes
 // build: g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -msse2 -mfpmath=sse -o tests/tools/libsched_lab.so tests/tools/sched_lab.cpp
 #include <algorithm>
@@ -79,7 +82,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     for (int ix = 0; ix < nnx; ++ix) for (int iz = 0; iz < nnz; ++iz)
         if (t_pinned(F[rec_index(nbz, iz, ix)].T)) { act(iz, ix - 1, 0.f); act(iz, ix + 1, 0.f); act(iz - 1, ix, 0.f); act(iz + 1, ix, 0.f); }
     cur.swap(next);
-    long key_routed = 0; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, trips256 = 0, trips128 = 0;
+    long key_routed = 0, extra_listed = 0; long rounds = 0, evals = 0, changes = 0, subpasses = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, trips256 = 0, trips128 = 0;
     float wnow = window;
     float best_tmin = -kInf, freeze = -kInf; int stall = 0; long freezes = 0;
     unsigned hist[4] = { 1u, 2u, 3u, 4u }, hsh = 0u;
@@ -165,7 +168,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
                 eval_batch(sub);
             }
         }
-        else if (mode == 1 || mode >= 5) {
+        else if (mode == 1 || mode >= 5) {   // (parity sub-passes)
             for (int p = 0; p < 2; ++p) {
                 { long cnt = 0; for (auto& r : ready) if (parity(r.id) == p) ++cnt; trips256 += (cnt + 255) / 256; trips128 += (cnt + 127) / 128; }
                 const int want = (mode == 8 && (rounds & 1)) ? p ^ 1 : p;
@@ -192,6 +195,24 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             std::stable_sort(ready.begin(), ready.end(), [](const R& a, const R& b) { return a.lb < b.lb; });
             for (auto& r : ready) { sub.assign(1, r.id); eval_batch(sub); } --subpasses; subpasses -= (long)ready.size() - 1 > 0 ? (long)ready.size() - 1 : 0; ++subpasses;
         }
+        if (mode == 14) {
+            for (int extra = 0; extra < (param > 0 ? param : 1); ++extra) {
+                // from `next`: what was activated with a key below theta; it leaves `next` (evaluated now)
+                std::vector<int> fast, keep;
+                for (int id : next) { if (key[id] < theta && tau_value(F[id].tau) >= freeze) fast.push_back(id); else keep.push_back(id); }
+                if (fast.empty()) break;
+                next.swap(keep);
+                extra_listed += (long)fast.size();
+                for (int p = 0; p < 2; ++p) {
+                    sub.clear();
+                    for (int id : fast) if (parity(id) == p) sub.push_back(id);
+                    if (p == 0) for (int id : fast) if (parity(id) == 0) { queued[id] = 0; key[id] = kInf; }
+                    if (p == 1) for (int id : sub) { queued[id] = 0; key[id] = kInf; }
+                    { long cnt = (long)sub.size(); trips256 += (cnt + 255) / 256; }
+                    eval_batch(sub);
+                }
+            }
+        }
         if (tmin > best_tmin) best_tmin = tmin;
         {
             const bool repeat = hsh != 0u && (hsh == hist[1] || hsh == hist[2] || hsh == hist[3] || hsh == hist[0]);
@@ -209,6 +230,6 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     }
     for (int ix = 0; ix < nnx; ++ix)
         for (int iz = 0; iz < nnz; ++iz) { const Rec r = F[rec_index(nbz, iz, ix)]; Tio[(size_t)ix * nnz + iz] = r.T; tauio[(size_t)ix * nnz + iz] = r.tau; }
-    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready; out[8] = trips256; out[9] = trips128; out[10] = key_routed;
+    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready; out[8] = trips256; out[9] = trips128; out[10] = key_routed; out[11] = extra_listed;
     return cur.empty() ? 0 : -1;
 }
