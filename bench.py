@@ -217,7 +217,13 @@ def main():
     device_index = local_rank % ndev
     shared = world > ndev
     dist = None
-    if world > 1:
+    # DSA_BENCH_FORCE_DIST=1: run the N-rank code path (RCCL process group, dsa_solve_device, device-to-device all-gather) with ONE rank --
+    # the only way to put that path on hardware where a single GPU is offered (tools/rccl_check.py, profiles/r03_bench_rccl_one_rank.log)
+    collective = world > 1 or bool(os.environ.get("DSA_BENCH_FORCE_DIST"))
+    if collective:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(device_index)
         if shared:
@@ -255,16 +261,16 @@ def main():
     dev = torch.device("cpu") if shared else torch.device("cuda", device_index)
     counts = sharding.ray_counts(units["nrec"], world)
 
-    mine = torch.empty(eng.ndata, dtype=torch.float32, device=dev) if (world > 1 and not shared) else None
+    mine = torch.empty(eng.ndata, dtype=torch.float32, device=dev) if (collective and not shared) else None
 
     def step():
-        if world > 1 and not shared:
+        if collective and not shared:
             # the path's one exchange step, device to device: the rank's receiver times stay in HBM (dsa_solve_device) and the RCCL
             # all-gather completes the vector on every rank; nothing visits the host before the collective
             eng.solve_device(mine.data_ptr())
             return sharding.all_gather_times(dist, mine, counts)
         t = eng.solve()
-        if world > 1:                                  # ranks sharing a device (1-GPU rehearsal): gloo, host tensors
+        if collective:                                 # ranks sharing a device (1-GPU rehearsal): gloo, host tensors
             return sharding.all_gather_times(dist, torch.from_numpy(t).to(dev), counts)
         return t
 

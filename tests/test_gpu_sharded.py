@@ -89,3 +89,17 @@ def test_bench_gpus_2_as_typed():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["value"] > 0 and rec["config"]["units_per_step"] == 16000
+
+
+def test_bench_collective_path_over_rccl_with_one_rank():
+    """the N-rank code path of bench.py on the hardware that is there: one rank, RCCL (`nccl` backend) process group, the rank's
+    receiver times left in HBM by dsa_solve_device, all_gather_into_tensor on the device tensor, host copy after the collective"""
+    env = dict(os.environ, DSA_BENCH_FORCE_DIST="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["units_per_step"] == 16000

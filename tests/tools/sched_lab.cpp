@@ -68,14 +68,18 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     std::vector<float> curkey, nextkey;
     std::vector<unsigned char> queued(n, 0);
     std::vector<float> key(n, kInf);
-    std::vector<unsigned char> pending_odd(n, 0), requeue(n, 0);
+    std::vector<unsigned char> pending_odd(n, 0), requeue(n, 0), was_deferred(n, 0);
+    std::vector<int> tile_act(n / 64 + 1, -1);      // round of the last activation landing in the tile
+    long sleeping_listings = 0, sleeping_tiles = 0, listed_tiles = 0;
     float theta = kInf;
+    long rounds_now = 0;
     float slot_w = 0.0f; long slotB = 0; int ring = 1 << 30, Wslots = 2;
     auto act = [&](int iz0, int ix0, float k) {
         if (ix0 < 0 || ix0 >= nnx || iz0 < 0 || iz0 >= nnz) return;
         if (slot_w > 0.0f) { long a = (long)floorf(k / slot_w); if (a < slotB) a = slotB; if (a > slotB + ring - 1) a = slotB + ring - 1; k = (float)a; }   // the key becomes a slot number
         const int id = rec_index(nbz, iz0, ix0);
         if (t_pinned(F[id].T)) return;
+        tile_act[id >> 6] = (int)rounds_now;
         if (queued[id]) { if (k < key[id]) key[id] = k; if (mode == 13 && pending_odd[id] && !(k < theta)) requeue[id] = 1; return; }
         queued[id] = 1; key[id] = k; next.push_back(id);
     };
@@ -127,6 +131,16 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
     while (!cur.empty()) {
         tmin = kInf; ready.clear();
         sum_listed += (long)cur.size();
+        {   // statistics: tiles all of whose listed nodes were deferred last round and that no activation has reached since ("sleeping")
+            std::vector<int> tiles;
+            for (int id : cur) tiles.push_back(id >> 6);
+            std::sort(tiles.begin(), tiles.end()); tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+            std::vector<char> awake(tiles.size(), 0);
+            for (int id : cur) { const size_t t = std::lower_bound(tiles.begin(), tiles.end(), id >> 6) - tiles.begin(); if (!was_deferred[id] || tile_act[id >> 6] >= (int)rounds_now - 1) awake[t] = 1; }
+            listed_tiles += (long)tiles.size();
+            for (size_t t = 0; t < tiles.size(); ++t) if (!awake[t]) ++sleeping_tiles;
+            for (int id : cur) { const size_t t = std::lower_bound(tiles.begin(), tiles.end(), id >> 6) - tiles.begin(); if (!awake[t]) ++sleeping_listings; }
+        }
         for (int id : cur) {
             if (tau_value(F[id].tau) < freeze) { queued[id] = 0; continue; }
             int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
@@ -154,6 +168,7 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
                 key[id] = kInf;
             }
             else { next.push_back(id); tmin = fminf(tmin, lb); }
+            was_deferred[id] = rdy ? 0 : 1;
         }
         sum_ready += (long)ready.size(); max_ready = std::max(max_ready, (long)ready.size());
         auto parity = [&](int id) { int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0); return (ix0 + iz0) & 1; };
@@ -225,11 +240,11 @@ extern "C" long lab_schedule(int nnx, int nnz, float* Tio, float* tauio, const f
             wnow = fminf(fmaxf(wnow, 0.25f * window), 4.0f * window);
         }
         if (mode == 12) slotB = (long)floorf(tmin / slot_w);
-        cur.swap(next); next.clear(); theta = tmin + wnow; ++rounds;
+        cur.swap(next); next.clear(); theta = tmin + wnow; ++rounds; rounds_now = rounds;
         if (rounds >= max_rounds) break;
     }
     for (int ix = 0; ix < nnx; ++ix)
         for (int iz = 0; iz < nnz; ++iz) { const Rec r = F[rec_index(nbz, iz, ix)]; Tio[(size_t)ix * nnz + iz] = r.T; tauio[(size_t)ix * nnz + iz] = r.tau; }
-    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready; out[8] = trips256; out[9] = trips128; out[10] = key_routed; out[11] = extra_listed;
+    out[0] = rounds; out[1] = evals; out[2] = changes; out[3] = freezes; out[4] = subpasses; out[5] = sum_ready; out[6] = sum_listed; out[7] = max_ready; out[8] = trips256; out[9] = trips128; out[10] = key_routed; out[11] = extra_listed; out[12] = sleeping_listings; out[13] = sleeping_tiles; out[14] = listed_tiles;
     return cur.empty() ? 0 : -1;
 }

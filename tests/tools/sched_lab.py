@@ -24,13 +24,13 @@ assert H.hc_coarse_problem(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD,
 ref = None
 for w in windows:
     for mode, param in modes:
-        T = T0.copy(); tau = tau0.copy(); out = np.zeros(12, np.int64)
+        T = T0.copy(); tau = tau0.copy(); out = np.zeros(16, np.int64)
         t0 = time.time()
         rc = lab.lab_schedule(N, N, L.ptr(T), L.ptr(tau), L.ptr(slow), L.ptr(ris), geom[0], geom[1], geom[2], np.float32(w * geom[3]), mode, param, 200000, L.ptr(out))
         same = "first" if ref is None else "identical=%s" % np.array_equal(np.abs(T).view(np.uint32), ref.view(np.uint32))
         if ref is None: ref = np.abs(T)
-        print("N=%d %s window %.2f mode %d:%d rc %d: rounds %5d subpasses %6d evals/node %.3f changes/node %.3f ready/round %6.0f listed/round %6.0f max ready %5d freezes %d trips256 %d trips128 %d key-routed %.2f extra-listed/round %.0f model_us %.0f | %s (%.1f s)" %
-              (N, kind, w, mode, param, rc, out[0], out[4], out[1] / (N * N), out[2] / (N * N), out[5] / max(out[0], 1), out[6] / max(out[0], 1), out[7], out[3], out[8], out[9], out[10] / max(out[6], 1), out[11] / max(out[0], 1), (out[0] * 19.0 + out[8] * 6.4) / 1000.0, same, time.time() - t0), flush=True)
+        print("N=%d %s window %.2f mode %d:%d rc %d: rounds %5d subpasses %6d evals/node %.3f changes/node %.3f ready/round %6.0f listed/round %6.0f max ready %5d freezes %d trips256 %d trips128 %d key-routed %.2f extra-listed/round %.0f sleeping listings %.2f tiles %.2f model_us %.0f | %s (%.1f s)" %
+              (N, kind, w, mode, param, rc, out[0], out[4], out[1] / (N * N), out[2] / (N * N), out[5] / max(out[0], 1), out[6] / max(out[0], 1), out[7], out[3], out[8], out[9], out[10] / max(out[6], 1), out[11] / max(out[0], 1), out[12] / max(out[6], 1), out[13] / max(out[14], 1), (out[0] * 19.0 + out[8] * 6.4) / 1000.0, same, time.time() - t0), flush=True)
 if os.environ.get("LAB_TAU_STATS"):
     Tf, kf = np.abs(T), np.abs(tau)
     fin = np.isfinite(Tf)
