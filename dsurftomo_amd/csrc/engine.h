@@ -82,7 +82,7 @@ struct Engine {
     // again by the literal Fast Marching; 2 = every unit by the literal Fast Marching only
     int exact_ties = 0;
     float tie_threshold = 2.0e-5f;     // a tie counts when taking the tied neighbour in moves the node's value by more than this (s); 0 = any tie
-    int exact_lds_slots = 768;         // tree slots kept in LDS per marching unit (8 bytes each)
+    int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each); 0 = by the number of units marching (768 .. 16384)
     int exact_pool = 0;                // units marching at a time (0 = by free memory, at most 4096)
     DevBuf<unsigned long long> X_pool, X_heap;   // per marching unit: (T, status) records of the whole grid; tree slots beyond the LDS part
     DevBuf<int> x_units;

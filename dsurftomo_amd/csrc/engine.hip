@@ -607,7 +607,17 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
 int Engine::run_exact(int first, int n, const std::vector<int>& xl)
 {
     (void)n;
-    const int lcap = std::max(64, exact_lds_slots);
+    // tree slots in LDS per marching unit: the option, or (0) as many as let all the units of the call march at once -- 16 workgroups per
+    // CU at 768 slots is the measured optimum for thousands of units; a few hundred units at 4097^2 (trees of ~16 k entries) get the whole CU
+    int lcap = exact_lds_slots;
+    if (lcap <= 0) {
+        const size_t per_cu = (xl.size() + 255) / 256;
+        const size_t bytes = (size_t)150 * 1024 / std::max<size_t>(per_cu, 1);
+        const long fit = bytes > exact_lds_bytes(0) ? (long)((bytes - exact_lds_bytes(0)) / 8) : 0;
+        lcap = (int)std::min<long>(std::min<long>(fit, 4L * (g.nnx + g.nnz) + 1024), 16384);
+        lcap = std::max(lcap, 768);
+    }
+    lcap = std::max(64, lcap);
     const int gcap = 16 * (g.nnx + g.nnz) + 4096;
     const size_t per = nrec_c * 8 + (size_t)gcap * 8;
     size_t pool = (size_t)exact_pool;
@@ -619,7 +629,7 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl)
     }
     pool = std::min(pool, xl.size());
     if (ensure(X_pool, pool * nrec_c) || ensure(X_heap, pool * (size_t)gcap)) return status;
-    if (exact_lds_bytes(lcap) > 64 * 1024) { fail(DSA_ERR_ARGUMENT, "exact_lds_slots %d needs more than 64 KB of LDS", lcap); return DSA_ERR_ARGUMENT; }
+    if (exact_lds_bytes(lcap) > 156 * 1024) { fail(DSA_ERR_ARGUMENT, "exact_lds_slots %d needs more than 156 KB of LDS", lcap); return DSA_ERR_ARGUMENT; }
     HIP_TRY(this, hipMemcpyAsync(x_units.p, xl.data(), xl.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemsetAsync(xinfo.p, 0, (size_t)n * 16, stream));
     for (size_t k = 0; k < xl.size(); k += pool) {
@@ -905,7 +915,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
-    if (n == "exact_lds_slots" && value >= 64 && value <= 8000) { en->exact_lds_slots = (int)value; return 0; }
+    if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 19000))) { en->exact_lds_slots = (int)value; return 0; }
     if (n == "exact_pool" && value >= 0) { en->exact_pool = (int)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);

@@ -203,7 +203,7 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  * ties (option "tie_threshold", seconds: the influence on the node's value a tie must have to count; default 2e-5, 0 = any tie) and the
  * units that met one are solved again by the reference's march itself, replayed on the device one wavefront per unit -- their
  * fields are then bit-identical to the reference's; 2 = every unit by the literal march.  Options "exact_lds_slots" (tree slots
- * in LDS per marching unit, default 768) and "exact_pool" (units marching at a time, 0 = by free memory).
+ * in LDS per marching unit; default 0 = chosen by the number of units that march: 768 for thousands, up to 16384 for a few hundred) and "exact_pool" (units marching at a time, 0 = by free memory).
  * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: met a tie, bit 1: solved by the literal march) and the largest
  * tie influence in seconds (either array may be NULL). */
 int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence);

@@ -30,7 +30,7 @@ def exact(engine):
     yield engine
     engine.set_option("exact_ties", 0)
     engine.set_option("tie_threshold", 2e-5)
-    engine.set_option("exact_lds_slots", 768)
+    engine.set_option("exact_lds_slots", 0)
 
 
 @pytest.mark.parametrize("nx,kind,gd,lds", [(18, "homog", 8, 2048), (35, "checker4", 8, 64), (35, "smooth", 5, 2048), (35, "rough", 8, 300), (35, "homog", 8, 2048)])
