@@ -337,6 +337,7 @@ def main():
                                    "stages": round(acc["ms_stages"] / args.steps, 2)},
             "evals_per_node": round(acc["evals_total"] / max(my_units, 1) / (n * n), 3),
             "setup_ms": round(setup_ms, 1),
+            "field_slots": int(st.get("field_slots", 0)), "footprint_mb": round(st.get("footprint_mb", 0.0), 1),     # coarse field slots of the launch (recycled when fewer than the units), HBM held by the solve
             "value_incl_setup": round(solves / (dt + setup_ms / 1000.0), 2),
             "max_abs_err": None,
         }

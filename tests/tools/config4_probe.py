@@ -27,9 +27,9 @@ for k in range(2):
     t0 = time.perf_counter(); t = e.solve(); dt = time.perf_counter() - t0
     st = e.stats()
     print("solve %d: %.2f s wall = %.1f solves/s | coarse fixed-point kernel %.1f ms (%.1f solves/s, %.1f GB/s of algorithmic bytes), refined %.1f ms, other stages %.1f ms | "
-          "rounds_max %d, evaluations per node %.2f, chunk %d units" %
+          "rounds_max %d, evaluations per node %.2f, %d units per launch through %d field slots, footprint %.1f GB" %
           (k, dt, nsrc * nper / dt, st["ms_fim_coarse"], nsrc * nper / (st["ms_fim_coarse"] / 1e3), nsrc * nper * (8.0 * e.nnx * e.nnz + 129 * 129 * 8) / (st["ms_fim_coarse"] / 1e3) / 1e9,
-           st["ms_fim_refined"], st["ms_stages"], st["rounds_max"], st["evals_total"] / (nsrc * nper) / (e.nnx * e.nnz), st["chunk"]), flush=True)
+           st["ms_fim_refined"], st["ms_stages"], st["rounds_max"], st["evals_total"] / (nsrc * nper) / (e.nnx * e.nnz), st["chunk"], st["field_slots"], st["footprint_mb"] / 1e3), flush=True)
 e.close()
 if nsample > 0:
     t = t.reshape(nsrc * nper, nrec)

@@ -1,0 +1,5 @@
+#!/bin/bash
+O=gpurun_out/r3_run11; mkdir -p $O
+timeout 900 python3 -m pytest tests/test_gpu_exact.py -x -q -k "not headline_size or literal" > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -2 $O/pytest.log | cut -c1-200
+DSA_PROBE_SKIP_THRESHOLDS=1 timeout 600 python3 tools/exact_probe.py 131 4096 checker 768 0 2>&1 | grep -E "fixed point  |exact_ties=2" | tee $O/exact_probe_4096.log
+DSA_PROBE_SKIP_THRESHOLDS=1 timeout 600 python3 tools/exact_probe.py 131 512 checker 4096 0 2>&1 | grep -E "fixed point  |exact_ties=2" | tee $O/exact_probe_512.log
