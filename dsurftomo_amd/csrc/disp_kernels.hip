@@ -13,8 +13,17 @@ namespace dsa {
 
 constexpr int kMaxDepths = 64;
 
+// DSA_DISP_WAVES: wavefronts per SIMD the register allocation aims at (0: the compiler's choice, 177 VGPRs = 2 for the Rayleigh kernel)
+#ifndef DSA_DISP_WAVES
+#define DSA_DISP_WAVES 0
+#endif
+#if DSA_DISP_WAVES > 0
+#define DSA_DISP_OCC __attribute__((amdgpu_waves_per_eu(DSA_DISP_WAVES)))
+#else
+#define DSA_DISP_OCC
+#endif
 template <int IFUNC>
-__global__ __launch_bounds__(64) void k_dispersion(const LayerGeom* __restrict__ G, const float* __restrict__ vels, int ncol,
+__global__ __launch_bounds__(64) DSA_DISP_OCC void k_dispersion(const LayerGeom* __restrict__ G, const float* __restrict__ vels, int ncol,
                                                    int npert, int igr, int kmax, const double* __restrict__ t,
                                                    float* __restrict__ ws, size_t nlanes, double* __restrict__ curves, int layers_in_lds,
                                                    int gshift, unsigned long long* __restrict__ diag)
