@@ -35,7 +35,7 @@ struct XLog { int id; int slot; };
 #define DSA_LDS
 #endif
 
-constexpr int kXLogCap = 128;               // (node, slot) assignments one accept step can make (5 sifts of <= 25 levels)
+constexpr int kXLogCap = 192;               // (node, slot) assignments one accept step can make: five sifts of <= 27 levels (trees below 2^26 entries) = 135
 constexpr int kXStage = kRefTiles * kRefTiles;   // coarse nodes under the refined box (17 x 17)
 
 struct XMarch {
@@ -102,14 +102,29 @@ DSA_HD XEntry xh_get(const XMarch& m, int s)
     return XEntry{ x_unif(e.key), x_uni(e.id) };
 }
 // entry into slot s: the tree, the node's status, the step's log.  LDS_ONLY: the caller knows s <= lcap
+// store one word of a record whose index every lane holds alike (lane 0 calls it): a vector offset on the field's scalar base -- one VALU
+// shift instead of four SALU instructions of 64-bit address arithmetic (the step is bound by the scalar unit: ~1000 scalar against ~500
+// vector instructions per accept)
+DSA_HD void x_store_word(XMarch& m, int id, int word, int bits)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned off;
+    asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(off) : "s"(id));
+    typedef __attribute__((address_space(1))) char GChar;
+    *(__attribute__((address_space(1))) int*)((GChar*)m.F + off + 4 * word) = bits;
+#else
+    reinterpret_cast<int*>(&m.F[id])[word] = bits;
+#endif
+}
+DSA_HD int x_float_bits(float f) { union { float f; int i; } u; u.f = f; return u.i; }
+// (the log cannot overflow inside a step, see kXLogCap; x_accept_root checks the count once, behind the step)
 template <bool LDS_ONLY = false>
 DSA_HD void xh_put(XMarch& m, int s, XEntry e)
 {
     m.nlog = x_uni(m.nlog);
-    if (m.nlog >= kXLogCap) { m.error = 2; return; }
     if (x_lane() == 0) {
         if (LDS_ONLY || s <= m.lcap) m.hl[s] = e; else m.hg[s - m.lcap - 1] = e;
-        m.F[e.id].st = s;
+        x_store_word(m, e.id, 1, s);
         m.log[m.nlog] = XLog{ e.id, s };
     }
     m.nlog += 1;
@@ -360,7 +375,7 @@ DSA_HD void x_accept_root(XMarch& m, XEntry root, int iz0, int ix0)
     for (int l = 0; l < 16; ++l) raws[l] = x_fetch_quad(m, rid[l >> 2], nzq[l >> 2], nxq[l >> 2], (l >> 1) & 1, l & 1);
 #endif
     m.nlog = 0;
-    if (x_lane() == 0) m.F[root.id].st = 0;
+    if (x_lane() == 0) x_store_word(m, root.id, 1, 0);
     x_pop_root(m);
 #if defined(__HIP_DEVICE_COMPILE__)
     float trial = kInf;
@@ -394,10 +409,11 @@ DSA_HD void x_accept_root(XMarch& m, XEntry root, int iz0, int ix0)
 #endif
     for (int q = 0; q < 4; ++q) {
         if (!nb_in[q] || nb_st[q] == 0) continue;
-        if (x_lane() == 0) m.F[rid[q]].T = nb_trial[q];               // fouds2 overwrites unconditionally (:758)
+        if (x_lane() == 0) x_store_word(m, rid[q], 0, x_float_bits(nb_trial[q]));       // fouds2 overwrites unconditionally (:758)
         if (nb_st[q] < 0) x_add(m, rid[q], nb_trial[q]);
         else x_sift_up(m, XEntry{ nb_trial[q], rid[q] }, x_current_slot(m, rid[q], nb_st[q]));
     }
+    if (m.nlog > kXLogCap - 48) m.error = 2;          // (cannot happen below 2^26 tree entries; the guard keeps the log inside its array)
     m.pops += 1u;
 }
 
