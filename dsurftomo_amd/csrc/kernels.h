@@ -123,8 +123,6 @@ struct BatchPtrs {
 constexpr int kSeedR = kRWin * kRWin;              // the start-up march cannot pin more than its window
 constexpr int kSeedC = kCWinMax * kCWinMax + 4 * kCWinMax;    // every node of the window at most once, plus its outer rim
 
-void launch_fill(float* d, size_t n, float v, hipStream_t stream);
-void launch_fill64(unsigned long long* d, size_t n, unsigned long long v, hipStream_t stream);
 void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_velv_all, size_t velv_stride,
                    const float* d_rbasis, hipStream_t stream);
 void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);

@@ -38,35 +38,6 @@ __device__ __forceinline__ void seed_node(Rec* F, int nbz, int* seed, int* nseed
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-__global__ void k_fill(float* __restrict__ d, size_t n, float v)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
-}
-
-__global__ void k_fill64(unsigned long long* __restrict__ d, size_t n, unsigned long long v)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
-}
-
-void launch_fill64(unsigned long long* d, size_t n, unsigned long long v, hipStream_t stream)
-{
-    if (n == 0) return;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_fill64, dim3((unsigned)blocks), dim3(256), 0, stream, d, n, v);
-}
-
-void launch_fill(float* d, size_t n, float v, hipStream_t stream)
-{
-    if (n == 0) return;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, stream, d, n, v);
-}
-
-// ---------------------------------------------------------------------------------------------
 // K1: dice one period's vertex map onto the propagation grid; z fastest -> lanes walk iz
 __global__ void k_gridder(GridDesc g, const float* __restrict__ velv, const float* __restrict__ basis,
                           float* __restrict__ veln, float* __restrict__ slow)
