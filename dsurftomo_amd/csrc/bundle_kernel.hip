@@ -1,0 +1,602 @@
+// Coarse fixed-point solve of a BUNDLE for gfx950 (CDNA4): the G periods of one source under one shared round schedule
+// (kernels.h: FimBundle).  Same fixed point per member as k_fim_sorted (fim_kernel.hip: the replacement for the reference's narrow-band
+// march `travel` / `fouds2` + binary tree, CalSurfG.f90:288-487, :587-759, :768-921); what changes is what a round costs:
+//
+//   * pass A (the tile sweep, the expansion of the node masks, lower bounds, routing) runs ONCE per bundle on the pilot's times
+//     (member 0) instead of once per unit -- it was 41 % of the solo kernel's vector instructions (the ledger);
+//   * pass B evaluates a ready node for all members: a wave takes 64 / (G/4) nodes, G/4 lanes per node, four members per lane.  The
+//     node's coordinates, stencil addresses and grid flags are computed once per lane and serve four evaluations; the nine field values of
+//     four members come in nine 16-byte loads (member-minor field: a node's G values are one contiguous segment, so a fetched line carries
+//     nothing that is not used); pruning and the activation masks are formed once per node from the members' OR;
+//   * the four barriers and the dependent memory round trips of a round are shared by G units.
+//
+// Schedule: routed by the pilot alone -- a listed node is ready when the pilot's lower bound lies inside the pilot's window (or the pilot
+// is pinned there: the members' march windows differ by a few nodes around the source).  A member whose front runs differently from the
+// pilot's is evaluated early or late at some nodes; early evaluations are repeated when the member's own upstream changes (its
+// activations go to the shared masks), so the fixed point is reached for every member -- tests/tools/bundle_lab.cpp replays exactly this
+// schedule on the CPU with the product's solve_node and compares every member with its solo run, bit for bit.
+// Cycles (exact 2-cycles among ulp-tied nodes, fim_kernel.hip): detected on the bundle's combined change hash, frozen by the pilot's
+// acceptance times.  A bundle that does not converge reports -1 to all its members and the engine solves them one by one.
+#include "kernels.h"
+#include "receiver_core.h"
+#include "wave_ops.h"
+
+namespace dsa {
+
+namespace {
+
+__device__ __forceinline__ unsigned bf2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float bu2f(unsigned u) { return __uint_as_float(u); }
+
+enum { BC_READY = 0, BC_READY_ODD, BC_TMIN, BC_THETA, BC_FREEZE, BC_HASH, BC_OVERFLOW, BC_CUR, BC_COUNT };
+constexpr int kBundleCycleRounds = 8;
+
+typedef __attribute__((address_space(1))) unsigned long long BGU64;
+typedef __attribute__((address_space(1))) char BGChar;
+typedef __attribute__((address_space(1))) float BGF32;
+typedef __attribute__((address_space(1))) const float BGCF32;
+typedef float __attribute__((ext_vector_type(4))) BV4;
+typedef __attribute__((address_space(1))) BV4 BGV4;
+
+// OR over the lanes of a node (CH consecutive lanes): quad permutes
+template <int CH>
+__device__ __forceinline__ unsigned node_or(unsigned v)
+{
+    if (CH >= 2) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    if (CH >= 4) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    return v;
+}
+
+}  // namespace
+
+template <int G>
+__global__ __launch_bounds__(256) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
+                                                    const FimEnds* __restrict__ ends)
+{
+    constexpr int NT = 256, NW = NT / 64;
+    constexpr int CH = G / 4;                  // lanes per node in pass B, four members each
+    constexpr int NPW = 64 / CH;               // nodes per wave trip
+    constexpr unsigned GB = G * 4u;            // bytes per node
+    extern __shared__ unsigned dyn_lds[];
+    __shared__ int sc[BC_COUNT];
+    constexpr int kWaveBuf = 256, kTileBuf = 256, kClrWords = 4;
+    __shared__ int wbuf[NW * kWaveBuf];
+    __shared__ int wtile[NW * kTileBuf];
+    __shared__ unsigned wclr[NW * kTileBuf * kClrWords];
+    constexpr int rhalf = NT * 4;
+    __shared__ int ready[2 * rhalf];
+    __shared__ int s_member[kBundleMax], s_map[kBundleMax];
+
+    const FimBundle* const bd = bundles + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nmem = bd->nmem;
+    if (tid < kBundleMax) { s_member[tid] = bd->member[tid < nmem ? tid : 0]; s_map[tid] = bd->map[tid < nmem ? tid : 0]; }
+    const FimProblem p = problems[bd->member[0]];      // grid, window, tables: the same for all members
+    BGChar* const Bb = (BGChar*)bd->B;
+    BGChar* const excb = (BGChar*)bd->exc;
+    const int xlog = bd->exc_log2cap;
+    BGChar* const slowb = (BGChar*)bd->slowI;
+    const unsigned npb = (unsigned)bd->np * 4u;         // bytes of slowness per node
+    BGCF32* const risti = (BGCF32*)p.risti;
+    const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
+    const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
+    BGChar* const maskb = (BGChar*)bd->lists;
+    constexpr int kMaskShift = 5;
+    auto mask_at = [&](int tile) -> BGU64* { return (BGU64*)(maskb + ((size_t)(unsigned)tile << kMaskShift)); };
+    unsigned* const tb = dyn_lds;
+    auto exc_at = [&](unsigned h) -> BGU64* { return (BGU64*)(excb + ((size_t)h << 3)); };
+    // exception entries are keyed by id * G + member
+    auto exc_lookup = [&](int key, bool* pinned) -> float {
+        const unsigned mask = (1u << xlog) - 1u;
+        unsigned h = exc_hash(key, xlog);
+        for (unsigned n = 0; n <= mask; ++n, h = (h + 1u) & mask) {
+            const unsigned long long e = *exc_at(h);
+            const int k = exc_key(e);
+            if (k == -1) break;
+            if ((k & 0x3fffffff) == key) { *pinned = (k & kExcPinned) != 0; return exc_tau(e); }
+        }
+        *pinned = false;
+        return kInf;
+    };
+    auto exc_upsert = [&](int key, float tau) -> bool {
+        const unsigned mask = (1u << xlog) - 1u;
+        unsigned h = exc_hash(key, xlog);
+        const unsigned long long mine = exc_pack(key, tau);
+        for (unsigned n = 0; n <= mask; ++n, h = (h + 1u) & mask) {
+            unsigned long long e = *exc_at(h);
+            if (exc_key(e) == -1) {
+                e = atomicCAS((unsigned long long*)exc_at(h), kExcEmpty, mine);
+                if (e == kExcEmpty) return true;
+            }
+            if ((exc_key(e) & 0x3fffffff) == key) { *exc_at(h) = mine; return true; }
+        }
+        return false;
+    };
+    const bool by_mul = nbz > 1 && (unsigned long long)ntile * (unsigned long long)nbz < (1ull << 32);
+    const unsigned nbz_inv = by_mul ? 0xffffffffu / (unsigned)nbz + 1u : 0u;
+    auto coords = [&](int id, int* iz0, int* ix0) {
+        const unsigned tile = (unsigned)id >> 6;
+        const unsigned bx = by_mul ? __umulhi(tile, nbz_inv) : tile / (unsigned)nbz;
+        const unsigned bz = tile - bx * (unsigned)nbz;
+        *ix0 = (int)(bx << kTileShift) + rec_ix_in_tile(id);
+        *iz0 = (int)(bz << kTileShift) + rec_iz_in_tile(id);
+    };
+    // the pilot's value of a node (member 0)
+    auto pv = [&](int id) -> float { return *(BGF32*)(Bb + (unsigned)id * GB); };
+
+    // ---- the bundle's field slot: wait for its previous user; every node of every member unreached, the table empty; the nodes each
+    // member's serial prologue pinned (window records, k_coarse_march) into both
+    __syncthreads();
+    bool dead = false;
+    {
+        int* const pg = bd->pool_gen;
+        if (pg) {
+            if (tid == 0) { const int want = bd->gen; while (__hip_atomic_load(pg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(64); }
+            __syncthreads();
+        }
+        const BV4 inf4 = { kInf, kInf, kInf, kInf };
+        for (int i = tid; i < ntile * (kTileRecs * G / 4); i += NT) ((BGV4*)Bb)[i] = inf4;
+        for (int i = tid; i < (1 << xlog); i += NT) *exc_at((unsigned)i) = kExcEmpty;
+        for (int i = tid; i < (ntile << (kMaskShift - 3)); i += NT) *(BGU64*)(maskb + ((size_t)i << 3)) = 0ull;
+        for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
+        if (tid == 0) {
+            sc[BC_READY] = 0; sc[BC_READY_ODD] = 0; sc[BC_TMIN] = 0x7f800000; sc[BC_THETA] = 0x7f800000;
+            sc[BC_FREEZE] = (int)0xff800000u; sc[BC_HASH] = 0; sc[BC_OVERFLOW] = 0; sc[BC_CUR] = 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        typedef __attribute__((address_space(1))) const Rec GCRec;
+        for (int m = 0; m < nmem; ++m) {
+            const FimEnds* const E = ends + s_member[m];
+            const FimProblem* const pm = problems + s_member[m];
+            GCRec* const W = (GCRec*)E->W;
+            const int cwz0 = E->cwz0, cwx0 = E->cwx0, cwnz = E->cwnz, nw = E->cwnx * cwnz;
+            for (int q = tid; q < nw; q += NT) {
+                const float wt = W[q].T, wk = W[q].tau;
+                if (!t_pinned(wt)) continue;
+                const int lx = q / cwnz, lz = q - lx * cwnz;
+                const int id = rec_index(nbz, cwz0 + lz, cwx0 + lx);
+                const int key = id * G + m;
+                const unsigned long long mine = exc_pack(key | kExcPinned, wk);
+                const unsigned mask = (1u << xlog) - 1u;
+                unsigned h = exc_hash(key, xlog);
+                bool placed = false;
+                for (unsigned n = 0; n <= mask && !placed; ++n, h = (h + 1u) & mask)
+                    placed = atomicCAS((unsigned long long*)exc_at(h), kExcEmpty, mine) == kExcEmpty;
+                if (!placed) { pm->info[2] = -2; sc[BC_OVERFLOW] = 1; }
+                *(BGF32*)(Bb + (unsigned)id * GB + (unsigned)m * 4u) = wt;      // -T: the sign bit marks the exceptional node
+            }
+            // the member's seeds: the rim of its pinned set
+            const int nseed = *pm->seed_count;
+            if (nseed > pm->seed_cap) { if (tid == 0) pm->info[2] = -1; dead = true; }
+            else
+                for (int i = tid; i < nseed; i += NT) {
+                    const int id = pm->seed[i];
+                    atomicOr((unsigned long long*)mask_at(id >> 6), 1ull << (id & 63));
+                    atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31));
+                }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (sc[BC_OVERFLOW]) dead = true;
+    }
+
+    int rounds = 0, stall = 0, freezes = 0;
+    unsigned hist[4] = { 1u, 2u, 3u, 4u };
+    float best_tmin = -kInf;
+    unsigned evals = 0, nchanged = 0;                        // member evaluations of this lane
+    // pass B: this lane's node slot, member chunk, member maps
+    const int sub = lane % CH, nslot = lane / CH;
+    const unsigned sub_b = (unsigned)sub * 16u;
+    unsigned mp[4], vmask = 0u;                               // (bit m: member sub * 4 + m exists)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { mp[m] = (unsigned)s_map[sub * 4 + m] * 4u; if (sub * 4 + m < nmem) vmask |= 1u << m; }
+
+    for (; !dead;) {
+        const float theta = bu2f((unsigned)sc[BC_THETA]);
+        const bool open = !(theta < kInf);
+        const float freeze = bu2f((unsigned)sc[BC_FREEZE]);
+        const bool frozen_any = freeze > -kInf;
+
+        // ---- pass A (as in k_fim_sorted, on the pilot's times): every wave sweeps its share of the tile bitmap, gathers the active tiles,
+        // expands their node masks in record order, computes the lower bounds and routes
+        int seen = 0;
+        float tmin_lane = kInf;
+        int* const nbuf = wbuf + wave * kWaveBuf;
+        int* const tbuf = wtile + wave * kTileBuf;
+        unsigned* const clr = wclr + wave * kTileBuf * kClrWords;
+        constexpr int kQ = kTileBuf / 64, kI = kWaveBuf / 64;
+        auto sweep_tiles = [&](int ntiles) {
+            __builtin_amdgcn_s_setprio(3);
+            int tl[kQ];
+            unsigned long long m[kQ];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                tl[q] = q * 64 + lane < ntiles ? tbuf[q * 64 + lane] : -1;
+                m[q] = 0ull;
+                if (tl[q] >= 0) {
+                    BGU64* const rec4 = mask_at(tl[q]);
+                    const unsigned long long E = rec4[0], O = rec4[1], R = rec4[2];
+                    const unsigned stamp = (unsigned)rec4[3];
+                    m[q] = (E & ~(stamp == (unsigned)rounds ? R : 0ull)) | O;
+                }
+                if (q * 64 < ntiles)
+                    for (int w4 = 0; w4 < kClrWords; ++w4) clr[kClrWords * (q * 64 + lane) + w4] = 0u;
+            }
+            int off[kQ], total = 0;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                off[q] = total;
+                if (q * 64 >= ntiles) continue;
+                if (tl[q] >= 0 && m[q] == 0ull) atomicAnd(&tb[tl[q] >> 5], ~(1u << (tl[q] & 31)));      // the tile has drained
+                const int n = __popcll(m[q]);
+                const int incl = wave_scan_incl(n);
+                off[q] = total + incl - n;
+                total += wave_last(incl);
+            }
+            seen += total;
+            for (int base = 0; base < total; base += kWaveBuf) {
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) {
+                    unsigned long long mm = m[q];
+                    int idx = off[q];
+                    while (mm) {
+                        const int nb = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1ull;
+                        if (idx >= base && idx < base + kWaveBuf) nbuf[idx - base] = ((q * 64 + lane) << 6) + nb;     // (tile slot, node)
+                        ++idx;
+                    }
+                }
+                const int nn = min(total - base, kWaveBuf);
+                int id[kI], par[kI], slot[kI];
+                float lb[kI], own[kI];
+                bool ppin[kI];
+#pragma unroll
+                for (int i = 0; i < kI; ++i) {
+                    id[i] = -1; par[i] = 0; slot[i] = 0; lb[i] = kInf; own[i] = kInf; ppin[i] = false;
+                    if (i * 64 >= nn) continue;
+                    const bool have = i * 64 + lane < nn;
+                    const int e = have ? nbuf[i * 64 + lane] : 0;
+                    slot[i] = e >> 6;
+                    id[i] = have ? (tbuf[slot[i]] << 6) + (e & 63) : -1;
+                    int iz, ix;
+                    coords(have ? id[i] : 0, &iz, &ix);
+                    par[i] = (ix + iz) & 1;
+                    if (have) {
+                        int nid[8];
+                        rec_stencil(nbz, id[i], nid);
+                        float a = ix > 0 ? pv(nid[0]) : kInf, b2 = ix + 1 < nnx ? pv(nid[1]) : kInf;
+                        float c2 = iz > 0 ? pv(nid[2]) : kInf, d2 = iz + 1 < nnz ? pv(nid[3]) : kInf;
+                        own[i] = pv(id[i]);
+                        if (__builtin_signbit(a) || __builtin_signbit(b2) || __builtin_signbit(c2) || __builtin_signbit(d2) || __builtin_signbit(own[i])) {
+                            bool pin;
+                            if (__builtin_signbit(a)) a = exc_lookup(nid[0] * G, &pin);
+                            if (__builtin_signbit(b2)) b2 = exc_lookup(nid[1] * G, &pin);
+                            if (__builtin_signbit(c2)) c2 = exc_lookup(nid[2] * G, &pin);
+                            if (__builtin_signbit(d2)) d2 = exc_lookup(nid[3] * G, &pin);
+                            if (__builtin_signbit(own[i])) { own[i] = exc_lookup(id[i] * G, &pin); ppin[i] = pin; }
+                        }
+                        lb[i] = fminf(fminf(a, b2), fminf(c2, d2));
+                    }
+                }
+                __builtin_amdgcn_s_setprio(2);
+                unsigned long long be[kI], bo[kI];
+                bool frozen[kI];
+                int ne = 0, no = 0;
+#pragma unroll
+                for (int i = 0; i < kI; ++i) {
+                    be[i] = 0ull; bo[i] = 0ull; frozen[i] = false;
+                    if (i * 64 >= nn) continue;
+                    const bool have = id[i] >= 0;
+                    frozen[i] = have && frozen_any && !ppin[i] && own[i] < freeze;
+                    const bool want = have && !frozen[i] && (open || lb[i] < theta || ppin[i]);     // (the pilot pinned here: the other members' turn cannot be told from its times)
+                    be[i] = __ballot(want && par[i] == 0);
+                    bo[i] = __ballot(want && par[i] != 0);
+                    ne += __popcll(be[i]); no += __popcll(bo[i]);
+                }
+                int base_e = 0, base_o = 0;
+                if (lane == 0) {
+                    if (ne) base_e = atomicAdd(&sc[BC_READY], ne);
+                    if (no) base_o = atomicAdd(&sc[BC_READY_ODD], no);
+                }
+                base_e = __builtin_amdgcn_readfirstlane(base_e);
+                base_o = __builtin_amdgcn_readfirstlane(base_o);
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int i = 0; i < kI; ++i) {
+                    if (i * 64 >= nn) continue;
+                    const bool have = id[i] >= 0;
+                    const bool want_e = (be[i] >> lane) & 1ull, want_o = (bo[i] >> lane) & 1ull;
+                    const int pe = base_e + __popcll(be[i] & below), po = base_o + __popcll(bo[i] & below);
+                    base_e += __popcll(be[i]); base_o += __popcll(bo[i]);
+                    const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
+                    if (got) ready[want_o ? rhalf + po : pe] = id[i];
+                    if ((got && !want_o) || frozen[i]) atomicOr(&clr[kClrWords * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
+                    if (got && want_o) atomicOr(&clr[kClrWords * slot[i] + 2 + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));     // evaluated by this round's odd half
+                    if (have && !frozen[i] && !got) tmin_lane = fminf(tmin_lane, lb[i]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+                if (tl[q] >= 0) {
+                    const unsigned* const cw = clr + kClrWords * (q * 64 + lane);
+                    const unsigned long long c = (unsigned long long)cw[0] | ((unsigned long long)cw[1] << 32);
+                    const unsigned long long ro = (unsigned long long)cw[2] | ((unsigned long long)cw[3] << 32);
+                    BGU64* const rec4 = mask_at(tl[q]);
+                    rec4[0] = m[q] & ~c & ~ro; rec4[1] = 0ull; rec4[2] = ro; rec4[3] = (unsigned long long)(unsigned)(rounds + 1);
+                }
+        };
+        int ntw = 0;
+        const int colw = nbz >> 5;
+        const int gs_col = colw >= 16 ? 4 : colw >= 8 ? 3 : colw >= 4 ? 2 : colw >= 2 ? 1 : 0;
+        const int gs = nwords >= 64 * NW ? gs_col : 0;
+        {
+            int wb = 0, tbase = 0, ttotal = 0, toff = 0, w = 0;
+            unsigned bits = 0u;
+            bool words_left = true;
+            while (words_left || ntw) {
+                while (words_left && ntw < kTileBuf) {
+                    if (tbase >= ttotal) {
+                        if (!(((wb * (64 >> gs) * NW + wave) << gs) < nwords)) { words_left = false; break; }
+                        w = (((wb * (64 >> gs) + (lane >> gs)) * NW + wave) << gs) + (lane & ((1 << gs) - 1));
+                        bits = w < nwords ? tb[w] : 0u;
+                        const int nt_lane = __popc(bits);
+                        const int tincl = wave_scan_incl(nt_lane);
+                        ttotal = wave_last(tincl);
+                        toff = tincl - nt_lane;
+                        tbase = 0;
+                        ++wb;
+                        if (ttotal == 0) continue;
+                    }
+                    const int take = min(kTileBuf - ntw, ttotal - tbase);
+                    unsigned bb = bits;
+                    int idx = toff;
+                    while (bb) {
+                        const int b2 = __ffs((int)bb) - 1;
+                        bb &= bb - 1u;
+                        if (idx >= tbase && idx < tbase + take) tbuf[ntw + idx - tbase] = (w << 5) + b2;
+                        ++idx;
+                    }
+                    ntw += take; tbase += take;
+                }
+                if (ntw) { sweep_tiles(ntw); ntw = 0; }
+            }
+        }
+        tmin_lane = wave_min(tmin_lane);
+        if (lane == 0) {
+            if (tmin_lane < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[BC_TMIN]), bf2u(tmin_lane));
+            if (seen) atomicAdd(&sc[BC_CUR], seen);
+        }
+        __syncthreads();
+        const int cnt = sc[BC_CUR];
+        if (cnt == 0) break;
+
+        // ---- pass B: the ready nodes for all members, even nodes first
+        const int nready_even = sc[BC_READY] < rhalf ? sc[BC_READY] : rhalf;
+        const int nready_odd = sc[BC_READY_ODD] < rhalf ? sc[BC_READY_ODD] : rhalf;
+        unsigned hv_lane = 0u;
+        float kmin_lane = kInf;
+        for (int half = 0; half < 2; ++half) {
+            const int nready = half ? nready_odd : nready_even;
+            for (int j0 = wave * NPW; j0 < nready; j0 += NW * NPW) {
+                const int j = j0 + nslot;
+                const bool act = j < nready;
+                const int id = act ? ready[half ? rhalf + j : j] : 0;
+                int iz, ix;
+                __builtin_amdgcn_s_setprio(3);
+                coords(id, &iz, &ix);
+                bool in[4], in_outer[4];
+                in[0] = act && ix > 0;          in_outer[0] = act && ix > 1;
+                in[1] = act && ix + 1 < nnx;    in_outer[1] = act && ix + 2 < nnx;
+                in[2] = act && iz > 0;          in_outer[2] = act && iz > 1;
+                in[3] = act && iz + 1 < nnz;    in_outer[3] = act && iz + 2 < nnz;
+                int nid[8];
+                rec_stencil(nbz, id, nid);
+                const BV4 inf4 = { kInf, kInf, kInf, kInf };
+                BV4 vn[4], vo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    vn[q] = in[q] ? *(BGV4*)(Bb + (unsigned)nid[q] * GB + sub_b) : inf4;
+                    vo[q] = in_outer[q] ? *(BGV4*)(Bb + (unsigned)nid[4 + q] * GB + sub_b) : inf4;
+                }
+                BV4 vown = { -1.0f, -1.0f, -1.0f, -1.0f };          // inactive lanes read as pinned
+                BV4 sl = { 1.0f, 1.0f, 1.0f, 1.0f };
+                if (act) {
+                    vown = *(BGV4*)(Bb + (unsigned)id * GB + sub_b);
+                    const unsigned sb = (unsigned)id * npb;
+                    sl.x = *(BGCF32*)(slowb + sb + mp[0]); sl.y = *(BGCF32*)(slowb + sb + mp[1]);
+                    sl.z = *(BGCF32*)(slowb + sb + mp[2]); sl.w = *(BGCF32*)(slowb + sb + mp[3]);
+                }
+                const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
+                __builtin_amdgcn_s_setprio(0);
+                BV4 outv = vown;
+                unsigned wm = 0u;                                    // dependents some member wants activated: bit q near, bit 4 + q outer
+                bool any_changed = false;
+                const int key0 = id * G + sub * 4;
+#pragma nounroll
+                for (int m = 0; m < 4; ++m) {
+                    Hood h;
+                    bool flagged = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a = vn[q].x, b = vo[q].x;
+                        h.in[q] = in[q]; h.in_outer[q] = in_outer[q];
+                        h.near_[q] = a; h.near_tau[q] = a; h.outer[q] = b; h.outer_tau[q] = b;
+                        flagged = flagged || __builtin_signbit(a) || __builtin_signbit(b);
+                    }
+                    const float raw = vown.x;
+                    const bool valid = act && ((vmask >> m) & 1u);
+                    float t_old = raw, k_old = raw;
+                    if (!valid) t_old = -1.0f;
+                    flagged = flagged || (valid && __builtin_signbit(raw));
+                    if (flagged) {          // exceptional nodes in this member's neighbourhood: tau (and pinned) from the table
+                        const int mo = sub * 4 + m;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bool pin;
+                            if (__builtin_signbit(h.near_[q])) { const float v = h.near_[q]; h.near_tau[q] = exc_lookup(nid[q] * G + mo, &pin); h.near_[q] = pin ? v : -v; }
+                            if (__builtin_signbit(h.outer[q])) { const float v = h.outer[q]; h.outer_tau[q] = exc_lookup(nid[4 + q] * G + mo, &pin); h.outer[q] = pin ? v : -v; }
+                        }
+                        if (valid && __builtin_signbit(raw)) { bool pin; k_old = exc_lookup(key0 + m, &pin); t_old = pin ? raw : -raw; }
+                    }
+                    bool changed = false;
+                    float c = 0.0f, k = kInf, newv = raw;
+                    if (!t_pinned(t_old)) {
+                        const float slown = sl.x;
+                        c = solve_node_t<false>(h, slown, geom, &k, nullptr);
+                        ++evals;
+                        changed = bf2u(c) != bf2u(t_old) || bf2u(k) != bf2u(k_old);
+                    }
+                    if (changed) {
+                        if (bf2u(c) == bf2u(k)) newv = c;
+                        else { if (!exc_upsert(key0 + m, k)) { p.info[2] = -2; sc[BC_OVERFLOW] = 1; } newv = -c; }
+                        ++nchanged;
+                        any_changed = true;
+                        hv_lane += ((unsigned)(key0 + m) * 2654435761u) ^ (bf2u(c) * 40503u) ^ (bf2u(k) * 2246822519u);
+                        if (sub == 0 && m == 0) kmin_lane = fminf(kmin_lane, k);                 // the pilot's changes hold the window back
+                        const float t_lo = fminf(t_value(t_old), c), k_lo = fminf(k_old, k);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float ky = h.near_tau[q];
+                            if (h.in[q] && !t_pinned(h.near_[q]) && k_lo <= ky) wm |= 1u << q;
+                            if (h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) && t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q]) wm |= 16u << q;
+                        }
+                    }
+                    // next member of this lane: rotate the vectors
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        vn[q] = BV4{ vn[q].y, vn[q].z, vn[q].w, vn[q].x };
+                        vo[q] = BV4{ vo[q].y, vo[q].z, vo[q].w, vo[q].x };
+                    }
+                    vown = BV4{ vown.y, vown.z, vown.w, vown.x };
+                    sl = BV4{ sl.y, sl.z, sl.w, sl.x };
+                    outv = BV4{ outv.y, outv.z, outv.w, newv };
+                }
+                __builtin_amdgcn_s_setprio(1);
+                if (any_changed) *(BGV4*)(Bb + (unsigned)id * GB + sub_b) = outv;
+                // dependents: the members' OR, one lane per node issues the activations (fim_kernel.hip: the mask bits are constant shifts
+                // of the node's own bit)
+                wm = node_or<CH>(wm);
+                if (sub == 0 && wm) {
+                    const int own_tile = id >> 6;
+                    const unsigned long long b = 1ull << (id & 63);
+                    auto sel = [](unsigned w, unsigned long long v) -> unsigned long long { return w ? v : 0ull; };
+                    const unsigned long long own_bits =
+                        sel(wm & 1u, b >> 8) | sel(wm & 16u, b >> 16) | sel(wm & 2u, b << 8) | sel(wm & 32u, b << 16) |
+                        sel(wm & 4u, (b >> 1) & 0x7f7f7f7f7f7f7f7full) | sel(wm & 64u, (b >> 2) & 0x3f3f3f3f3f3f3f3full) |
+                        sel(wm & 8u, (b << 1) & 0xfefefefefefefefeull) | sel(wm & 128u, (b << 2) & 0xfcfcfcfcfcfcfcfcull);
+                    const unsigned long long fxm = sel(wm & 1u, b << 56) | sel(wm & 16u, b << 48);
+                    const unsigned long long fxp = sel(wm & 2u, b >> 56) | sel(wm & 32u, b >> 48);
+                    const unsigned long long fzm = sel(wm & 4u, (b << 7) & 0x8080808080808080ull) | sel(wm & 64u, (b << 6) & 0xc0c0c0c0c0c0c0c0ull);
+                    const unsigned long long fzp = sel(wm & 8u, (b >> 7) & 0x0101010101010101ull) | sel(wm & 128u, (b >> 6) & 0x0303030303030303ull);
+                    auto activate = [&](int tile, unsigned long long bits) {
+                        if (bits) {
+                            atomicOr((unsigned long long*)(mask_at(tile) + half), bits);
+                            atomicOr(&tb[tile >> 5], 1u << (tile & 31));
+                        }
+                    };
+                    activate(own_tile - nbz, fxm);
+                    activate(own_tile + nbz, fxp);
+                    activate(own_tile - 1, fzm);
+                    activate(own_tile + 1, fzp);
+                    activate(own_tile, own_bits);
+                }
+            }
+            if (half == 1) {
+                const unsigned hv = wave_sum(hv_lane);
+                const float kmin = wave_min(kmin_lane);
+                if (lane == 0) {
+                    if (hv) atomicAdd(reinterpret_cast<unsigned*>(&sc[BC_HASH]), hv);
+                    if (kmin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[BC_TMIN]), bf2u(kmin));
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            sc[BC_READY] = 0; sc[BC_READY_ODD] = 0; sc[BC_CUR] = 0;
+            const float tmin = bu2f((unsigned)sc[BC_TMIN]);
+            sc[BC_THETA] = (int)bf2u(tmin + p.window);
+            sc[BC_TMIN] = 0x7f800000;
+            const unsigned hsh = (unsigned)sc[BC_HASH];
+            sc[BC_HASH] = 0;
+            if (tmin > best_tmin && tmin < kInf) best_tmin = tmin;
+            const bool repeat = hsh != 0u && (hsh == hist[1] || hsh == hist[2] || hsh == hist[3] || hsh == hist[0]);
+            hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = hsh;
+            if (repeat) { if (++stall >= kBundleCycleRounds) { sc[BC_FREEZE] = (int)bf2u(best_tmin + p.window); stall = 0; ++freezes; } }
+            else stall = 0;
+        }
+        ++rounds;
+        __syncthreads();
+        if (sc[BC_OVERFLOW]) break;                      // the exception table is full (info[2] = -2 at the pilot): the host grows it and solves the chunk again
+        if (rounds > p.max_rounds) { dead = true; break; }
+    }
+    const bool failed = rounds > p.max_rounds;
+
+    // ---- the members' ends: statistics, receiver times from the bundle's field (reference srtimes), the field itself where the engine
+    // keeps one per unit (rays and rows, field downloads), then the slot goes to the next bundle
+    {
+        unsigned long long e64 = evals, c64 = nchanged;
+        for (int o = 32; o > 0; o >>= 1) { e64 += __shfl_xor(e64, o); c64 += __shfl_xor(c64, o); }
+        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 4), e64); atomicAdd(reinterpret_cast<unsigned long long*>(p.info + 6), c64); }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int m = 0; m < nmem; ++m) {
+        const FimEnds* const E = ends + s_member[m];
+        const FimProblem* const pm = problems + s_member[m];
+        if (tid == 0) {
+            pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = m == 0 ? freezes : 0;
+            if (failed && pm->info[2] != -2) pm->info[2] = -1;
+            if (sc[BC_OVERFLOW]) pm->info[2] = -2;
+        }
+        if (E->rays) {
+            const GridDesc g = E->g;
+            for (int r = tid; r < E->nrays; r += NT) {
+                const RayDesc rd = E->rays[r];
+                if (!(rd.flags & kRayTime)) continue;
+                float t;
+                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)bd->B + m, E->veln, E->dpl, &t, G)) atomicExch(E->err, E->ray0 + r + 1);
+                E->out[rd.data] = t;
+            }
+        }
+        if (pm->Tc) {
+            BGF32* const dst = (BGF32*)pm->Tc;
+            for (int i = tid; i < ntile * kTileRecs; i += NT) dst[i] = fabsf(*(BGF32*)(Bb + (unsigned)i * GB + (unsigned)m * 4u));
+        }
+    }
+    if (bd->pool_gen) {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(bd->pool_gen, bd->gen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+size_t bundle_lds_bytes(int tile_words) { return (size_t)tile_words * 4; }
+
+void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream)
+{
+    if (nbundles <= 0) return;
+    const size_t lds = bundle_lds_bytes(tile_words);
+    if (G == 16) hipLaunchKernelGGL(k_fim_bundle<16>, dim3(nbundles), dim3(256), lds, stream, d_bundles, d_problems, d_ends);
+    else if (G == 8) hipLaunchKernelGGL(k_fim_bundle<8>, dim3(nbundles), dim3(256), lds, stream, d_bundles, d_problems, d_ends);
+    else hipLaunchKernelGGL(k_fim_bundle<4>, dim3(nbundles), dim3(256), lds, stream, d_bundles, d_problems, d_ends);
+}
+
+// slowI[id * np + m] = slow_all[m * field_stride + id]: the maps' slowness, member-minor
+__global__ void k_interleave_maps(const float* __restrict__ slow_all, size_t field_stride, int np, float* __restrict__ slowI)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= field_stride * (size_t)np) return;
+    const size_t id = i / (size_t)np;
+    const int m = (int)(i - id * (size_t)np);
+    slowI[i] = slow_all[(size_t)m * field_stride + id];
+}
+
+void launch_interleave_maps(const float* d_slow_all, size_t field_stride, int np, float* d_slowI, hipStream_t stream)
+{
+    const size_t n = field_stride * (size_t)np;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_interleave_maps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_slow_all, field_stride, np, d_slowI);
+}
+
+}  // namespace dsa

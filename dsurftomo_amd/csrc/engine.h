@@ -74,6 +74,20 @@ struct Engine {
     size_t per_slot_bytes = 0;
     size_t plan_budget = 0;            // bytes plan() worked with (solve() grows the slot pool inside it when a call needs every field afterwards)
     std::vector<int> h_launch_rank;
+    // bundles (bundle_kernel.hip, kernels.h: FimBundle): the units of one source -- its periods -- solved by one workgroup under one shared
+    // round schedule.  Option `bundle`: 0 = off, 1 = automatic (default: 16, 8 or 4 members by the sources' unit counts and the memory),
+    // 4 / 8 / 16 = that many members per bundle.  Default mode only (the tie detector and the literal march work per unit).
+    int bundle_opt = 1;
+    DevBuf<float> slowI, B_pool;       // member-minor slowness of all maps; bundle field slots
+    bool slowI_ready = false;
+    DevBuf<unsigned long long> exc_b;  // exception tables of the bundle slots
+    DevBuf<int> lists_b, bpool_gen, member_flag;
+    DevBuf<FimBundle> bundles_d;
+    std::vector<FimBundle> h_bundles;
+    std::vector<int> h_member_flag;
+    int bundle_slots = 0;
+    int choose_bundle_size(int step);
+    int plan_bundles(int first, int n, int G, int* nsolo, int* nbundles);
     size_t lists_stride = 0;
     int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)
     int fim_lds_pad = 0;               // dynamic LDS bytes per workgroup of the solve kernel (occupancy limiter)

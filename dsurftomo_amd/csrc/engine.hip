@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/dsurftomo_amd.h"
@@ -75,6 +76,7 @@ template int Engine::ensure<int>(DevBuf<int>&, size_t);
 template int Engine::ensure<unsigned char>(DevBuf<unsigned char>&, size_t);
 template int Engine::ensure<unsigned long long>(DevBuf<unsigned long long>&, size_t);
 template int Engine::ensure<unsigned short>(DevBuf<unsigned short>&, size_t);
+template int Engine::ensure<FimBundle>(DevBuf<FimBundle>&, size_t);
 
 Engine::~Engine()
 {
@@ -82,7 +84,7 @@ Engine::~Engine()
     auto rel = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     rel(velv); rel(veln); rel(slow); rel(risti_c); rel(cbasis); rel(rbasis);
     rel(src); rel(rays); rel(out); rel(err);
-    rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r); rel(launch_rank);
+    rel(slow_r); rel(F_r); rel(Tfin_r); rel(S_r); rel(risti_r); rel(vcorner); rel(seed_r); rel(nseed_r); rel(launch_rank); rel(slowI); rel(B_pool); rel(exc_b); rel(lists_b); rel(bpool_gen); rel(member_flag); rel(bundles_d);
     rel(rst); rel(cst); rel(cinit); rel(heap); rel(flags); rel(T_c); rel(exc_c); rel(W_c); rel(seed_c); rel(nseed_c);
     rel(prob_r); rel(prob_c); rel(paths); rel(path_n); rel(info); rel(clocks); rel(lists);
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
@@ -152,6 +154,7 @@ int Engine::finish_maps(int nm)
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = false;
     have_maps = true;
+    slowI_ready = false;
     if (g.nnx != grown_nnx || g.nnz != grown_nnz) { exc_log2cap_grown = 0; grown_nnx = g.nnx; grown_nnz = g.nnz; }
     return 0;
 }
@@ -456,11 +459,13 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     // the refined boxes are small (129^2): a wider window there costs nothing and saves rounds
     const float window_r = std::max(window_cells, 1.5f) * cell_c / (float)kSgdl;
     HIP_TRY(this, hipMemsetAsync(err.p, 0, 4 * sizeof(int32_t), stream));
+    const int bundle_G = exact_ties == 0 ? choose_bundle_size(step) : 0;
+    stats[DSA_STAT_BUNDLE_SIZE] = bundle_G;
     HIP_TRY(this, hipEventRecord(events[0], stream));
     std::vector<int32_t> h_info, h_flags;
     for (int first = 0; first < nunits; first += step) {
         const int n = std::min(step, nunits - first);
-        bool redo_chunk = false;
+        bool redo_chunk = false, bundle_off_chunk = false;
       do {
         redo_chunk = false;
         const BatchPtrs b = batch();
@@ -484,8 +489,15 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             HIP_TRY(this, hipMemcpyAsync(launch_rank.p, h_launch_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
         }
         const bool detect = exact_ties == 1;
+        // bundles: the units of one source side by side in one workgroup (bundle_kernel.hip).  Solo units keep the launch ranks
+        // 0 .. nsolo-1 (and the field slots those select), the members of the bundles follow, bundle by bundle.
+        int nsolo = n, nbundles = 0;
+        if (bundle_G > 0 && !bundle_off_chunk) {
+            if (plan_bundles(first, n, bundle_G, &nsolo, &nbundles) != 0) return status;
+        }
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
-                             detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p, stream);
+                             detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p,
+                             nbundles ? member_flag.p : nullptr, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         FimLaunch sr = shape_r, sc = shape_c;
         sr.tie = sc.tie = detect ? 1 : 0;
@@ -498,7 +510,10 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
         }
         HIP_TRY(this, hipEventRecord(events[4], stream));
-        if (exact_ties != 2) launch_fim(prob_c.p, n, sc, stream, ends_c.p);
+        if (exact_ties != 2) {
+            launch_fim(prob_c.p, nsolo, sc, stream, ends_c.p);
+            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, prob_c.p, ends_c.p, sc.tile_words, stream);
+        }
         HIP_TRY(this, hipEventRecord(events[5], stream));
         if (exact_ties) {
             // which units go through the literal march: all (2), or those whose fixed point met a tie / froze a cycle (1)
@@ -576,6 +591,12 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             break;
         }
         if (redo_chunk) continue;
+        if (nbundles) {     // a bundle that did not converge under the shared schedule: its chunk once more, every unit by itself
+            bool bad = false;
+            for (int u = 0; u < n && !bad; ++u) bad = h_member_flag[(size_t)u] && h_info[(size_t)u * 16 + 10] == -1;
+            if (bad) { bundle_off_chunk = true; redo_chunk = true; stats[DSA_STAT_RESCANS] += 1; continue; }
+            stats[DSA_STAT_BUNDLES] += nbundles; stats[DSA_STAT_BUNDLED_UNITS] += n - nsolo;
+        }
         for (int u = 0; u < n; ++u) {
             const int32_t* fi = &h_info[(size_t)u * 16];
             if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
@@ -602,6 +623,110 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     int32_t herr[4];
     HIP_TRY(this, hipMemcpy(herr, err.p, sizeof herr, hipMemcpyDeviceToHost));
     if (herr[0]) { fail(DSA_ERR_OUTSIDE, "Receiver lies outside model (ray %d)", herr[0] - 1); return DSA_ERR_OUTSIDE; }
+    return 0;
+}
+
+// Members per bundle for this call: the option, or (automatic) the largest of 16 / 8 / 4 that still gives the chip enough workgroups
+// and whose field slots fit the memory; 0 = no bundles.  `step` = units per launch.
+int Engine::choose_bundle_size(int step)
+{
+    if (bundle_opt == 0 || h_src.empty()) return 0;
+    // units per source (same coordinates bit for bit), in planned order
+    std::map<std::pair<uint32_t, uint32_t>, int> count;
+    for (const SourceDesc& sd : h_src) { uint32_t a, b2; std::memcpy(&a, &sd.scx, 4); std::memcpy(&b2, &sd.scz, 4); ++count[{ a, b2 }]; }
+    auto bundles_with = [&](int G) { long nb = 0; for (auto& kv : count) { nb += kv.second / G; if (kv.second % G >= 2) ++nb; } return nb; };
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;          // (what a previous call holds is reused)
+    auto slot_bytes = [&](int G) { int lg = G == 16 ? 4 : G == 8 ? 3 : 2; return (size_t)G * nrec_c * 4 + ((size_t)8 << (exc_log2cap + lg)) + lists_c_stride * 4; };
+    auto fits = [&](int G) {
+        if ((unsigned long long)nrec_c * (unsigned long long)G * 4ull >= (1ull << 32)) return false;          // 32-bit byte offsets inside a bundle field
+        if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
+        if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
+        const long nb = std::min<long>(bundles_with(G), (long)step);
+        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), 512);
+        return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.6 * (double)free_b);
+    };
+    if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) return fits(bundle_opt) && bundles_with(bundle_opt) > 0 ? bundle_opt : 0;
+    // automatic: a bundle is one workgroup where its members would have been G -- worth it only when the bundles still fill the chip
+    for (int G : { 16, 8, 4 })
+        if (bundles_with(G) >= 384 && fits(G)) return G;
+    return 0;
+}
+
+// Bundles of the resident chunk [first, first + n): launch ranks (solo units first, longest fronts first in both groups), the member
+// flags for k_make_problems, the bundle descriptors and their field slots.
+int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_out)
+{
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<int>> groups;
+    for (int u = 0; u < n; ++u) {
+        const SourceDesc& sd = h_src[(size_t)(first + u)];
+        uint32_t a, b2; std::memcpy(&a, &sd.scx, 4); std::memcpy(&b2, &sd.scz, 4);
+        groups[{ a, b2 }].push_back(u);
+    }
+    auto farness = [&](int u) {
+        const SourceDesc& sd = h_src[(size_t)(first + u)];
+        const float fx = (sd.scx - g.gox) / g.dnx, fz = (sd.scz - g.goz) / g.dnz;
+        const float dx = std::max(fx, (float)(g.nnx - 1) - fx), dz = std::max(fz, (float)(g.nnz - 1) - fz);
+        return -(dx * dx + dz * dz);
+    };
+    h_member_flag.assign((size_t)n, 0);
+    std::vector<std::pair<float, std::vector<int>>> pieces;
+    for (auto& kv : groups) {
+        const std::vector<int>& v = kv.second;
+        for (size_t k = 0; k < v.size(); k += (size_t)G) {
+            const size_t m = std::min<size_t>((size_t)G, v.size() - k);
+            if (m < 2) continue;
+            pieces.push_back({ farness(v[k]), std::vector<int>(v.begin() + (long)k, v.begin() + (long)(k + m)) });
+            for (size_t q = k; q < k + m; ++q) h_member_flag[(size_t)v[q]] = 1;
+        }
+    }
+    std::stable_sort(pieces.begin(), pieces.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    std::vector<std::pair<float, int>> solo;
+    for (int u = 0; u < n; ++u) if (!h_member_flag[(size_t)u]) solo.push_back({ farness(u), u });
+    std::stable_sort(solo.begin(), solo.end());
+    const int nsolo = (int)solo.size(), nb = (int)pieces.size();
+    *nsolo_out = nsolo; *nbundles_out = nb;
+    if (nb == 0) return 0;
+    h_launch_rank.assign((size_t)n, 0);
+    for (int r = 0; r < nsolo; ++r) h_launch_rank[(size_t)solo[(size_t)r].second] = r;
+    const int lg = G == 16 ? 4 : G == 8 ? 3 : 2;
+    const int xlog_b = exc_log2cap + lg;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+    free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;
+    const size_t slot_b = (size_t)G * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
+    const size_t room = (size_t)(0.7 * (double)free_b) / slot_b;
+    if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
+    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)1024, room });
+    const size_t BS = (size_t)bundle_slots;
+    if (ensure(B_pool, BS * G * nrec_c) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
+        ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
+    if (!slowI_ready) { launch_interleave_maps(slow.p, nrec_c, nmaps, slowI.p, stream); slowI_ready = true; }
+    h_bundles.assign((size_t)nb, FimBundle{});
+    int rank = nsolo;
+    for (int k = 0; k < nb; ++k) {
+        FimBundle& bd = h_bundles[(size_t)k];
+        const int slot = k % bundle_slots;
+        bd.B = B_pool.p + (size_t)slot * G * nrec_c;
+        bd.exc = exc_b.p + ((size_t)slot << xlog_b); bd.exc_log2cap = xlog_b;
+        bd.slowI = slowI.p; bd.np = nmaps;
+        bd.lists = lists_b.p + (size_t)slot * lists_c_stride;
+        bd.pool_gen = bundle_slots < nb ? bpool_gen.p + slot : nullptr; bd.gen = k / bundle_slots;
+        bd.nmem = (int)pieces[(size_t)k].second.size();
+        for (int m = 0; m < kBundleMax; ++m) { bd.member[m] = 0; bd.map[m] = 0; }
+        for (int m = 0; m < bd.nmem; ++m) {
+            const int u = pieces[(size_t)k].second[(size_t)m];
+            h_launch_rank[(size_t)u] = rank;
+            bd.member[m] = rank++;
+            bd.map[m] = h_src[(size_t)(first + u)].period;
+        }
+    }
+    HIP_TRY(this, hipMemsetAsync(bpool_gen.p, 0, BS * sizeof(int), stream));
+    HIP_TRY(this, hipMemcpyAsync(bundles_d.p, h_bundles.data(), (size_t)nb * sizeof(FimBundle), hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipMemcpyAsync(member_flag.p, h_member_flag.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipMemcpyAsync(launch_rank.p, h_launch_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    stats[DSA_STAT_BUNDLE_SLOTS] = bundle_slots;
     return 0;
 }
 
@@ -916,6 +1041,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
+    if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
     if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 19000))) { en->exact_lds_slots = (int)value; return 0; }

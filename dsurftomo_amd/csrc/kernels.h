@@ -86,6 +86,32 @@ struct FimLaunch {
     int tie;               // 1: the variant with the tie detector (k_fim_sorted only; eikonal_core.h solve_node_t<true>)
 };
 
+// A BUNDLE of coarse problems (round 3, bundle_kernel.hip): up to kBundleMax units of ONE source -- its periods -- solved by one workgroup
+// under one shared round schedule.  The members keep their own arithmetic (slowness, travel times, exception entries); what they share is
+// the active set (tile records, ready lists, causal window: routed by member 0, the pilot) and, per evaluated node, the addresses and the
+// stencil geometry.  The field is member-minor: B[id * G + m] (one 64-byte segment per node at G = 16), so every byte of a fetched line is
+// used; the slowness comes from the maps' member-minor copy slowI[id * np + map].  The fixed point is schedule independent
+// (tests/tools/bundle_lab.cpp measures what sharing costs: +4...+9 % evaluations for maps that are multiples of one pattern, +13...+20 % for
+// mixtures of patterns, +56 % for unrelated random maps), so each member's field is the one its own solve produces.
+constexpr int kBundleMax = 16;
+struct FimBundle {
+    float* B;                     // G floats per node record, tiled like the compact field
+    unsigned long long* exc;      // exception table of the bundle, keyed by id * G + m
+    int exc_log2cap;
+    const float* slowI;           // member-minor slowness of all maps: slowI[id * np + map]
+    int np;
+    int* lists;                   // tile records of the shared active set (kFimMaskInts ints per tile)
+    int* pool_gen; int gen;       // the bundle slot's use counter (null: the slot is this bundle's alone)
+    int nmem;
+    int member[kBundleMax];       // indices into the launch's FimProblem / FimEnds arrays (grid, seeds, window records, receivers, info)
+    int map[kBundleMax];
+};
+size_t bundle_lds_bytes(int tile_words);
+// G = 16, 8 or 4 members per bundle slot (members beyond nmem idle)
+void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream);
+// slowI[id * np + m] = slow_all[m * field_stride + id]
+void launch_interleave_maps(const float* d_slow_all, size_t field_stride, int np, float* d_slowI, hipStream_t stream);
+
 size_t fim_lds_bytes(const FimLaunch& l);
 void launch_fim(const FimProblem* d_problems, int nproblems, const FimLaunch& l, hipStream_t stream, const FimEnds* d_ends = nullptr);
 
@@ -133,7 +159,8 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
                           const int* d_launch_rank, int32_t* d_tie, float tie_threshold, FimEnds* d_ends_c, const RayDesc* d_rays /* null: no receiver times inside the solve */,
-                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, hipStream_t stream);
+                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err,
+                          const int* d_member_flag /* null or per unit: 1 = solved inside a bundle */, hipStream_t stream);
 
 // exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), one wavefront each,
 // workgroup j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per slot beyond the lcap in LDS);

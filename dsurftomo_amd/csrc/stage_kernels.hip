@@ -294,7 +294,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
                                 const float* risti_c, float window_r, float window_c, FimProblem* prob_r,
                                 FimProblem* prob_c, int32_t* info, unsigned long long* clocks, const int* __restrict__ launch_rank,
                                 int32_t* tie, float tie_threshold, FimEnds* ends_c, const RayDesc* __restrict__ rays, const float* __restrict__ veln_all,
-                                size_t veln_stride, float dpl, float* out, int32_t* err)
+                                size_t veln_stride, float dpl, float* out, int32_t* err, const int* __restrict__ member_flag)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -314,9 +314,13 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     const int rank = launch_rank ? launch_rank[s] : s;
     const bool recycled = b.pool < nsrc;
     const int slot = recycled ? rank % b.pool : s;
+    // a member of a bundle (bundle_kernel.hip) is solved inside its bundle's field: it has no slot of its own unless every unit has one
+    // (the bundle then leaves the member's field there for the rays)
+    const bool member = member_flag && member_flag[s];
     FimProblem c;
     c.F = nullptr;
     c.Tc = b.T_c + (size_t)slot * g.nbx * g.nbz * kTileRecs; c.exc = b.exc_c + ((size_t)slot << b.exc_log2cap); c.exc_log2cap = b.exc_log2cap;
+    if (member && recycled) { c.Tc = nullptr; c.exc = nullptr; }
     c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
     c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.seed_cap = kSeedC; c.lists = b.lists_c + (size_t)slot * b.lists_c_stride;
     c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
@@ -329,7 +333,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     if (ends_c) {
         FimEnds e;
         e.W = b.W_c + (size_t)s * kCWinMax * kCWinMax; e.cwz0 = sd.cwz0; e.cwx0 = sd.cwx0; e.cwnz = sd.cwnz; e.cwnx = sd.cwnx;
-        e.pool_gen = recycled ? b.pool_gen + slot : nullptr; e.gen = recycled ? rank / b.pool : 0;
+        e.pool_gen = recycled && !member ? b.pool_gen + slot : nullptr; e.gen = recycled && !member ? rank / b.pool : 0;
         e.rays = rays ? rays + sd.first_ray : nullptr; e.nrays = sd.nrec; e.ray0 = sd.first_ray;
         e.veln = veln_all + (size_t)sd.period * veln_stride; e.scx = sd.scx; e.scz = sd.scz; e.dpl = dpl; e.out = out; e.err = err; e.g = g;
         ends_c[rank] = e;
@@ -343,12 +347,12 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
                           const int* d_launch_rank, int32_t* d_tie, float tie_threshold, FimEnds* d_ends_c, const RayDesc* d_rays,
-                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, hipStream_t stream)
+                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, const int* d_member_flag, hipStream_t stream)
 {
     if (nsrc <= 0) return;
     hipLaunchKernelGGL(k_make_problems, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all,
                        field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks, d_launch_rank, d_tie, tie_threshold,
-                       d_ends_c, d_rays, d_veln_all, veln_stride, dpl, d_out, d_err);
+                       d_ends_c, d_rays, d_veln_all, veln_stride, dpl, d_out, d_err, d_member_flag);
 }
 
 // ---------------------------------------------------------------------------------------------

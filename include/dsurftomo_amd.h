@@ -63,7 +63,10 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  * the coarse solve: 0 default = four times the workgroups the GPU holds at once -- a dsa_solve over more units than that recycles the
  * slots, each workgroup resetting its slot, solving, and writing its unit's receiver times before it hands the slot on; -1 = one slot per
  * unit; > 0 = that many.  Fields stay readable (dsa_get_field) only when the units of the call fit the slots; rows / exact mode / keep_fields
- * calls never recycle), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
+ * calls never recycle), "bundle" (the units of one source -- its periods -- solved side by side by one workgroup under one shared round
+ * schedule: 1 default = automatic, 16 / 8 / 4 members per bundle when the call has at least 384 such bundles and their field slots fit the
+ * memory, else none; 0 = off; 4 / 8 / 16 = that size whatever the count.  Same travel times as unit by unit -- the fixed point does not
+ * depend on the schedule; default mode only, i.e. exact_ties = 0), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
  * Grid size limit: the coarse solve keeps one bit per 8x8-node tile in LDS (36 KB): up to about 4340 nodes per side (nx <= 545 at dicing 8);
  * dsa_plan returns DSA_ERR_ARGUMENT beyond. */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
@@ -217,7 +220,8 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_CHUNK, DSA_STAT_RESCANS, DSA_STAT_FREEZES, DSA_STAT_RAYS, DSA_STAT_RAY_STEPS,
        DSA_STAT_RAYS_CLAMPED, DSA_STAT_MS_RAYS, DSA_STAT_MS_ROWS, DSA_STAT_NAR, DSA_STAT_MS_DISPERSION,
        DSA_STAT_CURVES, DSA_STAT_CHANGES_TOTAL, DSA_STAT_TIE_UNITS, DSA_STAT_EXACT_UNITS, DSA_STAT_EXACT_POPS,
-       DSA_STAT_MS_EXACT, DSA_STAT_FIELD_SLOTS, DSA_STAT_FOOTPRINT_MB, DSA_STAT_COUNT };
+       DSA_STAT_MS_EXACT, DSA_STAT_FIELD_SLOTS, DSA_STAT_FOOTPRINT_MB, DSA_STAT_BUNDLE_SIZE, DSA_STAT_BUNDLES,
+       DSA_STAT_BUNDLED_UNITS, DSA_STAT_BUNDLE_SLOTS, DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */
