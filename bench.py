@@ -47,7 +47,7 @@ NSRC = 1000
 NREC = 32
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 TOL = 1e-4                   # north_star: travel times within 1e-4 s of the reference FMM
-KERNEL_SOURCES = ["fim_kernel.hip", "eikonal_core.h", "kernels.h", "engine.hip"]
+KERNEL_SOURCES = ["fim_kernel.hip", "bundle_kernel.hip", "wave_ops.h", "eikonal_core.h", "kernels.h", "engine.hip"]
 DISP_SOURCES = ["disp_kernels.hip", "dispersion_core.h"]
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector FP64 = half the 157.3 TFLOP/s vector FP32 peak of MI355X_MICROARCH.md
 
@@ -324,7 +324,8 @@ def main():
                        "parallelism": "units sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_fim_sorted<256, compact> (coarse fixed-point solve)", "bytes_per_solve": bps,
+                         "kernel": ("k_fim_bundle<%d> (coarse fixed-point solve, the %d periods of a source per workgroup)" % (int(st.get("bundle_size", 0)), int(st.get("bundle_size", 0)))
+                                    if st.get("bundle_size", 0) else "k_fim_sorted<256, compact> (coarse fixed-point solve)"), "bytes_per_solve": bps,
                          "launches": int(acc["launches_fim_coarse"]),
                          "avg_launch_ms": round(acc["ms_fim_coarse"] / launches, 3),
                          "solves_per_launch": round(my_units / launches, 1),
@@ -337,6 +338,7 @@ def main():
                                    "stages": round(acc["ms_stages"] / args.steps, 2)},
             "evals_per_node": round(acc["evals_total"] / max(my_units, 1) / (n * n), 3),
             "setup_ms": round(setup_ms, 1),
+            "bundles": {"members": int(st.get("bundle_size", 0)), "per_step": int(st.get("bundles", 0)), "field_slots": int(st.get("bundle_slots", 0))},
             "field_slots": int(st.get("field_slots", 0)), "footprint_mb": round(st.get("footprint_mb", 0.0), 1),     # coarse field slots of the launch (recycled when fewer than the units), HBM held by the solve
             "value_incl_setup": round(solves / (dt + setup_ms / 1000.0), 2),
             "max_abs_err": None,

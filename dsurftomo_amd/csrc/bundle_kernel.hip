@@ -49,8 +49,13 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 
 }  // namespace
 
+#ifdef DSA_BUNDLE_WAVES      // experiments: waves per SIMD the register allocation aims at (default: what 256 threads allow, 2 at ~217 VGPRs)
+#define DSA_BUNDLE_OCC __attribute__((amdgpu_waves_per_eu(DSA_BUNDLE_WAVES, DSA_BUNDLE_WAVES)))
+#else
+#define DSA_BUNDLE_OCC
+#endif
 template <int G>
-__global__ __launch_bounds__(256) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
+__global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
 {
     constexpr int NT = 256, NW = NT / 64;

@@ -50,6 +50,7 @@ int engine()
         if (const char* s = getenv("DSA_WINDOW_CELLS")) dsa_set_option(e, "window_cells", atof(s));
         if (const char* s = getenv("DSA_EXACT_TIES")) dsa_set_option(e, "exact_ties", atof(s));       // exact mode for an unchanged Fortran host
         if (const char* s = getenv("DSA_TIE_THRESHOLD")) dsa_set_option(e, "tie_threshold", atof(s));
+        if (const char* s = getenv("DSA_BUNDLE")) dsa_set_option(e, "bundle", atof(s));               // 0 off, 1 automatic (default), 4 / 8 / 16 members
         g_pool.push_back(e);
     }
     g_engine = g_pool[0];

@@ -78,6 +78,7 @@ struct Engine {
     // round schedule.  Option `bundle`: 0 = off, 1 = automatic (default: 16, 8 or 4 members by the sources' unit counts and the memory),
     // 4 / 8 / 16 = that many members per bundle.  Default mode only (the tie detector and the literal march work per unit).
     int bundle_opt = 1;
+    int bundle_pool_opt = 0;           // option bundle_pool: bundle field slots (0 = up to 1024; fewer than the bundles of a launch: recycled like the unit slots)
     DevBuf<float> slowI, B_pool;       // member-minor slowness of all maps; bundle field slots
     bool slowI_ready = false;
     DevBuf<unsigned long long> exc_b;  // exception tables of the bundle slots
@@ -102,6 +103,7 @@ struct Engine {
     DevBuf<int> x_units;
     DevBuf<int32_t> xinfo, tieinfo;
     std::vector<unsigned char> h_unit_flags;     // per planned unit after a solve: bit 0 tie met, bit 1 solved by the exact mode
+    std::vector<int> h_unit_rounds;               // rounds of the unit's coarse solve (of its bundle's, for a bundled unit)
     std::vector<float> h_unit_tie;               // largest tie influence of the unit (s)
     int run_exact(int first, int n, const std::vector<int>& local_units);
     DevBuf<int8_t> S_r, cinit;

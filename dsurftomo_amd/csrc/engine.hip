@@ -394,6 +394,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(tieinfo, C * 4) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
     h_unit_flags.assign((size_t)nunits, 0);
     h_unit_tie.assign((size_t)nunits, 0.0f);
+    h_unit_rounds.assign((size_t)nunits, 0);
     HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
     if (!h_trace.empty()) HIP_TRY(this, hipMemcpyAsync(trace_ids.p, h_trace.data(), h_trace.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -596,12 +597,15 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             for (int u = 0; u < n && !bad; ++u) bad = h_member_flag[(size_t)u] && h_info[(size_t)u * 16 + 10] == -1;
             if (bad) { bundle_off_chunk = true; redo_chunk = true; stats[DSA_STAT_RESCANS] += 1; continue; }
             stats[DSA_STAT_BUNDLES] += nbundles; stats[DSA_STAT_BUNDLED_UNITS] += n - nsolo;
+            stats[DSA_STAT_FOOTPRINT_MB] = std::max(stats[DSA_STAT_FOOTPRINT_MB], ((double)pool_slots * (double)per_slot_bytes + (double)chunk * (double)per_unit_bytes +
+                                                    (double)(B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4 + slowI.cap * 4)) / 1.0e6);
         }
         for (int u = 0; u < n; ++u) {
             const int32_t* fi = &h_info[(size_t)u * 16];
             if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
             if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
             stats[DSA_STAT_ROUNDS_MAX] = std::max(stats[DSA_STAT_ROUNDS_MAX], (double)fi[8]);
+            h_unit_rounds[(size_t)(first + u)] = fi[8];
             unsigned long long ev;
             std::memcpy(&ev, fi + 12, 8);
             stats[DSA_STAT_EVALS_TOTAL] += (double)ev;
@@ -698,7 +702,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     const size_t slot_b = (size_t)G * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
     const size_t room = (size_t)(0.7 * (double)free_b) / slot_b;
     if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
-    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)1024, room });
+    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : 1024), room });
     const size_t BS = (size_t)bundle_slots;
     if (ensure(B_pool, BS * G * nrec_c) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
@@ -1041,6 +1045,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
+    if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
@@ -1248,6 +1253,15 @@ int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence)
     const Engine* en = reinterpret_cast<const Engine*>(e);
     if (nunits < 0 || (size_t)nunits > en->h_unit_flags.size()) return DSA_ERR_ARGUMENT;
     for (int u = 0; u < nunits; ++u) { if (flags) flags[u] = en->h_unit_flags[(size_t)u]; if (influence) influence[u] = en->h_unit_tie[(size_t)u]; }
+    return 0;
+}
+
+int dsa_unit_rounds(const dsa_engine* e, int nunits, int* rounds)
+{
+    if (!e || !rounds) return DSA_ERR_ARGUMENT;
+    const Engine* en = reinterpret_cast<const Engine*>(e);
+    if (nunits < 0 || (size_t)nunits > en->h_unit_rounds.size()) return DSA_ERR_ARGUMENT;
+    for (int u = 0; u < nunits; ++u) rounds[u] = en->h_unit_rounds[(size_t)u];
     return 0;
 }
 

@@ -61,6 +61,7 @@ def load_library():
     L.dsa_get_refined.argtypes = [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp]
     L.dsa_get_stats.argtypes = [_vp, _vp]
     L.dsa_unit_ties.argtypes = [_vp, _i32, _vp, _vp]
+    L.dsa_unit_rounds.argtypes = [_vp, _i32, _vp]
     L.dsa_debug_counters.argtypes = [_vp, _vp]
     L.dsa_ray_paths.argtypes = [_vp, _vp, _vp, _vp]
     L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]
@@ -281,6 +282,13 @@ class Engine:
         fl = np.zeros(n, np.int32); inf = np.zeros(n, np.float32)
         self._check(self._L.dsa_unit_ties(self._h, n, _p(fl), _p(inf)))
         return fl, inf
+
+    def unit_rounds(self):
+        """rounds of each unit's coarse solve in the last solve"""
+        n = len(self._nrec_of_plan)
+        r = np.zeros(n, np.int32)
+        self._check(self._L.dsa_unit_rounds(self._h, n, _p(r)))
+        return r
 
     def stats(self):
         out = np.zeros(40, np.float64)

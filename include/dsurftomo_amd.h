@@ -66,7 +66,7 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  * calls never recycle), "bundle" (the units of one source -- its periods -- solved side by side by one workgroup under one shared round
  * schedule: 1 default = automatic, 16 / 8 / 4 members per bundle when the call has at least 384 such bundles and their field slots fit the
  * memory, else none; 0 = off; 4 / 8 / 16 = that size whatever the count.  Same travel times as unit by unit -- the fixed point does not
- * depend on the schedule; default mode only, i.e. exact_ties = 0), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
+ * depend on the schedule; default mode only, i.e. exact_ties = 0; "bundle_pool" = bundle field slots, 0 default = up to 1024, recycled when a launch has more bundles), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
  * Grid size limit: the coarse solve keeps one bit per 8x8-node tile in LDS (36 KB): up to about 4340 nodes per side (nx <= 545 at dicing 8);
  * dsa_plan returns DSA_ERR_ARGUMENT beyond. */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
@@ -210,6 +210,8 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: met a tie, bit 1: solved by the literal march) and the largest
  * tie influence in seconds (either array may be NULL). */
 int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence);
+/* rounds the coarse fixed-point solve of each planned unit took in the last dsa_solve (a bundled unit: its bundle's) */
+int dsa_unit_rounds(const dsa_engine* e, int nunits, int* rounds);
 
 /* probe builds only (-DDSA_LEDGER, tools/isa_ledger.py): trip counters of the coarse solve's phases, summed over the units of the last solve */
 int dsa_debug_counters(const dsa_engine* e, double* out24);

@@ -1,0 +1,169 @@
+"""Bundles (engine option bundle; csrc/bundle_kernel.hip): the periods of one source solved side by side by one workgroup under one
+shared round schedule.  Every member keeps its own arithmetic, and the fixed point does not depend on the schedule, so a bundled solve
+must give the travel times of the unit-by-unit solve -- bit for bit, except where a unit's field holds an exact time tie (two
+self-consistent states there): those cases are measured against the oracle like the unit-by-unit solve is.
+
+* forced bundle sizes 16 / 8 / 4 on small grids: receiver times and whole fields of every unit against the unit-by-unit solve, with
+  ragged period sets (sources with 1, 2, 5 and 16 periods: idle members, left-over solo units), different maps per member, bundle
+  field slots recycled inside a launch;
+* against the oracle (the reference's arithmetic): 1e-4 s over whole fields;
+* the rows path: Frechet rows traced on the fields a bundle leaves behind are those of the unit-by-unit solve;
+* headline size (1025^2, 16 periods): identical to unit by unit on the headline medium.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _libs as L
+import parity_log
+import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture()
+def bundles(engine):
+    yield engine
+    engine.set_option("bundle", 1)
+    engine.set_option("bundle_pool", 0)
+    engine.set_option("field_pool", 0)
+
+
+def mixed_maps(nx, nper):
+    """phase-velocity maps of one model at nper periods: two patterns whose weights change with the period"""
+    i = np.arange(nx, dtype=np.float64)[None, :]
+    j = np.arange(nx, dtype=np.float64)[:, None]
+    out = []
+    for p in range(nper):
+        w = p / max(nper - 1, 1)
+        v = (2.8 + 0.05 * p) * (1.0 + 0.10 * (1 - w) * np.sin(4 * np.pi * i / nx) * np.cos(4 * np.pi * j / nx)
+                                + 0.08 * w * np.sin(6 * np.pi * i / nx + 1.0) * np.sin(2 * np.pi * j / nx + 0.5))
+        out.append(np.ascontiguousarray(v.reshape(-1), np.float64))
+    return np.stack(out)
+
+
+def ragged_units(nx, nsrc, nper, nrec, counts):
+    """units in the reference's order (period outer, source inner); source s has data at its first counts[s % len(counts)] periods only"""
+    u = synth.units(nx, nsrc, nper, nrec)
+    keep = np.array([(k // nsrc) < counts[(k % nsrc) % len(counts)] for k in range(nsrc * nper)])
+    rkeep = np.repeat(keep, nrec)
+    return dict(map_index=u["map_index"][keep], scx=u["scx"][keep], scz=u["scz"][keep], nrec=u["nrec"][keep], rcx=u["rcx"][rkeep], rcz=u["rcz"][rkeep])
+
+
+@pytest.mark.parametrize("kind", ["smooth", "mixed", "rough"])
+def test_bundled_solve_equals_unit_by_unit(bundles, kind):
+    e = bundles
+    nx, nsrc, nper, nrec = 33, 14, 16, 5
+    pv = mixed_maps(nx, nper) if kind == "mixed" else np.stack([synth.medium(nx, kind, p) for p in range(nper)])
+    u = ragged_units(nx, nsrc, nper, nrec, (16, 5, 1, 2, 16, 9))
+    n = u["map_index"].size
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("field_pool", -1)            # a field per unit: the bundles leave their members' fields behind
+    ref_t = ref_f = None
+    for G, pool in ((0, 0), (16, 0), (8, 0), (4, 0), (16, 3), (4, 2)):
+        e.set_option("bundle", G)
+        e.set_option("bundle_pool", pool)
+        t = e.traveltimes(**u)
+        st = e.stats()
+        F = np.stack([e.field(k) for k in range(n)])
+        if G == 0:
+            assert st["bundles"] == 0
+            ref_t, ref_f = t, F
+            assert np.isfinite(F).all()
+            continue
+        assert st["bundle_size"] == G and st["bundles"] > 0 and st["bundled_units"] <= n
+        if pool: assert st["bundle_slots"] == pool
+        nbad_t = int((bits(t) != bits(ref_t)).sum())
+        nbad_f = int((bits(F) != bits(ref_f)).sum())
+        parity_log.add(f"bundles N={e.nnx} {kind} G={G} slots {int(st['bundle_slots'])}: {int(st['bundles'])} bundles, {int(st['bundled_units'])} of {n} units; vs unit by unit: "
+                       f"{nbad_t} of {t.size} times, {nbad_f} of {F.size} field nodes differ (max |dT| {float(np.abs(F - ref_f).max()):.3g} s)")
+        # identical by construction wherever the fixed point is unique; an exact tie has two states (see the module docstring)
+        assert np.abs(F - ref_f).max() <= 2e-5 and np.abs(t - ref_t).max() <= 2e-5
+        if kind != "rough": assert nbad_t == 0 and nbad_f == 0
+
+
+def test_bundled_fields_against_the_oracle(bundles):
+    e = bundles
+    nx, gd, nper = 35, 8, 4
+    kinds = ("checker4", "rough", "smooth", "rough")
+    pv = np.stack([synth.medium(nx, k, p) for p, k in enumerate(kinds)])
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+    sx, sz = synth.sources(nx, 6)
+    scx = np.tile(sx, nper); scz = np.tile(sz, nper)
+    mi = np.repeat(np.arange(nper, dtype=np.int32), sx.size)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("field_pool", -1)
+    e.set_option("bundle", 4)
+    rcx = np.roll(scx, 1); rcz = np.roll(scz, 1)
+    t = e.traveltimes(mi, scx, scz, np.ones(mi.size, np.int32), rcx, rcz)
+    st = e.stats()
+    assert st["bundles"] == sx.size and st["bundled_units"] == mi.size
+    worst = 0.0
+    for k in range(mi.size):
+        p = int(mi[k])
+        if kinds[p] == "checker4": continue          # the known exact-tie medium (tests/test_gpu_parity.py: TIE_CASES), measured there
+        veln = L.o_gridder(g, pv[p])
+        o = L.o_solve(g, pv[p], veln, scx[k], scz[k])
+        d = float(np.abs(e.field(k) - o["T"]).max())
+        worst = max(worst, d)
+        assert d <= TOL, (k, d)
+        tr = L.o_srtimes(g, veln, o["T"], scx[k], scz[k], rcx[k], rcz[k])
+        assert abs(float(t[k]) - float(tr)) <= TOL
+    parity_log.add(f"bundles of 4 different media at N={e.nnx}: worst field |dT| against the oracle {worst:.3g} s")
+
+
+def test_dropin_with_bundles_from_the_environment():
+    """DSA_BUNDLE=4 behind the drop-in boundary: whole CalSurfG calls (dispersion, solves, rays, rows; phase and group velocities,
+    Rayleigh and Love, so the members of a bundle use different maps) with the solves bundled -- travel times and every COO entry
+    are the oracle's, bit for bit, as they are unit by unit (tests/test_gpu_boundary.py)"""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _libs as L, synth
+from dsurftomo_amd import engine
+import ctypes as C
+lib = engine.load_library()
+lib.dsa_dropin_engine.restype = C.c_void_p
+for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, nsrc=8, nrcf=7, kRc=3, kRg=1, kLc=1, kLg=1)):
+    c = synth.boundary_case(**kw)
+    o = L.call_boundary(L.oracle().dso_calsurfg, c)
+    d = L.call_boundary(lib.dsa_calsurfg, c)
+    assert o["nar"] == d["nar"], (o["nar"], d["nar"])
+    assert (o["dsurf"].view(np.uint32) == d["dsurf"].view(np.uint32)).all()
+    assert (o["iw"] == d["iw"]).all() and (o["col"] == d["col"]).all()
+    assert (o["rw"].view(np.uint32) == d["rw"].view(np.uint32)).all()
+    st = np.zeros(40)
+    assert lib.dsa_get_stats(C.c_void_p(lib.dsa_dropin_engine()), st.ctypes.data_as(C.c_void_p)) == 0
+    assert st[26] == 4 and st[27] > 0 and st[28] > 0, st[:30]          # DSA_STAT_BUNDLE_SIZE, _BUNDLES, _BUNDLED_UNITS
+    print("bundles", int(st[27]), "units", int(st[28]), "of", int(st[5]))
+print("bundled ok")
+''' % (L.ROOT, os.path.join(L.ROOT, "tests"))
+    env = dict(os.environ, DSA_BUNDLE="4")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "bundled ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    parity_log.add("drop-in calls with DSA_BUNDLE=4: " + "; ".join(l for l in r.stdout.splitlines() if l.startswith("bundles")) + ": dsurf and all COO entries = oracle")
+
+
+def test_headline_size_bundles_equal_unit_by_unit(bundles):
+    e = bundles
+    nx, nsrc, nper, nrec = 131, 24, 16, 32
+    pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, nrec)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    out = {}
+    for G in (0, 16, 8):
+        e.set_option("bundle", G)
+        out[G] = e.traveltimes(**u)
+        st = e.stats()
+        assert st["bundles"] == (0 if G == 0 else nsrc * nper // G)
+    for G in (16, 8):
+        assert np.array_equal(bits(out[G]), bits(out[0])), G
+    parity_log.add(f"bundles at N=1025 (headline medium): {out[0].size} receiver times of {nsrc * nper} units, 16 and 8 members: bit-identical to unit by unit")

@@ -7,6 +7,10 @@
 //   0  solo: each member by itself (the reference point: evaluations and rounds of G separate solves)
 //   1  ANY: a listed node is ready when ANY member's lower bound lies inside that member's window; all members are evaluated
 //   2  PILOT: routed by member `pilot` alone (its lower bound, its window); all members are evaluated
+//   4  PILOT + hold-back: like 2, and a change of ANY member at a node holds the pilot's window back by the pilot's acceptance time there
+//      (what the pilot's own changes do): the window waits for the member that settles last, and a cycle in any member is seen inside it
+//   5  PILOT + hold-back for SMALL changes only (the new value within a few ulps of the old one: a cycle among ulp-tied nodes, or a last
+//      refinement): cycles of any member then stall the window as they do in a solo run, everything else runs as under rule 2
 //   3  EXACT: a pending bit per (node, member): a member is evaluated at a node exactly when its solo schedule would; the lanes of the
 //      members that are not due idle (reported as member fill)
 // build: g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -msse2 -mfpmath=sse -o tests/tools/libbundle_lab.so tests/tools/bundle_lab.cpp
@@ -43,7 +47,7 @@ extern "C" long lab_bundle(int G, int nnx, int nnz, float* Tio, float* tauio, co
         m.window = windows[g]; m.theta = kInf; m.tmin = kInf; m.best_tmin = -kInf; m.freeze = -kInf; m.hsh = 0u; m.stall = 0;
         m.hist[0] = 1u; m.hist[1] = 2u; m.hist[2] = 3u; m.hist[3] = 4u; m.evals = m.changes = m.freezes = 0;
     }
-    long rounds = 0, node_evals = 0, member_evals = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, changed_evals = 0, freezes = 0;
+    long small_changes = 0, rounds = 0, node_evals = 0, member_evals = 0, sum_ready = 0, sum_listed = 0, max_ready = 0, changed_evals = 0, freezes = 0;
     auto in_grid = [&](int iz0, int ix0) { return ix0 >= 0 && ix0 < nnx && iz0 >= 0 && iz0 < nnz; };
     auto hood = [&](const Member& m, int iz, int ix) {   // 0-based
         Hood h;
@@ -97,6 +101,8 @@ extern "C" long lab_bundle(int G, int nnx, int nnz, float* Tio, float* tauio, co
             if (!std::memcmp(&c, &m.F[id].T, 4) && !std::memcmp(&k, &m.F[id].tau, 4)) return;
             ++m.changes; ++changed_evals;
             const float t_lo = fminf(t_value(m.F[id].T), c), k_lo = fminf(tau_value(m.F[id].tau), k);
+            const bool small = fabsf(c - t_value(m.F[id].T)) <= 4e-7f * c && fabsf(k - tau_value(m.F[id].tau)) <= 4e-7f * k;
+            if (small) ++small_changes;
             m.F[id].T = c; m.F[id].tau = k;
             { unsigned a, b; std::memcpy(&a, &c, 4); std::memcpy(&b, &k, 4); m.hsh += ((unsigned)id * 2654435761u) ^ (a * 40503u) ^ (b * 2246822519u); }
             int iz0, ix0; rec_coords(nbz, id, &iz0, &ix0);
@@ -112,6 +118,7 @@ extern "C" long lab_bundle(int G, int nnx, int nnz, float* Tio, float* tauio, co
                 if (t_value(y.T) > t_lo && k_lo < tau_value(zr.tau)) act(zz, zx, g);
             }
             m.tmin = fminf(m.tmin, k);
+            if (rule == 4 || (rule == 5 && small)) { Member& pm = M[std::min(std::max(pilot, g0), g1 - 1)]; if (!t_pinned(pm.F[id].T)) pm.tmin = fminf(pm.tmin, tau_value(pm.F[id].tau)); }
         };
         auto eval_batch = [&](const std::vector<R>& sub) {
             if (sub.empty()) return;
@@ -148,7 +155,7 @@ extern "C" long lab_bundle(int G, int nnx, int nnz, float* Tio, float* tauio, co
                     lb[g - g0] = lower_bound(m, iz0, ix0);
                     if (!(m.theta < kInf) || lb[g - g0] < m.theta) due |= bit;
                 }
-                if (rule == 2) { const int pg = std::min(std::max(pilot, g0), g1 - 1) - g0; if ((cand >> pg) & 1) due = ((due >> pg) & 1) ? cand : 0; else due = due ? cand : 0; }   // (the pilot pinned or frozen here: any member)
+                if (rule == 2 || rule == 4 || rule == 5) { const int pg = std::min(std::max(pilot, g0), g1 - 1) - g0; if ((cand >> pg) & 1) due = ((due >> pg) & 1) ? cand : 0; else due = due ? cand : 0; }   // (the pilot pinned or frozen here: any member)
                 if (rule == 1 || rule == 0) due = due ? cand : 0;
                 const int par = (iz0 + ix0) & 1;
                 if (!cand) { queued[id] = 0; continue; }
@@ -200,6 +207,6 @@ extern "C" long lab_bundle(int G, int nnx, int nnz, float* Tio, float* tauio, co
     for (int g = 0; g < G; ++g)
         for (int ix = 0; ix < nnx; ++ix)
             for (int iz = 0; iz < nnz; ++iz) { const Rec q = M[g].F[rec_index(nbz, iz, ix)]; Tio[g * nrm + (size_t)ix * nnz + iz] = q.T; tauio[g * nrm + (size_t)ix * nnz + iz] = q.tau; }
-    out[0] = rounds; out[1] = node_evals; out[2] = member_evals; out[3] = sum_ready; out[4] = sum_listed; out[5] = freezes; out[6] = max_ready; out[7] = changed_evals;
+    out[0] = rounds; out[1] = node_evals; out[2] = member_evals; out[3] = sum_ready; out[4] = sum_listed; out[5] = freezes; out[6] = max_ready; out[7] = changed_evals; out[8] = small_changes;
     return rc;
 }

@@ -34,7 +34,7 @@ def medium(p):
 
 g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
 N = g.nnx
-sx, sz = synth.sources(nx, 8)
+sx, sz = synth.sources(nx, int(os.environ.get("LAB_NSRC", "8")))
 T0 = np.zeros((G, N, N), np.float32); tau0 = np.zeros((G, N, N), np.float32); slow = np.zeros((G, N, N), np.float32)
 ris = np.zeros(N, np.float32); geom = np.zeros(4, np.float32); win = np.zeros(G, np.float32)
 for p in range(G):
@@ -51,8 +51,8 @@ for rule in rules:
     if rule[0] == 0: solo = out.copy()
     rel = "" if solo is None else " | vs solo: member-evals x%.3f, node-evals (listing, addresses) x%.3f of solo's per member, rounds x%.2f of a solo run" % (
         out[2] / solo[2], out[1] / (solo[1] / G), out[0] / (solo[0] / G))
-    print("N=%d %s G=%d src %d rule %s rc %d: rounds %d node-evals %d member-evals %d (fill %.3f) ready/round %.0f listed/round %.0f max ready %d freezes %d%s | %s (%.1f s)" %
-          (N, kind, G, isrc, ":".join(map(str, rule)), rc, out[0], out[1], out[2], out[2] / max(out[1] * G, 1) if rule[0] else 1.0, out[3] / max(out[0], 1), out[4] / max(out[0], 1), out[6], out[5], rel, same, time.time() - t0), flush=True)
+    print("N=%d %s G=%d src %d rule %s rc %d: rounds %d node-evals %d member-evals %d (fill %.3f) ready/round %.0f listed/round %.0f max ready %d freezes %d small changes %.4f of changes%s | %s (%.1f s)" %
+          (N, kind, G, isrc, ":".join(map(str, rule)), rc, out[0], out[1], out[2], out[2] / max(out[1] * G, 1) if rule[0] else 1.0, out[3] / max(out[0], 1), out[4] / max(out[0], 1), out[6], out[5], out[8] / max(out[7], 1), rel, same, time.time() - t0), flush=True)
     if ref is not None and not np.array_equal(np.abs(T).view(np.uint32), ref.view(np.uint32)):
         d = np.abs(np.abs(T) - ref); bad = np.abs(T).view(np.uint32) != ref.view(np.uint32)
         print("    differing nodes %d of %d, members %s, max |dT| %.3g, first at %s" % (bad.sum(), bad.size, sorted(set(np.nonzero(bad)[0].tolist())), np.nanmax(np.where(bad, d, 0)), [tuple(int(v) for v in x) for x in np.argwhere(bad)[:4]]))

@@ -32,6 +32,9 @@ n = nsrc * nper
 e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
 ref = None; ref_fields = None
 for G in sizes:
+    if G < 0:      # a solo run with another causal window: is the solo answer itself schedule dependent here?
+        e.set_option('window_cells', 1.0); G = 0
+    else: e.set_option('window_cells', 1.25)
     e.set_option('bundle', G)
     if what == "check": e.set_option('field_pool', -1)
     e.plan(**u)
@@ -40,9 +43,12 @@ for G in sizes:
     for rep in range(1 if what == "check" else 3):
         t0 = time.time(); t = e.solve(); best = min(best, time.time() - t0)
     st = e.stats()
-    line = f'N={e.nnx} {kind} {n} units ({nsrc} sources x {nper}), bundle {G:2d}: {n/best:9.0f} solves/s, coarse kernel(s) {st["ms_fim_coarse"]:8.1f} ms, bundles {int(st["bundles"])} of size {int(st["bundle_size"])} ({int(st["bundled_units"])} units, {int(st["bundle_slots"])} slots), rounds max {int(st["rounds_max"])}, member evals/node {st["evals_total"]/n/(e.nnx*e.nnz):.3f}'
+    line = f'N={e.nnx} {kind} {n} units ({nsrc} sources x {nper}), bundle {G:2d}: {n/best:9.0f} solves/s, coarse kernel(s) {st["ms_fim_coarse"]:8.1f} ms, bundles {int(st["bundles"])} of size {int(st["bundle_size"])} ({int(st["bundled_units"])} units, {int(st["bundle_slots"])} slots), rounds max {int(st["rounds_max"])}, freezes {int(st["freezes"])}, member evals/node {st["evals_total"]/n/(e.nnx*e.nnz):.3f}'
     if ref is None: ref = t
-    else: line += f', times identical={np.array_equal(ref.view(np.uint32), t.view(np.uint32))} (max |dt| {np.abs(ref - t).max():.3g})'
+    else:
+        bad_t = ref.view(np.uint32) != t.view(np.uint32)
+        nrec_u = t.size // n
+        line += f', times identical={not bad_t.any()} (max |dt| {np.abs(ref - t).max():.3g}, {int(bad_t.sum())} of {t.size} times in {int(bad_t.reshape(n, nrec_u).any(axis=1).sum())} units: (period, source) {[(int(k) // nsrc, int(k) % nsrc) for k in np.nonzero(bad_t.reshape(n, nrec_u).any(axis=1))[0][:6]]})'
     if what == "check":
         F = np.stack([e.field(k) for k in range(n)])
         if ref_fields is None: ref_fields = F
@@ -50,3 +56,7 @@ for G in sizes:
             bad = F.view(np.uint32) != ref_fields.view(np.uint32)
             line += f', fields: {int(bad.sum())} of {bad.size} nodes differ (max |dT| {np.nanmax(np.where(bad, np.abs(F - ref_fields), 0)):.3g}; units {sorted(set(np.nonzero(bad)[0].tolist()))[:8]})'
     print(line, flush=True)
+    if os.environ.get('DSA_PROBE_ROUNDS'):
+        r = e.unit_rounds(); q = np.percentile(r, [0, 10, 50, 90, 99, 100]).astype(int).tolist()
+        worst = np.argsort(-r)[:4]
+        print(f'    rounds per unit: min/10/50/90/99/max {q}; slowest units (period, source, rounds): {[(int(k) // nsrc, int(k) % nsrc, int(r[k])) for k in worst]}', flush=True)
