@@ -235,12 +235,13 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    # ---- workload, sharded by contiguous unit slices (whole periods per rank for N | 16) ----------
+    # ---- workload, sharded by SOURCES: every period of a source on the same rank, so that the engine can solve them side by side
+    # (bundles); a rank's units are a strided subset of the reference's (period, source) order (sharding.source_shard)
     units = synth.units(NX, NSRC, NPER, NREC)
     total_units = NSRC * NPER
-    lo, hi = sharding.unit_range(total_units, world, rank)
-    sl = slice(lo, hi)
-    rsl = slice(lo * NREC, hi * NREC)
+    sl = sharding.source_shard(NSRC, NPER, world, rank)
+    rsl = sharding.ray_positions(units["nrec"], sl)
+    lo, hi = 0, int(sl.size)                                      # (units of this rank)
     pv = np.stack([synth.medium(NX, "smooth", p) for p in range(NPER)])
 
     eng = Engine(device_index)
@@ -259,7 +260,8 @@ def main():
     n = eng.nnx
 
     dev = torch.device("cpu") if shared else torch.device("cuda", device_index)
-    counts = sharding.ray_counts(units["nrec"], world)
+    counts, order_np = sharding.gather_order(units["nrec"], NSRC, NPER, world)
+    order = torch.from_numpy(order_np).to(dev)
 
     mine = torch.empty(eng.ndata, dtype=torch.float32, device=dev) if (collective and not shared) else None
 
@@ -268,10 +270,10 @@ def main():
             # the path's one exchange step, device to device: the rank's receiver times stay in HBM (dsa_solve_device) and the RCCL
             # all-gather completes the vector on every rank; nothing visits the host before the collective
             eng.solve_device(mine.data_ptr())
-            return sharding.all_gather_times(dist, mine, counts)
+            return sharding.all_gather_ordered(dist, mine, counts, order)
         t = eng.solve()
         if collective:                                 # ranks sharing a device (1-GPU rehearsal): gloo, host tensors
-            return sharding.all_gather_times(dist, torch.from_numpy(t).to(dev), counts)
+            return sharding.all_gather_ordered(dist, torch.from_numpy(t).to(dev), counts, order)
         return t
 
     def fence():
@@ -321,7 +323,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 1025x1025 grid (nx=ny=131, dicing 8), 16 periods x 1000 sources, 32 receivers each, smooth +-10% velocity",
                        "grid": n, "units_per_step": total_units, "receivers_per_step": total_units * NREC,
-                       "parallelism": "units sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
+                       "parallelism": "sources (all their periods) sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("k_fim_bundle<%d> (coarse fixed-point solve, the %d periods of a source per workgroup)" % (int(st.get("bundle_size", 0)), int(st.get("bundle_size", 0)))

@@ -652,10 +652,27 @@ int Engine::choose_bundle_size(int step)
         return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.6 * (double)free_b);
     };
     if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) return fits(bundle_opt) && bundles_with(bundle_opt) > 0 ? bundle_opt : 0;
-    // automatic: a bundle is one workgroup where its members would have been G -- worth it only when the bundles still fill the chip
-    for (int G : { 16, 8, 4 })
-        if (bundles_with(G) >= 384 && fits(G)) return G;
-    return 0;
+    // automatic: a bundle is one workgroup where its members would have been G, so it pays only while the bundles still fill the chip
+    // (512 resident workgroups).  Estimated solves/s from the rates measured at 1025^2 with the chip full (unit by unit 10.4 k, bundles of
+    // 4 / 8 / 16: 14.7 k / 19.5 k / 22.7 k; profiles/r03_bundle_sizes.log) times the fill; the best estimate wins.  Grids below 700 nodes
+    // per side stay unit by unit: their solves are short and run 128 threads wide, and no bundle measurement beats them there.
+    if (std::min(g.nnx, g.nnz) < 700) return 0;
+    const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
+    double best = 10.4 * std::min(1.0, n_units / 1100.0) * 1.05;
+    int pick = 0;
+    const double rate[3] = { 22.7, 19.5, 14.7 };
+    const int sizes[3] = { 16, 8, 4 };
+    for (int k = 0; k < 3; ++k) {
+        const int G = sizes[k];
+        long nb = 0, covered = 0;
+        for (auto& kv : count) { nb += kv.second / G; covered += (kv.second / G) * G; if (kv.second % G >= 2) { ++nb; covered += kv.second % G; } }
+        if (nb == 0 || !fits(G)) continue;
+        const double frac = (double)covered / (double)h_src.size();                  // units that end up in bundles ...
+        const double fill = (double)covered / ((double)nb * G);                       // ... and how full the bundles are
+        const double est = frac * rate[k] * fill * std::min(1.0, (double)std::min<long>(nb, (long)step) / 560.0) + (1.0 - frac) * 10.4 * std::min(1.0, n_units / 1100.0);
+        if (est > best) { best = est; pick = G; }
+    }
+    return pick;
 }
 
 // Bundles of the resident chunk [first, first + n): launch ranks (solo units first, longest fronts first in both groups), the member

@@ -63,3 +63,51 @@ def test_unit_ranges_tile_the_list():
     # whole periods per rank when the rank count divides the period count
     lo, hi = sharding.unit_range(16 * 1000, 8, 3)
     assert lo % 1000 == 0 and hi % 1000 == 0
+
+
+def _worker_sources(rank, world, port, nsrc, nper, nrec, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nrec = np.asarray(nrec)
+    mine_units = sharding.source_shard(nsrc, nper, world, rank)
+    pos = sharding.ray_positions(nrec, mine_units)
+    mine = torch.from_numpy(pos.astype(np.float32) * 0.5 + 1.0)                # "times" of my rays, in my plan's order
+    counts, order = sharding.gather_order(nrec, nsrc, nper, world)
+    full = sharding.all_gather_ordered(dist, mine, counts, torch.from_numpy(order))
+    q.put((rank, full.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nsrc,nper,nrec", [(6, 4, None), (5, 3, [2, 0, 3, 1, 4, 2, 2, 5, 1, 0, 3, 2, 1, 1, 6])])
+def test_two_ranks_sharded_by_sources_assemble_the_reference_order(nsrc, nper, nrec):
+    """bench.py's partition since round 3: whole sources per rank (all their periods: the engine bundles them); the all-gather's
+    rank-major pieces go to their places in the reference's (period, source, receiver) order"""
+    world = 2
+    if nrec is None:
+        nrec = [3] * (nsrc * nper)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sources, args=(r, world, port, nsrc, nper, nrec, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.arange(sum(nrec), dtype=np.float32) * 0.5 + 1.0
+    for r in range(world):
+        assert np.array_equal(got[r], expect)
+
+
+def test_source_shards_tile_the_units():
+    for nsrc, nper in ((1000, 16), (7, 3), (1, 5)):
+        for world in (1, 2, 3, 8):
+            parts = [sharding.source_shard(nsrc, nper, world, r) for r in range(world)]
+            allu = np.sort(np.concatenate(parts))
+            assert np.array_equal(allu, np.arange(nsrc * nper))
+            for part in parts:                      # every period of a source on one rank
+                srcs = set((part % nsrc).tolist())
+                assert part.size == len(srcs) * nper
