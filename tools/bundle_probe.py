@@ -34,8 +34,9 @@ ref = None; ref_fields = None
 for G in sizes:
     if G < 0:      # a solo run with another causal window: is the solo answer itself schedule dependent here?
         e.set_option('window_cells', 1.0); G = 0
-    else: e.set_option('window_cells', 1.25)
+    else: e.set_option('window_cells', float(os.environ.get('DSA_PROBE_WINDOW', '1.25')))
     e.set_option('bundle', G)
+    if os.environ.get('DSA_PROBE_BWINDOW'): e.set_option('bundle_window_cells', float(os.environ['DSA_PROBE_BWINDOW']))
     if what == "check": e.set_option('field_pool', -1)
     e.plan(**u)
     e.solve()                                   # (allocations)
