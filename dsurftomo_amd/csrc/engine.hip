@@ -654,13 +654,15 @@ int Engine::choose_bundle_size(int step)
     if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) return fits(bundle_opt) && bundles_with(bundle_opt) > 0 ? bundle_opt : 0;
     // automatic: a bundle is one workgroup where its members would have been G, so it pays only while the bundles still fill the chip
     // (512 resident workgroups).  Estimated solves/s from the rates measured at 1025^2 with the chip full (unit by unit 10.4 k, bundles of
-    // 4 / 8 / 16: 14.7 k / 19.5 k / 22.7 k; profiles/r03_bundle_sizes.log) times the fill; the best estimate wins.  Grids below 700 nodes
-    // per side stay unit by unit: their solves are short and run 128 threads wide, and no bundle measurement beats them there.
-    if (std::min(g.nnx, g.nnz) < 700) return 0;
+    // 4 / 8 / 16: 15.5 k / 20.4 k / 24.5 k; profiles/r03_bundle_sizes.log) times the fill; the best estimate wins.  The ratios hold from 497^2
+    // (40 k unit by unit, 64 k in bundles of 16) to 2033^2 (2.45 k against 3.1 k in bundles of 4); at 4081^2 the bundle kernel's 256
+    // threads and 2 x 1024 ready nodes per round are too few for the front (205 solves/s against 563), so grids beyond 2100 nodes per
+    // side stay unit by unit, and so do grids below 400, whose solves are short.
+    if (std::min(g.nnx, g.nnz) < 400 || std::max(g.nnx, g.nnz) > 2100) return 0;
     const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
     double best = 10.4 * std::min(1.0, n_units / 1100.0) * 1.05;
     int pick = 0;
-    const double rate[3] = { 22.7, 19.5, 14.7 };
+    const double rate[3] = { 24.5, 20.4, 15.5 };
     const int sizes[3] = { 16, 8, 4 };
     for (int k = 0; k < 3; ++k) {
         const int G = sizes[k];
