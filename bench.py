@@ -251,6 +251,8 @@ def main():
         eng.set_memory_budget(int(float(os.environ["DSA_MEM_BUDGET_GB"]) * 1e9))
     elif shared:
         eng.set_memory_budget(int(200e9 / ((world + ndev - 1) // ndev)))
+    if os.environ.get("DSA_BUNDLE"):                      # 0 = unit by unit (the dominant kernel of rounds 1-2), 4 / 8 / 16 = that bundle size
+        eng.set_option("bundle", int(os.environ["DSA_BUNDLE"]))
     if os.environ.get("DSA_FIM_SORTED"):
         eng.set_option("fim_sorted", int(os.environ["DSA_FIM_SORTED"]))
     t_setup = time.perf_counter()

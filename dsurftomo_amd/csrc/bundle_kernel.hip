@@ -564,10 +564,27 @@ __global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBund
                 E->out[rd.data] = t;
             }
         }
-        if (pm->Tc) {
-            BGF32* const dst = (BGF32*)pm->Tc;
-            for (int i = tid; i < ntile * kTileRecs; i += NT) dst[i] = fabsf(*(BGF32*)(Bb + (unsigned)i * GB + (unsigned)m * 4u));
-        }
+    }
+    {   // the members' fields into their unit slots (the engine keeps one per unit when rays follow): one pass over the bundle's field,
+        // a node's G values read as 16-byte pieces, every member's array written in node order
+        __shared__ float* s_dst[kBundleMax];
+        __syncthreads();
+        if (tid < kBundleMax) s_dst[tid] = tid < nmem ? problems[s_member[tid]].Tc : nullptr;
+        __syncthreads();
+        bool any_dst = false;
+        for (int m = 0; m < nmem; ++m) any_dst = any_dst || s_dst[m] != nullptr;
+        if (any_dst)
+            for (int i = tid; i < ntile * kTileRecs; i += NT) {
+#pragma unroll
+                for (int c4 = 0; c4 < CH; ++c4) {
+                    const BV4 v = *(BGV4*)(Bb + (unsigned)i * GB + (unsigned)c4 * 16u);
+                    BGF32* d;
+                    if ((d = (BGF32*)s_dst[4 * c4 + 0])) d[i] = fabsf(v.x);
+                    if ((d = (BGF32*)s_dst[4 * c4 + 1])) d[i] = fabsf(v.y);
+                    if ((d = (BGF32*)s_dst[4 * c4 + 2])) d[i] = fabsf(v.z);
+                    if ((d = (BGF32*)s_dst[4 * c4 + 3])) d[i] = fabsf(v.w);
+                }
+            }
     }
     if (bd->pool_gen) {
         __threadfence();

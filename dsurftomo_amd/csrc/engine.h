@@ -89,6 +89,7 @@ struct Engine {
     std::vector<FimBundle> h_bundles;
     std::vector<int> h_member_flag;
     int bundle_slots = 0;
+    size_t solve_stage_bytes() const;
     int choose_bundle_size(int step);
     int plan_bundles(int first, int n, int G, int* nsolo, int* nbundles);
     size_t lists_stride = 0;

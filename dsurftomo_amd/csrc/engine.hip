@@ -342,6 +342,9 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     // chunk size from the memory budget
     size_t free_b = 0, total_b = 0;
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+    // (what an earlier plan / solve of this engine allocated for the same purpose is reused, not needed again: without this the second
+    // call of an inversion saw half the memory and cut its units into two launches -- and its sources' periods into two bundles each)
+    free_b += solve_stage_bytes();
     // default: 60 % of free HBM, at most 150 GB per chunk of sources (one launch for the 16 000 units of the
     // headline configuration: +3 % over two launches, whose tails leave CUs idle)
     size_t budget = mem_budget ? mem_budget : std::min<size_t>((size_t)(0.6 * (double)free_b), (size_t)150 << 30);
@@ -402,6 +405,15 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     planned = true;
     last_chunk_first = -1;
     return 0;
+}
+
+// bytes held by the buffers plan() and solve() size (reused by the next plan)
+size_t Engine::solve_stage_bytes() const
+{
+    auto b = [](const auto& d) { return d.cap * sizeof(*d.p); };
+    return b(lists) + b(lists_c) + b(pool_gen) + b(ends_c) + b(src) + b(slow_r) + b(F_r) + b(Tfin_r) + b(S_r) + b(risti_r) + b(vcorner) + b(seed_r) + b(nseed_r) +
+           b(rst) + b(cst) + b(cinit) + b(heap) + b(flags) + b(T_c) + b(exc_c) + b(W_c) + b(seed_c) + b(nseed_c) + b(launch_rank) + b(prob_r) + b(prob_c) +
+           b(info) + b(clocks) + b(tieinfo) + b(xinfo) + b(x_units) + b(B_pool) + b(exc_b) + b(lists_b) + b(bpool_gen) + b(bundles_d) + b(member_flag);
 }
 
 BatchPtrs Engine::batch() const

@@ -89,9 +89,11 @@ def units(nx, nsrc, nper, nrec, gd=8, seed=SEED):
 
 
 def boundary_case(nx=12, ny=11, nz=5, kRc=3, kRg=2, kLc=2, kLg=1, nsrc=4, nrcf=5, dvd=0.05, seed=SEED, deep=False,
-                  ragged=True):
+                  ragged=True, stations=False):
     """Arguments of one CalSurfG / synthetic call (CalSurfG.f90:939-943) as a dict of numpy arrays in
-    Fortran memory order. Period slots run Rc, Rg, Lc, Lg like main.f90:215-245."""
+    Fortran memory order. Period slots run Rc, Rg, Lc, Lg like main.f90:215-245.
+    stations: source s sits at the same place in every period slot (a station of a real data set: surfdata.dat lists the same
+    stations period after period); default: an own random place per (source, slot)."""
     f = np.float32
     r = LCG(seed + 101)
     kmax = kRc + kRg + kLc + kLg
@@ -128,6 +130,8 @@ def boundary_case(nx=12, ny=11, nz=5, kRc=3, kRg=2, kLc=2, kLg=1, nsrc=4, nrcf=5
                 wavetype[s, slot], igrt[s, slot], periods[s, slot] = wt, gr, p + 1
                 scxf[s, slot] = f((90.0 - lat(u[0])) * np.pi / 180.0)
                 sczf[s, slot] = f(lon(u[1]) * np.pi / 180.0)
+                if stations and slot > 0:
+                    scxf[s, slot], sczf[s, slot] = scxf[s, 0], sczf[s, 0]
                 nr = nrcf - ((s + slot) % 3 if ragged else 0)
                 nrc1[s, slot] = nr
                 for q in range(nr):

@@ -21,7 +21,7 @@ def main():
     nsrc = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     lib = E.load_library()
     t0 = time.perf_counter()
-    c = synth.boundary_case(nx=131, ny=131, nz=9, kRc=16, kRg=0, kLc=0, kLg=0, nsrc=nsrc, nrcf=nrec, dvd=0.01, ragged=False)
+    c = synth.boundary_case(nx=131, ny=131, nz=9, kRc=16, kRg=0, kLc=0, kLg=0, nsrc=nsrc, nrcf=nrec, dvd=0.01, ragged=False, stations=bool(int(os.environ.get('DSA_STATIONS', '1'))))
     c["tRc"] = np.linspace(2.0, 17.0, 16)
     print("case built in %.1f s: ndata %d, nparpi %d" % (time.perf_counter() - t0, c["ndata"], c["nparpi"]), flush=True)
     nd, npar = c["ndata"], c["nparpi"]

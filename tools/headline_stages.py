@@ -15,9 +15,10 @@ from dsurftomo_amd import engine as E   # noqa: E402
 
 nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nsrc = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-c = synth.boundary_case(nx=131, ny=131, nz=9, kRc=16, kRg=0, kLc=0, kLg=0, nsrc=nsrc, nrcf=nrec, dvd=0.01, ragged=False)
+c = synth.boundary_case(nx=131, ny=131, nz=9, kRc=16, kRg=0, kLc=0, kLg=0, nsrc=nsrc, nrcf=nrec, dvd=0.01, ragged=False, stations=bool(int(os.environ.get('DSA_STATIONS', '1'))))
 c["tRc"] = np.linspace(2.0, 17.0, 16)
 e = E.Engine(0)
+if os.environ.get("DSA_BUNDLE"): e.set_option("bundle", int(os.environ["DSA_BUNDLE"]))
 if os.environ.get("DSA_RAY_BUDGET_GB"): e.set_option("ray_budget", float(os.environ["DSA_RAY_BUDGET_GB"]) * 1e9)
 vel = np.ascontiguousarray(c["vels"].T)
 maps, sx, sz, nr, rx, rz, slot = [], [], [], [], [], [], []
@@ -39,7 +40,7 @@ for k in range(2):
     t4 = time.perf_counter()
     st = e.stats()
     print("pass %d: dispersion %.0f ms, maps+kernels %.0f ms, plan %.0f ms (%d units), solve_rows %.0f ms wall [solve kernels: coarse %.0f refined %.0f "
-          "stages %.0f | rays %.0f rows (incl. copy out) %.0f], nar %d" %
+          "stages %.0f | rays %.0f rows (incl. copy out) %.0f], nar %d; bundles %d of %d members (%d units), distinct sources %d" %
           (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), len(maps), 1e3 * (t4 - t3), st["ms_fim_coarse"], st["ms_fim_refined"], st["ms_stages"],
-           st["ms_rays"], st["ms_rows"], out[1].size), flush=True)
+           st["ms_rays"], st["ms_rows"], out[1].size, st["bundles"], st["bundle_size"], st["bundled_units"], len(set(zip(np.asarray(sx, np.float32).tolist(), np.asarray(sz, np.float32).tolist())))), flush=True)
 e.close()
