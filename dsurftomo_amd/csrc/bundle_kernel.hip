@@ -418,18 +418,27 @@ __global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBund
                 unsigned wm = 0u;                                    // dependents some member wants activated: bit q near, bit 4 + q outer
                 bool any_changed = false;
                 const int key0 = id * G + sub * 4;
+                // four copies of the member body with fixed vector components (default), or -DDSA_BUNDLE_ROTATE: one body, the vectors rotating
+                // by a component per trip (18 KB less code, 37 moves more per member: 616 -> 587 ms per headline launch for the copies,
+                // profiles/r03_bundle_sizes.log)
+#ifndef DSA_BUNDLE_ROTATE
+#define DSA_BM(v) (v)[m]
+#pragma unroll
+#else
+#define DSA_BM(v) (v).x
 #pragma nounroll
+#endif
                 for (int m = 0; m < 4; ++m) {
                     Hood h;
                     bool flagged = false;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float a = vn[q].x, b = vo[q].x;
+                        const float a = DSA_BM(vn[q]), b = DSA_BM(vo[q]);
                         h.in[q] = in[q]; h.in_outer[q] = in_outer[q];
                         h.near_[q] = a; h.near_tau[q] = a; h.outer[q] = b; h.outer_tau[q] = b;
                         flagged = flagged || __builtin_signbit(a) || __builtin_signbit(b);
                     }
-                    const float raw = vown.x;
+                    const float raw = DSA_BM(vown);
                     const bool valid = act && ((vmask >> m) & 1u);
                     float t_old = raw, k_old = raw;
                     if (!valid) t_old = -1.0f;
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBund
                     bool changed = false;
                     float c = 0.0f, k = kInf, newv = raw;
                     if (!t_pinned(t_old)) {
-                        const float slown = sl.x;
+                        const float slown = DSA_BM(sl);
                         c = solve_node_t<false>(h, slown, geom, &k, nullptr);
                         ++evals;
                         changed = bf2u(c) != bf2u(t_old) || bf2u(k) != bf2u(k_old);
@@ -467,6 +476,9 @@ __global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBund
                             if (h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) && t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q]) wm |= 16u << q;
                         }
                     }
+#ifndef DSA_BUNDLE_ROTATE
+                    outv[m] = newv;
+#else
                     // next member of this lane: rotate the vectors
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -476,7 +488,9 @@ __global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBund
                     vown = BV4{ vown.y, vown.z, vown.w, vown.x };
                     sl = BV4{ sl.y, sl.z, sl.w, sl.x };
                     outv = BV4{ outv.y, outv.z, outv.w, newv };
+#endif
                 }
+#undef DSA_BM
                 __builtin_amdgcn_s_setprio(1);
                 if (any_changed) *(BGV4*)(Bb + (unsigned)id * GB + sub_b) = outv;
                 // dependents: the members' OR, one lane per node issues the activations (fim_kernel.hip: the mask bits are constant shifts
