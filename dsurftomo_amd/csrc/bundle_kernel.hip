@@ -54,11 +54,14 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 #else
 #define DSA_BUNDLE_OCC
 #endif
+#ifndef DSA_BUNDLE_THREADS
+#define DSA_BUNDLE_THREADS 256     // (128: four workgroups per CU, 512: one -- measured, see DESIGN.md 4 "Bundles")
+#endif
 template <int G>
-__global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
+__global__ __launch_bounds__(DSA_BUNDLE_THREADS) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
 {
-    constexpr int NT = 256, NW = NT / 64;
+    constexpr int NT = DSA_BUNDLE_THREADS, NW = NT / 64;
     constexpr int CH = G / 4;                  // lanes per node in pass B, four members each
     constexpr int NPW = 64 / CH;               // nodes per wave trip
     constexpr unsigned GB = G * 4u;            // bytes per node
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) DSA_BUNDLE_OCC void k_fim_bundle(const FimBund
     __shared__ int wbuf[NW * kWaveBuf];
     __shared__ int wtile[NW * kTileBuf];
     __shared__ unsigned wclr[NW * kTileBuf * kClrWords];
-    constexpr int rhalf = NT * 4;
+    constexpr int rhalf = 1024;                // ready nodes of one colour a round can take (the rest keep their bits)
     __shared__ int ready[2 * rhalf];
     __shared__ int s_member[kBundleMax], s_map[kBundleMax];
 
@@ -613,9 +616,9 @@ void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, const F
 {
     if (nbundles <= 0) return;
     const size_t lds = bundle_lds_bytes(tile_words);
-    if (G == 16) hipLaunchKernelGGL(k_fim_bundle<16>, dim3(nbundles), dim3(256), lds, stream, d_bundles, d_problems, d_ends);
-    else if (G == 8) hipLaunchKernelGGL(k_fim_bundle<8>, dim3(nbundles), dim3(256), lds, stream, d_bundles, d_problems, d_ends);
-    else hipLaunchKernelGGL(k_fim_bundle<4>, dim3(nbundles), dim3(256), lds, stream, d_bundles, d_problems, d_ends);
+    if (G == 16) hipLaunchKernelGGL(k_fim_bundle<16>, dim3(nbundles), dim3(DSA_BUNDLE_THREADS), lds, stream, d_bundles, d_problems, d_ends);
+    else if (G == 8) hipLaunchKernelGGL(k_fim_bundle<8>, dim3(nbundles), dim3(DSA_BUNDLE_THREADS), lds, stream, d_bundles, d_problems, d_ends);
+    else hipLaunchKernelGGL(k_fim_bundle<4>, dim3(nbundles), dim3(DSA_BUNDLE_THREADS), lds, stream, d_bundles, d_problems, d_ends);
 }
 
 // slowI[id * np + m] = slow_all[m * field_stride + id]: the maps' slowness, member-minor
