@@ -54,24 +54,23 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 #else
 #define DSA_BUNDLE_OCC
 #endif
-#ifndef DSA_BUNDLE_THREADS
-#define DSA_BUNDLE_THREADS 256     // (128: four workgroups per CU, 512: one -- measured, see DESIGN.md 4 "Bundles")
-#endif
-template <int G>
-__global__ __launch_bounds__(DSA_BUNDLE_THREADS) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
+// NT = 256 threads per workgroup up to 1500 nodes per side (128: -1.7 %, 512: -13 % at 1025^2), 512 beyond: a 4097^2 front has ~2700 ready
+// nodes per round, four times what 256 threads and their 2 x 1024 ready slots take
+template <int G, int NT>
+__global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
 {
-    constexpr int NT = DSA_BUNDLE_THREADS, NW = NT / 64;
+    constexpr int NW = NT / 64;
     constexpr int CH = G / 4;                  // lanes per node in pass B, four members each
     constexpr int NPW = 64 / CH;               // nodes per wave trip
     constexpr unsigned GB = G * 4u;            // bytes per node
     extern __shared__ unsigned dyn_lds[];
     __shared__ int sc[BC_COUNT];
-    constexpr int kWaveBuf = 256, kTileBuf = 256, kClrWords = 4;
+    constexpr int kWaveBuf = 256, kTileBuf = NT > 256 ? 128 : 256, kClrWords = 4;      // (512 threads: the per-tile scratch of eight waves has to fit the static LDS)
     __shared__ int wbuf[NW * kWaveBuf];
     __shared__ int wtile[NW * kTileBuf];
     __shared__ unsigned wclr[NW * kTileBuf * kClrWords];
-    constexpr int rhalf = 1024;                // ready nodes of one colour a round can take (the rest keep their bits)
+    constexpr int rhalf = NT * 4;              // ready nodes of one colour a round can take (the rest keep their bits)
     __shared__ int ready[2 * rhalf];
     __shared__ int s_member[kBundleMax], s_map[kBundleMax];
 
@@ -612,13 +611,14 @@ __global__ __launch_bounds__(DSA_BUNDLE_THREADS) DSA_BUNDLE_OCC void k_fim_bundl
 
 size_t bundle_lds_bytes(int tile_words) { return (size_t)tile_words * 4; }
 
-void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream)
+void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int threads, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream)
 {
     if (nbundles <= 0) return;
     const size_t lds = bundle_lds_bytes(tile_words);
-    if (G == 16) hipLaunchKernelGGL(k_fim_bundle<16>, dim3(nbundles), dim3(DSA_BUNDLE_THREADS), lds, stream, d_bundles, d_problems, d_ends);
-    else if (G == 8) hipLaunchKernelGGL(k_fim_bundle<8>, dim3(nbundles), dim3(DSA_BUNDLE_THREADS), lds, stream, d_bundles, d_problems, d_ends);
-    else hipLaunchKernelGGL(k_fim_bundle<4>, dim3(nbundles), dim3(DSA_BUNDLE_THREADS), lds, stream, d_bundles, d_problems, d_ends);
+#define DSA_LAUNCH_BUNDLE(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
+    if (threads == 512) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 512); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 512); else DSA_LAUNCH_BUNDLE(4, 512); }
+    else { if (G == 16) DSA_LAUNCH_BUNDLE(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 256); else DSA_LAUNCH_BUNDLE(4, 256); }
+#undef DSA_LAUNCH_BUNDLE
 }
 
 // slowI[id * np + m] = slow_all[m * field_stride + id]: the maps' slowness, member-minor

@@ -90,7 +90,8 @@ struct Engine {
     std::vector<int> h_member_flag;
     int bundle_slots = 0;
     size_t solve_stage_bytes() const;
-    int choose_bundle_size(int step);
+    int bundle_threads() const;
+    int choose_bundle_size(int step, long* solo_units = nullptr);
     int plan_bundles(int first, int n, int G, int* nsolo, int* nbundles);
     size_t lists_stride = 0;
     int fim_threads = 0;               // workgroup size of the solve kernel; 0 = by grid size (launch_shape)

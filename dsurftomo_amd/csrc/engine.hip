@@ -372,6 +372,12 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         // measured at 121^2, 8000 units: 186 k solves/s with a slot per unit, 75 k through 1024 slots, profiles/r03_recycle_stress.log)
         const size_t roomy = std::min<size_t>(16384, ((size_t)16 << 30) / per_slot_bytes);
         size_t P = field_pool_opt > 0 ? (size_t)field_pool_opt : std::max<size_t>((size_t)4 * resident, roomy);
+        // units that will be solved inside bundles (bundle_kernel.hip) need no slot of their own unless rays follow (solve() grows the
+        // pool then): the pool shrinks to what the left-over units can use, and the memory goes to the bundle fields
+        if (field_pool_opt == 0 && !keep_fields && exact_ties == 0) {
+            long solo_units = 0;
+            if (choose_bundle_size(nunits, &solo_units) > 0) P = std::min<size_t>(P, (size_t)std::max<long>(256, 2 * solo_units));
+        }
         if (field_pool_opt < 0 || keep_fields) P = (size_t)std::max(nunits, 1);
         P = std::min<size_t>(P, (size_t)std::max(nunits, 1));
         if (max_chunk > 0) P = std::min<size_t>(P, (size_t)max_chunk);
@@ -415,6 +421,9 @@ size_t Engine::solve_stage_bytes() const
            b(rst) + b(cst) + b(cinit) + b(heap) + b(flags) + b(T_c) + b(exc_c) + b(W_c) + b(seed_c) + b(nseed_c) + b(launch_rank) + b(prob_r) + b(prob_c) +
            b(info) + b(clocks) + b(tieinfo) + b(xinfo) + b(x_units) + b(B_pool) + b(exc_b) + b(lists_b) + b(bpool_gen) + b(bundles_d) + b(member_flag);
 }
+
+// workgroup size of the bundle kernel (bundle_kernel.hip)
+int Engine::bundle_threads() const { return std::max(g.nnx, g.nnz) > 1500 ? 512 : 256; }
 
 BatchPtrs Engine::batch() const
 {
@@ -525,7 +534,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipEventRecord(events[4], stream));
         if (exact_ties != 2) {
             launch_fim(prob_c.p, nsolo, sc, stream, ends_c.p);
-            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, prob_c.p, ends_c.p, sc.tile_words, stream);
+            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream);
         }
         HIP_TRY(this, hipEventRecord(events[5], stream));
         if (exact_ties) {
@@ -644,8 +653,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
 
 // Members per bundle for this call: the option, or (automatic) the largest of 16 / 8 / 4 that still gives the chip enough workgroups
 // and whose field slots fit the memory; 0 = no bundles.  `step` = units per launch.
-int Engine::choose_bundle_size(int step)
+int Engine::choose_bundle_size(int step, long* solo_units)
 {
+    if (solo_units) *solo_units = (long)h_src.size();
     if (bundle_opt == 0 || h_src.empty()) return 0;
     // units per source (same coordinates bit for bit), in planned order
     std::map<std::pair<uint32_t, uint32_t>, int> count;
@@ -660,17 +670,22 @@ int Engine::choose_bundle_size(int step)
         if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
         if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
         const long nb = std::min<long>(bundles_with(G), (long)step);
-        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), 512);
+        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), bundle_threads() == 512 ? 288 : 512);      // (bundles resident at a time, and a few more)
         return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.6 * (double)free_b);
     };
-    if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) return fits(bundle_opt) && bundles_with(bundle_opt) > 0 ? bundle_opt : 0;
+    if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) {
+        if (!(fits(bundle_opt) && bundles_with(bundle_opt) > 0)) return 0;
+        if (solo_units) { long cov = 0; for (auto& kv : count) { cov += (kv.second / bundle_opt) * bundle_opt; if (kv.second % bundle_opt >= 2) cov += kv.second % bundle_opt; } *solo_units = (long)h_src.size() - cov; }
+        return bundle_opt;
+    }
     // automatic: a bundle is one workgroup where its members would have been G, so it pays only while the bundles still fill the chip
     // (512 resident workgroups).  Estimated solves/s from the rates measured at 1025^2 with the chip full (unit by unit 10.4 k, bundles of
     // 4 / 8 / 16: 15.5 k / 20.4 k / 24.5 k; profiles/r03_bundle_sizes.log) times the fill; the best estimate wins.  The ratios hold from 497^2
     // (40 k unit by unit, 64 k in bundles of 16) to 2033^2 (2.45 k against 3.1 k in bundles of 4); at 4081^2 the bundle kernel's 256
     // threads and 2 x 1024 ready nodes per round are too few for the front (205 solves/s against 563), so grids beyond 2100 nodes per
     // side stay unit by unit, and so do grids below 400, whose solves are short.
-    if (std::min(g.nnx, g.nnz) < 400 || std::max(g.nnx, g.nnz) > 2100) return 0;
+    // Round 3, late: beyond 1500 nodes per side the bundle kernel runs 512 threads wide with 2 x 2048 ready slots (one workgroup per CU).
+    if (std::min(g.nnx, g.nnz) < 400) return 0;
     const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
     double best = 10.4 * std::min(1.0, n_units / 1100.0) * 1.05;
     int pick = 0;
@@ -683,8 +698,8 @@ int Engine::choose_bundle_size(int step)
         if (nb == 0 || !fits(G)) continue;
         const double frac = (double)covered / (double)h_src.size();                  // units that end up in bundles ...
         const double fill = (double)covered / ((double)nb * G);                       // ... and how full the bundles are
-        const double est = frac * rate[k] * fill * std::min(1.0, (double)std::min<long>(nb, (long)step) / 560.0) + (1.0 - frac) * 10.4 * std::min(1.0, n_units / 1100.0);
-        if (est > best) { best = est; pick = G; }
+        const double est = frac * rate[k] * fill * std::min(1.0, (double)std::min<long>(nb, (long)step) / (bundle_threads() == 512 ? 280.0 : 560.0)) + (1.0 - frac) * 10.4 * std::min(1.0, n_units / 1100.0);
+        if (est > best) { best = est; pick = G; if (solo_units) *solo_units = (long)h_src.size() - covered; }
     }
     return pick;
 }
@@ -733,7 +748,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     const size_t slot_b = (size_t)G * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
     const size_t room = (size_t)(0.7 * (double)free_b) / slot_b;
     if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
-    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : 1024), room });
+    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (bundle_threads() == 512 ? 512 : 1024)), room });
     const size_t BS = (size_t)bundle_slots;
     if (ensure(B_pool, BS * G * nrec_c) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
@@ -1078,7 +1093,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
     if (n == "bundle_window_cells" && value > 0) { en->bundle_window_cells = (float)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
-    if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->bundle_opt = (int)value; return 0; }
+    if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
     if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 19000))) { en->exact_lds_slots = (int)value; return 0; }

@@ -19,6 +19,7 @@ nsrc = nunits // nper
 u = synth.units(nx, nsrc, nper, nrec)
 pv = np.stack([synth.medium(nx, "checker", p) for p in range(nper)])
 e = Engine(0)
+if os.environ.get('DSA_BUNDLE'): e.set_option('bundle', int(os.environ['DSA_BUNDLE']))
 t0 = time.perf_counter()
 e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
 e.plan(**u)
@@ -27,9 +28,9 @@ for k in range(2):
     t0 = time.perf_counter(); t = e.solve(); dt = time.perf_counter() - t0
     st = e.stats()
     print("solve %d: %.2f s wall = %.1f solves/s | coarse fixed-point kernel %.1f ms (%.1f solves/s, %.1f GB/s of algorithmic bytes), refined %.1f ms, other stages %.1f ms | "
-          "rounds_max %d, evaluations per node %.2f, %d units per launch through %d field slots, footprint %.1f GB" %
+          "rounds_max %d, evaluations per node %.2f, %d units per launch through %d field slots, footprint %.1f GB; bundles %d of %d members in %d slots" %
           (k, dt, nsrc * nper / dt, st["ms_fim_coarse"], nsrc * nper / (st["ms_fim_coarse"] / 1e3), nsrc * nper * (8.0 * e.nnx * e.nnz + 129 * 129 * 8) / (st["ms_fim_coarse"] / 1e3) / 1e9,
-           st["ms_fim_refined"], st["ms_stages"], st["rounds_max"], st["evals_total"] / (nsrc * nper) / (e.nnx * e.nnz), st["chunk"], st["field_slots"], st["footprint_mb"] / 1e3), flush=True)
+           st["ms_fim_refined"], st["ms_stages"], st["rounds_max"], st["evals_total"] / (nsrc * nper) / (e.nnx * e.nnz), st["chunk"], st["field_slots"], st["footprint_mb"] / 1e3, st["bundles"], st["bundle_size"], st["bundle_slots"]), flush=True)
 e.close()
 if nsample > 0:
     t = t.reshape(nsrc * nper, nrec)
