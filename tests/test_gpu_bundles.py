@@ -167,3 +167,22 @@ def test_headline_size_bundles_equal_unit_by_unit(bundles):
     for G in (16, 8):
         assert np.array_equal(bits(out[G]), bits(out[0])), G
     parity_log.add(f"bundles at N=1025 (headline medium): {out[0].size} receiver times of {nsrc * nper} units, 16 and 8 members: bit-identical to unit by unit")
+
+
+@pytest.mark.parametrize("nx,nsrc,nper,G", [(257, 3, 8, 8), (513, 2, 4, 4)])
+def test_big_grids_use_the_512_thread_bundle_kernel(bundles, nx, nsrc, nper, G):
+    """beyond 1500 nodes per side the bundle kernel runs 512 threads wide (2 x 2048 ready nodes per round): 2033^2 and 4081^2 against unit by unit"""
+    e = bundles
+    pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, 16)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    out = {}
+    for g in (0, G):
+        e.set_option("bundle", g)
+        out[g] = e.traveltimes(**u)
+        st = e.stats()
+        assert st["bundles"] == (0 if g == 0 else nsrc * nper // G)
+    d = np.abs(out[G] - out[0])
+    nbad = int((bits(out[G]) != bits(out[0])).sum())
+    parity_log.add(f"bundles at N={e.nnx} (512-thread kernel), {nsrc * nper} units in bundles of {G}: {nbad} of {d.size} receiver times differ from unit by unit (max |dt| {float(d.max()):.3g} s)")
+    assert np.isfinite(out[G]).all() and d.max() <= 1e-4
