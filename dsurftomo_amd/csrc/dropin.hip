@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/dsurftomo_amd.h"
@@ -191,21 +192,39 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     *nar = 0;
     g_rbint_notes = 0; g_disp_count = 0;
 
-    // Every engine runs the dispersion stage for the whole model (it is small next to the solves) and then
-    // its contiguous slice of the unit list; the two units of a group-velocity datum stay together.
+    // Every engine runs the dispersion stage for the whole model (it is small next to the solves) and then its share of the unit
+    // list.  Round 3: the share is a set of SOURCES with all their units -- the engine solves the periods of a source side by side
+    // (bundles, bundle_kernel.hip), so a split by contiguous slices (whole periods) would leave every engine 1/ne of each source's periods.
+    // The two units of a group-velocity datum have the same source and stay together by construction.
     const int ne = (int)g_pool.size(), nu = (int)U.map.size();
-    std::vector<int> cut(ne + 1, nu);
-    cut[0] = 0;
-    for (int k = 1; k < ne; ++k) {
-        int c = (int)((long long)nu * k / ne);
-        while (c > 0 && c < nu && U.data[c] == U.data[c - 1] && U.mode[c] == 2) ++c;      // do not split a (times, rays) pair
-        cut[k] = std::max(c, cut[k - 1]);
+    std::vector<int> owner((size_t)nu, 0);
+    if (ne > 1) {
+        std::map<std::pair<uint32_t, uint32_t>, int> src_of;       // source (coordinates bit for bit) -> index in order of first appearance
+        std::vector<int> src_units, unit_src((size_t)nu);
+        for (int u = 0; u < nu; ++u) {
+            uint32_t a, b2; std::memcpy(&a, &U.sx[(size_t)u], 4); std::memcpy(&b2, &U.sz[(size_t)u], 4);
+            auto it = src_of.find({ a, b2 });
+            if (it == src_of.end()) { it = src_of.insert({ { a, b2 }, (int)src_units.size() }).first; src_units.push_back(0); }
+            unit_src[(size_t)u] = it->second; ++src_units[(size_t)it->second];
+        }
+        // blocks of consecutive sources with about nu / ne units each
+        std::vector<int> src_engine(src_units.size(), 0);
+        long long acc = 0; int k = 0;
+        for (size_t q = 0; q < src_units.size(); ++q) {
+            while (k + 1 < ne && acc >= (long long)nu * (k + 1) / ne) ++k;
+            src_engine[q] = k; acc += src_units[q];
+        }
+        for (int u = 0; u < nu; ++u) owner[(size_t)u] = src_engine[(size_t)unit_src[(size_t)u]];
     }
     std::vector<size_t> ray0(nu + 1, 0);
     for (int u = 0; u < nu; ++u) ray0[u + 1] = ray0[u] + (size_t)U.nrec[u];
     struct Part { std::vector<float> rw; std::vector<int> iw, col; long long n = 0; int rc = 0; std::string err; int first_clamped = -1;
-                  long long disp_count = 0; int disp_first[5] = { 0, 0, 0, 0, 0 }; double disp_period = 0.0; };
+                  long long disp_count = 0; int disp_first[5] = { 0, 0, 0, 0, 0 }; double disp_period = 0.0;
+                  std::vector<int> units; std::vector<float> times; };       // (several engines: the engine's units in call order; its receiver times by datum)
     std::vector<Part> part(ne);
+    size_t ndata_all = 0;
+    for (int u = 0; u < nu; ++u) ndata_all = std::max(ndata_all, (size_t)U.data[(size_t)u] + (size_t)U.nrec[(size_t)u]);
+    if (ne > 1) for (int u = 0; u < nu; ++u) part[(size_t)owner[(size_t)u]].units.push_back(u);
     auto work = [&](int k) {
         dsa_engine* e = g_pool[k];
         dsa::Engine* en = reinterpret_cast<dsa::Engine*>(e);
@@ -227,21 +246,33 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
         }
         if ((r = dsa_maps_from_dispersion(e, *goxdf, *gozdf, *dvxdf, *dvzdf, 8)) != 0) return bad(r);
         if ((r = dsa_kernels_from_dispersion(e)) != 0) return bad(r);
-        const int a = cut[k], b = cut[k + 1];
-        if ((r = dsa_plan_units(e, b - a, U.map.data() + a, U.sx.data() + a, U.sz.data() + a, U.nrec.data() + a, U.rx.data() + ray0[a],
-                                U.rz.data() + ray0[a], U.mode.data() + a, U.slot.data() + a, U.data.data() + a)) != 0) return bad(r);
         if (ne == 1) {
+            if ((r = dsa_plan_units(e, nu, U.map.data(), U.sx.data(), U.sz.data(), U.nrec.data(), U.rx.data(), U.rz.data(), U.mode.data(), U.slot.data(), U.data.data())) != 0) return bad(r);
             en->rows_on_device = device_rows;
             r = dsa_solve_rows(e, dsurf, rw, device_rows ? nullptr : iw + 1, col, cap, &P.n);          // the reference fills iw(nar+1)
         } else {
+            // this engine's units, in call order, with their receivers gathered; data indices stay those of the whole call
+            const std::vector<int>& mine = P.units;
+            const int nm = (int)mine.size();
+            std::vector<int> m_map((size_t)nm), m_nrec((size_t)nm), m_mode((size_t)nm), m_slot((size_t)nm), m_data((size_t)nm);
+            std::vector<float> m_sx((size_t)nm), m_sz((size_t)nm), m_rx, m_rz;
+            for (int q = 0; q < nm; ++q) {
+                const size_t u = (size_t)mine[(size_t)q];
+                m_map[(size_t)q] = U.map[u]; m_sx[(size_t)q] = U.sx[u]; m_sz[(size_t)q] = U.sz[u]; m_nrec[(size_t)q] = U.nrec[u];
+                m_mode[(size_t)q] = U.mode[u]; m_slot[(size_t)q] = U.slot[u]; m_data[(size_t)q] = U.data[u];
+                m_rx.insert(m_rx.end(), U.rx.begin() + (long)ray0[u], U.rx.begin() + (long)ray0[u + 1]);
+                m_rz.insert(m_rz.end(), U.rz.begin() + (long)ray0[u], U.rz.begin() + (long)ray0[u + 1]);
+            }
+            if ((r = dsa_plan_units(e, nm, m_map.data(), m_sx.data(), m_sz.data(), m_nrec.data(), m_rx.data(), m_rz.data(), m_mode.data(), m_slot.data(), m_data.data())) != 0) return bad(r);
+            P.times.assign(std::max<size_t>(ndata_all, 1), 0.0f);
             en->grow_rw = &P.rw; en->grow_iw = &P.iw; en->grow_col = &P.col;
-            r = en->solve(dsurf, nullptr, nullptr, nullptr, cap, &P.n);
+            r = nm ? en->solve(P.times.data(), nullptr, nullptr, nullptr, cap, &P.n) : 0;
             en->grow_rw = nullptr; en->grow_iw = nullptr; en->grow_col = nullptr;
         }
         if (r != 0) return bad(r);
         long long nclamped = 0;
         int fu = -1;
-        if (dsa_ray_diagnostics(e, &nclamped, &fu) == 0 && fu >= 0) P.first_clamped = a + fu;       // unit of the whole call
+        if (dsa_ray_diagnostics(e, &nclamped, &fu) == 0 && fu >= 0) P.first_clamped = ne == 1 ? fu : P.units[(size_t)fu];       // unit of the whole call
         dsa_dispersion_diagnostics(e, &P.disp_count, P.disp_first, &P.disp_period);
     };
     if (ne == 1) work(0);
@@ -254,14 +285,26 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     int first_clamped = -1;
     for (int k = 0; k < ne; ++k) {
         if (part[k].rc != 0) { g_dropin_error = part[k].err; return part[k].rc; }
-        if (ne > 1) {
-            if (n + part[k].n > cap) { g_dropin_error = "dsa_calsurfg: more matrix entries than the stated capacity (increase sparsity fraction)"; return DSA_ERR_CAPACITY; }
-            std::memcpy(rw + n, part[k].rw.data(), (size_t)part[k].n * 4);
-            std::memcpy(iw + 1 + n, part[k].iw.data(), (size_t)part[k].n * 4);
-            std::memcpy(col + n, part[k].col.data(), (size_t)part[k].n * 4);
-        }
         n += part[k].n;
         if (part[k].first_clamped >= 0 && (first_clamped < 0 || part[k].first_clamped < first_clamped)) first_clamped = part[k].first_clamped;
+    }
+    if (ne > 1) {
+        if (n > cap) { g_dropin_error = "dsa_calsurfg: more matrix entries than the stated capacity (increase sparsity fraction)"; return DSA_ERR_CAPACITY; }
+        // receiver times: every engine's own data; matrix entries: the reference appends them datum by datum in call order, and a datum's
+        // rows come from one unit, i.e. from one engine, whose list holds them in order -- so the whole list is the engines' runs placed
+        // by datum (iw = the datum's 1-based row)
+        for (int k = 0; k < ne; ++k)
+            for (int u : part[k].units)
+                for (int q = 0; q < U.nrec[(size_t)u]; ++q) { const size_t d = (size_t)U.data[(size_t)u] + (size_t)q; if (U.mode[(size_t)u] & 1) dsurf[d] = part[k].times[d]; }
+        std::vector<long long> first_of(ndata_all + 2, 0);
+        for (int k = 0; k < ne; ++k) for (long long q = 0; q < part[k].n; ++q) ++first_of[(size_t)part[k].iw[(size_t)q] + 1];       // (iw 1-based: count of datum d-1 at [d+1])
+        for (size_t d = 1; d < first_of.size(); ++d) first_of[d] += first_of[d - 1];
+        std::vector<long long> fill(first_of.begin(), first_of.end());
+        for (int k = 0; k < ne; ++k)
+            for (long long q = 0; q < part[k].n; ++q) {
+                const long long pos = fill[(size_t)part[k].iw[(size_t)q]]++;
+                rw[pos] = part[k].rw[(size_t)q]; iw[1 + pos] = part[k].iw[(size_t)q]; col[pos] = part[k].col[(size_t)q];
+            }
     }
     // every engine ran the same dispersion stage: engine 0 speaks for all
     g_disp_count = part[0].disp_count; g_disp_period = part[0].disp_period;

@@ -311,16 +311,18 @@ def test_fortran_shim(tmp_path):
 
 
 def test_dropin_sharded_over_engines():
-    """DSA_DEVICES: the drop-in call splits its units over several engines (one per GPU; here two engines
-    on GPU 0, in a fresh process because the engine pool is made once per process) and stitches dsurf and
-    the COO rows back in the reference's order"""
+    """DSA_DEVICES: the drop-in call splits its units over several engines (one per GPU; here three engines
+    on GPU 0, in a fresh process because the engine pool is made once per process) -- by SOURCES since round 3, all units of a
+    source on one engine, which bundles them (DSA_BUNDLE=4 here) -- and puts dsurf and the COO rows back in the reference's order;
+    the last case has stations: the same sources at every period slot"""
     code = r'''
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import _libs as L, synth
 from dsurftomo_amd import engine
 lib = engine.load_library()
-for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, nsrc=8, nrcf=7, kRc=3, kRg=1, kLc=1, kLg=1)):
+for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, nsrc=8, nrcf=7, kRc=3, kRg=1, kLc=1, kLg=1),
+           dict(nx=16, ny=15, nz=6, nsrc=7, nrcf=5, kRc=4, kRg=2, kLc=3, kLg=1, stations=True)):
     c = synth.boundary_case(**kw)
     o = L.call_boundary(L.oracle().dso_calsurfg, c)
     d = L.call_boundary(lib.dsa_calsurfg, c)
@@ -330,7 +332,7 @@ for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, ns
     assert (o["rw"].view(np.uint32) == d["rw"].view(np.uint32)).all()
 print("sharded ok")
 ''' % (L.ROOT, os.path.join(L.ROOT, "tests"))
-    env = dict(os.environ, DSA_DEVICES="0,0,0")
+    env = dict(os.environ, DSA_DEVICES="0,0,0", DSA_BUNDLE="4")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
