@@ -15,6 +15,7 @@ for k in range(ncases):
     kw = dict(nx=(28 if big else 6) + int(u[0] * (12 if big else 16)), ny=(28 if big else 6) + int(u[1] * (12 if big else 16)), nz=3 + int(u[2] * 6), kRc=int(u[3] * 4), kRg=int(u[4] * 3), kLc=int(u[5] * 3), kLg=int(u[6] * 2),
               nsrc=2 + int(u[7] * 6), nrcf=2 + int(u[8] * 6), dvd=0.02 + 0.08 * u[9], seed=int(u[10] * 1e6), deep=bool(u[11] > 0.7))
     if kw["kRc"] + kw["kRg"] + kw["kLc"] + kw["kLg"] == 0: kw["kRc"] = 1
+    if os.environ.get('DSA_FUZZ_STATIONS'): kw["stations"] = True        # the same sources at every period slot (with DSA_BUNDLE=4|8|16: bundled solves)
     c = synth.boundary_case(**kw)
     o = L.call_boundary(L.oracle().dso_calsurfg, c)
     try:
