@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
     __shared__ int wbuf[NW * kWaveBuf];
     __shared__ int wtile[NW * kTileBuf];
     __shared__ unsigned wclr[NW * kTileBuf * kClrWords];
-    constexpr int rhalf = NT * 4;              // ready nodes of one colour a round can take (the rest keep their bits)
+    constexpr int rhalf = NT < 256 ? 1024 : NT * 4;      // ready nodes of one colour a round can take (the rest keep their bits)
     __shared__ int ready[2 * rhalf];
     __shared__ int s_member[kBundleMax], s_map[kBundleMax];
 
@@ -199,6 +199,12 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
 #pragma unroll
     for (int m = 0; m < 4; ++m) { mp[m] = (unsigned)s_map[sub * 4 + m] * 4u; if (sub * 4 + m < nmem) vmask |= 1u << m; }
 
+#ifdef DSA_BUNDLE_CLOCKS      // probe: where a round's wall clock goes (thread 0: pass A incl. its barrier, even half, odd half, bookkeeping), into clocks[0..3] of the pilot
+    unsigned long long bt[4] = { 0, 0, 0, 0 }, bt0 = wall_clock64();
+#define DSA_BCLK(k) do { const unsigned long long t1_ = wall_clock64(); bt[k] += t1_ - bt0; bt0 = t1_; } while (0)
+#else
+#define DSA_BCLK(k) do { } while (0)
+#endif
     for (; !dead;) {
         const float theta = bu2f((unsigned)sc[BC_THETA]);
         const bool open = !(theta < kInf);
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
             if (seen) atomicAdd(&sc[BC_CUR], seen);
         }
         __syncthreads();
+        DSA_BCLK(0);
         const int cnt = sc[BC_CUR];
         if (cnt == 0) break;
 
@@ -532,6 +539,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 }
             }
             __syncthreads();
+            DSA_BCLK(1 + half);
         }
         if (tid == 0) {
             sc[BC_READY] = 0; sc[BC_READY_ODD] = 0; sc[BC_CUR] = 0;
@@ -548,10 +556,14 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         }
         ++rounds;
         __syncthreads();
+        DSA_BCLK(3);
         if (sc[BC_OVERFLOW]) break;                      // the exception table is full (info[2] = -2 at the pilot): the host grows it and solves the chunk again
         if (rounds > p.max_rounds) { dead = true; break; }
     }
     const bool failed = rounds > p.max_rounds;
+#ifdef DSA_BUNDLE_CLOCKS
+    if (tid == 0 && p.clocks) { p.clocks[0] = bt[0]; p.clocks[1] = bt[1]; p.clocks[2] = bt[2]; p.clocks[3] = bt[3]; }
+#endif
 
     // ---- the members' ends: statistics, receiver times from the bundle's field (reference srtimes), the field itself where the engine
     // keeps one per unit (rays and rows, field downloads), then the slot goes to the next bundle
@@ -617,6 +629,8 @@ void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int thr
     const size_t lds = bundle_lds_bytes(tile_words);
 #define DSA_LAUNCH_BUNDLE(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
     if (threads == 512) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 512); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 512); else DSA_LAUNCH_BUNDLE(4, 512); }
+    else if (threads == 64) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 64); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 64); else DSA_LAUNCH_BUNDLE(4, 64); }
+    else if (threads == 128) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 128); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 128); else DSA_LAUNCH_BUNDLE(4, 128); }
     else { if (G == 16) DSA_LAUNCH_BUNDLE(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 256); else DSA_LAUNCH_BUNDLE(4, 256); }
 #undef DSA_LAUNCH_BUNDLE
 }

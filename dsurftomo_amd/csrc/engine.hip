@@ -423,7 +423,11 @@ size_t Engine::solve_stage_bytes() const
 }
 
 // workgroup size of the bundle kernel (bundle_kernel.hip)
-int Engine::bundle_threads() const { return std::max(g.nnx, g.nnz) > 1500 ? 512 : 256; }
+int Engine::bundle_threads() const
+{
+    if (bundle_threads_opt == 64 || bundle_threads_opt == 128 || bundle_threads_opt == 256 || bundle_threads_opt == 512) return bundle_threads_opt;
+    return std::max(g.nnx, g.nnz) > 1500 ? 512 : 256;
+}
 
 BatchPtrs Engine::batch() const
 {
@@ -1092,6 +1096,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
     if (n == "bundle_window_cells" && value > 0) { en->bundle_window_cells = (float)value; return 0; }
+    if (n == "bundle_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }

@@ -36,6 +36,8 @@ for G in sizes:
         e.set_option('window_cells', 1.0); G = 0
     else: e.set_option('window_cells', float(os.environ.get('DSA_PROBE_WINDOW', '1.25')))
     e.set_option('bundle', G)
+    if os.environ.get('DSA_PROBE_BTHREADS'): e.set_option('bundle_threads', int(os.environ['DSA_PROBE_BTHREADS']))
+    if os.environ.get('DSA_PROBE_BPOOL'): e.set_option('bundle_pool', int(os.environ['DSA_PROBE_BPOOL']))
     if os.environ.get('DSA_PROBE_BWINDOW'): e.set_option('bundle_window_cells', float(os.environ['DSA_PROBE_BWINDOW']))
     if what == "check": e.set_option('field_pool', -1)
     e.plan(**u)
@@ -57,6 +59,8 @@ for G in sizes:
             bad = F.view(np.uint32) != ref_fields.view(np.uint32)
             line += f', fields: {int(bad.sum())} of {bad.size} nodes differ (max |dT| {np.nanmax(np.where(bad, np.abs(F - ref_fields), 0)):.3g}; units {sorted(set(np.nonzero(bad)[0].tolist()))[:8]})'
     print(line, flush=True)
+    if os.environ.get('DSA_PROBE_CLOCKS'):
+        pt = np.array(st['phase_ticks'][:4]); print(f'    wall clock of the rounds (thread 0 of every bundle, -DDSA_BUNDLE_CLOCKS builds): pass A {100*pt[0]/pt.sum():.1f} %, even half {100*pt[1]/pt.sum():.1f} %, odd half {100*pt[2]/pt.sum():.1f} %, bookkeeping {100*pt[3]/pt.sum():.1f} %; per bundle-round {pt.sum()/100.0/max(st["bundles"],1)/max(np.median(e.unit_rounds()),1):.1f} us', flush=True)
     if os.environ.get('DSA_PROBE_ROUNDS'):
         r = e.unit_rounds(); q = np.percentile(r, [0, 10, 50, 90, 99, 100]).astype(int).tolist()
         worst = np.argsort(-r)[:4]
