@@ -186,3 +186,27 @@ def test_big_grids_use_the_512_thread_bundle_kernel(bundles, nx, nsrc, nper, G):
     nbad = int((bits(out[G]) != bits(out[0])).sum())
     parity_log.add(f"bundles at N={e.nnx} (512-thread kernel), {nsrc * nper} units in bundles of {G}: {nbad} of {d.size} receiver times differ from unit by unit (max |dt| {float(d.max()):.3g} s)")
     assert np.isfinite(out[G]).all() and d.max() <= 1e-4
+
+
+def test_bundle_exception_table_overflows_and_grows(bundles):
+    """+-45 % random vertices (hundreds of non-causal nodes per field): a bundle whose shared exception table is far too small reports the
+    overflow, the engine quadruples the tables and solves the chunk again -- same receiver times as with the regular table and as unit by unit
+    (up to the tie noise of this medium)"""
+    e = bundles
+    nx, nper, nsrc = 65, 4, 3
+    pv = np.stack([synth.medium(nx, "wild", p) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, 12)
+    out = {}
+    try:
+        for tag, G, cap in (("solo", 0, 0), ("bundle", 4, 0), ("small", 4, 6)):
+            e.set_option("exc_log2cap", cap)
+            e.set_option("bundle", G)
+            e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+            out[tag] = e.traveltimes(**u)
+            st = e.stats()
+            if tag == "small": assert st["rescans"] >= 1 and st["bundles"] == nsrc
+    finally:
+        e.set_option("exc_log2cap", 0)
+    assert np.array_equal(bits(out["small"]), bits(out["bundle"]))
+    assert np.abs(out["bundle"] - out["solo"]).max() <= 1e-4
+    parity_log.add(f"bundles, wild medium N={e.nnx}: table of 64 x 4 entries overflows and grows; times = regular table; vs unit by unit max |dt| {float(np.abs(out['bundle'] - out['solo']).max()):.3g} s")
