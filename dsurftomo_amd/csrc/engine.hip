@@ -523,7 +523,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         }
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
                              detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p,
-                             nbundles ? member_flag.p : nullptr, bundle_window_cells * cell_c, stream);
+                             nbundles ? member_flag.p : nullptr, bundle_window_cells * cell_c, bundle_max_rounds, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         FimLaunch sr = shape_r, sc = shape_c;
         sr.tie = sc.tie = detect ? 1 : 0;
@@ -1097,6 +1097,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
     if (n == "bundle_window_cells" && value > 0) { en->bundle_window_cells = (float)value; return 0; }
     if (n == "bundle_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
+    if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }

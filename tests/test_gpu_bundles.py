@@ -210,3 +210,23 @@ def test_bundle_exception_table_overflows_and_grows(bundles):
     assert np.array_equal(bits(out["small"]), bits(out["bundle"]))
     assert np.abs(out["bundle"] - out["solo"]).max() <= 1e-4
     parity_log.add(f"bundles, wild medium N={e.nnx}: table of 64 x 4 entries overflows and grows; times = regular table; vs unit by unit max |dt| {float(np.abs(out['bundle'] - out['solo']).max()):.3g} s")
+
+
+def test_bundle_that_does_not_converge_falls_back_to_unit_by_unit(bundles):
+    """a bundle that runs out of rounds (forced here with a limit of 40) reports it; the engine solves the chunk again unit by unit"""
+    e = bundles
+    nx, nper, nsrc = 33, 4, 5
+    pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, 6)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("bundle", 0)
+    ref = e.traveltimes(**u)
+    try:
+        e.set_option("bundle", 4)
+        e.set_option("bundle_max_rounds", 40)
+        t = e.traveltimes(**u)
+        st = e.stats()
+    finally:
+        e.set_option("bundle_max_rounds", 0)
+    assert st["rescans"] >= 1 and st["bundles"] == 0
+    assert np.array_equal(bits(t), bits(ref))
