@@ -685,10 +685,9 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     // automatic: a bundle is one workgroup where its members would have been G, so it pays only while the bundles still fill the chip
     // (512 resident workgroups).  Estimated solves/s from the rates measured at 1025^2 with the chip full (unit by unit 10.4 k, bundles of
     // 4 / 8 / 16: 15.5 k / 20.4 k / 24.5 k; profiles/r03_bundle_sizes.log) times the fill; the best estimate wins.  The ratios hold from 497^2
-    // (40 k unit by unit, 64 k in bundles of 16) to 2033^2 (2.45 k against 3.1 k in bundles of 4); at 4081^2 the bundle kernel's 256
-    // threads and 2 x 1024 ready nodes per round are too few for the front (205 solves/s against 563), so grids beyond 2100 nodes per
-    // side stay unit by unit, and so do grids below 400, whose solves are short.
-    // Round 3, late: beyond 1500 nodes per side the bundle kernel runs 512 threads wide with 2 x 2048 ready slots (one workgroup per CU).
+    // (40 k unit by unit, 64 k in bundles of 16) to 2033^2 (2.4 k against 4.75 k in bundles of 8) and 4081^2 (0.57 k against 1.1-1.4 k in
+    // bundles of 8); beyond 1500 nodes per side the bundle kernel runs 512 threads wide with 2 x 2048 ready slots, one workgroup per CU
+    // (bundle_threads(): half as many bundles fill the chip).  Grids below 400 nodes per side stay unit by unit: their solves are short.
     if (std::min(g.nnx, g.nnz) < 400) return 0;
     const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
     double best = 10.4 * std::min(1.0, n_units / 1100.0) * 1.05;
