@@ -230,3 +230,32 @@ def test_bundle_that_does_not_converge_falls_back_to_unit_by_unit(bundles):
         e.set_option("bundle_max_rounds", 0)
     assert st["rescans"] >= 1 and st["bundles"] == 0
     assert np.array_equal(bits(t), bits(ref))
+
+
+def test_bundled_receivers_at_scale_against_the_oracle(bundles):
+    """16 sources x 16 periods at the headline size and medium (1025^2, configs[2]) in bundles of 16: every one of the 8192 receiver times
+    against the oracle's Fast Marching (pinned to the reference at this size: tests/test_oracle_vs_ref.py), oracle solves spread over the host cores"""
+    from concurrent.futures import ThreadPoolExecutor
+    e = bundles
+    nx, nsrc, nper, nrec = 131, 16, 16, 32
+    u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 5)
+    pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("bundle", 16)
+    t = e.traveltimes(**u).reshape(nsrc * nper, nrec)
+    st = e.stats()
+    assert st["bundles"] == nsrc and st["bundled_units"] == nsrc * nper
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    veln = [L.o_gridder(g, pv[p]) for p in range(nper)]
+
+    def one(k):
+        p = int(u["map_index"][k])
+        o = L.o_solve(g, pv[p], veln[p], u["scx"][k], u["scz"][k])
+        return np.array([L.o_srtimes(g, veln[p], o["T"], u["scx"][k], u["scz"][k], u["rcx"][k * nrec + r], u["rcz"][k * nrec + r]) for r in range(nrec)], np.float32)
+
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        ref = np.stack(list(ex.map(one, range(nsrc * nper))))
+    d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
+    parity_log.add(f"bundled receivers at scale N=1025 smooth: {d.size} receiver times of {nsrc * nper} units in {nsrc} bundles of 16, max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())}, "
+                   f"not bit-identical {int((bits(t) != bits(ref)).sum())}")
+    assert d.max() <= TOL
