@@ -128,8 +128,11 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         *ix0 = (int)(bx << kTileShift) + rec_ix_in_tile(id);
         *iz0 = (int)(bz << kTileShift) + rec_iz_in_tile(id);
     };
-    // the pilot's value of a node (member 0)
-    auto pv = [&](int id) -> float { return *(BGF32*)(Bb + (unsigned)id * GB); };
+    // The pilot's value of a node (member 0), from its dense shadow copy P (one float per node, tiled like the field): pass A routes ~700
+    // listed nodes per round by five pilot values each, and reading them from the member-minor field moved a 128-byte line per value --
+    // two thirds of the kernel's fetched bytes (profiles/r03_bundle_sizes.log).  Written next to the field by the lane that owns member 0.
+    BGChar* const Pb = (BGChar*)bd->P;
+    auto pv = [&](int id) -> float { return *(BGF32*)(Pb + ((unsigned)id << 2)); };
 
     // ---- the bundle's field slot: wait for its previous user; every node of every member unreached, the table empty; the nodes each
     // member's serial prologue pinned (window records, k_coarse_march) into both
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         }
         const BV4 inf4 = { kInf, kInf, kInf, kInf };
         for (int i = tid; i < ntile * (kTileRecs * G / 4); i += NT) ((BGV4*)Bb)[i] = inf4;
+        for (int i = tid; i < ntile * (kTileRecs / 4); i += NT) ((BGV4*)Pb)[i] = inf4;
         for (int i = tid; i < (1 << xlog); i += NT) *exc_at((unsigned)i) = kExcEmpty;
         for (int i = tid; i < (ntile << (kMaskShift - 3)); i += NT) *(BGU64*)(maskb + ((size_t)i << 3)) = 0ull;
         for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                     placed = atomicCAS((unsigned long long*)exc_at(h), kExcEmpty, mine) == kExcEmpty;
                 if (!placed) { pm->info[2] = -2; sc[BC_OVERFLOW] = 1; }
                 *(BGF32*)(Bb + (unsigned)id * GB + (unsigned)m * 4u) = wt;      // -T: the sign bit marks the exceptional node
+                if (m == 0) *(BGF32*)(Pb + ((unsigned)id << 2)) = wt;
             }
             // the member's seeds: the rim of its pinned set
             const int nseed = *pm->seed_count;
@@ -501,7 +506,10 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 }
 #undef DSA_BM
                 __builtin_amdgcn_s_setprio(1);
-                if (any_changed) *(BGV4*)(Bb + (unsigned)id * GB + sub_b) = outv;
+                if (any_changed) {
+                    *(BGV4*)(Bb + (unsigned)id * GB + sub_b) = outv;
+                    if (sub == 0) *(BGF32*)(Pb + ((unsigned)id << 2)) = outv.x;       // the pilot's shadow copy (unchanged pilots rewrite their value)
+                }
                 // dependents: the members' OR, one lane per node issues the activations (fim_kernel.hip: the mask bits are constant shifts
                 // of the node's own bit)
                 wm = node_or<CH>(wm);

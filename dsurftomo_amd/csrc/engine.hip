@@ -668,7 +668,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
     free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;          // (what a previous call holds is reused)
-    auto slot_bytes = [&](int G) { int lg = G == 16 ? 4 : G == 8 ? 3 : 2; return (size_t)G * nrec_c * 4 + ((size_t)8 << (exc_log2cap + lg)) + lists_c_stride * 4; };
+    auto slot_bytes = [&](int G) { int lg = G == 16 ? 4 : G == 8 ? 3 : 2; return (size_t)(G + 1) * nrec_c * 4 + ((size_t)8 << (exc_log2cap + lg)) + lists_c_stride * 4; };
     auto fits = [&](int G) {
         if ((unsigned long long)nrec_c * (unsigned long long)G * 4ull >= (1ull << 32)) return false;          // 32-bit byte offsets inside a bundle field
         if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
@@ -748,12 +748,12 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     size_t free_b = 0, total_b = 0;
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
     free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;
-    const size_t slot_b = (size_t)G * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
+    const size_t slot_b = (size_t)(G + 1) * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
     const size_t room = (size_t)(0.7 * (double)free_b) / slot_b;
     if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
     bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (bundle_threads() == 512 ? 512 : 1024)), room });
     const size_t BS = (size_t)bundle_slots;
-    if (ensure(B_pool, BS * G * nrec_c) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
+    if (ensure(B_pool, BS * (G + 1) * nrec_c) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
     if (!slowI_ready) { launch_interleave_maps(slow.p, nrec_c, nmaps, slowI.p, stream); slowI_ready = true; }
     h_bundles.assign((size_t)nb, FimBundle{});
@@ -761,7 +761,8 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     for (int k = 0; k < nb; ++k) {
         FimBundle& bd = h_bundles[(size_t)k];
         const int slot = k % bundle_slots;
-        bd.B = B_pool.p + (size_t)slot * G * nrec_c;
+        bd.B = B_pool.p + (size_t)slot * (G + 1) * nrec_c;
+        bd.P = bd.B + (size_t)G * nrec_c;
         bd.exc = exc_b.p + ((size_t)slot << xlog_b); bd.exc_log2cap = xlog_b;
         bd.slowI = slowI.p; bd.np = nmaps;
         bd.lists = lists_b.p + (size_t)slot * lists_c_stride;

@@ -96,6 +96,7 @@ struct FimLaunch {
 constexpr int kBundleMax = 16;
 struct FimBundle {
     float* B;                     // G floats per node record, tiled like the compact field
+    float* P;                     // member 0's values once more, one float per node (what pass A routes by)
     unsigned long long* exc;      // exception table of the bundle, keyed by id * G + m
     int exc_log2cap;
     const float* slowI;           // member-minor slowness of all maps: slowI[id * np + map]
