@@ -28,8 +28,10 @@ namespace {
 __device__ __forceinline__ unsigned bf2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float bu2f(unsigned u) { return __uint_as_float(u); }
 
-enum { BC_READY = 0, BC_READY_ODD, BC_TMIN, BC_THETA, BC_FREEZE, BC_HASH, BC_OVERFLOW, BC_CUR, BC_COUNT };
+enum { BC_READY = 0, BC_READY_ODD, BC_TMIN, BC_THETA, BC_FREEZE, BC_HASH, BC_OVERFLOW, BC_CUR, BC_STALE, BC_STALEMIN, BC_COUNT };
 constexpr int kBundleCycleRounds = 8;
+constexpr float kStaleWindows = 16.0f;      // see pass B: a change this many windows behind the pilot's front counts as stale
+constexpr int kStaleRounds = 6;             // ... and pulls the window back when it has stayed at one node for so many rounds
 
 typedef __attribute__((address_space(1))) unsigned long long BGU64;
 typedef __attribute__((address_space(1))) char BGChar;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         for (int i = tid; i < nwords; i += NT) tb[i] = 0u;
         if (tid == 0) {
             sc[BC_READY] = 0; sc[BC_READY_ODD] = 0; sc[BC_TMIN] = 0x7f800000; sc[BC_THETA] = 0x7f800000;
-            sc[BC_FREEZE] = (int)0xff800000u; sc[BC_HASH] = 0; sc[BC_OVERFLOW] = 0; sc[BC_CUR] = 0;
+            sc[BC_FREEZE] = (int)0xff800000u; sc[BC_HASH] = 0; sc[BC_OVERFLOW] = 0; sc[BC_CUR] = 0; sc[BC_STALE] = (int)0xff800000u; sc[BC_STALEMIN] = 0x7f800000;
         }
         __threadfence_block();
         __syncthreads();
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         if (sc[BC_OVERFLOW]) dead = true;
     }
 
-    int rounds = 0, stall = 0, freezes = 0;
+    int rounds = 0, stall = 0, freezes = 0, sm_same = 0;
+    float sm_prev = kInf, sm_prev2 = kInf;
     unsigned hist[4] = { 1u, 2u, 3u, 4u };
     float best_tmin = -kInf;
     unsigned evals = 0, nchanged = 0;                        // member evaluations of this lane
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         const bool open = !(theta < kInf);
         const float freeze = bu2f((unsigned)sc[BC_FREEZE]);
         const bool frozen_any = freeze > -kInf;
+        const float stale = bu2f((unsigned)sc[BC_STALE]);      // the farthest the window's lower edge has been, less kStaleWindows windows (pass B)
 
         // ---- pass A (as in k_fim_sorted, on the pilot's times): every wave sweeps its share of the tile bitmap, gathers the active tiles,
         // expands their node masks in record order, computes the lower bounds and routes
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         const int nready_even = sc[BC_READY] < rhalf ? sc[BC_READY] : rhalf;
         const int nready_odd = sc[BC_READY_ODD] < rhalf ? sc[BC_READY_ODD] : rhalf;
         unsigned hv_lane = 0u;
-        float kmin_lane = kInf;
+        float kmin_lane = kInf, smin_lane = kInf;
         for (int half = 0; half < 2; ++half) {
             const int nready = half ? nready_odd : nready_even;
             for (int j0 = wave * NPW; j0 < nready; j0 += NW * NPW) {
@@ -513,6 +517,18 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 // dependents: the members' OR, one lane per node issues the activations (fim_kernel.hip: the mask bits are constant shifts
                 // of the node's own bit)
                 wm = node_or<CH>(wm);
+                // A change far BEHIND the front (the window's lower edge has been kStaleWindows windows beyond this node) is a member that lags
+                // that much, a late refinement on its way downstream -- or a cycle (exact 2-cycles among ulp-tied nodes, fim_kernel.hip), which
+                // in a member other than the pilot would flip on, and spread its flips downstream, until the rest of the bundle has converged
+                // (+2000 rounds for such a bundle at a 1.5-cell window).  The earliest such change of the round is recorded; when it stays at
+                // the SAME node round after round (a cycle does, a wave moves on) the bookkeeping below pulls the window back to it, as every
+                // change does in a unit-by-unit solve: nothing ahead moves, the repetition shows in the change hash, the freeze horizon covers
+                // the node, and the window returns to the front.
+                {
+                    const unsigned chg = node_or<CH>(any_changed ? 1u : 0u);
+                    const float pt = outv.x;                                     // (lane sub == 0: the pilot's value at this node, new or unchanged)
+                    if (sub == 0 && chg && !__builtin_signbit(pt) && pt < stale) smin_lane = fminf(smin_lane, pt);
+                }
                 if (sub == 0 && wm) {
                     const int own_tile = id >> 6;
                     const unsigned long long b = 1ull << (id & 63);
@@ -540,10 +556,11 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
             }
             if (half == 1) {
                 const unsigned hv = wave_sum(hv_lane);
-                const float kmin = wave_min(kmin_lane);
+                const float kmin = wave_min(kmin_lane), smin = wave_min(smin_lane);
                 if (lane == 0) {
                     if (hv) atomicAdd(reinterpret_cast<unsigned*>(&sc[BC_HASH]), hv);
                     if (kmin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[BC_TMIN]), bf2u(kmin));
+                    if (smin < kInf) atomicMin(reinterpret_cast<unsigned*>(&sc[BC_STALEMIN]), bf2u(smin));
                 }
             }
             __syncthreads();
@@ -551,15 +568,26 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         }
         if (tid == 0) {
             sc[BC_READY] = 0; sc[BC_READY_ODD] = 0; sc[BC_CUR] = 0;
-            const float tmin = bu2f((unsigned)sc[BC_TMIN]);
+            float tmin = bu2f((unsigned)sc[BC_TMIN]);
+            {   // a stale change that stays at one node (see pass B): the window goes back there until the freeze has dealt with it
+                const float sm = bu2f((unsigned)sc[BC_STALEMIN]);
+                sc[BC_STALEMIN] = 0x7f800000;
+                if (sm < kInf && (bf2u(sm) == bf2u(sm_prev) || bf2u(sm) == bf2u(sm_prev2))) ++sm_same; else sm_same = 0;
+                sm_prev2 = sm_prev; sm_prev = sm;
+                if (sm_same >= kStaleRounds) tmin = fminf(tmin, sm);
+            }
             sc[BC_THETA] = (int)bf2u(tmin + p.window);
             sc[BC_TMIN] = 0x7f800000;
             const unsigned hsh = (unsigned)sc[BC_HASH];
             sc[BC_HASH] = 0;
             if (tmin > best_tmin && tmin < kInf) best_tmin = tmin;
+            sc[BC_STALE] = (int)bf2u(best_tmin - kStaleWindows * p.window);
             const bool repeat = hsh != 0u && (hsh == hist[1] || hsh == hist[2] || hsh == hist[3] || hsh == hist[0]);
             hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = hsh;
-            if (repeat) { if (++stall >= kBundleCycleRounds) { sc[BC_FREEZE] = (int)bf2u(best_tmin + p.window); stall = 0; ++freezes; } }
+            // (with the window pulled back to a cycle, see above: everything up to THAT window's edge has stopped moving, no more -- members
+            // that lag may still be busy between there and the front)
+            if (repeat) { if (++stall >= kBundleCycleRounds) { const float fz = (sm_same >= kStaleRounds ? sm_prev : best_tmin) + p.window;
+                                                                 if (fz > bu2f((unsigned)sc[BC_FREEZE])) sc[BC_FREEZE] = (int)bf2u(fz); stall = 0; ++freezes; } }
             else stall = 0;
         }
         ++rounds;

@@ -85,6 +85,7 @@ struct Engine {
     int bundle_pool_opt = 0;           // option bundle_pool: bundle field slots (0 = up to 1024; fewer than the bundles of a launch: recycled like the unit slots)
     DevBuf<float> slowI, B_pool;       // member-minor slowness of all maps; bundle field slots
     bool slowI_ready = false;
+    bool bundles_failed = false;       // a bundle of the current maps ran out of rounds: the automatic mode stays unit by unit until the maps change
     DevBuf<unsigned long long> exc_b;  // exception tables of the bundle slots
     DevBuf<int> lists_b, bpool_gen, member_flag;
     DevBuf<FimBundle> bundles_d;

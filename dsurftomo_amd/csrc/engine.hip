@@ -155,6 +155,7 @@ int Engine::finish_maps(int nm)
     planned = false;
     have_maps = true;
     slowI_ready = false;
+    bundles_failed = false;
     if (g.nnx != grown_nnx || g.nnz != grown_nnz) { exc_log2cap_grown = 0; grown_nnx = g.nnx; grown_nnz = g.nnz; }
     return 0;
 }
@@ -620,7 +621,13 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         if (nbundles) {     // a bundle that did not converge under the shared schedule: its chunk once more, every unit by itself
             bool bad = false;
             for (int u = 0; u < n && !bad; ++u) bad = h_member_flag[(size_t)u] && h_info[(size_t)u * 16 + 10] == -1;
-            if (bad) { bundle_off_chunk = true; redo_chunk = true; stats[DSA_STAT_RESCANS] += 1; continue; }
+            if (bad) {
+                if (getenv("DSA_DEBUG_BUNDLE"))
+                    for (int u = 0; u < n; ++u) if (h_member_flag[(size_t)u] && h_info[(size_t)u * 16 + 10] == -1) { fprintf(stderr, "bundle member %d (unit %d) gave up after %d rounds (freezes %d)\n", u, first + u, h_info[(size_t)u * 16 + 8], h_info[(size_t)u * 16 + 11]); break; }
+                bundle_off_chunk = true; redo_chunk = true; stats[DSA_STAT_RESCANS] += 1;
+                bundles_failed = true;          // these maps do not bundle (fronts of the periods too different): unit by unit until the maps change
+                continue;
+            }
             stats[DSA_STAT_BUNDLES] += nbundles; stats[DSA_STAT_BUNDLED_UNITS] += n - nsolo;
             stats[DSA_STAT_FOOTPRINT_MB] = std::max(stats[DSA_STAT_FOOTPRINT_MB], ((double)pool_slots * (double)per_slot_bytes + (double)chunk * (double)per_unit_bytes +
                                                     (double)(B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4 + slowI.cap * 4)) / 1.0e6);
@@ -660,7 +667,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
 int Engine::choose_bundle_size(int step, long* solo_units)
 {
     if (solo_units) *solo_units = (long)h_src.size();
-    if (bundle_opt == 0 || h_src.empty()) return 0;
+    if (bundle_opt == 0 || h_src.empty() || (bundles_failed && bundle_opt == 1)) return 0;
     // units per source (same coordinates bit for bit), in planned order
     std::map<std::pair<uint32_t, uint32_t>, int> count;
     for (const SourceDesc& sd : h_src) { uint32_t a, b2; std::memcpy(&a, &sd.scx, 4); std::memcpy(&b2, &sd.scz, 4); ++count[{ a, b2 }]; }

@@ -325,7 +325,8 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.seed_cap = kSeedC; c.lists = b.lists_c + (size_t)slot * b.lists_c_stride;
     c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
     c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = member ? window_b : window_c;
-    c.max_rounds = member && max_rounds_b > 0 ? max_rounds_b : 64 * (g.nnx + g.nnz) + 4096;
+    // (a bundle whose members' fronts have nothing in common re-evaluates without end: it gives up sixteen times sooner and its chunk goes unit by unit)
+    c.max_rounds = member ? (max_rounds_b > 0 ? max_rounds_b : 4 * (g.nnx + g.nnz) + 2048) : 64 * (g.nnx + g.nnz) + 4096;
     c.clocks = clocks ? clocks + (size_t)s * kClockSlots : nullptr;
     c.info = info + (size_t)s * 16 + 8;
     c.tie = tie ? tie + (size_t)s * 4 + 2 : nullptr; c.tie_threshold = tie_threshold;
