@@ -259,3 +259,26 @@ def test_bundled_receivers_at_scale_against_the_oracle(bundles):
     parity_log.add(f"bundled receivers at scale N=1025 smooth: {d.size} receiver times of {nsrc * nper} units in {nsrc} bundles of 16, max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())}, "
                    f"not bit-identical {int((bits(t) != bits(ref)).sum())}")
     assert d.max() <= TOL
+
+
+def test_bundles_in_a_chunked_call(bundles):
+    """a call cut into several launches (max_chunk): the launches cut the unit list by periods, so every launch bundles the periods it
+    holds of each source (3-4 of the 8 here) -- same receiver times as one launch and as unit by unit"""
+    e = bundles
+    nx, nsrc, nper, nrec = 33, 10, 8, 5
+    pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, nrec)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    out = {}
+    try:
+        for tag, G, chunk in (("solo", 0, 0), ("one", 8, 0), ("cut", 8, 35), ("cut4", 4, 27)):
+            e.set_option("bundle", G)
+            e.set_option("max_chunk", chunk)
+            out[tag] = e.traveltimes(**u)
+            st = e.stats()
+            if tag == "one": assert st["bundles"] == nsrc
+            if tag.startswith("cut"): assert st["launches_fim_coarse"] >= 3 and st["bundles"] > nsrc
+    finally:
+        e.set_option("max_chunk", 0)
+    for tag in ("one", "cut", "cut4"):
+        assert np.array_equal(bits(out[tag]), bits(out["solo"])), tag
