@@ -11,6 +11,8 @@
 //      (what the pilot's own changes do): the window waits for the member that settles last, and a cycle in any member is seen inside it
 //   5  PILOT + hold-back for SMALL changes only (the new value within a few ulps of the old one: a cycle among ulp-tied nodes, or a last
 //      refinement): cycles of any member then stall the window as they do in a solo run, everything else runs as under rule 2
+//   6  PILOT, and a node waits for its SECOND earliest neighbour to be inside the window (or for the earliest to lie `pilot` per cent of a window
+//      back: the parameter is passed in the pilot argument, the pilot is member 0): fewer evaluations, more rounds (sched_lab mode 9)
 //   3  EXACT: a pending bit per (node, member): a member is evaluated at a node exactly when its solo schedule would; the lanes of the
 //      members that are not due idle (reported as member fill)
 // build: g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -msse2 -mfpmath=sse -o tests/tools/libbundle_lab.so tests/tools/bundle_lab.cpp
@@ -153,9 +155,15 @@ extern "C" long lab_bundle(int G, int nnx, int nnz, float* Tio, float* tauio, co
                     if (tau_value(m.F[id].tau) < m.freeze) { if (rule == 3) pending[id] &= (unsigned short)~bit; continue; }
                     cand |= bit;
                     lb[g - g0] = lower_bound(m, iz0, ix0);
+                    if (rule == 6 && g == g0 && m.theta < kInf) {
+                        auto tv = [&](int z, int x) { return in_grid(z, x) ? tau_value(m.F[rec_index(nbz, z, x)].tau) : kInf; };
+                        float a[4] = { tv(iz0, ix0 - 1), tv(iz0, ix0 + 1), tv(iz0 - 1, ix0), tv(iz0 + 1, ix0) };
+                        std::sort(a, a + 4);
+                        if (a[1] < m.theta || a[0] < m.theta - m.window * 0.01f * (float)pilot) due |= bit;
+                    } else
                     if (!(m.theta < kInf) || lb[g - g0] < m.theta) due |= bit;
                 }
-                if (rule == 2 || rule == 4 || rule == 5) { const int pg = std::min(std::max(pilot, g0), g1 - 1) - g0; if ((cand >> pg) & 1) due = ((due >> pg) & 1) ? cand : 0; else due = due ? cand : 0; }   // (the pilot pinned or frozen here: any member)
+                if (rule == 2 || rule == 4 || rule == 5 || rule == 6) { const int pg = rule == 6 ? 0 : std::min(std::max(pilot, g0), g1 - 1) - g0; if ((cand >> pg) & 1) due = ((due >> pg) & 1) ? cand : 0; else due = due ? cand : 0; }   // (the pilot pinned or frozen here: any member)
                 if (rule == 1 || rule == 0) due = due ? cand : 0;
                 const int par = (iz0 + ix0) & 1;
                 if (!cand) { queued[id] = 0; continue; }

@@ -40,7 +40,7 @@ ris = np.zeros(N, np.float32); geom = np.zeros(4, np.float32); win = np.zeros(G,
 for p in range(G):
     pv = medium(p)
     assert H.hc_coarse_problem(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8, L.ptr(pv), sx[isrc], sz[isrc], L.ptr(T0[p]), L.ptr(tau0[p]), L.ptr(slow[p]), L.ptr(ris), L.ptr(geom)) == 0
-    win[p] = np.float32(1.25) * geom[3]
+    win[p] = np.float32(float(os.environ.get('LAB_WINDOW', '1.25'))) * geom[3]
 ref = None; solo = None
 for rule in rules:
     T = T0.copy(); tau = tau0.copy(); out = np.zeros(16, np.int64)
