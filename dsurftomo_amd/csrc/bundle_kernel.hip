@@ -81,15 +81,35 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
     const int nmem = bd->nmem;
     if (tid < kBundleMax) { s_member[tid] = bd->member[tid < nmem ? tid : 0]; s_map[tid] = bd->map[tid < nmem ? tid : 0]; }
     const FimProblem p = problems[bd->member[0]];      // grid, window, tables: the same for all members
-    BGChar* const Bb = (BGChar*)bd->B;
-    BGChar* const excb = (BGChar*)bd->exc;
+    // the bundle's field slot: its own, or the first free one of the pool (claimed by thread 0; released at the very end)
+    __shared__ int s_slot;
+    if (tid == 0) {
+        int slot = bd->slot;
+        if (bd->slot_busy) {
+            const int P = bd->nslots;
+            int s0 = (int)(blockIdx.x % (unsigned)P), q = s0;
+            for (;;) {
+                if (atomicCAS(&bd->slot_busy[q], 0, 1) == 0) break;
+                q = q + 1 == P ? 0 : q + 1;
+                if (q == s0) __builtin_amdgcn_s_sleep(64);
+            }
+            __threadfence();                            // (what the slot's previous user wrote is behind us)
+            slot = q;
+        }
+        s_slot = slot;
+    }
+    __syncthreads();
+    const int my_slot = s_slot;
+    float* const Bslot = bd->B + (size_t)my_slot * bd->b_stride;
+    BGChar* const Bb = (BGChar*)Bslot;
+    BGChar* const excb = (BGChar*)(bd->exc + (size_t)my_slot * bd->exc_stride);
     const int xlog = bd->exc_log2cap;
     BGChar* const slowb = (BGChar*)bd->slowI;
     const unsigned npb = (unsigned)bd->np * 4u;         // bytes of slowness per node
     BGCF32* const risti = (BGCF32*)p.risti;
     const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
     const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
-    BGChar* const maskb = (BGChar*)bd->lists;
+    BGChar* const maskb = (BGChar*)(bd->lists + (size_t)my_slot * bd->lists_stride);
     constexpr int kMaskShift = 5;
     auto mask_at = [&](int tile) -> BGU64* { return (BGU64*)(maskb + ((size_t)(unsigned)tile << kMaskShift)); };
     unsigned* const tb = dyn_lds;
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
     // The pilot's value of a node (member 0), from its dense shadow copy P (one float per node, tiled like the field): pass A routes ~700
     // listed nodes per round by five pilot values each, and reading them from the member-minor field moved a 128-byte line per value --
     // two thirds of the kernel's fetched bytes (profiles/r03_bundle_sizes.log).  Written next to the field by the lane that owns member 0.
-    BGChar* const Pb = (BGChar*)bd->P;
+    BGChar* const Pb = (BGChar*)(Bslot + bd->p_offset);
     auto pv = [&](int id) -> float { return *(BGF32*)(Pb + ((unsigned)id << 2)); };
 
     // ---- the bundle's field slot: wait for its previous user; every node of every member unreached, the table empty; the nodes each
@@ -141,11 +161,6 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
     __syncthreads();
     bool dead = false;
     {
-        int* const pg = bd->pool_gen;
-        if (pg) {
-            if (tid == 0) { const int want = bd->gen; while (__hip_atomic_load(pg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(64); }
-            __syncthreads();
-        }
         const BV4 inf4 = { kInf, kInf, kInf, kInf };
         for (int i = tid; i < ntile * (kTileRecs * G / 4); i += NT) ((BGV4*)Bb)[i] = inf4;
         for (int i = tid; i < ntile * (kTileRecs / 4); i += NT) ((BGV4*)Pb)[i] = inf4;
@@ -624,7 +639,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 const RayDesc rd = E->rays[r];
                 if (!(rd.flags & kRayTime)) continue;
                 float t;
-                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)bd->B + m, E->veln, E->dpl, &t, G)) atomicExch(E->err, E->ray0 + r + 1);
+                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)Bslot + m, E->veln, E->dpl, &t, G)) atomicExch(E->err, E->ray0 + r + 1);
                 E->out[rd.data] = t;
             }
         }
@@ -650,10 +665,10 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 }
             }
     }
-    if (bd->pool_gen) {
+    if (bd->slot_busy) {
         __threadfence();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(bd->pool_gen, bd->gen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&bd->slot_busy[my_slot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -681,7 +681,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
         if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
         const long nb = std::min<long>(bundles_with(G), (long)step);
-        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), bundle_threads() == 512 ? 288 : 512);      // (bundles resident at a time, and a few more)
+        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), bundle_threads() == 512 ? 288 : 576);      // (bundles resident at a time, and a few more)
         return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.6 * (double)free_b);
     };
     if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) {
@@ -758,22 +758,24 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     const size_t slot_b = (size_t)(G + 1) * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
     const size_t room = (size_t)(0.7 * (double)free_b) / slot_b;
     if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
-    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (bundle_threads() == 512 ? 512 : 1024)), room });
+    // field slots: one per bundle, or -- more bundles than the chip holds at a time -- as many as can be resident and a few more; a bundle
+    // claims a free one when it starts (FimBundle::slot_busy)
+    const size_t resident = bundle_threads() == 512 ? 256 : 512;
+    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (int)(resident + resident / 8)), room });
     const size_t BS = (size_t)bundle_slots;
-    if (ensure(B_pool, BS * (G + 1) * nrec_c) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
+    const size_t b_stride = (size_t)(G + 1) * nrec_c;
+    if (ensure(B_pool, BS * b_stride) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
     if (!slowI_ready) { launch_interleave_maps(slow.p, nrec_c, nmaps, slowI.p, stream); slowI_ready = true; }
     h_bundles.assign((size_t)nb, FimBundle{});
     int rank = nsolo;
     for (int k = 0; k < nb; ++k) {
         FimBundle& bd = h_bundles[(size_t)k];
-        const int slot = k % bundle_slots;
-        bd.B = B_pool.p + (size_t)slot * (G + 1) * nrec_c;
-        bd.P = bd.B + (size_t)G * nrec_c;
-        bd.exc = exc_b.p + ((size_t)slot << xlog_b); bd.exc_log2cap = xlog_b;
+        bd.B = B_pool.p; bd.b_stride = b_stride; bd.p_offset = (size_t)G * nrec_c;
+        bd.exc = exc_b.p; bd.exc_stride = (size_t)1 << xlog_b; bd.exc_log2cap = xlog_b;
+        bd.lists = lists_b.p; bd.lists_stride = lists_c_stride;
+        bd.slot_busy = bundle_slots < nb ? bpool_gen.p : nullptr; bd.nslots = bundle_slots; bd.slot = bundle_slots < nb ? 0 : k;
         bd.slowI = slowI.p; bd.np = nmaps;
-        bd.lists = lists_b.p + (size_t)slot * lists_c_stride;
-        bd.pool_gen = bundle_slots < nb ? bpool_gen.p + slot : nullptr; bd.gen = k / bundle_slots;
         bd.nmem = (int)pieces[(size_t)k].second.size();
         for (int m = 0; m < kBundleMax; ++m) { bd.member[m] = 0; bd.map[m] = 0; }
         for (int m = 0; m < bd.nmem; ++m) {

@@ -95,14 +95,22 @@ struct FimLaunch {
 // mixtures of patterns, +56 % for unrelated random maps), so each member's field is the one its own solve produces.
 constexpr int kBundleMax = 16;
 struct FimBundle {
-    float* B;                     // G floats per node record, tiled like the compact field
-    float* P;                     // member 0's values once more, one float per node (what pass A routes by)
-    unsigned long long* exc;      // exception table of the bundle, keyed by id * G + m
+    // the pool of bundle field slots (round 3, late: a bundle CLAIMS a free slot when it starts -- `slot_busy`, one flag per slot -- instead
+    // of being given one by number: with the bundles launched longest first, "slot = number mod slots" made the second generation wait
+    // for the longest bundles of the first, +37 % at the headline size with 768 slots for 1000 bundles; claimed slots need no more than the
+    // bundles resident at a time)
+    float* B;                     // slot 0: G floats per node record, tiled like the compact field; then member 0's values once more, one float
+    size_t b_stride;              //         per node (what pass A routes by), at B + G * nrec; floats per slot
+    unsigned long long* exc;      // slot 0: exception table of the bundle, keyed by id * G + m
+    size_t exc_stride;            //         entries per slot = 2^exc_log2cap
     int exc_log2cap;
+    int* lists;                   // slot 0: tile records of the shared active set (kFimMaskInts ints per tile)
+    size_t lists_stride;
+    size_t p_offset;              // floats from a slot's B to its P
+    int* slot_busy;               // null: the bundle owns slot `slot` (as many slots as bundles)
+    int nslots, slot;
     const float* slowI;           // member-minor slowness of all maps: slowI[id * np + map]
     int np;
-    int* lists;                   // tile records of the shared active set (kFimMaskInts ints per tile)
-    int* pool_gen; int gen;       // the bundle slot's use counter (null: the slot is this bundle's alone)
     int nmem;
     int member[kBundleMax];       // indices into the launch's FimProblem / FimEnds arrays (grid, seeds, window records, receivers, info)
     int map[kBundleMax];
