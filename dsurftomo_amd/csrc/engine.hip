@@ -682,7 +682,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
         const long nb = std::min<long>(bundles_with(G), (long)step);
         const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), bundle_threads() == 512 ? 288 : 576);      // (bundles resident at a time, and a few more)
-        return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.6 * (double)free_b);
+        return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.7 * (double)free_b);      // (what plan_bundles allows itself)
     };
     if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) {
         if (!(fits(bundle_opt) && bundles_with(bundle_opt) > 0)) return 0;
