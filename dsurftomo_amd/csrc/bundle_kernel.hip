@@ -16,7 +16,9 @@
 // activations go to the shared masks), so the fixed point is reached for every member -- tests/tools/bundle_lab.cpp replays exactly this
 // schedule on the CPU with the product's solve_node and compares every member with its solo run, bit for bit.
 // Cycles (exact 2-cycles among ulp-tied nodes, fim_kernel.hip): detected on the bundle's combined change hash, frozen by the pilot's
-// acceptance times.  A bundle that does not converge reports -1 to all its members and the engine solves them one by one.
+// acceptance times; a cycle far behind the front pulls the window back to itself first (pass B, "stale" changes).  A bundle that runs out
+// of rounds -- members whose fronts have nothing in common -- reports -1 to all its members and the engine solves them one by one.
+// Field slots: a bundle claims a free one of the pool when it starts and releases it at the end (FimBundle::slot_busy).
 #include "kernels.h"
 #include "receiver_core.h"
 #include "wave_ops.h"
@@ -51,7 +53,7 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 
 }  // namespace
 
-#ifdef DSA_BUNDLE_WAVES      // experiments: waves per SIMD the register allocation aims at (default: what 256 threads allow, 2 at ~217 VGPRs)
+#ifdef DSA_BUNDLE_WAVES      // experiments: waves per SIMD the register allocation aims at (default: what 256 threads allow, 2 at 207 VGPRs)
 #define DSA_BUNDLE_OCC __attribute__((amdgpu_waves_per_eu(DSA_BUNDLE_WAVES, DSA_BUNDLE_WAVES)))
 #else
 #define DSA_BUNDLE_OCC
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
     BGChar* const Pb = (BGChar*)(Bslot + bd->p_offset);
     auto pv = [&](int id) -> float { return *(BGF32*)(Pb + ((unsigned)id << 2)); };
 
-    // ---- the bundle's field slot: wait for its previous user; every node of every member unreached, the table empty; the nodes each
-    // member's serial prologue pinned (window records, k_coarse_march) into both
+    // ---- the bundle's field slot (claimed above): every node of every member unreached, the table empty; the nodes each member's serial
+    // prologue pinned (window records, k_coarse_march) into both
     __syncthreads();
     bool dead = false;
     {
