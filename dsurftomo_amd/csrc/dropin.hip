@@ -272,7 +272,10 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
         if (r != 0) return bad(r);
         long long nclamped = 0;
         int fu = -1;
-        if (dsa_ray_diagnostics(e, &nclamped, &fu) == 0 && fu >= 0) P.first_clamped = ne == 1 ? fu : P.units[(size_t)fu];       // unit of the whole call
+        // (an engine that was given no sources did not solve: its diagnostics are those of an earlier call)
+        const bool solved = ne == 1 || !P.units.empty();
+        if (solved && dsa_ray_diagnostics(e, &nclamped, &fu) == 0 && fu >= 0 && (ne == 1 ? fu < nu : (size_t)fu < P.units.size()))
+            P.first_clamped = ne == 1 ? fu : P.units[(size_t)fu];       // unit of the whole call
         dsa_dispersion_diagnostics(e, &P.disp_count, P.disp_first, &P.disp_period);
     };
     if (ne == 1) work(0);

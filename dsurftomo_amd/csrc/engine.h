@@ -104,10 +104,11 @@ struct Engine {
     // again by the literal Fast Marching; 2 = every unit by the literal Fast Marching only
     int exact_ties = 0;
     float tie_threshold = 2.0e-5f;     // a tie counts when taking the tied neighbour in moves the node's value by more than this (s); 0 = any tie
-    int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each); 0 = by the number of units marching (768 .. 16384)
-    int exact_pool = 0;                // units marching at a time (0 = by free memory, at most 4096)
+    int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each, made odd); 0 = by the number of units marching (.. 4799)
+    int exact_pool = 0;                // units marching at a time (0 = by free memory, at most 10 240)
     DevBuf<unsigned long long> X_pool, X_heap;   // per marching unit: (T, status) records of the whole grid; tree slots beyond the LDS part
-    DevBuf<int> x_units;
+    DevBuf<int> x_units, x_nstart;
+    DevBuf<unsigned long long> x_starts;         // the coarse stage's starting tree per marching unit (kernels.h: exact_start_bytes)
     DevBuf<int32_t> xinfo, tieinfo;
     std::vector<unsigned char> h_unit_flags;     // per planned unit after a solve: bit 0 tie met, bit 1 solved by the exact mode
     std::vector<int> h_unit_rounds;               // rounds of the unit's coarse solve (of its bundle's, for a bundled unit)

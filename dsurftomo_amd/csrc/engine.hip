@@ -90,7 +90,7 @@ Engine::~Engine()
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
-    rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(X_pool); rel(X_heap); rel(x_units); rel(xinfo); rel(tieinfo);
+    rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(X_pool); rel(X_heap); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -411,6 +411,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = true;
     last_chunk_first = -1;
+    rays_clamped = 0; first_clamped_unit = -1;      // (diagnostics belong to the plan they were measured on)
     return 0;
 }
 
@@ -798,34 +799,36 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
 int Engine::run_exact(int first, int n, const std::vector<int>& xl)
 {
     (void)n;
-    // tree slots in LDS per marching unit: the option, or (0) as many as let all the units of the call march at once -- 16 workgroups per
-    // CU at 768 slots is the measured optimum for thousands of units; a few hundred units at 4097^2 (trees of ~16 k entries) get the whole CU
-    int lcap = exact_lds_slots;
-    if (lcap <= 0) {
-        const size_t per_cu = (xl.size() + 255) / 256;
-        const size_t bytes = (size_t)150 * 1024 / std::max<size_t>(per_cu, 1);
-        const long fit = bytes > exact_lds_bytes(0) ? (long)((bytes - exact_lds_bytes(0)) / 8) : 0;
-        lcap = (int)std::min<long>(std::min<long>(fit, 4L * (g.nnx + g.nnz) + 1024), 16384);
-        lcap = std::max(lcap, 768);
-    }
-    lcap = std::max(64, lcap);
-    const int gcap = 16 * (g.nnx + g.nnz) + 4096;
-    const size_t per = nrec_c * 8 + (size_t)gcap * 8;
+    // (a tree holds at most 65 535 nodes -- sixteen levels, one per lane of a unit's group; narrow bands are a few times nnx + nnz)
+    const int gcap_max = std::min(16 * (g.nnx + g.nnz) + 4096, 65534);
+    const size_t per = nrec_c * 8 + (size_t)gcap_max * 8 + exact_start_bytes() + 4;
     size_t pool = (size_t)exact_pool;
     if (!pool) {
+        // units marching at a time: as many as half the free memory holds, at most 10 240 (four units per wavefront: ten wavefronts per CU)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
-        const size_t have = X_pool.cap * 8 + X_heap.cap * 8;
-        pool = std::min<size_t>(4096, std::max<size_t>(1, (size_t)(0.5 * (double)(free_b + have)) / per));
+        const size_t have = X_pool.cap * 8 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4;
+        pool = std::min<size_t>(10240, std::max<size_t>(1, (size_t)(0.5 * (double)(free_b + have)) / per));
     }
     pool = std::min(pool, xl.size());
-    if (ensure(X_pool, pool * nrec_c) || ensure(X_heap, pool * (size_t)gcap)) return status;
-    if (exact_lds_bytes(lcap) > 156 * 1024) { fail(DSA_ERR_ARGUMENT, "exact_lds_slots %d needs more than 156 KB of LDS", lcap); return DSA_ERR_ARGUMENT; }
+    // tree slots in LDS per marching unit (odd: the two children of a slot then lie on one side of the LDS / global split): the option, or
+    // (0) what lets all the wavefronts of a batch be resident -- a wavefront holds four units' tree tops, 8 bytes per slot
+    int lcap = exact_lds_slots;
+    if (lcap <= 0) {
+        const size_t waves_per_cu = std::max<size_t>(1, ((pool + 3) / 4 + 255) / 256);
+        const size_t bytes = (size_t)156 * 1024 / waves_per_cu;
+        const long fit = (long)(bytes / 32) - 1;
+        lcap = (int)std::min<long>(std::min<long>(fit, 4L * (g.nnx + g.nnz) + 1023), 4799);
+    }
+    lcap = std::max(63, lcap) | 1;
+    const int gcap = std::min(gcap_max, 65534 - lcap) & ~1;
+    if (exact_lds_bytes(lcap) > 156 * 1024) { fail(DSA_ERR_ARGUMENT, "exact_lds_slots %d needs more than 156 KB of LDS (four units per wavefront)", lcap); return DSA_ERR_ARGUMENT; }
+    if (ensure(X_pool, pool * nrec_c) || ensure(X_heap, pool * (size_t)gcap) || ensure(x_starts, pool * (exact_start_bytes() / 8)) || ensure(x_nstart, pool)) return status;
     HIP_TRY(this, hipMemcpyAsync(x_units.p, xl.data(), xl.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemsetAsync(xinfo.p, 0, (size_t)n * 16, stream));
     for (size_t k = 0; k < xl.size(); k += pool) {
         const int m = (int)std::min(pool, xl.size() - k);
-        launch_exact(g, batch(), x_units.p + k, m, slow.p, nrec_c, risti_c.p, X_pool.p, nrec_c, X_heap.p, gcap, lcap, xinfo.p, stream);
+        launch_exact(g, batch(), x_units.p + k, m, slow.p, nrec_c, risti_c.p, X_pool.p, nrec_c, X_heap.p, gcap, lcap, x_starts.p, x_nstart.p, xinfo.p, stream);
     }
     HIP_TRY(this, hipGetLastError());
     std::vector<int32_t> h_x((size_t)n * 4);
@@ -833,7 +836,7 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl)
     HIP_TRY(this, hipStreamSynchronize(stream));
     for (int u : xl) {
         const int32_t* x = &h_x[(size_t)u * 4];
-        if (x[2]) { fail(DSA_ERR_INTERNAL, "unit %d: exact march guard %d (1 tree capacity %d, 2 step log)", first + u, x[2], lcap + gcap); return DSA_ERR_INTERNAL; }
+        if (x[2]) { fail(DSA_ERR_INTERNAL, "unit %d: exact march guard %d (1: tree capacity %d)", first + u, x[2], lcap + gcap); return DSA_ERR_INTERNAL; }
         stats[DSA_STAT_EXACT_POPS] += (double)x[0] + (double)x[1];
         h_unit_flags[(size_t)(first + u)] |= 2;
     }
@@ -1111,7 +1114,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
-    if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 19000))) { en->exact_lds_slots = (int)value; return 0; }
+    if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4991))) { en->exact_lds_slots = (int)value; return 0; }
     if (n == "exact_pool" && value >= 0) { en->exact_pool = (int)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);

@@ -1,46 +1,362 @@
-// K3x: exact mode of the eikonal solve -- the reference's Fast Marching replayed literally, one wavefront per unit
+// K3x: exact mode of the eikonal solve -- the reference's Fast Marching replayed literally, four units per wavefront
 // (exact_march.h; reference CalSurfG.f90:288-487 `travel`, :587-759 `fouds2`, :768-921 the tree, :1287-1349 the hand-off).
 // The engine runs it for the units whose fixed-point solve met an exact time tie (option exact_ties = 1) or for all of them
 // (exact_ties = 2); it replaces the unit's refined snapshot (Tfin_r, S_r) and its compact coarse field with the march's own.
 #include "kernels.h"
 
+#include <algorithm>
+
 #include "exact_march.h"
 
 namespace dsa {
 
-__global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int* __restrict__ units, int n,
-                                             const float* __restrict__ slow_all, size_t field_stride, const float* __restrict__ risti_c,
-                                             XRec* pool, size_t pool_stride, XEntry* heap_pool, int gcap, int lcap, int32_t* xinfo)
+// ================================================================================================================================
+// Round 4: FOUR units per wavefront.  Round 3's march -- one wavefront per unit -- was bound by the SCALAR unit (one per CU: ~1000 scalar
+// instructions per accept, 1165 cycles per accept per CU measured against 1000 predicted), because everything sequential -- the tree, the
+// statuses -- was made wave-uniform.  Here a unit owns a GROUP of sixteen lanes (the sixteen quadrant lanes of the stencil, as before) and
+// a wavefront carries four groups: what was scalar is vector work that serves four units at once (the tree arithmetic is done alike by the
+// sixteen lanes of a group, stores are issued by the group's first lane), and the four units' marches run in lockstep, each in its own
+// exec-masked control flow.  Per accept step of a group:
+//   * root from the tree (LDS), its coordinates, the record indices of its four neighbours and of the quadrant each lane owns;
+//   * six loads per lane (the quadrant's four stencil records, the neighbour's slowness, its column's risti), in flight while
+//   * the root leaves the tree (reference downtree, :800-858): one 16-byte read per level (both children); lane l of the group keeps the
+//     move of level l, and all moves -- tree entry (LDS / global beyond lcap) and the moved node's status (its slot; reference nsts) -- are
+//     stored in ONE pass behind the walk;
+//   * the neighbours' statuses are read AFTER those stores (the wave's memory operations on one address keep their order), so a slot is
+//     never stale from the root's removal -- the step log of the one-wavefront kernel is gone --, and their latency hides behind
+//   * the quadrant candidates (exact_march.h: x_quad_candidates, fouds2's own expressions), the 4-lane minimum per neighbour (DPP);
+//   * the four neighbours in the reference's order x-, x+, z-, z+: trial value stored, the node added (far) or moved up (in the tree;
+//     reference updtree / addtree, towards the root while strictly smaller) -- WITHOUT a loop: the ancestors of a slot are known in advance,
+//     the group reads fifteen of them at once, votes, and stores the moves in one pass (xg_sift_up); the sixteenth lane checks that the
+//     node still sits where its status said (an earlier neighbour's moves of the same step may have pushed it down a level).
+// Same tree, same insertion order, same comparisons: the same field as the reference's Fast Marching, bit for bit (tests/test_gpu_exact.py).
+// The stages around the marches (resetting the fields, snapshot + hand-off, the compact copy) are kernels of their own, all lanes busy.
+
+// exchange inside a group of four lanes: quad_perm [1,0,3,2] (the other k) and [2,3,0,1] (the other j)
+__device__ __forceinline__ int x_dpp_other_k(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
+__device__ __forceinline__ int x_dpp_other_j(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }
+__device__ __forceinline__ float x_dpp_min4(float v)
+{
+    float o = __int_as_float(x_dpp_other_k(__float_as_int(v)));
+    v = (o < v) ? o : v;
+    o = __int_as_float(x_dpp_other_j(__float_as_int(v)));
+    return (o < v) ? o : v;
+}
+
+struct XStart { int id; float T; };          // one node of the coarse stage's starting tree (reference scan order ix outer, iz inner, :341-347)
+
+// (explicit address spaces: a tree slot lives in LDS or in global memory, and with generic pointers the compiler folds the two reads into ONE
+// flat load -- whose wait also covers every global load in flight, i.e. the stencil fetch the tree work is meant to hide)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSA_GLB __attribute__((address_space(1)))
+#else
+#define DSA_GLB
+#endif
+struct XG {                                  // the march of one unit; every lane of its group holds the same values
+    DSA_GLB XRec* F; DSA_GLB const float* slow; DSA_GLB const float* risti;
+    int nbz, nnx, nnz; unsigned nbz_inv;
+    float ri, dnx, dnz;
+    DSA_LDS XEntry* hl; DSA_GLB XEntry* hg;
+    int lcap, gcap;
+    int ntr, err;
+    unsigned pops;
+};
+
+// Tree entries move as 8- / 16-byte vectors through pointers of an EXPLICIT address space.  (Copying an XEntry struct goes through its
+// implicit copy constructor, i.e. through a generic reference: the compiler then folds "slot in LDS ? LDS read : global read" into ONE flat
+// load of a selected generic pointer -- a load that counts on both memory counters, so that waiting for it also waits for every global
+// load in flight: the stencil fetch the tree work is meant to hide.)
+typedef float xf2 __attribute__((ext_vector_type(2)));
+typedef float xf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ XEntry xg_entry(xf2 v) { return XEntry{ v.x, __float_as_int(v.y) }; }
+__device__ __forceinline__ xf2 xg_vec(XEntry e) { xf2 v; v.x = e.key; v.y = __int_as_float(e.id); return v; }
+// slot s of the tree; the lanes of a group may ask for different slots.  The LDS read is unconditional (slot 1 stands in for a slot
+// beyond the LDS part), the global one sits behind a branch the whole wavefront skips when no lane needs it
+__device__ __forceinline__ XEntry xg_get(const XG& m, int s)
+{
+    xf2 v = *(DSA_LDS const xf2*)(m.hl + (s <= m.lcap ? s : 1));
+    if (s > m.lcap) v = *(DSA_GLB const xf2*)(m.hg + (s - m.lcap - 1));
+    return xg_entry(v);
+}
+// entry into slot s -- the tree and the node's status (reference nsts) -- for the lanes with `on`; the lanes hold different (slot, entry)
+// pairs.  LDS slot 0 is nobody's: lanes that have nothing for the LDS part write there instead of branching around the store
+__device__ __forceinline__ void xg_put(XG& m, bool on, int s, XEntry e)
+{
+    *(DSA_LDS xf2*)(m.hl + ((on && s <= m.lcap) ? s : 0)) = xg_vec(e);
+    if (on) {
+        if (s > m.lcap) *(DSA_GLB xf2*)(m.hg + (s - m.lcap - 1)) = xg_vec(e);
+        m.F[e.id].st = s;
+    }
+}
+// the sixteen bits of a group in a wavefront-wide vote
+__device__ __forceinline__ unsigned xg_vote16(bool c, int lane) { return (unsigned)(__ballot(c) >> (lane & 48)) & 0xffffu; }
+
+// reference updtree / the tail of addtree (:768-790, :906-920): entry e, at slot s, moves towards the root while strictly smaller than
+// its parent.  The ancestors of a slot are known in advance (s >> 1, s >> 2, ...), so the group reads fifteen of them at once (lane l:
+// ancestor l + 1), votes on `e.key < ancestor's key`, and the run of ancestors BELOW the first one that says no -- the literal loop's
+// moves; the reference's tree is not always a valid heap, so it is the first no that counts, not the last yes -- goes one level down in
+// one store pass.  `check` (the entry was in the tree; s is the status read behind the root's removal): lane 15 reads slot s itself and
+// checks that the node is still there -- an earlier neighbour's moves of this step may have pushed it down a level; then the status is
+// read again (the wave's stores and loads on one address keep their order).  (A tree has at most sixteen levels: xg capacity.)
+// (one attempt: false when lane 15 found another node at slot s -- nothing is stored then)
+__device__ __forceinline__ bool xg_sift_try(XG& m, XEntry e, int s, bool check, int gl, int lane)
+{
+    const int a = gl < 15 ? (s >> (gl + 1)) : s;
+    const bool have = a >= 1 && (gl < 15 || check);
+    const XEntry p = xg_get(m, have ? a : 1);
+    const bool c = gl < 15 ? (have && e.key < p.key) : (check && p.id != e.id);
+    const unsigned b = xg_vote16(c, lane);
+    if (b & 0x8000u) return false;
+    const int moves = __builtin_ctz(~b);
+    xg_put(m, gl < moves, s >> gl, p);
+    xg_put(m, gl == 15, s >> moves, e);
+    return true;
+}
+__device__ __forceinline__ void xg_sift_up(XG& m, XEntry e, int s, bool check, int gl, int lane)
+{
+    if (!xg_sift_try(m, e, s, check, gl, lane)) {
+        // (rare: the node was pushed down a level by an earlier neighbour of this step; its status says where to)
+        s = m.F[e.id].st;
+        (void)xg_sift_try(m, e, s, false, gl, lane);
+    }
+}
+__device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lane)
+{
+    if (m.ntr + 1 > m.lcap + m.gcap) { m.err = 1; return; }
+    m.ntr += 1;
+    xg_sift_up(m, XEntry{ key, id }, m.ntr, false, gl, lane);
+}
+// reference downtree (:800-858): the last entry replaces the root and sinks; of two children with equal keys the left one is taken
+// (`>`), a child moves up only when strictly smaller.  The walk down reads one 16-byte pair of children per level (lcap is odd: the
+// children (tpc, tpc + 1), tpc even, lie on one side of the LDS / global split together, 16-byte aligned on either side) and leaves the
+// move of level l with lane l of the group (at most fifteen moves and the sinking entry itself: sixteen levels); the moves -- tree
+// entries and statuses -- are stored in one pass behind the walk.  Two loops, the levels in LDS and the levels beyond, so that the first
+// carries no code of the second; no branches inside a level.
+#define DSA_XG_LEVEL(PAIR)                                                                   \
+    {                                                                                        \
+        const xf4 c = (PAIR);                                                                \
+        const bool right = c.x > c.z;                                                        \
+        const float ak = right ? c.z : c.x;                                                  \
+        const int ai = __float_as_int(right ? c.w : c.y);                                    \
+        tpc += right ? 1 : 0;                                                                \
+        const bool mv = ak < e.key;                                                          \
+        const bool cap = mv && gl == level;                                                  \
+        mine.key = cap ? ak : mine.key; mine.id = cap ? ai : mine.id; mydst = cap ? tpp : mydst; \
+        level += mv ? 1 : 0; tpp = mv ? tpc : tpp; tpc = mv ? 2 * tpc : m.ntr + 1;          \
+    }
+__device__ __forceinline__ void xg_pop_root(XG& m, int gl)
+{
+    if (m.ntr == 1) { m.ntr = 0; return; }
+    const XEntry e = xg_get(m, m.ntr);
+    m.ntr -= 1;
+    int tpp = 1, tpc = 2, level = 0, mydst = 0;
+    XEntry mine = e;
+    const int lim = m.ntr < m.lcap ? m.ntr : m.lcap;
+    while (tpc < lim) DSA_XG_LEVEL(*(DSA_LDS const xf4*)(m.hl + tpc))
+    while (tpc < m.ntr) DSA_XG_LEVEL(*(DSA_GLB const xf4*)(m.hg + (tpc - m.lcap - 1)))
+    if (tpc == m.ntr) {
+        const XEntry a = xg_get(m, tpc);
+        const bool mv = a.key < e.key, cap = mv && gl == level;
+        mine.key = cap ? a.key : mine.key; mine.id = cap ? a.id : mine.id; mydst = cap ? tpp : mydst;
+        level += mv ? 1 : 0; tpp = mv ? tpc : tpp;
+    }
+    if (gl == level) { mine = e; mydst = tpp; }
+    xg_put(m, gl <= level, mydst, mine);
+}
+#undef DSA_XG_LEVEL
+
+// value of the lane at byte address 4 * lane of the wavefront
+__device__ __forceinline__ int xg_from_lane(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
+
+// what a lane is within its group, fixed for the whole march: lane 4 q + 2 j + k owns quadrant (j: the x- / x+ side, k: the z- / z+ side)
+// of neighbour q (x-, x+, z-, z+) of whatever node is being accepted
+struct XLane {
+    int gl, j, k;
+    int dx, dz;          // neighbour q's offset from the accepted node
+    int xs, zs;          // the quadrant's direction: -1 / +1
+    bool rootj, rootk;   // the accepted node IS this quadrant's x / z stencil neighbour (it lies on the far side of neighbour q)
+    int base;            // byte address of the group's first lane (ds_bpermute)
+};
+__device__ __forceinline__ XLane xg_lane(int lane)
+{
+    XLane L;
+    L.gl = lane & 15;
+    const int q = L.gl >> 2;
+    L.j = (L.gl >> 1) & 1; L.k = L.gl & 1;
+    L.dx = q == 0 ? -1 : q == 1 ? 1 : 0;
+    L.dz = q == 2 ? -1 : q == 3 ? 1 : 0;
+    L.xs = L.j ? 1 : -1; L.zs = L.k ? 1 : -1;
+    L.rootj = (q == 0 && L.j == 1) || (q == 1 && L.j == 0);
+    L.rootk = (q == 2 && L.k == 1) || (q == 3 && L.k == 0);
+    L.base = (lane & 48) << 2;
+    return L;
+}
+// record index of node (iz0, ix0), 0-based (eikonal_core.h rec_index; the tile product on the 24-bit multiplier)
+__device__ __forceinline__ int xg_rec(int nbz, int iz0, int ix0)
+{
+    return (int)(((__umul24((unsigned)ix0 >> 3, (unsigned)nbz) + ((unsigned)iz0 >> 3)) << 6) | (((unsigned)ix0 & 7u) << 3) | ((unsigned)iz0 & 7u));
+}
+
+// One accept step of reference travel (:417-485) for the group's unit.  No branches outside the tree work: a lane's loads are issued
+// whatever the grid's edges say (a node outside reads the root's record, which exists, and the value is dropped)
+__device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int ix0, const XLane& L, int lane)
+{
+    const bool lead = L.gl == 0;
+    // my neighbour, my quadrant of its stencil: coordinates, who lies inside the grid, record indices
+    const int mx0 = ix0 + L.dx, mz0 = iz0 + L.dz;
+    const bool in = (unsigned)mx0 < (unsigned)m.nnx && (unsigned)mz0 < (unsigned)m.nnz;
+    const int xj = mx0 + L.xs, xj2 = xj + L.xs, zk = mz0 + L.zs, zk2 = zk + L.zs;
+    const bool inj = in && (unsigned)xj < (unsigned)m.nnx, inj2 = in && (unsigned)xj2 < (unsigned)m.nnx;
+    const bool ink = in && (unsigned)zk < (unsigned)m.nnz, ink2 = in && (unsigned)zk2 < (unsigned)m.nnz;
+    const int mid = in ? xg_rec(m.nbz, mz0, mx0) : root.id;
+    const int idj = inj ? xg_rec(m.nbz, mz0, xj) : root.id, idj2 = inj2 ? xg_rec(m.nbz, mz0, xj2) : root.id;
+    const int idk = ink ? xg_rec(m.nbz, zk, mx0) : root.id, idk2 = ink2 ? xg_rec(m.nbz, zk2, mx0) : root.id;
+    // six loads per lane in flight while the root leaves the tree
+    const XRec vj = m.F[idj], vj2 = m.F[idj2], vk = m.F[idk], vk2 = m.F[idk2];
+    const float slown = m.slow[mid], risti = m.risti[in ? mx0 : 0];
+    if (lead) m.F[root.id].st = 0;
+    xg_pop_root(m, L.gl);
+    // my neighbour's status, behind the stores of the root's removal (outside the grid: the root's, 0 = nothing to do)
+    const int st_mem = m.F[mid].st;
+    const int st = in ? st_mem : 0;
+    XQuadState s;
+    s.ej = inj; s.ek = ink;
+    s.aj = inj && (vj.st == 0 || L.rootj);  s.oj = inj2 && vj2.st == 0;
+    s.ak = ink && (vk.st == 0 || L.rootk);  s.ok = ink2 && vk2.st == 0;
+    s.tj = vj.T; s.tj2 = vj2.T; s.tk = vk.T; s.tk2 = vk2.T;
+    const int dk = (s.ek && !s.ak) ? 1 : 0, dj = (s.ej && !s.aj) ? 1 : 0;
+    // (bitwise or: with `||` the exchange would sit behind a branch, and a lane that skips it reads as 0 to its partner)
+    const int dk_other = x_dpp_other_k(dk), dj_other = x_dpp_other_j(dj);
+    const bool k_dead = (dk | dk_other) != 0, j_dead = (dj | dj_other) != 0;
+    const NodeGeom g = { m.ri, risti, m.dnx, m.dnz };
+    const float c = x_quad_lane(s, k_dead, j_dead, L.j, L.k, slown, g);
+    const float trial = x_dpp_min4(in ? c : kInf);
+    // (fouds2 overwrites the trial value unconditionally, :758): the first lane of each neighbour's four stores it
+    if ((L.gl & 3) == 0 && st != 0) m.F[mid].T = trial;
+    // what the group needs to know of the four neighbours: lane 4 q of the group holds neighbour q's
+    const int tb = __float_as_int(trial);
+    const int st0 = xg_from_lane(L.base, st), st1 = xg_from_lane(L.base + 16, st), st2 = xg_from_lane(L.base + 32, st), st3 = xg_from_lane(L.base + 48, st);
+    const int id0 = xg_from_lane(L.base, mid), id1 = xg_from_lane(L.base + 16, mid), id2 = xg_from_lane(L.base + 32, mid), id3 = xg_from_lane(L.base + 48, mid);
+    const float tr0 = __int_as_float(xg_from_lane(L.base, tb)), tr1 = __int_as_float(xg_from_lane(L.base + 16, tb));
+    const float tr2 = __int_as_float(xg_from_lane(L.base + 32, tb)), tr3 = __int_as_float(xg_from_lane(L.base + 48, tb));
+    if (m.ntr + 4 > m.lcap + m.gcap) { m.err = 1; return; }
+    // the four neighbours in the reference's order: added (far: the next free slot) or moved up (in the tree)
+#define DSA_XG_NEIGHBOUR(stq, idq, trq)                                                                              \
+    if ((stq) != 0) {                                                                                                \
+        const bool isnew = (stq) < 0;                                                                                \
+        m.ntr += isnew ? 1 : 0;                                                                                      \
+        xg_sift_up(m, XEntry{ (trq), (idq) }, isnew ? m.ntr : (stq), !isnew, L.gl, lane);                            \
+    }
+    DSA_XG_NEIGHBOUR(st0, id0, tr0)
+    DSA_XG_NEIGHBOUR(st1, id1, tr1)
+    DSA_XG_NEIGHBOUR(st2, id2, tr2)
+    DSA_XG_NEIGHBOUR(st3, id3, tr3)
+#undef DSA_XG_NEIGHBOUR
+    m.pops += 1u;
+}
+
+// the marches of up to four units per wavefront, until every tree is empty.  REFINED: travel(urg = 1) on the refined boxes from the four
+// corners of the source cell; the reference's exit -- the root lies on an edge of the box that is not an edge of the model by the literal
+// test of :396-407 -- marks that node alive and stops.  Otherwise: travel(urg = 2) on the propagation grid from the hand-off's tree
+template <bool REFINED>
+__global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const int* __restrict__ units, int n, const float* __restrict__ slow_all,
+                                               size_t field_stride, const float* __restrict__ risti_c, XRec* pool, size_t pool_stride,
+                                               XEntry* heap_pool, int gcap, int lcap, const XStart* __restrict__ starts, const int* __restrict__ nstart,
+                                               int32_t* xinfo)
 {
     extern __shared__ unsigned char x_lds[];
+    const int lane = threadIdx.x, grp = lane >> 4;
+    const bool lead = (lane & 15) == 0;
+    const int slot = blockIdx.x * 4 + grp;
+    const bool live = slot < n;
+    const int s = units[live ? slot : n - 1];
+    XG m;
+    m.hl = (DSA_LDS XEntry*)x_lds + (size_t)grp * (size_t)(lcap + 1);
+    m.lcap = lcap; m.hg = (DSA_GLB XEntry*)(heap_pool + (size_t)(live ? slot : 0) * gcap); m.gcap = gcap;
+    m.ntr = 0; m.err = 0; m.pops = 0u; m.ri = g.earth;
+    int rnx = 0, rnz = 0, oxl = 0, oxh = 0, ozl = 0, ozh = 0;
+    if (REFINED) {
+        const SourceDesc* sd = b.src + s;
+        m.F = (DSA_GLB XRec*)(b.F_r + (size_t)s * kRefRecs); m.slow = (DSA_GLB const float*)(b.slow_r + (size_t)s * kRefRecs); m.risti = (DSA_GLB const float*)(b.risti_r + (size_t)s * kRefMax);
+        rnx = sd->rnx; rnz = sd->rnz; oxl = sd->open_xlo; oxh = sd->open_xhi; ozl = sd->open_zlo; ozh = sd->open_zhi;
+        x_set_grid(m, sd->nbz_r, rnx, rnz); m.dnx = sd->rdnx; m.dnz = sd->rdnz;
+        if (live) {
+            // the four corners of the source cell, values with distances in radians (:360-375)
+            const float* vc = b.vcorner + (size_t)s * 4;
+            float vss[2][2];
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) vss[i][j] = vc[i * 2 + j];
+            const float dsx = sd->dsx_r, dsz = sd->dsz_r;
+            const float vsrc = bilinear4(vss, m.dnx, m.dnz, dsx, dsz);
+            const int isx = sd->isx_r, isz = sd->isz_r;
+            for (int i = 1; i <= 2; ++i)
+                for (int j = 1; j <= 2; ++j) {
+                    const float ds = sqrtf(sq(dsx - (float)(i - 1) * m.dnx) + sq(dsz - (float)(j - 1) * m.dnz));
+                    const float t = 2.0f * ds / (vss[i - 1][j - 1] + vsrc);
+                    const int id = rec_index(m.nbz, isz - 2 + j, isx - 2 + i);
+                    if (lead) m.F[id].T = t;
+                    xg_add(m, id, t, lane & 15, lane);
+                }
+        }
+    } else {
+        const SourceDesc* sd = b.src + s;
+        m.F = (DSA_GLB XRec*)(pool + (size_t)(live ? slot : 0) * pool_stride); m.slow = (DSA_GLB const float*)(slow_all + (size_t)sd->period * field_stride); m.risti = (DSA_GLB const float*)risti_c;
+        x_set_grid(m, g.nbz, g.nnx, g.nnz); m.dnx = g.dnx; m.dnz = g.dnz;
+        if (live) {
+            const int cnt = nstart[slot];
+            const XStart* st = starts + (size_t)slot * kXStage;
+            for (int q = 0; q < cnt; ++q) { const XStart e = st[q]; xg_add(m, e.id, e.T, lane & 15, lane); }
+        }
+    }
+    const XLane L = xg_lane(lane);
+    bool active = live;
+    for (;;) {
+        active = active && m.ntr > 0 && m.err == 0;
+        if (!__any(active)) break;
+        if (active) {
+            const XEntry root = xg_entry(*(DSA_LDS const xf2*)(m.hl + 1));
+            int iz0, ix0;
+            x_coords(m, root.id, &iz0, &ix0);
+            bool stop = false;
+            if (REFINED) {
+                const int iz = iz0 + 1, ix = ix0 + 1;
+                stop = (ix == 1 && oxl) || (ix == rnx && oxh) || (iz == 1 && ozl) || (iz == rnz && ozh);
+            }
+            if (stop) { if (lead) m.F[root.id].st = 0; active = false; }
+            else xg_accept_root(m, root, iz0, ix0, L, lane);
+        }
+    }
+    if (live && lead) {
+        if (REFINED) { xinfo[4 * s + 0] = (int)m.pops; xinfo[4 * s + 2] = m.err; xinfo[4 * s + 3] = 0; }
+        else { xinfo[4 * s + 1] = (int)m.pops; if (m.err) xinfo[4 * s + 2] = m.err; }
+    }
+}
+
+// every record far, value 0 (the reference's nsts = -1): the refined boxes of the batch's units and their pool slots
+__global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restrict__ units, XRec* pool, size_t pool_stride, int nrec)
+{
+    const int slot = blockIdx.y;
+    const int s = units[slot];
+    const uint4 v = { 0u, 0xffffffffu, 0u, 0xffffffffu };              // two records {0.0f, -1}
+    uint4* const Fr = (uint4*)(b.F_r + (size_t)s * kRefRecs);
+    uint4* const Fc = (uint4*)(pool + (size_t)slot * pool_stride);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = t; i < (size_t)kRefRecs / 2; i += step) Fr[i] = v;
+    for (size_t i = t; i < (size_t)nrec / 2; i += step) Fc[i] = v;
+}
+
+// between the two marches, one workgroup per unit: the snapshot the ray tracer reads (reference ttnr / nstsr, :1287-1288), every sgdl-th
+// refined node -- status and, for status >= 0, value -- onto the propagation grid (:1293-1303), alive nodes that touch a far node back
+// into the narrow band (:1332-1349), and the starting tree's nodes in the reference's scan order (:341-347)
+__global__ __launch_bounds__(64) void k_xhandoff(GridDesc g, BatchPtrs b, const int* __restrict__ units, XRec* pool, size_t pool_stride,
+                                                 XStart* starts, int* nstart)
+{
+    __shared__ int stage_st[kXStage];
+    __shared__ float stage_T[kXStage];
     const int slot = blockIdx.x, lane = threadIdx.x;
-    if (slot >= n) return;
     const int s = units[slot];
     const SourceDesc sd = b.src[s];
-    DSA_LDS XEntry* const hl = (DSA_LDS XEntry*)x_lds;                         // slots 1..lcap
-    DSA_LDS XLog* const log = (DSA_LDS XLog*)(hl + lcap + 1);
-    DSA_LDS int* const stage_st = (DSA_LDS int*)(log + kXLogCap);
-    DSA_LDS float* const stage_T = (DSA_LDS float*)(stage_st + kXStage);
     const size_t rr = (size_t)kRefMax * kRefMax;
-
-    XMarch m;
-    m.hl = hl; m.lcap = lcap; m.hg = heap_pool + (size_t)slot * gcap; m.gcap = gcap; m.log = log;
-    m.ntr = 0; m.error = 0; m.nlog = 0; m.pops = 0u;
-    m.ri = g.earth;
-
-    // ---- refined stage: travel(urg = 1) on the box
-    XRec* const Fr = (XRec*)(b.F_r + (size_t)s * kRefRecs);
-    for (int i = lane; i < kRefRecs; i += 64) Fr[i] = XRec{ 0.0f, -1 };
-    __threadfence_block();
-    m.F = Fr; m.slow = b.slow_r + (size_t)s * kRefRecs; m.risti = b.risti_r + (size_t)s * kRefMax;
-    x_set_grid(m, sd.nbz_r, sd.rnx, sd.rnz); m.dnx = sd.rdnx; m.dnz = sd.rdnz;
-    x_refined_start(m, sd, b.vcorner + (size_t)s * 4);
-    x_march<true>(m, sd);
-    __threadfence_block();
-    const unsigned pops_r = m.pops;
-    int err = m.error;
-    // the snapshot the ray tracer reads (reference ttnr / nstsr, :1287-1288) and the hand-off: every sgdl-th refined node, status
-    // and -- for status >= 0 -- value, onto the propagation grid (:1293-1303)
+    const XRec* const Fr = (const XRec*)(b.F_r + (size_t)s * kRefRecs);
     float* const Tfin = b.Tfin_r + (size_t)s * rr;
     int8_t* const Sr = b.S_r + (size_t)s * rr;
     const int nref = sd.rnx * sd.rnz;
@@ -58,7 +374,6 @@ __global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int
         stage_T[q] = r.T;
     }
     __syncthreads();
-    // alive nodes that touch a far node go back into the narrow band (:1332-1349); nodes outside the box are far
     unsigned promote = 0u;                                                      // bit t: this lane's t-th node
     for (int q = lane, t = 0; q < bxn * bzn; q += 64, ++t) {
         if (stage_st[q] != 0) continue;
@@ -76,53 +391,63 @@ __global__ __launch_bounds__(64) void k_exact(GridDesc g, BatchPtrs b, const int
     __syncthreads();
     for (int q = lane, t = 0; q < bxn * bzn; q += 64, ++t) if ((promote >> t) & 1u) stage_st[q] = 1;
     __syncthreads();
-
-    // ---- coarse stage: travel(urg = 2) from the injected state
     XRec* const Fc = pool + (size_t)slot * pool_stride;
-    const int nrec = g.nbx * g.nbz * kTileRecs;
-    for (int i = lane; i < nrec; i += 64) Fc[i] = XRec{ 0.0f, -1 };
-    __threadfence_block();
-    m.F = Fc; m.slow = slow_all + (size_t)sd.period * field_stride; m.risti = risti_c;
-    x_set_grid(m, g.nbz, g.nnx, g.nnz); m.dnx = g.dnx; m.dnz = g.dnz;
-    m.ntr = 0; m.nlog = 0; m.pops = 0u;
-    for (int q = lane; q < bxn * bzn; q += 64)
-        if (stage_st[q] == 0) {
-            const int bx = q / bzn, bz = q - bx * bzn;
-            Fc[rec_index(g.nbz, sd.vnt + bz - 1, sd.vnl + bx - 1)] = XRec{ stage_T[q], 0 };
-        }
-    __threadfence_block();
-    // tree start in the reference's scan order: ix outer, iz inner (:341-347)
-    for (int q = 0; q < bxn * bzn; ++q) {
-        if (x_uni(stage_st[q]) <= 0) continue;
-        const int bx = q / bzn, bz = q - bx * bzn;
+    XStart* const out = starts + (size_t)slot * kXStage;
+    int count = 0;
+    for (int q0 = 0; q0 < bxn * bzn; q0 += 64) {
+        const int q = q0 + lane;
+        const bool have = q < bxn * bzn;
+        const int st = have ? stage_st[q] : -1;
+        const int bx = have ? q / bzn : 0, bz = have ? q - bx * bzn : 0;
         const int id = rec_index(g.nbz, sd.vnt + bz - 1, sd.vnl + bx - 1);
-        const float tq = x_unif(stage_T[q]);
-        if (lane == 0) Fc[id].T = tq;
-        x_add(m, id, tq);
+        const float tq = have ? stage_T[q] : 0.0f;
+        if (st == 0) Fc[id] = XRec{ tq, 0 };
+        const unsigned long long mask = __ballot(st > 0);
+        if (st > 0) {
+            Fc[id].T = tq;
+            out[count + __popcll(mask & ((1ull << lane) - 1ull))] = XStart{ id, tq };
+        }
+        count += __popcll(mask);
     }
-    x_march<false>(m, sd);
-    __threadfence_block();
-    err = err ? err : m.error;
-    // the unit's compact coarse field: plain values, no exceptional nodes (every node was accepted once, in order)
-    float* const T_c = b.T_c + (size_t)s * g.nbx * g.nbz * kTileRecs;
-    for (int i = lane; i < nrec; i += 64) {
+    if (lane == 0) nstart[slot] = count;
+}
+
+// the unit's compact coarse field: plain values, no exceptional nodes (every node was accepted once, in order)
+__global__ __launch_bounds__(256) void k_xfinish(GridDesc g, BatchPtrs b, const int* __restrict__ units, const XRec* pool, size_t pool_stride, int nrec)
+{
+    const int slot = blockIdx.y;
+    const int s = units[slot];
+    const XRec* const Fc = pool + (size_t)slot * pool_stride;
+    float* const T_c = b.T_c + (size_t)s * nrec;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)nrec; i += (size_t)gridDim.x * blockDim.x) {
         const XRec r = Fc[i];
         T_c[i] = r.st == 0 ? r.T : kInf;
     }
-    if (lane == 0) { xinfo[4 * s + 0] = (int)pops_r; xinfo[4 * s + 1] = (int)m.pops; xinfo[4 * s + 2] = err; xinfo[4 * s + 3] = 0; }
 }
 
-size_t exact_lds_bytes(int lcap) { return (size_t)(lcap + 1) * sizeof(XEntry) + (size_t)kXLogCap * sizeof(XLog) + (size_t)kXStage * 8; }
+size_t exact_lds_bytes(int lcap) { return (size_t)4 * (size_t)(lcap + 1) * sizeof(XEntry); }
+size_t exact_start_bytes() { return (size_t)kXStage * sizeof(XStart); }
 
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
-                  const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, int32_t* d_xinfo,
-                  hipStream_t stream)
+                  const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
+                  int32_t* d_xinfo, hipStream_t stream)
 {
     if (n <= 0) return;
     const size_t lds = exact_lds_bytes(lcap);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (per device: set every time)
-    hipLaunchKernelGGL(k_exact, dim3(n), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c,
-                       (XRec*)d_pool, pool_stride, (XEntry*)d_heap_pool, gcap, lcap, d_xinfo);
+    if (lds > 48 * 1024) {   // (per device: set every time)
+        (void)hipFuncSetAttribute((const void*)k_xmarch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_xmarch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int nrec = g.nbx * g.nbz * kTileRecs;
+    const int fill_blocks = (int)std::min<size_t>(((size_t)nrec / 2 + 255) / 256, 64);
+    hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (XRec*)d_pool, pool_stride, nrec);
+    const int waves = (n + 3) / 4;
+    hipLaunchKernelGGL(k_xmarch<true>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (XRec*)d_pool, pool_stride,
+                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo);
+    hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (XRec*)d_pool, pool_stride, (XStart*)d_starts, d_nstart);
+    hipLaunchKernelGGL(k_xmarch<false>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (XRec*)d_pool, pool_stride,
+                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo);
+    hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const XRec*)d_pool, pool_stride, nrec);
 }
 
 }  // namespace dsa

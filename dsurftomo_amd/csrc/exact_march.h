@@ -1,24 +1,16 @@
-// Exact mode: the reference's Fast Marching itself, one wavefront per (period, source) unit.
+// Exact mode: the reference's Fast Marching itself (engine option `exact_ties`).
 //
 // The fixed-point solve (fim_kernel.hip) lands on the reference's travel times everywhere except downstream of exact time
 // ties between neighbouring narrow-band nodes, where the reference's answer depends on which of the two its binary tree
 // happens to hold nearer the root (reference CalSurfG.f90:417-485 with the tree of :768-921).  That cannot be
-// derived locally, so for the units the tie detector flags (engine option `exact_ties`) the march is replayed literally:
-// `travel(urg=1)` on the refined box, the hand-off of :1287-1349, `travel(urg=2)` on the propagation grid -- the same tree,
-// the same insertion order, the same comparisons -- and the result is bit-identical to the reference's.
+// derived locally, so the march is replayed literally: `travel(urg=1)` on the refined box, the hand-off of :1287-1349,
+// `travel(urg=2)` on the propagation grid -- the same tree, the same insertion order, the same comparisons -- and the result is
+// bit-identical to the reference's.
 //
-// How a serial algorithm is laid on a wavefront:
-//   * the tree lives in LDS (slots 1..lcap; deeper slots, if a front ever needs them, in global memory), each entry carrying
-//     its key and the node's record index, so a sift step is one LDS access and no field access;
-//   * per accept step, sixteen lanes own the four quadrants of the four neighbours of the accepted node: they fetch what their
-//     quadrant of the stencil needs (seven independent loads per lane, one memory round trip for the step) BEFORE the root is
-//     sifted down, and evaluate the stencil afterwards, so the tree work hides the memory latency;
-//   * a neighbour's tree slot fetched before the sift is stale when the step itself moved that entry; the slot is checked
-//     against the tree (one LDS read) and, when stale, looked up in the step's log of (node, slot) assignments in LDS by all
-//     lanes at once;
-//   * everything that is sequential (tree, statuses) is wave-uniform: values read from LDS are made scalar (readfirstlane),
-//     so index arithmetic and branches run on the scalar unit; stores are issued by lane 0.
-// Written __host__ __device__ so that tests/hostcheck.cpp can run the same logic on a CPU against the oracle.
+// This header holds what the device kernels (exact_kernel.hip: four units per wavefront, a group of sixteen lanes each) and the CPU
+// model of the march (tests/hostcheck.cpp runs it against the oracle) share: the record / tree entry types, the quadrant form of the
+// stencil -- sixteen (neighbour, quadrant) pairs per accept step, one per lane on the device -- and, for the CPU model only, a plain
+// serial march `XMarch` with the tree split into a "near" and a "far" part like the device's LDS / global split.
 #pragma once
 
 #include "source_stage.h"
@@ -27,7 +19,6 @@ namespace dsa {
 
 struct XEntry { float key; int id; };       // id = record index of the node in the tiled field (eikonal_core.h rec_index)
 struct XRec { float T; int st; };           // st: -1 far, 0 alive, > 0 slot in the tree (reference nsts, CalSurfG.f90:227)
-struct XLog { int id; int slot; };
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DSA_LDS __attribute__((address_space(3)))
@@ -35,9 +26,9 @@ struct XLog { int id; int slot; };
 #define DSA_LDS
 #endif
 
-constexpr int kXLogCap = 192;               // (node, slot) assignments one accept step can make: five sifts of <= 27 levels (trees below 2^26 entries) = 135
 constexpr int kXStage = kRefTiles * kRefTiles;   // coarse nodes under the refined box (17 x 17)
 
+// CPU model of one unit's march (the device keeps the same state per group of sixteen lanes: exact_kernel.hip XG)
 struct XMarch {
     XRec* F;              // tiled records of the grid being marched
     const float* slow;    // tiled slowness
@@ -45,49 +36,24 @@ struct XMarch {
     int nbz, nnx, nnz;
     unsigned nbz_inv;     // ceil(2^32 / nbz): tile -> (bx, bz) without a division
     float ri, dnx, dnz;
-    DSA_LDS XEntry* hl;   // tree slots 1..lcap at hl[1..lcap]
+    XEntry* hl;           // tree slots 1..lcap at hl[1..lcap] (the device: LDS)
     int lcap;
-    XEntry* hg;           // tree slots lcap+1 .. lcap+gcap at hg[0..gcap-1]
+    XEntry* hg;           // tree slots lcap+1 .. lcap+gcap at hg[0..gcap-1] (the device: global memory)
     int gcap;
     int ntr;
-    int error;            // 1: tree capacity, 2: log capacity
-    DSA_LDS XLog* log;    // kXLogCap entries
-    int nlog;
+    int error;            // 1: tree capacity
     unsigned pops;
 };
 
-DSA_HD int x_lane()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (int)(threadIdx.x & 63u);
-#else
-    return 0;
-#endif
-}
-// a value every lane holds alike, told to the compiler (scalar register)
-DSA_HD int x_uni(int v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_readfirstlane(v);
-#else
-    return v;
-#endif
-}
-DSA_HD float x_unif(float v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-#else
-    return v;
-#endif
-}
-DSA_HD void x_set_grid(XMarch& m, int nbz, int nnx, int nnz)
+template <class M>
+DSA_HD void x_set_grid(M& m, int nbz, int nnx, int nnz)
 {
     m.nbz = nbz; m.nnx = nnx; m.nnz = nnz;
     m.nbz_inv = nbz > 1 ? 0xffffffffu / (unsigned)nbz + 1u : 0u;
 }
-// 0-based coordinates of record id
-DSA_HD void x_coords(const XMarch& m, int id, int* iz0, int* ix0)
+// 0-based coordinates of record id (M: any march state with nbz, nbz_inv)
+template <class M>
+DSA_HD void x_coords(const M& m, int id, int* iz0, int* ix0)
 {
     const unsigned tile = (unsigned)id >> 6;
     const unsigned bx = m.nbz > 1 ? (unsigned)(((unsigned long long)tile * m.nbz_inv) >> 32) : tile;
@@ -96,68 +62,22 @@ DSA_HD void x_coords(const XMarch& m, int id, int* iz0, int* ix0)
     *iz0 = (int)(bz << kTileShift) + rec_iz_in_tile(id);
 }
 
-DSA_HD XEntry xh_get(const XMarch& m, int s)
-{
-    const XEntry e = s <= m.lcap ? m.hl[s] : m.hg[s - m.lcap - 1];
-    return XEntry{ x_unif(e.key), x_uni(e.id) };
-}
-// entry into slot s: the tree, the node's status, the step's log.  LDS_ONLY: the caller knows s <= lcap
-// store one word of a record whose index every lane holds alike (lane 0 calls it): a vector offset on the field's scalar base -- one VALU
-// shift instead of four SALU instructions of 64-bit address arithmetic (the step is bound by the scalar unit: ~1000 scalar against ~500
-// vector instructions per accept)
-DSA_HD void x_store_word(XMarch& m, int id, int word, int bits)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned off;
-    asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(off) : "s"(id));
-    typedef __attribute__((address_space(1))) char GChar;
-    *(__attribute__((address_space(1))) int*)((GChar*)m.F + off + 4 * word) = bits;
-#else
-    reinterpret_cast<int*>(&m.F[id])[word] = bits;
-#endif
-}
-DSA_HD int x_float_bits(float f) { union { float f; int i; } u; u.f = f; return u.i; }
-// (the log cannot overflow inside a step, see kXLogCap; x_accept_root checks the count once, behind the step)
-template <bool LDS_ONLY = false>
+DSA_HD XEntry xh_get(const XMarch& m, int s) { return s <= m.lcap ? m.hl[s] : m.hg[s - m.lcap - 1]; }
+// entry into slot s: the tree and the node's status
 DSA_HD void xh_put(XMarch& m, int s, XEntry e)
 {
-    m.nlog = x_uni(m.nlog);
-    if (x_lane() == 0) {
-        if (LDS_ONLY || s <= m.lcap) m.hl[s] = e; else m.hg[s - m.lcap - 1] = e;
-        x_store_word(m, e.id, 1, s);
-        m.log[m.nlog] = XLog{ e.id, s };
-    }
-    m.nlog += 1;
+    if (s <= m.lcap) m.hl[s] = e; else m.hg[s - m.lcap - 1] = e;
+    m.F[e.id].st = s;
 }
-// slot of a node that was in the tree when its status was fetched at the start of the step: unless the step itself moved it
-DSA_HD int x_current_slot(const XMarch& m, int id, int fetched)
-{
-    if (fetched <= m.ntr && xh_get(m, fetched).id == id) return fetched;
-    int best = -1;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int lane = x_lane();
-    for (int base = 0; base < m.nlog; base += 64) {
-        const int i = base + lane;
-        const bool hit = i < m.nlog && m.log[i].id == id;
-        const unsigned long long b = __ballot(hit);
-        if (b) best = base + 63 - __clzll((long long)b);
-    }
-    return x_uni(best >= 0 ? m.log[best].slot : fetched);
-#else
-    for (int i = 0; i < m.nlog; ++i) if (m.log[i].id == id) best = i;
-    return best >= 0 ? m.log[best].slot : fetched;
-#endif
-}
-
 // reference updtree / the tail of addtree (CalSurfG.f90:768-790, :906-920): towards the root while strictly smaller
 DSA_HD void x_sift_up(XMarch& m, XEntry e, int tpc)
 {
-    tpc = x_uni(tpc);
     int tpp = tpc >> 1;
     while (tpp > 0) {
         const XEntry p = xh_get(m, tpp);
-        if (e.key < p.key) { xh_put(m, tpc, p); tpc = tpp; tpp = tpc >> 1; }
-        else break;
+        if (!(e.key < p.key)) break;
+        xh_put(m, tpc, p);
+        tpc = tpp; tpp = tpc >> 1;
     }
     xh_put(m, tpc, e);
 }
@@ -171,30 +91,16 @@ DSA_HD void x_add(XMarch& m, int id, float key)
 // left one is taken (`>`), a child moves up only when strictly smaller
 DSA_HD void x_pop_root(XMarch& m)
 {
-    m.ntr = x_uni(m.ntr);
     if (m.ntr == 1) { m.ntr = 0; return; }
     const XEntry e = xh_get(m, m.ntr);
     m.ntr -= 1;
     int tpp = 1, tpc = 2;
-    // the levels that lie in LDS altogether (children tpc, tpc + 1 <= lcap, hence the parent too): no look at where a slot lives
-    const int lim = m.ntr < m.lcap ? m.ntr : m.lcap;
-    while (tpc < lim) {
-        const XEntry a0 = m.hl[tpc], b0 = m.hl[tpc + 1];              // the two children sit side by side (one 16-byte read)
-        XEntry a = XEntry{ x_unif(a0.key), x_uni(a0.id) };
-        const XEntry b = XEntry{ x_unif(b0.key), x_uni(b0.id) };
-        if (a.key > b.key) { a = b; tpc += 1; }
-        if (a.key < e.key) { xh_put<true>(m, tpp, a); tpp = tpc; tpc = 2 * tpp; }
-        else { tpc = m.ntr + 1; break; }
-    }
     while (tpc < m.ntr) {
-        XEntry a, b;
-        if (tpc + 1 <= m.lcap) {
-            const XEntry a0 = m.hl[tpc], b0 = m.hl[tpc + 1];
-            a = XEntry{ x_unif(a0.key), x_uni(a0.id) }; b = XEntry{ x_unif(b0.key), x_uni(b0.id) };
-        } else { a = xh_get(m, tpc); b = xh_get(m, tpc + 1); }
+        XEntry a = xh_get(m, tpc);
+        const XEntry b = xh_get(m, tpc + 1);
         if (a.key > b.key) { a = b; tpc += 1; }
-        if (a.key < e.key) { xh_put(m, tpp, a); tpp = tpc; tpc = 2 * tpp; }
-        else tpc = m.ntr + 1;
+        if (!(a.key < e.key)) { tpc = m.ntr + 1; break; }
+        xh_put(m, tpp, a); tpp = tpc; tpc = 2 * tpp;
     }
     if (tpc == m.ntr) {
         const XEntry a = xh_get(m, tpc);
@@ -217,7 +123,9 @@ struct XQuad {
     XRec own, rj, rj2, rk, rk2;
     float slown, risti;
 };
-DSA_HD XQuad x_fetch_quad(const XMarch& m, int id, int nz, int nx, int j, int k)
+// OWN = false: the neighbour's own record is not fetched (the caller reads its status later, behind the step's tree moves)
+template <bool OWN = true, class M>
+DSA_HD XQuad x_fetch_quad(const M& m, int id, int nz, int nx, int j, int k)
 {
     XQuad r;
     r.in = nx >= 1 && nx <= m.nnx && nz >= 1 && nz <= m.nnz;
@@ -231,7 +139,7 @@ DSA_HD XQuad x_fetch_quad(const XMarch& m, int id, int nz, int nx, int j, int k)
     const bool ink = k ? nz < m.nnz : nz > 1, ink2 = k ? nz + 1 < m.nnz : nz > 2;
     r.idj = inj ? (j ? nid[1] : nid[0]) : -1;   r.idj2 = inj2 ? (j ? nid[5] : nid[4]) : -1;
     r.idk = ink ? (k ? nid[3] : nid[2]) : -1;   r.idk2 = ink2 ? (k ? nid[7] : nid[6]) : -1;
-    r.own = m.F[id];
+    if (OWN) r.own = m.F[id];
     if (inj) r.rj = m.F[r.idj];
     if (inj2) r.rj2 = m.F[r.idj2];
     if (ink) r.rk = m.F[r.idk];
@@ -324,9 +232,71 @@ DSA_HD float x_quad_candidates(const XQuadState& s, bool k_dead, bool j_dead, fl
     }
     return best;
 }
+// What the device evaluates per lane (round 4): the same candidates, cut for a lane's instruction count -- no branches, and every lane
+// does ONE one-sided candidate instead of two: of a node's four one-sided steps (from x-, x+, z-, z+) lane (j, k) takes the x step of its
+// side j when j == k and the z step of its side k otherwise -- (0,0): x-, (1,1): x+, (0,1): z+, (1,0): z-, each from the lane's own
+// stencil values -- so the four lanes of a node cover all four, and the minimum over the lanes is fouds2's minimum.  The two-sided
+// candidate is the one formula with selected operands of eikonal_core.h's solve_node (same table, same roundings; checked there against
+// the literal fouds2 on 2e7 neighbourhoods, and here by tests/hostcheck.cpp: hc_quads_compare).
+// A = (ri dnx)^2, B = (risti dnz)^2.
+DSA_HD float x_quad_lane(const XQuadState& s, bool k_dead, bool j_dead, int j, int k, float slown, const NodeGeom& g)
+{
+    const float s2 = sq(slown);
+    const bool aj = s.ej && s.aj, ak = s.ek && s.ak;
+    const bool sj = aj && s.oj && (s.tj > s.tj2);
+    const bool sk = ak && s.ok && (s.tk > s.tk2);
+    // the lane's one-sided step
+    const bool dirx = j == k;
+    const bool a1 = dirx ? aj : ak, sw1 = dirx ? sj : sk, dead = dirx ? k_dead : j_dead;
+    const float t1 = dirx ? s.tj : s.tk, t12 = dirx ? s.tj2 : s.tk2;
+    const float R = dirx ? g.ri : g.risti, d = dirx ? g.dnx : g.dnz;
+    const float u2 = 2.0f * R * d;
+    const float arg = sw1 ? sq(u2) * s2 : s2 * sq(R) * sq(d);
+    const float root1 = sqrt_pos(arg);
+    const float one = sw1 ? div3((4.0f * t1 - t12) + root1) : t1 + root1;
+    float best = (dead && a1) ? one : kInf;
+    // the quadrant's two-sided step
+    {
+        const float A = sq(g.ri * g.dnx), B = sq(g.risti * g.dnz);
+        const float s2A = A * s2, s2B = B * s2;
+        const float a00 = A + B, a11 = 4.0f * a00, a10 = 4.0f * A + 9.0f * B, a01 = 4.0f * B + 9.0f * A;
+        const float tj = s.tj, tj2 = s.tj2, tk = s.tk, tk2 = s.tk2;
+        const float Pj = fmaf(4.0f, tj, -tj2);                                  // 4 tj - tj2 (4 tj is exact)
+        const bool both = sj && sk, onesw = sj != sk;
+        const float p = sj ? (sk ? Pj : 3.0f * tk) : (sk ? 3.0f * tj : tk);
+        const float q_ = (sj && !sk) ? 4.0f * tj : (sk ? 4.0f * tk : tj);
+        const float r = sk ? tk2 : (sj ? tj2 : 0.0f);
+        const float U = (sj && !sk) ? B : A;
+        const float S = (sj && !sk) ? 4.0f * s2A : (sk ? 4.0f * s2B : s2B);
+        const float a = sj ? (sk ? a11 : a10) : (sk ? a01 : a00);
+        const float tref = sj ? (sk ? Pj : tk) : tj;
+        const float em = (p - q_) + r;
+        const float b = (both ? 8.0f : (onesw ? 1.0f : -2.0f)) * (((onesw ? 6.0f : 1.0f) * em) * U);
+        const float cc = (both ? 4.0f : 1.0f) * (U * (sq(em) - S));
+        float rd1 = sq(b) - 4.0f * a * cc;
+        if (rd1 < 0.0f) rd1 = 0.0f;
+        const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+        float trav = tref + tdsh;
+        if (both) trav = div3(trav);
+        best = (aj && ak && trav < best) ? trav : best;
+    }
+    return best;
+}
 // the trial value of a node from the states of its four quadrants (index 2 j + k); what the sixteen lanes compute, in one place
 // for the host (and for the comparison with fouds2 in tests/hostcheck.cpp)
 DSA_HD float x_trial_of_quads(const XQuadState* q4, float slown, const NodeGeom& g)
+{
+    const bool k_dead = (q4[0].ek && !q4[0].ak) || (q4[1].ek && !q4[1].ak);
+    const bool j_dead = (q4[0].ej && !q4[0].aj) || (q4[2].ej && !q4[2].aj);
+    float best = kInf;
+    for (int i = 0; i < 4; ++i) {
+        const float c = x_quad_lane(q4[i], k_dead, j_dead, i >> 1, i & 1, slown, g);
+        best = (c < best) ? c : best;
+    }
+    return best;
+}
+// (the literal per-quadrant form, x_quad_candidates above, stays as the second witness: hc_quads_compare checks both against fouds2)
+DSA_HD float x_trial_of_quads_literal(const XQuadState* q4, float slown, const NodeGeom& g)
 {
     const bool k_dead = (q4[0].ek && !q4[0].ak) || (q4[1].ek && !q4[1].ak);
     const bool j_dead = (q4[0].ej && !q4[0].aj) || (q4[2].ej && !q4[2].aj);
@@ -338,82 +308,42 @@ DSA_HD float x_trial_of_quads(const XQuadState* q4, float slown, const NodeGeom&
     return best;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// exchange inside a group of four lanes: quad_perm [1,0,3,2] (the other k) and [2,3,0,1] (the other j)
-DSA_HD int x_dpp_other_k(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
-DSA_HD int x_dpp_other_j(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }
-DSA_HD float x_dpp_min4(float v)
-{
-    float o = __int_as_float(x_dpp_other_k(__float_as_int(v)));
-    v = (o < v) ? o : v;
-    o = __int_as_float(x_dpp_other_j(__float_as_int(v)));
-    return (o < v) ? o : v;
-}
-#endif
-
-// One accept step of reference travel (CalSurfG.f90:417-485): the root becomes alive, leaves the tree, and its four neighbours
-// x-, x+, z-, z+ (in that order) get a new trial value and enter the tree / move in it.
+// One accept step of reference travel (CalSurfG.f90:417-485), CPU model in the device's order of events: the stencil records of the four
+// neighbours' quadrants are fetched, the root becomes alive and leaves the tree, the neighbours' statuses are read BEHIND the tree moves
+// of that removal, and the four neighbours x-, x+, z-, z+ (in that order) get a new trial value and enter the tree / move up in it.  A
+// later neighbour whose entry an earlier one's move pushed down a level is no longer at the slot its status said: the slot is checked
+// against the tree and the status read again (the device: the sixteenth lane of the group, exact_kernel.hip xg_sift_up).
 DSA_HD void x_accept_root(XMarch& m, XEntry root, int iz0, int ix0)
 {
     const int iz = iz0 + 1, ix = ix0 + 1;
     int rid[8];
     rec_stencil(m.nbz, root.id, rid);
     const int nzq[4] = { iz, iz, iz - 1, iz + 1 }, nxq[4] = { ix - 1, ix + 1, ix, ix };
+    XQuad raws[16];
+    for (int l = 0; l < 16; ++l) raws[l] = x_fetch_quad<false>(m, rid[l >> 2], nzq[l >> 2], nxq[l >> 2], (l >> 1) & 1, l & 1);
+    m.F[root.id].st = 0;
+    x_pop_root(m);
     int nb_in[4], nb_st[4];
     float nb_trial[4];
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int lane = x_lane();
-    const int ql = (lane >> 2) & 3, jl = (lane >> 1) & 1, kl = lane & 1;
-    const int mz = ql == 0 ? nzq[0] : ql == 1 ? nzq[1] : ql == 2 ? nzq[2] : nzq[3];
-    const int mx = ql == 0 ? nxq[0] : ql == 1 ? nxq[1] : ql == 2 ? nxq[2] : nxq[3];
-    const int mid = ql == 0 ? rid[0] : ql == 1 ? rid[1] : ql == 2 ? rid[2] : rid[3];
-    XQuad raw;
-    raw.in = 0;
-    if (lane < 16) raw = x_fetch_quad(m, mid, mz, mx, jl, kl);   // seven loads per lane in flight
-#else
-    XQuad raws[16];
-    for (int l = 0; l < 16; ++l) raws[l] = x_fetch_quad(m, rid[l >> 2], nzq[l >> 2], nxq[l >> 2], (l >> 1) & 1, l & 1);
-#endif
-    m.nlog = 0;
-    if (x_lane() == 0) x_store_word(m, root.id, 1, 0);
-    x_pop_root(m);
-#if defined(__HIP_DEVICE_COMPILE__)
-    float trial = kInf;
-    int st = 0, in = 0;
-    if (lane < 16) {
-        in = raw.in; st = raw.own.st;
-        const XQuadState s = x_quad_state(raw, root);
-        // the other k of my j, the other j of my k: who is inside the grid and not alive
-        const int dk = (s.ek && !s.ak) ? 1 : 0, dj = (s.ej && !s.aj) ? 1 : 0;
-        const bool k_dead = dk || x_dpp_other_k(dk), j_dead = dj || x_dpp_other_j(dj);
-        const NodeGeom g = { m.ri, raw.risti, m.dnx, m.dnz };
-        float c = kInf;
-        if (in && st != 0) c = x_quad_candidates(s, k_dead, j_dead, raw.slown, g);
-        trial = x_dpp_min4(c);
-    }
     for (int q = 0; q < 4; ++q) {
-        nb_in[q] = __builtin_amdgcn_readlane(in, 4 * q);
-        nb_st[q] = __builtin_amdgcn_readlane(st, 4 * q);
-        nb_trial[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(trial), 4 * q));
-    }
-#else
-    for (int q = 0; q < 4; ++q) {
-        nb_in[q] = raws[4 * q].in; nb_st[q] = raws[4 * q].own.st; nb_trial[q] = kInf;
+        nb_in[q] = raws[4 * q].in; nb_st[q] = nb_in[q] ? m.F[rid[q]].st : 0; nb_trial[q] = kInf;
         if (nb_in[q] && nb_st[q] != 0) {
             XQuadState s4[4];
-            for (int i = 0; i < 4; ++i) s4[i] = x_quad_state(raws[4 * q + i], root);
+            for (int i = 0; i < 4; ++i) { raws[4 * q + i].own.st = nb_st[q]; s4[i] = x_quad_state(raws[4 * q + i], root); }
             const NodeGeom g = { m.ri, raws[4 * q].risti, m.dnx, m.dnz };
             nb_trial[q] = x_trial_of_quads(s4, raws[4 * q].slown, g);
         }
     }
-#endif
     for (int q = 0; q < 4; ++q) {
         if (!nb_in[q] || nb_st[q] == 0) continue;
-        if (x_lane() == 0) x_store_word(m, rid[q], 0, x_float_bits(nb_trial[q]));       // fouds2 overwrites unconditionally (:758)
+        m.F[rid[q]].T = nb_trial[q];                                           // fouds2 overwrites unconditionally (:758)
         if (nb_st[q] < 0) x_add(m, rid[q], nb_trial[q]);
-        else x_sift_up(m, XEntry{ nb_trial[q], rid[q] }, x_current_slot(m, rid[q], nb_st[q]));
+        else {
+            int slot = nb_st[q];
+            if (xh_get(m, slot).id != rid[q]) slot = m.F[rid[q]].st;
+            x_sift_up(m, XEntry{ nb_trial[q], rid[q] }, slot);
+        }
     }
-    if (m.nlog > kXLogCap - 48) m.error = 2;          // (cannot happen below 2^26 tree entries; the guard keeps the log inside its array)
     m.pops += 1u;
 }
 
@@ -427,7 +357,7 @@ DSA_HD void x_march(XMarch& m, const SourceDesc& sd)
         int iz0, ix0;
         x_coords(m, root.id, &iz0, &ix0);
         if (REFINED && is_open_edge(sd, iz0 + 1, ix0 + 1)) {
-            if (x_lane() == 0) m.F[root.id].st = 0;
+            m.F[root.id].st = 0;
             break;
         }
         x_accept_root(m, root, iz0, ix0);
@@ -443,9 +373,9 @@ DSA_HD void x_refined_start(XMarch& m, const SourceDesc& s, const float* vcorner
     for (int i = 1; i <= 2; ++i)
         for (int j = 1; j <= 2; ++j) {
             const float ds = sqrtf(sq(s.dsx_r - (float)(i - 1) * s.rdnx) + sq(s.dsz_r - (float)(j - 1) * s.rdnz));
-            const float t = x_unif(2.0f * ds / (vss[i - 1][j - 1] + vsrc));
+            const float t = 2.0f * ds / (vss[i - 1][j - 1] + vsrc);
             const int id = rec_index(m.nbz, s.isz_r - 2 + j, s.isx_r - 2 + i);
-            if (x_lane() == 0) m.F[id].T = t;
+            m.F[id].T = t;
             x_add(m, id, t);
         }
 }

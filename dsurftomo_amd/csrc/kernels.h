@@ -172,13 +172,16 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           const int* d_member_flag /* null or per unit: 1 = solved inside a bundle */, float window_b /* causal window of the bundles */,
                           int max_rounds_b /* > 0: round limit of the bundles (tests of the fallback) */, hipStream_t stream);
 
-// exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), one wavefront each,
-// workgroup j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per slot beyond the lcap in LDS);
-// xinfo[4 u ..]: accepts of the refined / coarse stage, error code (1 tree capacity, 2 log capacity)
+// exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), FOUR units per wavefront
+// (a group of sixteen lanes each), unit j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per
+// slot beyond the lcap -- odd -- kept in LDS; d_starts / d_nstart: exact_start_bytes() + 4 bytes per slot for the coarse stage's starting tree);
+// five launches: reset, refined march, snapshot + hand-off, coarse march, compact copy.
+// xinfo[4 u ..]: accepts of the refined / coarse stage, error code (1 tree capacity)
 size_t exact_lds_bytes(int lcap);
+size_t exact_start_bytes();
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
-                  const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, int32_t* d_xinfo,
-                  hipStream_t stream);
+                  const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
+                  int32_t* d_xinfo, hipStream_t stream);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
 // RayDesc::src is a global unit index; unit_base is the first unit held by the batch arrays

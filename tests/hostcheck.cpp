@@ -518,7 +518,8 @@ extern "C" long hc_solve_node_compare(unsigned long long seed, long n, long* sta
 }
 
 
-// Exact mode (csrc/exact_march.h) on the CPU: the same march functions the device kernel k_exact runs, sequenced like the kernel
+// Exact mode (csrc/exact_march.h) on the CPU: the CPU model of the device's march (same order of events per accept step, same quadrant
+// arithmetic), sequenced like the device's launches
 // (refined stage, snapshot, hand-off, coarse stage); `lcap` tree slots in the "LDS" part, the rest in the "global" part, so that
 // the split is exercised.  Outputs row-major like hc_solve_source; returns 0, or the march's error code.
 extern "C" int hc_exact_solve(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const double* pv, float x, float z,
@@ -544,10 +545,9 @@ extern "C" int hc_exact_solve(int nx, int ny, float goxd, float gozd, float dvxd
             if ((lx == s.isx_r || lx == s.isx_r + 1) && (kz == s.isz_r || kz == s.isz_r + 1)) vcorner[(lx - s.isx_r) * 2 + (kz - s.isz_r)] = v;
         }
     std::vector<XEntry> hl((size_t)lcap + 1), hg((size_t)gcap + 1);
-    std::vector<XLog> log(kXLogCap);
     XMarch m;
-    m.hl = hl.data(); m.lcap = lcap; m.hg = hg.data(); m.gcap = gcap; m.log = log.data();
-    m.ntr = 0; m.error = 0; m.nlog = 0; m.pops = 0u; m.ri = g.earth;
+    m.hl = hl.data(); m.lcap = lcap; m.hg = hg.data(); m.gcap = gcap;
+    m.ntr = 0; m.error = 0; m.pops = 0u; m.ri = g.earth;
     std::vector<XRec> Fr(kRefRecs, XRec{ 0.0f, -1 });
     m.F = Fr.data(); m.slow = slow_r.data(); m.risti = risti_r.data();
     x_set_grid(m, s.nbz_r, s.rnx, s.rnz); m.dnx = s.rdnx; m.dnz = s.rdnz;
@@ -585,7 +585,7 @@ extern "C" int hc_exact_solve(int nx, int ny, float goxd, float gozd, float dvxd
     std::vector<XRec> Fc(nrc, XRec{ 0.0f, -1 });
     m.F = Fc.data(); m.slow = slow_c.data(); m.risti = risti_c.data();
     x_set_grid(m, g.nbz, g.nnx, g.nnz); m.dnx = g.dnx; m.dnz = g.dnz;
-    m.ntr = 0; m.nlog = 0; m.pops = 0u;
+    m.ntr = 0; m.pops = 0u;
     for (int q = 0; q < bxn * bzn; ++q)
         if (st[q] == 0) Fc[rec_index(g.nbz, s.vnt + q % bzn - 1, s.vnl + q / bzn - 1)] = XRec{ sT[q], 0 };
     for (int q = 0; q < bxn * bzn; ++q) {
@@ -650,8 +650,8 @@ extern "C" long hc_quads_compare(unsigned long long seed, long n)
                 q.ej = s.ej[j]; q.aj = s.aj[j]; q.oj = s.oj[j]; q.tj = s.tj[j]; q.tj2 = s.tj2[j];
                 q.ek = s.ek[k]; q.ak = s.ak[k]; q.ok = s.ok[k]; q.tk = s.tk[k]; q.tk2 = s.tk2[k];
             }
-        const float a = fouds2(s, slown, g), b = x_trial_of_quads(q4, slown, g);
-        if (std::memcmp(&a, &b, 4) != 0) { if (bad < 5) std::fprintf(stderr, "quadrant form differs at case %ld: %.9g vs %.9g\n", i, (double)a, (double)b); ++bad; }
+        const float a = fouds2(s, slown, g), b = x_trial_of_quads(q4, slown, g), b2 = x_trial_of_quads_literal(q4, slown, g);
+        if (std::memcmp(&a, &b, 4) != 0 || std::memcmp(&a, &b2, 4) != 0) { if (bad < 5) std::fprintf(stderr, "quadrant form differs at case %ld: %.9g vs %.9g\n", i, (double)a, (double)b); ++bad; }
     }
     return bad;
 }

@@ -221,7 +221,10 @@ def test_recycled_field_slots_give_the_same_times(engine):
 KNOWN = {
     # name: (receiver times beyond 1e-4 s, largest |dt| as printed with 9 digits)
     "config4_receivers": (139, "0.000686645508"),      # of 4096 receiver times of 128 units at 4097^2 (times up to 217.6 s); measured r03 (profiles/r03_parity_report.txt)
-    "rough1025_fields": (35, "0.00126647949"),         # of 64 fields; 643 nodes of 67.2 M beyond 1e-4 s
+    # the rough medium is NOT pinned to one figure: its exact ties can settle in either of their two states from run to run (one ulp, "which
+    # wave's store lands first": DESIGN.md 4 "Repeatability", 2-3 of millions of receiver times), so the measured r03 figures -- 35 of 64
+    # fields with a node beyond 1e-4 s, worst node 0.00126647949 s, 643 of 67.2 M nodes -- are asserted as a band
+    "rough1025_fields": ((33, 37), 1.3e-3, 700),
 }
 
 
@@ -254,15 +257,25 @@ def test_receivers_at_scale_config4_known_tie_deviation(engine):
         engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
         tx = engine.traveltimes(**u).reshape(n, nrec)
         st = engine.stats()
+        engine.set_option("exact_ties", 1)          # tie detector + literal march for the flagged units
+        engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        t1 = engine.traveltimes(**u).reshape(n, nrec)
+        st1 = engine.stats()
+        flags1, _ = engine.unit_ties()
     finally:
         engine.set_option("exact_ties", 0)
         engine.set_option("max_chunk", 0)
     d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
+    d1 = np.abs(t1.astype(np.float64) - ref.astype(np.float64))
+    marched = (flags1 & 2) != 0
     beyond, worst = int((d > TOL).sum()), "%.9g" % d.max()
     parity_log.add(f"configs[4] medium N=4097, {n} units x {nrec} receivers [known tie deviation]: default mode max |dt| {worst} s, beyond 1e-4 s {beyond} of {d.size}, "
                    f"not bit-identical {int((bits(t) != bits(ref)).sum())} (times up to {ref.max():.1f} s) | exact mode: not bit-identical {int((bits(tx) != bits(ref)).sum())}, "
-                   f"{st['exact_pops'] / max(st['ms_exact'], 1e-9) / 1e3:.0f} M accepts/s")
+                   f"{st['exact_pops'] / max(st['ms_exact'], 1e-9) / 1e3:.0f} M accepts/s | exact_ties=1: {int(marched.sum())} of {n} units flagged and marched, "
+                   f"receiver times beyond 1e-4 s {int((d1 > TOL).sum())}, max |dt| {d1.max():.3g} s ({st1['exact_pops'] / max(st1['ms_exact'], 1e-9) / 1e3:.0f} M accepts/s)")
     assert (bits(tx) != bits(ref)).sum() == 0
+    assert (bits(t1[marched]) != bits(ref[marched])).sum() == 0          # flagged units: the reference's bits
+    assert (d1 > TOL).sum() == 0                                         # exact_ties = 1 holds north_star's tolerance on configs[4]'s medium
     assert d.max() <= 1.2e-3 and beyond <= 0.05 * d.size
     if KNOWN["config4_receivers"] is not None:
         assert (beyond, worst) == KNOWN["config4_receivers"]
@@ -295,12 +308,23 @@ def test_fields_at_headline_size_rough_known_tie_deviation(engine):
         engine.set_option("exact_ties", 2)
         engine.traveltimes(*args)
         exact_bad = sum(int((bits(engine.field(k)) != bits(sols[k])).sum()) for k in range(nsrc))
+        engine.set_option("exact_ties", 1)
+        t1 = engine.traveltimes(*args)
+        flags1, _ = engine.unit_ties()
+        marched = (flags1 & 2) != 0
+        dm1 = np.array([np.abs(engine.field(k) - sols[k]).max() for k in range(nsrc)])
+        bad1 = sum(int((bits(engine.field(k)) != bits(sols[k])).sum()) for k in range(nsrc) if marched[k])
     finally:
         engine.set_option("exact_ties", 0)
+    ref1 = np.array([L.o_srtimes(g, veln, sols[k], sx[k], sz[k], rx[k], rz[k]) for k in range(nsrc)], np.float32)
     fields_bad, worst = int((dm > TOL).sum()), "%.9g" % dm.max()
     parity_log.add(f"N=1025 rough, {nsrc} random sources [known tie deviation]: default mode {fields_bad} fields with a node beyond 1e-4 s (worst node {worst} s, "
-                   f"{int(nbeyond.sum())} nodes of {nsrc * N * N} beyond) | exact mode: nodes not bit-identical {exact_bad}")
+                   f"{int(nbeyond.sum())} nodes of {nsrc * N * N} beyond) | exact mode: nodes not bit-identical {exact_bad} | exact_ties=1: {int(marched.sum())} of {nsrc} units marched "
+                   f"(nodes not bit-identical in them {bad1}), fields left to the fixed point: worst node {dm1[~marched].max() if (~marched).any() else 0.0:.3g} s, "
+                   f"receiver times beyond 1e-4 s {int((np.abs(t1 - ref1) > TOL).sum())}")
     assert exact_bad == 0
+    assert bad1 == 0 and (np.abs(t1 - ref1) > TOL).sum() == 0
+    assert (dm1[~marched] <= TOL).all() if (~marched).any() else True
     assert dm.max() <= 3e-3 and nbeyond.sum() <= 1e-4 * nsrc * N * N
-    if KNOWN["rough1025_fields"] is not None:
-        assert (fields_bad, worst) == KNOWN["rough1025_fields"]
+    (lo, hi), worst_cap, nodes_cap = KNOWN["rough1025_fields"]
+    assert lo <= fields_bad <= hi and dm.max() <= worst_cap and nbeyond.sum() <= nodes_cap
