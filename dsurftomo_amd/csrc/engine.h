@@ -105,7 +105,8 @@ struct Engine {
     int exact_ties = 0;
     float tie_threshold = 2.0e-5f;     // a tie counts when taking the tied neighbour in moves the node's value by more than this (s); 0 = any tie
     int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each, made odd); 0 = by the number of units marching (.. 4799)
-    int exact_pool = 0;                // units marching at a time (0 = by free memory, at most 10 240)
+    int exact_pool = 0;                // units marching at a time (0 = by free memory, at most exact_pool_max)
+    size_t exact_pool_max = 16384;     // option exact_pool_max: four units per wavefront, sixteen wavefronts per CU (measured at 1025^2: 10 240 units 1 500, 12 288 1 600, 16 384 1 700 solves/s)
     DevBuf<unsigned long long> X_pool, X_heap;   // per marching unit: (T, status) records of the whole grid; tree slots beyond the LDS part
     DevBuf<int> x_units, x_nstart;
     DevBuf<unsigned long long> x_starts;         // the coarse stage's starting tree per marching unit (kernels.h: exact_start_bytes)
@@ -113,7 +114,7 @@ struct Engine {
     std::vector<unsigned char> h_unit_flags;     // per planned unit after a solve: bit 0 tie met, bit 1 solved by the exact mode
     std::vector<int> h_unit_rounds;               // rounds of the unit's coarse solve (of its bundle's, for a bundled unit)
     std::vector<float> h_unit_tie;               // largest tie influence of the unit (s)
-    int run_exact(int first, int n, const std::vector<int>& local_units);
+    int run_exact(int first, int n, const std::vector<int>& local_units, bool receivers, bool compact);
     DevBuf<int8_t> S_r, cinit;
     DevBuf<int16_t> rst, cst;
     DevBuf<int32_t> heap, flags, info;

@@ -379,6 +379,9 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
             long solo_units = 0;
             if (choose_bundle_size(nunits, &solo_units) > 0) P = std::min<size_t>(P, (size_t)std::max<long>(256, 2 * solo_units));
         }
+        // exact_ties = 2: the march has fields of its own and writes its units' receiver times itself; the compact slots only serve
+        // dsa_get_field / rays afterwards (a launch with more units than slots leaves none behind, as with recycled slots): 16 GB of them at most
+        if (field_pool_opt == 0 && !keep_fields && exact_ties == 2) P = std::min<size_t>(P, std::max<size_t>(1, ((size_t)16 << 30) / per_slot_bytes));
         if (field_pool_opt < 0 || keep_fields) P = (size_t)std::max(nunits, 1);
         P = std::min<size_t>(P, (size_t)std::max(nunits, 1));
         if (max_chunk > 0) P = std::min<size_t>(P, (size_t)max_chunk);
@@ -464,7 +467,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
     // the solve (rays and rows, the exact mode, keep_fields) a launch takes one unit per slot
     const bool may_recycle = !rows && exact_ties == 0 && !keep_fields;
-    if (!may_recycle && field_pool_opt == 0 && pool_slots < std::min(chunk, nunits)) {
+    // exact_ties = 2 with nothing wanted but receiver times: every unit the per-unit arrays hold in one launch, times from the marched fields
+    const bool exact_fused = exact_ties == 2 && !rows && !keep_fields;
+    if (!may_recycle && !exact_fused && field_pool_opt == 0 && pool_slots < std::min(chunk, nunits)) {
         // every field of a launch is needed after it (rays and rows, the literal march): a slot per unit for as many units as the
         // budget holds, so that the call is one launch if it can be (four launches of 4096 have four tails: +4 % on the headline call)
         const size_t units_b = (size_t)chunk * per_unit_bytes;
@@ -475,7 +480,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             pool_slots = (int)want;
         }
     }
-    const int step = may_recycle ? chunk : std::min(chunk, pool_slots);
+    const int step = (may_recycle || exact_fused) ? chunk : std::min(chunk, pool_slots);
     const bool fused_times = exact_ties == 0;          // the coarse solve writes its unit's receiver times itself
     stats[DSA_STAT_UNITS] = nunits;
     stats[DSA_STAT_CHUNK] = step;
@@ -564,14 +569,14 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             }
             if (!xl.empty()) {
                 const auto w0 = std::chrono::steady_clock::now();
-                if (run_exact(first, n, xl) != 0) return status;
+                if (run_exact(first, n, xl, exact_fused, !exact_fused || n <= pool_slots) != 0) return status;
                 stats[DSA_STAT_MS_EXACT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
             }
         }
         // receivers of this chunk
         const int r0 = h_src[first].first_ray;
         const int r1 = h_src[first + n - 1].first_ray + h_src[first + n - 1].nrec;
-        if (!fused_times && r1 > r0) launch_srtimes_chunk(r0, r1 - r0, first);
+        if (!fused_times && !exact_fused && r1 > r0) launch_srtimes_chunk(r0, r1 - r0, first);
         HIP_TRY(this, hipEventRecord(events[6], stream));
         HIP_TRY(this, hipGetLastError());
         h_info.resize((size_t)n * 16);
@@ -796,7 +801,8 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
 
 // literal Fast Marching (exact_kernel.hip) for the chunk-local units `xl` of the resident chunk [first, first + n), in batches of
 // as many units as the pool holds
-int Engine::run_exact(int first, int n, const std::vector<int>& xl)
+// `receivers`: the batches write their units' receiver times themselves; `compact`: the units' compact fields go to their slots (T_c)
+int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receivers, bool compact)
 {
     (void)n;
     // (a tree holds at most 65 535 nodes -- sixteen levels, one per lane of a unit's group; narrow bands are a few times nnx + nnz)
@@ -804,20 +810,26 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl)
     const size_t per = nrec_c * 8 + (size_t)gcap_max * 8 + exact_start_bytes() + 4;
     size_t pool = (size_t)exact_pool;
     if (!pool) {
-        // units marching at a time: as many as half the free memory holds, at most 10 240 (four units per wavefront: ten wavefronts per CU)
+        // units marching at a time: as many as 65 % of the free memory holds, at most exact_pool_max (four units per wavefront)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
         const size_t have = X_pool.cap * 8 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4;
-        pool = std::min<size_t>(10240, std::max<size_t>(1, (size_t)(0.5 * (double)(free_b + have)) / per));
+        pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.65 * (double)(free_b + have)) / per));
     }
     pool = std::min(pool, xl.size());
+    {   // batches of equal size (10 240 + 6 144 units take as long as two full batches)
+        const size_t nb = (xl.size() + pool - 1) / pool;
+        pool = (xl.size() + nb - 1) / nb;
+    }
     // tree slots in LDS per marching unit (odd: the two children of a slot then lie on one side of the LDS / global split): the option, or
     // (0) what lets all the wavefronts of a batch be resident -- a wavefront holds four units' tree tops, 8 bytes per slot
     int lcap = exact_lds_slots;
     if (lcap <= 0) {
+        // (every wavefront of a batch must be resident at once -- a second generation would double the batch's time --, so the LDS of a CU is
+        // divided with a margin: 148 of its 160 KB; 16 scratch entries per unit on top of the lcap + 1 tree slots)
         const size_t waves_per_cu = std::max<size_t>(1, ((pool + 3) / 4 + 255) / 256);
-        const size_t bytes = (size_t)156 * 1024 / waves_per_cu;
-        const long fit = (long)(bytes / 32) - 1;
+        const size_t bytes = (size_t)148 * 1024 / waves_per_cu;
+        const long fit = (long)(bytes / 32) - 17;
         lcap = (int)std::min<long>(std::min<long>(fit, 4L * (g.nnx + g.nnz) + 1023), 4799);
     }
     lcap = std::max(63, lcap) | 1;
@@ -828,7 +840,9 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl)
     HIP_TRY(this, hipMemsetAsync(xinfo.p, 0, (size_t)n * 16, stream));
     for (size_t k = 0; k < xl.size(); k += pool) {
         const int m = (int)std::min(pool, xl.size() - k);
-        launch_exact(g, batch(), x_units.p + k, m, slow.p, nrec_c, risti_c.p, X_pool.p, nrec_c, X_heap.p, gcap, lcap, x_starts.p, x_nstart.p, xinfo.p, stream);
+        const XReceivers rc{ rays.p, veln.p, nfield, dpl, out.p, err.p };
+        launch_exact(g, batch(), x_units.p + k, m, slow.p, nrec_c, risti_c.p, X_pool.p, nrec_c, X_heap.p, gcap, lcap, x_starts.p, x_nstart.p, xinfo.p, clocks.p,
+                     receivers ? &rc : nullptr, compact, stream);
     }
     HIP_TRY(this, hipGetLastError());
     std::vector<int32_t> h_x((size_t)n * 4);
@@ -1116,6 +1130,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
     if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4991))) { en->exact_lds_slots = (int)value; return 0; }
     if (n == "exact_pool" && value >= 0) { en->exact_pool = (int)value; return 0; }
+    if (n == "exact_pool_max" && value >= 4 && value <= 32768) { en->exact_pool_max = (size_t)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);
     return DSA_ERR_ARGUMENT;

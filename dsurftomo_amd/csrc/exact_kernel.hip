@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "exact_march.h"
+#include "receiver_core.h"
 
 namespace dsa {
 
@@ -57,9 +58,11 @@ struct XG {                                  // the march of one unit; every lan
     int nbz, nnx, nnz; unsigned nbz_inv;
     float ri, dnx, dnz;
     DSA_LDS XEntry* hl; DSA_GLB XEntry* hg;
+    DSA_LDS XEntry* sc;                      // sixteen entries of LDS scratch: the levels of the tree beyond lcap, three at a time (xg_pop_root)
     int lcap, gcap;
     int ntr, err;
     unsigned pops;
+    XEntry last;                             // tree[ntr], fetched at the end of the step before: the entry the next removal of the root sinks
 };
 
 // Tree entries move as 8- / 16-byte vectors through pointers of an EXPLICIT address space.  (Copying an XEntry struct goes through its
@@ -78,15 +81,22 @@ __device__ __forceinline__ XEntry xg_get(const XG& m, int s)
     if (s > m.lcap) v = *(DSA_GLB const xf2*)(m.hg + (s - m.lcap - 1));
     return xg_entry(v);
 }
-// entry into slot s -- the tree and the node's status (reference nsts) -- for the lanes with `on`; the lanes hold different (slot, entry)
-// pairs.  LDS slot 0 is nobody's: lanes that have nothing for the LDS part write there instead of branching around the store
-__device__ __forceinline__ void xg_put(XG& m, bool on, int s, XEntry e)
+// entry into slot s of the tree for the lanes with `on`; the lanes hold different (slot, entry) pairs.  LDS slot 0 is nobody's: lanes that
+// have nothing for the LDS part write there instead of branching around the store
+__device__ __forceinline__ void xg_put_tree(XG& m, bool on, int s, XEntry e)
 {
     *(DSA_LDS xf2*)(m.hl + ((on && s <= m.lcap) ? s : 0)) = xg_vec(e);
-    if (on) {
-        if (s > m.lcap) *(DSA_GLB xf2*)(m.hg + (s - m.lcap - 1)) = xg_vec(e);
-        m.F[e.id].st = s;
-    }
+    if (on && s > m.lcap) *(DSA_GLB xf2*)(m.hg + (s - m.lcap - 1)) = xg_vec(e);
+}
+// ... and the node's status (reference nsts: its slot)
+__device__ __forceinline__ void xg_put_status(XG& m, bool on, int s, XEntry e)
+{
+    if (on) m.F[e.id].st = s;
+}
+__device__ __forceinline__ void xg_put(XG& m, bool on, int s, XEntry e)
+{
+    xg_put_tree(m, on, s, e);
+    xg_put_status(m, on, s, e);
 }
 // the sixteen bits of a group in a wavefront-wide vote
 __device__ __forceinline__ unsigned xg_vote16(bool c, int lane) { return (unsigned)(__ballot(c) >> (lane & 48)) & 0xffffu; }
@@ -98,26 +108,34 @@ __device__ __forceinline__ unsigned xg_vote16(bool c, int lane) { return (unsign
 // one store pass.  `check` (the entry was in the tree; s is the status read behind the root's removal): lane 15 reads slot s itself and
 // checks that the node is still there -- an earlier neighbour's moves of this step may have pushed it down a level; then the status is
 // read again (the wave's stores and loads on one address keep their order).  (A tree has at most sixteen levels: xg capacity.)
-// (one attempt: false when lane 15 found another node at slot s -- nothing is stored then)
-__device__ __forceinline__ bool xg_sift_try(XG& m, XEntry e, int s, bool check, int gl, int lane)
+// the group's look at the path of slot s: lane l < 15 its ancestor l + 1, lane 15 (check) the slot itself
+__device__ __forceinline__ XEntry xg_path(const XG& m, int s, bool check, int gl)
 {
     const int a = gl < 15 ? (s >> (gl + 1)) : s;
     const bool have = a >= 1 && (gl < 15 || check);
-    const XEntry p = xg_get(m, have ? a : 1);
+    return xg_get(m, have ? a : 1);
+}
+// (one attempt with the path entries p: false when lane 15 found another node at slot s -- nothing is stored then; *moved: entries went down)
+__device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e, int s, bool check, XEntry p, int gl, int lane, bool* moved)
+{
+    const int a = gl < 15 ? (s >> (gl + 1)) : s;
+    const bool have = a >= 1 && (gl < 15 || check);
     const bool c = gl < 15 ? (have && e.key < p.key) : (check && p.id != e.id);
     const unsigned b = xg_vote16(c, lane);
     if (b & 0x8000u) return false;
     const int moves = __builtin_ctz(~b);
     xg_put(m, gl < moves, s >> gl, p);
     xg_put(m, gl == 15, s >> moves, e);
+    *moved = moves > 0;
     return true;
 }
 __device__ __forceinline__ void xg_sift_up(XG& m, XEntry e, int s, bool check, int gl, int lane)
 {
-    if (!xg_sift_try(m, e, s, check, gl, lane)) {
+    bool moved;
+    if (!xg_sift_apply(m, e, s, check, xg_path(m, s, check, gl), gl, lane, &moved)) {
         // (rare: the node was pushed down a level by an earlier neighbour of this step; its status says where to)
         s = m.F[e.id].st;
-        (void)xg_sift_try(m, e, s, false, gl, lane);
+        (void)xg_sift_apply(m, e, s, false, xg_path(m, s, false, gl), gl, lane, &moved);
     }
 }
 __device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lane)
@@ -132,7 +150,7 @@ __device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lan
 // move of level l with lane l of the group (at most fifteen moves and the sinking entry itself: sixteen levels); the moves -- tree
 // entries and statuses -- are stored in one pass behind the walk.  Two loops, the levels in LDS and the levels beyond, so that the first
 // carries no code of the second; no branches inside a level.
-#define DSA_XG_LEVEL(PAIR)                                                                   \
+#define DSA_XG_LEVEL(PAIR, MORE)                                                             \
     {                                                                                        \
         const xf4 c = (PAIR);                                                                \
         const bool right = c.x > c.z;                                                        \
@@ -141,27 +159,49 @@ __device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lan
         tpc += right ? 1 : 0;                                                                \
         const bool mv = ak < e.key;                                                          \
         const bool cap = mv && gl == level;                                                  \
-        mine.key = cap ? ak : mine.key; mine.id = cap ? ai : mine.id; mydst = cap ? tpp : mydst; \
+        mine.key = cap ? ak : mine.key; mine.id = cap ? ai : mine.id; mydst = cap ? tpp : mydst; myold = cap ? tpc : myold; \
         level += mv ? 1 : 0; tpp = mv ? tpc : tpp; tpc = mv ? 2 * tpc : m.ntr + 1;          \
+        MORE                                                                                 \
     }
-__device__ __forceinline__ void xg_pop_root(XG& m, int gl)
+// What the walk leaves behind (XPop): lane l < moves holds the entry that went from slot `from` up to slot `to` = from / 2 at level l, lane
+// `moves` the sunk entry and its slot; the TREE is updated (LDS part and the part beyond), the statuses of the moved nodes are the caller's
+// to store (xg_put_status) -- at the end of the step, behind every load of it: on this hardware a load's wait also waits for the stores
+// issued before it, and a scattered store into a field that no cache holds takes as long as a miss.
+struct XPop { XEntry mine; int to, from, moves; };
+__device__ __forceinline__ XPop xg_pop_root(XG& m, int gl)
 {
-    if (m.ntr == 1) { m.ntr = 0; return; }
-    const XEntry e = xg_get(m, m.ntr);
+    XPop P;
+    P.mine = m.last; P.to = 0; P.from = 0; P.moves = -1;
+    if (m.ntr == 1) { m.ntr = 0; return P; }
+    const XEntry e = m.last;
     m.ntr -= 1;
-    int tpp = 1, tpc = 2, level = 0, mydst = 0;
+    int tpp = 1, tpc = 2, level = 0, mydst = 0, myold = 0;
     XEntry mine = e;
     const int lim = m.ntr < m.lcap ? m.ntr : m.lcap;
-    while (tpc < lim) DSA_XG_LEVEL(*(DSA_LDS const xf4*)(m.hl + tpc))
-    while (tpc < m.ntr) DSA_XG_LEVEL(*(DSA_GLB const xf4*)(m.hg + (tpc - m.lcap - 1)))
-    if (tpc == m.ntr) {
-        const XEntry a = xg_get(m, tpc);
+    while (tpc < lim) DSA_XG_LEVEL(*(DSA_LDS const xf4*)(m.hl + tpc), )
+    if (tpc == m.ntr && tpc <= m.lcap) {                      // (an only child, in LDS)
+        const XEntry a = xg_entry(*(DSA_LDS const xf2*)(m.hl + tpc));
         const bool mv = a.key < e.key, cap = mv && gl == level;
-        mine.key = cap ? a.key : mine.key; mine.id = cap ? a.id : mine.id; mydst = cap ? tpp : mydst;
+        mine.key = cap ? a.key : mine.key; mine.id = cap ? a.id : mine.id; mydst = cap ? tpp : mydst; myold = cap ? tpc : myold;
         level += mv ? 1 : 0; tpp = mv ? tpc : tpp;
+        tpc = m.ntr + 1;
+    }
+    // the levels beyond the LDS part, three per memory round trip: fourteen lanes fetch the descendants of tpp down to its great-
+    // grandchildren (a slot beyond the tree's end reads as +inf: an only child then wins its "pair" as the reference's tail rule has it)
+    // into LDS scratch laid out as a little tree of its own (children at 2..3, their children at 4..7, 8..15), and the walk goes on there
+    while (tpc <= m.ntr) {
+        const int d = gl < 2 ? 1 : gl < 6 ? 2 : 3, off = gl - ((1 << d) - 2);
+        const int slot = (tpp << d) + off;
+        xf2 v; v.x = kInf; v.y = 0.0f;
+        if (gl < 14 && slot <= m.ntr) v = *(DSA_GLB const xf2*)(m.hg + (slot - m.lcap - 1));
+        *(DSA_LDS xf2*)(m.sc + (gl < 14 ? (1 << d) + off : gl - 14)) = v;
+        int lpc = 2;
+        while (lpc < 16 && tpc <= m.ntr) DSA_XG_LEVEL(*(DSA_LDS const xf4*)(m.sc + lpc), lpc = 2 * (lpc + (right ? 1 : 0));)
     }
     if (gl == level) { mine = e; mydst = tpp; }
-    xg_put(m, gl <= level, mydst, mine);
+    xg_put_tree(m, gl <= level, mydst, mine);
+    P.mine = mine; P.to = mydst; P.from = myold; P.moves = level;
+    return P;
 }
 #undef DSA_XG_LEVEL
 
@@ -199,7 +239,16 @@ __device__ __forceinline__ int xg_rec(int nbz, int iz0, int ix0)
 
 // One accept step of reference travel (:417-485) for the group's unit.  No branches outside the tree work: a lane's loads are issued
 // whatever the grid's edges say (a node outside reads the root's record, which exists, and the value is dropped)
-__device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int ix0, const XLane& L, int lane)
+#ifdef DSA_X_CLOCKS
+#define DSA_XCLK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); xc[k] += now_ - xt; xt = now_; }
+#else
+#define DSA_XCLK(k)
+#endif
+__device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int ix0, const XLane& L, int lane
+#ifdef DSA_X_CLOCKS
+                                               , unsigned long long* xc, unsigned long long& xt
+#endif
+                                               )
 {
     const bool lead = L.gl == 0;
     // my neighbour, my quadrant of its stencil: coordinates, who lies inside the grid, record indices
@@ -211,14 +260,41 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
     const int mid = in ? xg_rec(m.nbz, mz0, mx0) : root.id;
     const int idj = inj ? xg_rec(m.nbz, mz0, xj) : root.id, idj2 = inj2 ? xg_rec(m.nbz, mz0, xj2) : root.id;
     const int idk = ink ? xg_rec(m.nbz, zk, mx0) : root.id, idk2 = ink2 ? xg_rec(m.nbz, zk2, mx0) : root.id;
-    // six loads per lane in flight while the root leaves the tree
+    // seven loads per lane in flight while the root leaves the tree: the quadrant's stencil, the neighbour's slowness and status
     const XRec vj = m.F[idj], vj2 = m.F[idj2], vk = m.F[idk], vk2 = m.F[idk2];
+    const int st_pre = m.F[mid].st;
     const float slown = m.slow[mid], risti = m.risti[in ? mx0 : 0];
-    if (lead) m.F[root.id].st = 0;
-    xg_pop_root(m, L.gl);
-    // my neighbour's status, behind the stores of the root's removal (outside the grid: the root's, 0 = nothing to do)
-    const int st_mem = m.F[mid].st;
-    const int st = in ? st_mem : 0;
+    DSA_XCLK(1)
+    const int ntr_old = m.ntr;
+    const XPop P = xg_pop_root(m, L.gl);
+    DSA_XCLK(2)
+    // my neighbour's slot after the root's removal: its status was fetched BEFORE it, so if the neighbour is one of the entries the walk
+    // moved -- from a slot on the walk's path to that slot's parent, or (the tree's last entry) to where it sank -- the slot follows it.
+    // The path's slot at the depth of mine sits with the lane of that level.
+    int st = in ? st_pre : 0;
+    {
+        const int lv = 30 - __builtin_clz(st > 1 ? st : 2);                       // level of the move that would have taken slot st: depth - 1
+        const int sunk = xg_from_lane(L.base + 4 * (P.moves < 0 ? 0 : P.moves), P.to);
+        const int from = xg_from_lane(L.base + 4 * (lv & 15), P.from);
+        st = (st > 1 && lv < P.moves && from == st) ? (st >> 1) : st;
+        st = (st_pre == ntr_old && in && P.moves >= 0) ? sunk : st;
+    }
+#ifdef DSA_X_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DSA_XCLK(3)
+#endif
+    // what the group needs to know of the four neighbours: lane 4 q of the group holds neighbour q's
+    const int st0 = xg_from_lane(L.base, st), st1 = xg_from_lane(L.base + 16, st), st2 = xg_from_lane(L.base + 32, st), st3 = xg_from_lane(L.base + 48, st);
+    const int id0 = xg_from_lane(L.base, mid), id1 = xg_from_lane(L.base + 16, mid), id2 = xg_from_lane(L.base + 32, mid), id3 = xg_from_lane(L.base + 48, mid);
+    if (m.ntr + 4 > m.lcap + m.gcap) { m.err = 1; return; }
+    // their slots in the tree -- added (far: the next free slot) or already in it -- and their paths, fetched together BEFORE any of them
+    // is updated: one memory round trip for the four where the paths leave the LDS part
+    const bool new0 = st0 < 0, new1 = st1 < 0, new2 = st2 < 0, new3 = st3 < 0;
+    const int c1 = m.ntr + (new0 ? 1 : 0), c2 = c1 + (new1 ? 1 : 0), c3 = c2 + (new2 ? 1 : 0);
+    const int s0 = st0 == 0 ? 0 : new0 ? m.ntr + 1 : st0, s1 = st1 == 0 ? 0 : new1 ? c1 + 1 : st1;
+    const int s2 = st2 == 0 ? 0 : new2 ? c2 + 1 : st2, s3 = st3 == 0 ? 0 : new3 ? c3 + 1 : st3;
+    m.ntr = c3 + (new3 ? 1 : 0);
+    const XEntry p0 = xg_path(m, s0, !new0, L.gl), p1 = xg_path(m, s1, !new1, L.gl), p2 = xg_path(m, s2, !new2, L.gl), p3 = xg_path(m, s3, !new3, L.gl);
     XQuadState s;
     s.ej = inj; s.ek = ink;
     s.aj = inj && (vj.st == 0 || L.rootj);  s.oj = inj2 && vj2.st == 0;
@@ -231,27 +307,59 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
     const NodeGeom g = { m.ri, risti, m.dnx, m.dnz };
     const float c = x_quad_lane(s, k_dead, j_dead, L.j, L.k, slown, g);
     const float trial = x_dpp_min4(in ? c : kInf);
-    // (fouds2 overwrites the trial value unconditionally, :758): the first lane of each neighbour's four stores it
-    if ((L.gl & 3) == 0 && st != 0) m.F[mid].T = trial;
-    // what the group needs to know of the four neighbours: lane 4 q of the group holds neighbour q's
+    DSA_XCLK(4)
     const int tb = __float_as_int(trial);
-    const int st0 = xg_from_lane(L.base, st), st1 = xg_from_lane(L.base + 16, st), st2 = xg_from_lane(L.base + 32, st), st3 = xg_from_lane(L.base + 48, st);
-    const int id0 = xg_from_lane(L.base, mid), id1 = xg_from_lane(L.base + 16, mid), id2 = xg_from_lane(L.base + 32, mid), id3 = xg_from_lane(L.base + 48, mid);
     const float tr0 = __int_as_float(xg_from_lane(L.base, tb)), tr1 = __int_as_float(xg_from_lane(L.base + 16, tb));
     const float tr2 = __int_as_float(xg_from_lane(L.base + 32, tb)), tr3 = __int_as_float(xg_from_lane(L.base + 48, tb));
-    if (m.ntr + 4 > m.lcap + m.gcap) { m.err = 1; return; }
-    // the four neighbours in the reference's order: added (far: the next free slot) or moved up (in the tree)
-#define DSA_XG_NEIGHBOUR(stq, idq, trq)                                                                              \
-    if ((stq) != 0) {                                                                                                \
-        const bool isnew = (stq) < 0;                                                                                \
-        m.ntr += isnew ? 1 : 0;                                                                                      \
-        xg_sift_up(m, XEntry{ (trq), (idq) }, isnew ? m.ntr : (stq), !isnew, L.gl, lane);                            \
+    // From here on the step only stores (but for the rare second look at a path): the root alive, the statuses of the entries its removal
+    // moved, the neighbours' trial values (fouds2 overwrites them unconditionally, :758: the first lane of each neighbour's four stores it) ...
+    // (the paths fetched above are waited for HERE, before the first store: inside the loop below the wait would also cover the stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+    if (lead) m.F[root.id].st = 0;
+    xg_put_status(m, L.gl <= P.moves, P.to, P.mine);
+    if ((L.gl & 3) == 0 && st != 0) m.F[mid].T = trial;
+    // ... and the four neighbours in the reference's order, moving up while strictly smaller than the parent (xg_sift_apply).  ONE copy of
+    // the code, the neighbours' values rotated through it.  A neighbour takes a second look at its path when an earlier one of this step
+    // has changed what it would see: entries moved (`dirty`), or the earlier neighbour's own slot lies on this one's path.
+    {
+        int stq = st0, idq = id0, sq = s0, st_b = st1, id_b = id1, s_b = s1, st_c = st2, id_c = id2, s_c = s2, st_d = st3, id_d = id3, s_d = s3;
+        float trq = tr0, tr_b = tr1, tr_c = tr2, tr_d = tr3;
+        XEntry pq = p0, p_b = p1, p_c = p2, p_d = p3;
+        int e1 = -2, e2 = -2, e3 = -2;                 // slots of the earlier neighbours of this step
+        bool dirty = false;
+#define DSA_XG_ROTATE                                                    \
+            stq = st_b; st_b = st_c; st_c = st_d; st_d = 0;              \
+            idq = id_b; id_b = id_c; id_c = id_d;                        \
+            sq = s_b; s_b = s_c; s_c = s_d;                              \
+            trq = tr_b; tr_b = tr_c; tr_c = tr_d;                        \
+            pq = p_b; p_b = p_c; p_c = p_d;
+        // the loop that only stores (no load in it: a wait for one would also wait for the stores of the iterations before) ...
+        int q = 0;
+#pragma unroll 1
+        for (; q < 4; ++q) {
+            if (stq != 0) {
+                const int a_ = L.gl < 15 ? (sq >> (L.gl + 1)) : -1;          // (0 beyond the root: never an earlier neighbour's slot)
+                if (dirty || xg_vote16(a_ == e1 || a_ == e2 || a_ == e3, lane) != 0u) break;
+                bool moved_ = false;
+                if (!xg_sift_apply(m, XEntry{ trq, idq }, sq, stq > 0, pq, L.gl, lane, &moved_)) break;
+                dirty = moved_;
+                e3 = e2; e2 = e1; e1 = sq;
+            }
+            DSA_XG_ROTATE
+        }
+#ifdef DSA_X_CLOCKS
+        { const unsigned long long now_ = __builtin_readcyclecounter(); xc[6] += now_ - xt; xt = now_; if (q < 4) xc[7] += 1; }
+#endif
+        // ... and, from the first neighbour that needs a second look at its path on, the loop that reads again
+#pragma unroll 1
+        for (; q < 4; ++q) {
+            if (stq != 0) xg_sift_up(m, XEntry{ trq, idq }, stq < 0 ? sq : m.F[idq].st, stq > 0, L.gl, lane);
+            DSA_XG_ROTATE
+        }
+#undef DSA_XG_ROTATE
     }
-    DSA_XG_NEIGHBOUR(st0, id0, tr0)
-    DSA_XG_NEIGHBOUR(st1, id1, tr1)
-    DSA_XG_NEIGHBOUR(st2, id2, tr2)
-    DSA_XG_NEIGHBOUR(st3, id3, tr3)
-#undef DSA_XG_NEIGHBOUR
+    DSA_XCLK(5)
+    if (m.ntr > 0) m.last = xg_get(m, m.ntr);
     m.pops += 1u;
 }
 
@@ -262,7 +370,7 @@ template <bool REFINED>
 __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const int* __restrict__ units, int n, const float* __restrict__ slow_all,
                                                size_t field_stride, const float* __restrict__ risti_c, XRec* pool, size_t pool_stride,
                                                XEntry* heap_pool, int gcap, int lcap, const XStart* __restrict__ starts, const int* __restrict__ nstart,
-                                               int32_t* xinfo)
+                                               int32_t* xinfo, unsigned long long* clk)
 {
     extern __shared__ unsigned char x_lds[];
     const int lane = threadIdx.x, grp = lane >> 4;
@@ -272,6 +380,8 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
     const int s = units[live ? slot : n - 1];
     XG m;
     m.hl = (DSA_LDS XEntry*)x_lds + (size_t)grp * (size_t)(lcap + 1);
+    m.sc = (DSA_LDS XEntry*)x_lds + (size_t)4 * (size_t)(lcap + 1) + (size_t)grp * 16;
+    m.last = XEntry{ 0.0f, 0 };
     m.lcap = lcap; m.hg = (DSA_GLB XEntry*)(heap_pool + (size_t)(live ? slot : 0) * gcap); m.gcap = gcap;
     m.ntr = 0; m.err = 0; m.pops = 0u; m.ri = g.earth;
     int rnx = 0, rnz = 0, oxl = 0, oxh = 0, ozl = 0, ozh = 0;
@@ -308,6 +418,10 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
         }
     }
     const XLane L = xg_lane(lane);
+    if (live && m.ntr > 0) m.last = xg_get(m, m.ntr);
+#ifdef DSA_X_CLOCKS
+    unsigned long long xc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, xt = __builtin_readcyclecounter();
+#endif
     bool active = live;
     for (;;) {
         active = active && m.ntr > 0 && m.err == 0;
@@ -322,9 +436,16 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
                 stop = (ix == 1 && oxl) || (ix == rnx && oxh) || (iz == 1 && ozl) || (iz == rnz && ozh);
             }
             if (stop) { if (lead) m.F[root.id].st = 0; active = false; }
+#ifdef DSA_X_CLOCKS
+            else { DSA_XCLK(0) xg_accept_root(m, root, iz0, ix0, L, lane, xc, xt); }
+#else
             else xg_accept_root(m, root, iz0, ix0, L, lane);
+#endif
         }
     }
+#ifdef DSA_X_CLOCKS
+    if (!REFINED && clk && lane == 0 && live) for (int q = 0; q < 8; ++q) clk[(size_t)s * kClockSlots + 8 + q] = xc[q];
+#endif
     if (live && lead) {
         if (REFINED) { xinfo[4 * s + 0] = (int)m.pops; xinfo[4 * s + 2] = m.err; xinfo[4 * s + 3] = 0; }
         else { xinfo[4 * s + 1] = (int)m.pops; if (m.err) xinfo[4 * s + 2] = m.err; }
@@ -425,12 +546,36 @@ __global__ __launch_bounds__(256) void k_xfinish(GridDesc g, BatchPtrs b, const 
     }
 }
 
-size_t exact_lds_bytes(int lcap) { return (size_t)4 * (size_t)(lcap + 1) * sizeof(XEntry); }
+// the batch's receiver times straight from the marched fields (reference srtimes, receiver_core.h): a call that wants nothing but times
+// needs no compact copy of its units' fields -- at 4097^2 that copy is 67 MB per unit
+struct MarchFieldT {
+    const XRec* F;
+    __device__ __forceinline__ float operator()(int id) const { const XRec r = F[id]; return r.st == 0 ? r.T : kInf; }
+};
+__global__ __launch_bounds__(64) void k_xreceivers(GridDesc g, BatchPtrs b, const int* __restrict__ units, const XRec* pool, size_t pool_stride,
+                                                   const RayDesc* __restrict__ rays, const float* __restrict__ veln_all, size_t veln_stride, float dpl,
+                                                   float* __restrict__ out, int32_t* __restrict__ err)
+{
+    const int slot = blockIdx.x;
+    const int s = units[slot];
+    const SourceDesc sd = b.src[s];
+    const MarchFieldT field{ pool + (size_t)slot * pool_stride };
+    const float* veln = veln_all + (size_t)sd.period * veln_stride;
+    for (int r = threadIdx.x; r < sd.nrec; r += 64) {
+        const RayDesc rd = rays[sd.first_ray + r];
+        if (!(rd.flags & kRayTime)) continue;
+        float t;
+        if (!receiver_time_f(g, sd.scx, sd.scz, rd, field, veln, dpl, &t)) { atomicExch(err, sd.first_ray + r + 1); t = 0.0f; }
+        out[rd.data] = t;
+    }
+}
+
+size_t exact_lds_bytes(int lcap) { return (size_t)4 * (size_t)(lcap + 1 + 16) * sizeof(XEntry); }
 size_t exact_start_bytes() { return (size_t)kXStage * sizeof(XStart); }
 
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
                   const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
-                  int32_t* d_xinfo, hipStream_t stream)
+                  int32_t* d_xinfo, unsigned long long* d_clocks, const XReceivers* rc, bool compact_copy, hipStream_t stream)
 {
     if (n <= 0) return;
     const size_t lds = exact_lds_bytes(lcap);
@@ -443,11 +588,13 @@ void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int
     hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (XRec*)d_pool, pool_stride, nrec);
     const int waves = (n + 3) / 4;
     hipLaunchKernelGGL(k_xmarch<true>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (XRec*)d_pool, pool_stride,
-                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo);
+                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks);
     hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (XRec*)d_pool, pool_stride, (XStart*)d_starts, d_nstart);
     hipLaunchKernelGGL(k_xmarch<false>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (XRec*)d_pool, pool_stride,
-                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo);
-    hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const XRec*)d_pool, pool_stride, nrec);
+                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks);
+    if (compact_copy) hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const XRec*)d_pool, pool_stride, nrec);
+    if (rc) hipLaunchKernelGGL(k_xreceivers, dim3(n), dim3(64), 0, stream, g, b, d_units, (const XRec*)d_pool, pool_stride, rc->rays, rc->veln_all, rc->veln_stride,
+                               rc->dpl, rc->out, rc->err);
 }
 
 }  // namespace dsa

@@ -175,13 +175,16 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
 // exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), FOUR units per wavefront
 // (a group of sixteen lanes each), unit j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per
 // slot beyond the lcap -- odd -- kept in LDS; d_starts / d_nstart: exact_start_bytes() + 4 bytes per slot for the coarse stage's starting tree);
-// five launches: reset, refined march, snapshot + hand-off, coarse march, compact copy.
+// launches: reset, refined march, snapshot + hand-off, coarse march, then the compact copy and / or the batch's receiver times.
 // xinfo[4 u ..]: accepts of the refined / coarse stage, error code (1 tree capacity)
 size_t exact_lds_bytes(int lcap);
 size_t exact_start_bytes();
+// the batch's receiver times from the marched fields themselves (RayDesc::src indexes the resident chunk like d_units does)
+struct XReceivers { const RayDesc* rays; const float* veln_all; size_t veln_stride; float dpl; float* out; int32_t* err; };
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
                   const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
-                  int32_t* d_xinfo, hipStream_t stream);
+                  int32_t* d_xinfo, unsigned long long* d_clocks /* probe builds (DSA_X_CLOCKS): cycle counts per phase of the accept step */,
+                  const XReceivers* receivers /* null: no receiver times here */, bool compact_copy /* the units' compact fields into BatchPtrs::T_c */, hipStream_t stream);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
 // RayDesc::src is a global unit index; unit_base is the first unit held by the batch arrays

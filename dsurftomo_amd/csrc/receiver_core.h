@@ -7,9 +7,16 @@
 
 namespace dsa {
 
+// the travel time of record `id` as the field's storage has it: the compact field of the fixed-point solve (one float per node, or G of
+// them for a bundle) ...
+struct CompactFieldT {
+    const float* Tc; int tstride;
+    __device__ __forceinline__ float operator()(int id) const { return t_value(Tc[(size_t)id * tstride]); }
+};
 // returns false when the receiver lies outside the grid (the caller reports it); *t: the time, 0 where the reference leaves 0
-__device__ __forceinline__ bool receiver_time(const GridDesc& g, float scx, float scz, const RayDesc& rd, const float* __restrict__ Tc,
-                                              const float* __restrict__ veln, float dpl, float* t, int tstride = 1 /* floats between the field's nodes (bundles: G) */)
+template <class Field>
+__device__ __forceinline__ bool receiver_time_f(const GridDesc& g, float scx, float scz, const RayDesc& rd, Field field,
+                                                const float* __restrict__ veln, float dpl, float* t)
 {
     const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, earth = g.earth;
     const float rcx1 = rd.rx, rcz1 = rd.rz;
@@ -54,7 +61,7 @@ __device__ __forceinline__ bool receiver_time(const GridDesc& g, float scx, floa
             for (int l = 1; l <= 2; ++l) {
                 const float produ = (1.0f - fabsf(((float)(l - 1) * dnz - drz) / dnz)) *
                                     (1.0f - fabsf(((float)(k - 1) * dnx - drx) / dnx));
-                trr = trr + t_value(Tc[(size_t)rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1) * tstride]) * produ;
+                trr = trr + field(rec_index(g.nbz, irz - 1 + l - 1, irx - 1 + k - 1)) * produ;
             }
     }
     // A source inside the last cell next to a high model edge ends the reference's refined stage at once and
@@ -63,6 +70,11 @@ __device__ __forceinline__ bool receiver_time(const GridDesc& g, float scx, floa
     if (!(trr < kInf)) trr = 0.0f;
     *t = trr;
     return true;
+}
+__device__ __forceinline__ bool receiver_time(const GridDesc& g, float scx, float scz, const RayDesc& rd, const float* __restrict__ Tc,
+                                              const float* __restrict__ veln, float dpl, float* t, int tstride = 1 /* floats between the field's nodes (bundles: G) */)
+{
+    return receiver_time_f(g, scx, scz, rd, CompactFieldT{ Tc, tstride }, veln, dpl, t);
 }
 
 }  // namespace dsa

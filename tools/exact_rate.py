@@ -26,3 +26,8 @@ for l in lds:
         st = e.stats()
         print(f'N={e.nnx} {kind} {n} units, exact_ties=2, lds slots {l}, pool {p}: {n/dt:8.1f} solves/s (call), march {st["ms_exact"]:.0f} ms = {n/st["ms_exact"]*1e3:8.1f} solves/s = '
               f'{st["exact_pops"]/st["ms_exact"]/1e3:.1f} M accepts/s, {st["ms_exact"]*1e3/(st["exact_pops"]/n):.3f} us per accept per unit', flush=True)
+        c = e.debug_counters()
+        if c[:8].sum() > 0:          # probe build -DDSA_X_CLOCKS: cycles per phase of the accept step, summed over the wavefronts' first lanes
+            names = ["root+coords", "indices+fetch issue", "pop", "slot fix-up + fetch wait", "paths + candidates", "second-look loop + last", "store loop"]
+            steps = st["exact_pops"] / n * (n / 4.0)
+            print("    cycles per step: " + ", ".join(f"{nm} {c[i]/steps:.0f}" for i, nm in enumerate(names)) + f" | total {c[:7].sum()/steps:.0f} | steps with a second look {c[7]/steps:.3f}", flush=True)
