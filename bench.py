@@ -66,15 +66,13 @@ def kernel_source_hash(names=None):
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(budget_units=96):
-    """Reference CPU path on a bounded sample: per unit dicing (the reference re-dices per source,
-    CalSurfG.f90:1186), refined + coarse Fast Marching and the 32 receiver times; one core.
-    Returns (record, unit indices, reference receiver times [units, NREC])."""
+def reference_times(units, pick, kind):
+    """Receiver times of the units `pick` by the reference CPU path -- the reference's own Fortran (oracle/_ref) when that library is there,
+    else the C oracle: per unit dicing (the reference re-dices per source, CalSurfG.f90:1186), refined + coarse Fast Marching and the unit's
+    receiver times; one core.  Returns (times [len(pick), NREC], seconds, "reference" | "port")."""
     import numpy as np
     import _libs as L
     import synth
-    units = synth.units(NX, NSRC, NPER, NREC)
-    pick = np.linspace(0, NSRC * NPER - 1, budget_units).astype(int)
     times = np.zeros((len(pick), NREC), np.float32)
     ref = L.ref()
     if ref is not None:
@@ -82,29 +80,142 @@ def cpu_baseline(budget_units=96):
         t0 = time.perf_counter()
         for k, u in enumerate(pick):
             p = int(units["map_index"][u])
-            wb.L.ref_wb_gridder(L.ptr(np.ascontiguousarray(synth.medium(NX, "smooth", p))))
+            wb.L.ref_wb_gridder(L.ptr(np.ascontiguousarray(synth.medium(NX, kind, p))))
             wb.L.ref_wb_solve(float(units["scx"][u]), float(units["scz"][u]))
             for r in range(NREC):
                 times[k, r] = wb.L.ref_wb_srtimes(float(units["scx"][u]), float(units["scz"][u]),
                                                   float(units["rcx"][u * NREC + r]), float(units["rcz"][u * NREC + r]))
         dt = time.perf_counter() - t0
         wb.close()
-        kind = "reference"
-    else:
-        g = L.grid(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
-        t0 = time.perf_counter()
-        for k, u in enumerate(pick):
-            pv = synth.medium(NX, "smooth", int(units["map_index"][u]))
-            veln = L.o_gridder(g, pv)
-            sol = L.o_solve(g, pv, veln, units["scx"][u], units["scz"][u])
-            for r in range(NREC):
-                times[k, r] = L.o_srtimes(g, veln, sol["T"], units["scx"][u], units["scz"][u], units["rcx"][u * NREC + r], units["rcz"][u * NREC + r])
-        dt = time.perf_counter() - t0
-        kind = "port"
+        return times, dt, "reference"
+    g = L.grid(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    t0 = time.perf_counter()
+    for k, u in enumerate(pick):
+        pv = synth.medium(NX, kind, int(units["map_index"][u]))
+        veln = L.o_gridder(g, pv)
+        sol = L.o_solve(g, pv, veln, units["scx"][u], units["scz"][u])
+        for r in range(NREC):
+            times[k, r] = L.o_srtimes(g, veln, sol["T"], units["scx"][u], units["scz"][u], units["rcx"][u * NREC + r], units["rcz"][u * NREC + r])
+    return times, time.perf_counter() - t0, "port"
+
+
+def cpu_baseline(budget_units=96):
+    """Reference CPU path on a bounded sample of the headline workload.  Returns (record, unit indices, reference receiver times [units, NREC])."""
+    import numpy as np
+    import synth
+    units = synth.units(NX, NSRC, NPER, NREC)
+    pick = np.linspace(0, NSRC * NPER - 1, budget_units).astype(int)
+    times, dt, kind = reference_times(units, pick, "smooth")
     rec = {"value": round(len(pick) / dt, 4), "unit": "solves/s", "cores": 1, "kind": kind,
            "sample": "%d of the %d (period, source) units, evenly spaced; dicing + refined/coarse FMM + %d receiver times each" % (len(pick), NSRC * NPER, NREC),
            "seconds": round(dt, 2)}
     return rec, pick, times
+
+
+def exact_secondary(eng, with_reference=True):
+    """The in-tolerance mode on the tie-prone medium: configs[2]'s grid with configs[4]'s checkerboard, 512 sources x 16
+    periods = 8192 units x 32 receivers (the march fills the chip from ~8000 units on: 4096 units run at ~880, 16 000 at ~1740 solves/s).  exact_ties = 2 -- the reference's Fast Marching replayed on the device (csrc/exact_kernel.hip) --
+    timed with the engine's HIP events over the whole call, and checked bit for bit against the reference on 16 of the units; exact_ties = 1
+    -- tie detector, literal march for the flagged units -- with the flagged fraction and the worst receiver of the units it left alone
+    (against the exact_ties = 2 times, which ARE the reference's)."""
+    import numpy as np
+    import synth
+    nsrc = 512
+    units = synth.units(NX, nsrc, NPER, NREC, seed=synth.SEED + 41)
+    n = nsrc * NPER
+    pv = np.stack([synth.medium(NX, "checker", p) for p in range(NPER)])
+    out = {"workload": "1025x1025 grid, checkerboard +-8 %% (configs[4]'s medium), %d sources x %d periods = %d units, %d receivers each" % (nsrc, NPER, n, NREC)}
+    try:
+        eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        eng.set_option("exact_ties", 2)
+        eng.plan(**units)
+        eng.solve()                                   # (first use allocates the marching pool)
+        tx = eng.solve().reshape(n, NREC)
+        st = eng.stats()
+        rec = {"mode": "exact_ties=2: every unit by the literal march, four units per wavefront (k_xmarch)",
+               "solves_per_s": round(n / (st["ms_total"] / 1e3), 1), "ms": round(st["ms_total"], 1), "timed_with": "HIP events on the engine's stream, whole call",
+               "march_accepts_per_s": round(st["exact_pops"] / (st["ms_exact"] / 1e3), 0)}
+        if with_reference:
+            pick = np.linspace(0, n - 1, 16).astype(int)
+            ref, dt, kind = reference_times(units, pick, "checker")
+            rec["not_bit_identical"] = int((tx[pick].view(np.uint32) != ref.view(np.uint32)).sum())
+            rec["checked_receiver_times"] = int(ref.size)
+            rec["against"] = kind
+            rec["vs_one_reference_core"] = round(rec["solves_per_s"] / (len(pick) / dt), 1)
+        out["exact"] = rec
+        eng.set_option("exact_ties", 1)
+        eng.plan(**units)
+        t1 = eng.solve().reshape(n, NREC)
+        st1 = eng.stats()
+        flags, infl = eng.unit_ties()
+        marched = (flags & 2) != 0
+        d = np.abs(t1.astype(np.float64) - tx.astype(np.float64)).max(axis=1)
+        out["exact_ties1"] = {"mode": "exact_ties=1: fixed point + tie detector (tie_threshold 2e-5 s), literal march for the flagged units",
+                              "solves_per_s": round(n / (st1["ms_total"] / 1e3), 1), "ms": round(st1["ms_total"], 1),
+                              "flagged_fraction": round(float(marched.mean()), 4), "flagged_units": int(marched.sum()),
+                              "flagged_not_bit_identical_to_exact": int((t1[marched].view(np.uint32) != tx[marched].view(np.uint32)).sum()),
+                              "unflagged_worst_abs_dt_s": float(d[~marched].max()) if (~marched).any() else 0.0,
+                              "unflagged_units_beyond_1e-4_s": int((d[~marched] > TOL).sum())}
+    finally:
+        eng.set_option("exact_ties", 0)
+    return out
+
+
+def bundling_secondary(eng):
+    """What the headline's bundles are worth when the periods' maps have nothing in common: the same grid and sizes with
+    +-10 % random vertices, a different draw per period (256 sources x 16 periods), bundled as the engine chooses and unit by unit."""
+    import numpy as np
+    import synth
+    nsrc = 256
+    units = synth.units(NX, nsrc, NPER, NREC, seed=synth.SEED + 43)
+    n = nsrc * NPER
+    pv = np.stack([synth.medium(NX, "rough", p) for p in range(NPER)])
+    out = {"workload": "1025x1025 grid, +-10 %% random vertices, an unrelated draw per period; %d sources x %d periods = %d units" % (nsrc, NPER, n)}
+    try:
+        eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        for tag, opt in (("bundled", 1), ("unit_by_unit", 0)):
+            eng.set_option("bundle", opt)
+            eng.plan(**units)
+            eng.solve()
+            eng.solve()
+            st = eng.stats()
+            out[tag] = {"solves_per_s": round(n / (st["ms_total"] / 1e3), 1), "bundle_size": int(st.get("bundle_size", 0)),
+                        "evals_per_node": round(st["evals_total"] / n / (eng.nnx * eng.nnz), 3)}
+    finally:
+        eng.set_option("bundle", 1)
+    return out
+
+
+def rays_secondary(eng):
+    """Rays and Frechet rows at the headline grid (SURVEY.md 8d secondary metric; reference rpaths CalSurfG.f90:1771-2318 and the row assembly
+    :1383-1432): 256 sources x 32 receivers on the smooth map of period 0, synthetic depth kernels (nz = 9), rows left on the device."""
+    import numpy as np
+    import synth
+    nsrc, nz = 256, 9
+    u = synth.units(NX, nsrc, 1, NREC)
+    pv = synth.medium(NX, "smooth", 0)
+    ncol = NX * NX
+    rng = synth.LCG(5)
+    vel = (2.5 + 0.2 * np.arange(nz)[:, None, None] + 0.0 * np.zeros((nz, NX, NX))).astype(np.float32)
+    depz = (np.arange(nz) * 5.0).astype(np.float32)
+    sen = [0.02 + 0.05 * rng.uniform(nz * ncol).reshape(nz, 1, ncol) for _ in range(3)]
+    try:
+        eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        eng.set_depth_kernels(vel, depz, *sen)
+        eng.set_option("rows_on_device", 1)
+        eng.plan(u["map_index"], u["scx"], u["scz"], u["nrec"], u["rcx"], u["rcz"])
+        eng.solve_rows_device()
+        eng.solve_rows_device()
+        st = eng.stats()
+    finally:
+        eng.set_option("rows_on_device", 0)
+    rays, nar = st["rays"], st["nar"]
+    return {"kernel": "k_rays (one lane per ray) + k_row_list / k_row_emit / k_scan",
+            "workload": "%d sources x %d receivers at 1025^2, smooth map, nz = %d depth layers; rows left on the device" % (nsrc, NREC, nz),
+            "rays": int(rays), "matrix_entries": int(nar), "entries_per_ray": round(nar / max(rays, 1), 1), "steps_per_ray": round(st["ray_steps"] / max(rays, 1), 1),
+            "ms_rays": round(st["ms_rays"], 2), "ms_rows": round(st["ms_rows"], 2),
+            "rays_per_s": round(rays / (st["ms_rays"] / 1e3), 0), "rays_per_s_incl_rows": round(rays / ((st["ms_rays"] + st["ms_rows"]) / 1e3), 0),
+            "entries_per_s": round(nar / ((st["ms_rays"] + st["ms_rows"]) / 1e3), 0)}
 
 
 def pmc_record():
@@ -324,6 +435,8 @@ def main():
             "ms_per_step": round(1000.0 * dt / args.steps, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 1025x1025 grid (nx=ny=131, dicing 8), 16 periods x 1000 sources, 32 receivers each, smooth +-10% velocity",
+                       "medium_note": "the 16 maps are one pattern times a scale per period (BASELINE configs[2]): the best case for the bundle kernel, which solves the periods of a "
+                                      "source under one shared schedule; secondary.bundling_on_unrelated_maps holds the figure for maps that have nothing in common",
                        "grid": n, "units_per_step": total_units, "receivers_per_step": total_units * NREC,
                        "parallelism": "sources (all their periods) sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -363,11 +476,14 @@ def main():
             line["parity"] = {"checked_receiver_times": int(d.size), "units": int(len(pick)), "beyond_1e-4_s": int((d > TOL).sum()),
                               "not_bit_identical": int((got.view(np.uint32) != ref_times.view(np.uint32)).sum()),
                               "against": rec["kind"], "tolerance_s": TOL}
-        if world == 1:
+        # secondary legs (rank 0, after the timed region; none of them may take the headline line down with it)
+        line["secondary"] = {}
+        for name, leg in (("exact_mode", lambda: exact_secondary(eng, with_reference=not args.no_cpu_baseline)), ("bundling_on_unrelated_maps", lambda: bundling_secondary(eng)),
+                          ("rays", lambda: rays_secondary(eng)), ("dispersion", lambda: dispersion_secondary(eng))):
             try:
-                line["secondary"] = {"dispersion": dispersion_secondary(eng)}
-            except Exception as ex:                                     # the headline line must not depend on the secondary one
-                line["secondary"] = {"dispersion": {"error": str(ex)[:200]}}
+                line["secondary"][name] = leg()
+            except Exception as ex:
+                line["secondary"][name] = {"error": str(ex)[:300]}
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

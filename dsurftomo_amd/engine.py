@@ -171,6 +171,13 @@ class Engine:
         n = nar.value
         return out, rw[:n].copy(), iw[:n].copy(), col[:n].copy()
 
+    def solve_rows_device(self):
+        """receiver times; the Frechet rows stay on the device (set_option('rows_on_device', 1) before it): returns (times, number of entries)"""
+        out = np.zeros(self._ndata, np.float32)
+        nar = C.c_longlong(0)
+        self._check(self._L.dsa_solve_rows(self._h, _p(out), None, None, None, C.c_longlong(1 << 62), C.byref(nar)))
+        return out, nar.value
+
     def ray_paths(self, cap):
         """paths of the rays traced by the last solve_rows (set_option('ray_path_cap', cap) before it): list of
         (datum, points) with points an (n, 2) array of (latitude, longitude) in degrees, receiver first, source last --
