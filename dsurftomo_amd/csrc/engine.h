@@ -50,6 +50,7 @@ struct Engine {
     float window_cells = 1.25f;        // causal window of the coarse solve in cell travel times (measured optimum 1.0-1.5)
     int list_cap = 0, ready_cap = 0;   // 0 = derive from the grid
     int last_chunk_first = -1, last_chunk_n = 0;
+    bool fields_resident = false;      // the last chunk's coarse fields are still in their slots (not so after a launch that recycled them)
 
     DevBuf<SourceDesc> src;
     DevBuf<RayDesc> rays;
@@ -93,6 +94,8 @@ struct Engine {
     std::vector<int> h_member_flag;
     int bundle_slots = 0;
     size_t solve_stage_bytes() const;
+    size_t bundle_room(size_t free_b) const;
+    bool grow_unit_pool();
     int bundle_threads() const;
     int choose_bundle_size(int step, long* solo_units = nullptr);
     int plan_bundles(int first, int n, int G, int* nsolo, int* nbundles);

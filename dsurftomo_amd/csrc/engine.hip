@@ -413,9 +413,28 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     if (!h_trace.empty()) HIP_TRY(this, hipMemcpyAsync(trace_ids.p, h_trace.data(), h_trace.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
     planned = true;
-    last_chunk_first = -1;
+    last_chunk_first = -1; fields_resident = false;
     rays_clamped = 0; first_clamped_unit = -1;      // (diagnostics belong to the plan they were measured on)
     return 0;
+}
+
+// The unit field pool back to its regular size (four times the resident workgroups, within the plan's budget) when plan() had cut it
+// down for a call it expected to bundle and the call runs unit by unit after all: through a pool of 256 slots a unit-by-unit launch
+// crawls (75 k against 186 k solves/s at 121^2).  Returns false on an allocation error.
+bool Engine::grow_unit_pool()
+{
+    if (field_pool_opt != 0 || keep_fields || exact_ties != 0) return true;
+    const int resident = 256 * std::max(1, std::min(4, 1024 / std::max(shape_c.threads, 1)));
+    const size_t roomy = std::min<size_t>(16384, ((size_t)16 << 30) / per_slot_bytes);
+    size_t P = std::min<size_t>(std::max<size_t>((size_t)4 * resident, roomy), (size_t)std::max<size_t>(h_src.size(), 1));
+    if (max_chunk > 0) P = std::min<size_t>(P, (size_t)max_chunk);
+    const size_t units_b = (size_t)chunk * per_unit_bytes;
+    const size_t fit = plan_budget > units_b ? (size_t)(0.7 * (double)(plan_budget - units_b)) / per_slot_bytes : 0;
+    P = std::min(P, fit);
+    if (P <= (size_t)pool_slots) return true;
+    if (ensure(T_c, P * nrec_c) || ensure(exc_c, P << exc_log2cap) || ensure(lists_c, P * lists_c_stride) || ensure(pool_gen, P)) return false;
+    pool_slots = (int)P;
+    return true;
 }
 
 // bytes held by the buffers plan() and solve() size (reused by the next plan)
@@ -494,6 +513,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     HIP_TRY(this, hipMemsetAsync(err.p, 0, 4 * sizeof(int32_t), stream));
     const int bundle_G = exact_ties == 0 ? choose_bundle_size(step) : 0;
     stats[DSA_STAT_BUNDLE_SIZE] = bundle_G;
+    if (bundle_G == 0 && !grow_unit_pool()) return status;      // (plan() shrank the unit pool for bundles this call will not use)
     HIP_TRY(this, hipEventRecord(events[0], stream));
     std::vector<int32_t> h_info, h_flags;
     for (int first = 0; first < nunits; first += step) {
@@ -631,6 +651,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                 if (getenv("DSA_DEBUG_BUNDLE"))
                     for (int u = 0; u < n; ++u) if (h_member_flag[(size_t)u] && h_info[(size_t)u * 16 + 10] == -1) { fprintf(stderr, "bundle member %d (unit %d) gave up after %d rounds (freezes %d)\n", u, first + u, h_info[(size_t)u * 16 + 8], h_info[(size_t)u * 16 + 11]); break; }
                 bundle_off_chunk = true; redo_chunk = true; stats[DSA_STAT_RESCANS] += 1;
+                if (!grow_unit_pool()) return status;
                 bundles_failed = true;          // these maps do not bundle (fronts of the periods too different): unit by unit until the maps change
                 continue;
             }
@@ -640,6 +661,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         }
         for (int u = 0; u < n; ++u) {
             const int32_t* fi = &h_info[(size_t)u * 16];
+            if (fi[10] == -3) { fail(DSA_ERR_INTERNAL, "unit %d: its field slot was never released by the slot's previous user (recycled slots assume in-order workgroup dispatch; set option field_pool = -1 for a slot per unit)", first + u); return DSA_ERR_INTERNAL; }
             if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
             if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
             stats[DSA_STAT_ROUNDS_MAX] = std::max(stats[DSA_STAT_ROUNDS_MAX], (double)fi[8]);
@@ -652,8 +674,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
         }
-        last_chunk_first = n <= pool_slots ? first : -1;       // (recycled slots: the fields are gone)
+        last_chunk_first = first;                               // the per-unit arrays (refined snapshots, ...) of this chunk stay resident ...
         last_chunk_n = n;
+        fields_resident = n <= pool_slots;                      // ... the coarse fields only when every unit had a slot (recycled slots: gone)
         if (rows && trace_chunk(first, n, rw, iw, col, cap, nar) != 0) return status;
       } while (redo_chunk);
     }
@@ -666,6 +689,17 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     HIP_TRY(this, hipMemcpy(herr, err.p, sizeof herr, hipMemcpyDeviceToHost));
     if (herr[0]) { fail(DSA_ERR_OUTSIDE, "Receiver lies outside model (ray %d)", herr[0] - 1); return DSA_ERR_OUTSIDE; }
     return 0;
+}
+
+// What the bundle field slots may take: the free memory, or -- a memory budget is set (dsa_set_memory_budget: several ranks on one device) --
+// what the budget leaves beside the unit slots and the per-unit arrays, so that two ranks planning at once cannot both claim the device
+// (ADVICE r03).  (The callers take 70 % of it.)
+size_t Engine::bundle_room(size_t free_b) const
+{
+    if (mem_budget == 0) return free_b;
+    const size_t held = (size_t)pool_slots * per_slot_bytes + (size_t)chunk * per_unit_bytes;
+    const size_t room = plan_budget > held ? plan_budget - held : 0;
+    return std::min(free_b, (size_t)((double)room / 0.7));
 }
 
 // Members per bundle for this call: the option, or (automatic) the largest of 16 / 8 / 4 that still gives the chip enough workgroups
@@ -681,6 +715,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
     free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;          // (what a previous call holds is reused)
+    free_b = bundle_room(free_b);
     auto slot_bytes = [&](int G) { int lg = G == 16 ? 4 : G == 8 ? 3 : 2; return (size_t)(G + 1) * nrec_c * 4 + ((size_t)8 << (exc_log2cap + lg)) + lists_c_stride * 4; };
     auto fits = [&](int G) {
         if ((unsigned long long)nrec_c * (unsigned long long)G * 4ull >= (1ull << 32)) return false;          // 32-bit byte offsets inside a bundle field
@@ -761,6 +796,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     size_t free_b = 0, total_b = 0;
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
     free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;
+    free_b = bundle_room(free_b);
     const size_t slot_b = (size_t)(G + 1) * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
     const size_t room = (size_t)(0.7 * (double)free_b) / slot_b;
     if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
@@ -1042,7 +1078,7 @@ int Engine::fetch_compact(int slot, int which, float* out)
 
 int Engine::get_field(int unit, float* ttn)
 {
-    if (last_chunk_first < 0 || unit < last_chunk_first || unit >= last_chunk_first + last_chunk_n) { fail(DSA_ERR_STATE, "get_field: unit %d is not resident (last chunk covers %d..%d)", unit, last_chunk_first, last_chunk_first + last_chunk_n - 1); return DSA_ERR_STATE; }
+    if (last_chunk_first < 0 || !fields_resident || unit < last_chunk_first || unit >= last_chunk_first + last_chunk_n) { fail(DSA_ERR_STATE, "get_field: unit %d is not resident (last chunk covers %d..%d%s)", unit, last_chunk_first, last_chunk_first + last_chunk_n - 1, fields_resident ? "" : "; its field slots were recycled"); return DSA_ERR_STATE; }
     HIP_TRY(this, hipSetDevice(device));
     if (fetch_compact(unit - last_chunk_first, 0, ttn)) return status;
     for (size_t k = 0; k < nfield; ++k) ttn[k] = fabsf(ttn[k]);
@@ -1294,6 +1330,7 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out)
     if (!e || !out) return DSA_ERR_ARGUMENT;
     Engine* en = reinterpret_cast<Engine*>(e);
     if (en->last_chunk_first < 0 || unit < en->last_chunk_first || unit >= en->last_chunk_first + en->last_chunk_n) return DSA_ERR_STATE;
+    if (which < 2 && !en->fields_resident) return DSA_ERR_STATE;
     const size_t slot = (size_t)(unit - en->last_chunk_first);
     if (which < 2) return en->fetch_compact((int)slot, which, out);
     const dsa::SourceDesc& s = en->h_src[unit];

@@ -466,8 +466,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         const FimEnds* const E = ends + blockIdx.x;
         int* const pg = E->pool_gen;
         if (pg) {
-            if (tid == 0) { const int want = E->gen; while (__hip_atomic_load(pg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(64); }
+            // (the slot's previous user is workgroup blockIdx.x - pool of this launch: dispatched earlier, so done or running -- an assumption
+            // about dispatch order the hardware does not promise; a wait that outlasts any solve therefore gives up: the unit
+            // reports -3 and the engine fails loudly instead of hanging the device.  The bundle slots are claimed, not assigned: no such wait.)
+            __shared__ int s_slot_ok;
+            if (tid == 0) {
+                const int want = E->gen;
+                long long spins = 0;
+                while (__hip_atomic_load(pg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want && spins < (1ll << 26)) { __builtin_amdgcn_s_sleep(64); ++spins; }
+                s_slot_ok = spins < (1ll << 26) ? 1 : 0;
+            }
             __syncthreads();
+            if (!s_slot_ok) { if (tid == 0) { p.info[2] = -3; p.info[0] = 0; } return; }
         }
         typedef float __attribute__((ext_vector_type(4))) V4;
         typedef __attribute__((address_space(1))) V4 GV4;
