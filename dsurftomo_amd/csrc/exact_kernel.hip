@@ -123,9 +123,11 @@ __device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e, int s, bool check
     const bool c = gl < 15 ? (have && e.key < p.key) : (check && p.id != e.id);
     const unsigned b = xg_vote16(c, lane);
     if (b & 0x8000u) return false;
+    // one store pass: lane l < moves its ancestor's entry a level down (slot s >> l), lane `moves` the entry itself where it stops
     const int moves = __builtin_ctz(~b);
-    xg_put(m, gl < moves, s >> gl, p);
-    xg_put(m, gl == 15, s >> moves, e);
+    XEntry w = p;
+    if (gl == moves) w = e;
+    xg_put(m, gl <= moves, s >> gl, w);
     *moved = moves > 0;
     return true;
 }
@@ -283,18 +285,17 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DSA_XCLK(3)
 #endif
-    // what the group needs to know of the four neighbours: lane 4 q of the group holds neighbour q's
-    const int st0 = xg_from_lane(L.base, st), st1 = xg_from_lane(L.base + 16, st), st2 = xg_from_lane(L.base + 32, st), st3 = xg_from_lane(L.base + 48, st);
-    const int id0 = xg_from_lane(L.base, mid), id1 = xg_from_lane(L.base + 16, mid), id2 = xg_from_lane(L.base + 32, mid), id3 = xg_from_lane(L.base + 48, mid);
     if (m.ntr + 4 > m.lcap + m.gcap) { m.err = 1; return; }
-    // their slots in the tree -- added (far: the next free slot) or already in it -- and their paths, fetched together BEFORE any of them
-    // is updated: one memory round trip for the four where the paths leave the LDS part
-    const bool new0 = st0 < 0, new1 = st1 < 0, new2 = st2 < 0, new3 = st3 < 0;
-    const int c1 = m.ntr + (new0 ? 1 : 0), c2 = c1 + (new1 ? 1 : 0), c3 = c2 + (new2 ? 1 : 0);
-    const int s0 = st0 == 0 ? 0 : new0 ? m.ntr + 1 : st0, s1 = st1 == 0 ? 0 : new1 ? c1 + 1 : st1;
-    const int s2 = st2 == 0 ? 0 : new2 ? c2 + 1 : st2, s3 = st3 == 0 ? 0 : new3 ? c3 + 1 : st3;
-    m.ntr = c3 + (new3 ? 1 : 0);
-    const XEntry p0 = xg_path(m, s0, !new0, L.gl), p1 = xg_path(m, s1, !new1, L.gl), p2 = xg_path(m, s2, !new2, L.gl), p3 = xg_path(m, s3, !new3, L.gl);
+    // The four neighbours, each in its OWN four lanes (lane r of neighbour q's quad): its slot in the tree -- added (far: the next free
+    // slots, in the reference's order x-, x+, z-, z+) or already in it --, and the part of its path an update normally touches: lanes 0..2 the
+    // three nearest ancestors, lane 3 (a node already in the tree) the slot itself.  One LDS read, one memory round trip where the paths
+    // leave the LDS part, issued before the stencil arithmetic so that it hides behind it.
+    const int r4 = L.gl & 3, q4 = L.gl & 12;
+    const bool isnew = st < 0;
+    const unsigned newq = xg_vote16(isnew && r4 == 0, lane);
+    const int sq = st == 0 ? 0 : isnew ? m.ntr + 1 + __popc(newq & ((1u << q4) - 1u)) : st;
+    const int aq = r4 < 3 ? (sq >> (r4 + 1)) : (isnew ? 0 : sq);
+    const XEntry pq = xg_get(m, aq >= 1 ? aq : 1);
     XQuadState s;
     s.ej = inj; s.ek = ink;
     s.aj = inj && (vj.st == 0 || L.rootj);  s.oj = inj2 && vj2.st == 0;
@@ -308,55 +309,64 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
     const float c = x_quad_lane(s, k_dead, j_dead, L.j, L.k, slown, g);
     const float trial = x_dpp_min4(in ? c : kInf);
     DSA_XCLK(4)
-    const int tb = __float_as_int(trial);
-    const float tr0 = __int_as_float(xg_from_lane(L.base, tb)), tr1 = __int_as_float(xg_from_lane(L.base + 16, tb));
-    const float tr2 = __int_as_float(xg_from_lane(L.base + 32, tb)), tr3 = __int_as_float(xg_from_lane(L.base + 48, tb));
-    // From here on the step only stores (but for the rare second look at a path): the root alive, the statuses of the entries its removal
-    // moved, the neighbours' trial values (fouds2 overwrites them unconditionally, :758: the first lane of each neighbour's four stores it) ...
-    // (the paths fetched above are waited for HERE, before the first store: inside the loop below the wait would also cover the stores)
+    // The updates of the four neighbours at once.  Each quad votes on `trial < ancestor's key` (lane 3: is the node still where its status
+    // said) and finds how many levels its node climbs: 0..2 -- or it asks for the sequential way (3: more ancestors to look at; a node not
+    // at its slot).  The reference updates the neighbours one after the other, each seeing the tree the one before left: the quads may go
+    // together only if no EARLIER neighbour writes a slot a LATER one reads or writes.  An update of node at slot s that climbs `up` levels
+    // writes s, s/2 .. s >> up and reads one ancestor more; two such chains meet at the depth of the slots' lowest common ancestor, so six
+    // lanes -- one per pair of neighbours -- compare that depth with the depths the two chains reach.
+    const bool cq = r4 < 3 ? (aq >= 1 && trial < pq.key) : (aq >= 1 && pq.id != mid);
+    const unsigned vq = (xg_vote16(cq, lane) >> q4) & 15u;
+    const int up = __builtin_ctz(~(vq & 7u));
+    bool seq = st != 0 && (up == 3 || (vq & 8u) != 0u);
+    {
+        // pair p of (earlier, later) neighbours: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+        const int pe = L.gl < 3 ? 0 : L.gl < 5 ? 1 : 2, pl = L.gl < 3 ? L.gl + 1 : L.gl < 5 ? L.gl - 1 : 3;
+        const int se = xg_from_lane(L.base + 16 * pe, sq), ue = xg_from_lane(L.base + 16 * pe, up);
+        const int sl = xg_from_lane(L.base + 16 * pl, sq), ul = xg_from_lane(L.base + 16 * pl, up);
+        const int de = 31 - __builtin_clz(se | 1), dl = 31 - __builtin_clz(sl | 1), dm = de < dl ? de : dl;
+        const unsigned x = (unsigned)(se >> (de - dm)) ^ (unsigned)(sl >> (dl - dm));
+        const int lca = dm - (x ? 32 - __builtin_clz(x) : 0);
+        const int reach_e = de - ue, reach_l = dl - ul - 1;
+        seq = seq || (L.gl < 6 && se > 0 && sl > 0 && lca >= (reach_e > reach_l ? reach_e : reach_l));
+    }
+    const bool sequential = xg_vote16(seq, lane) != 0u;
+    // From here on the step only stores (but for the rare sequential way): the root alive, the statuses of the entries its removal moved,
+    // the neighbours' trial values (fouds2 overwrites them unconditionally, :758: the first lane of each neighbour's four stores it) ...
+    // (the paths fetched above are waited for HERE, before the first store: a wait further down would also cover the stores)
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
     if (lead) m.F[root.id].st = 0;
     xg_put_status(m, L.gl <= P.moves, P.to, P.mine);
-    if ((L.gl & 3) == 0 && st != 0) m.F[mid].T = trial;
-    // ... and the four neighbours in the reference's order, moving up while strictly smaller than the parent (xg_sift_apply).  ONE copy of
-    // the code, the neighbours' values rotated through it.  A neighbour takes a second look at its path when an earlier one of this step
-    // has changed what it would see: entries moved (`dirty`), or the earlier neighbour's own slot lies on this one's path.
-    {
-        int stq = st0, idq = id0, sq = s0, st_b = st1, id_b = id1, s_b = s1, st_c = st2, id_c = id2, s_c = s2, st_d = st3, id_d = id3, s_d = s3;
-        float trq = tr0, tr_b = tr1, tr_c = tr2, tr_d = tr3;
-        XEntry pq = p0, p_b = p1, p_c = p2, p_d = p3;
-        int e1 = -2, e2 = -2, e3 = -2;                 // slots of the earlier neighbours of this step
-        bool dirty = false;
-#define DSA_XG_ROTATE                                                    \
-            stq = st_b; st_b = st_c; st_c = st_d; st_d = 0;              \
-            idq = id_b; id_b = id_c; id_c = id_d;                        \
-            sq = s_b; s_b = s_c; s_c = s_d;                              \
-            trq = tr_b; tr_b = tr_c; tr_c = tr_d;                        \
-            pq = p_b; p_b = p_c; p_c = p_d;
-        // the loop that only stores (no load in it: a wait for one would also wait for the stores of the iterations before) ...
-        int q = 0;
-#pragma unroll 1
-        for (; q < 4; ++q) {
-            if (stq != 0) {
-                const int a_ = L.gl < 15 ? (sq >> (L.gl + 1)) : -1;          // (0 beyond the root: never an earlier neighbour's slot)
-                if (dirty || xg_vote16(a_ == e1 || a_ == e2 || a_ == e3, lane) != 0u) break;
-                bool moved_ = false;
-                if (!xg_sift_apply(m, XEntry{ trq, idq }, sq, stq > 0, pq, L.gl, lane, &moved_)) break;
-                dirty = moved_;
-                e3 = e2; e2 = e1; e1 = sq;
-            }
-            DSA_XG_ROTATE
-        }
+    if (r4 == 0 && st != 0) m.F[mid].T = trial;
+    if (!sequential) {
+        // ... and the neighbours' updates, one store pass for the four: lane r < up its ancestor's entry a level down (slot s >> r), lane `up`
+        // the node itself where it stops
+        XEntry w = pq;
+        if (r4 == up) w = XEntry{ trial, mid };
+        xg_put(m, st != 0 && r4 <= up, sq >> r4, w);
+        m.ntr += __popc(newq);
+    } else {
+        // the sequential way (reference order, each neighbour reading its path after the one before has stored): lane 4 q of the group
+        // holds neighbour q's values
 #ifdef DSA_X_CLOCKS
-        { const unsigned long long now_ = __builtin_readcyclecounter(); xc[6] += now_ - xt; xt = now_; if (q < 4) xc[7] += 1; }
+        xc[7] += 1;
 #endif
-        // ... and, from the first neighbour that needs a second look at its path on, the loop that reads again
+        const int tb = __float_as_int(trial);
+        int stq = xg_from_lane(L.base, st), st_b = xg_from_lane(L.base + 16, st), st_c = xg_from_lane(L.base + 32, st), st_d = xg_from_lane(L.base + 48, st);
+        int idq = xg_from_lane(L.base, mid), id_b = xg_from_lane(L.base + 16, mid), id_c = xg_from_lane(L.base + 32, mid), id_d = xg_from_lane(L.base + 48, mid);
+        float trq = __int_as_float(xg_from_lane(L.base, tb)), tr_b = __int_as_float(xg_from_lane(L.base + 16, tb));
+        float tr_c = __int_as_float(xg_from_lane(L.base + 32, tb)), tr_d = __int_as_float(xg_from_lane(L.base + 48, tb));
 #pragma unroll 1
-        for (; q < 4; ++q) {
-            if (stq != 0) xg_sift_up(m, XEntry{ trq, idq }, stq < 0 ? sq : m.F[idq].st, stq > 0, L.gl, lane);
-            DSA_XG_ROTATE
+        for (int q = 0; q < 4; ++q) {
+            if (stq != 0) {
+                const bool fresh = stq < 0;
+                m.ntr += fresh ? 1 : 0;
+                xg_sift_up(m, XEntry{ trq, idq }, fresh ? m.ntr : m.F[idq].st, !fresh, L.gl, lane);
+            }
+            stq = st_b; st_b = st_c; st_c = st_d; st_d = 0;
+            idq = id_b; id_b = id_c; id_c = id_d;
+            trq = tr_b; tr_b = tr_c; tr_c = tr_d;
         }
-#undef DSA_XG_ROTATE
     }
     DSA_XCLK(5)
     if (m.ntr > 0) m.last = xg_get(m, m.ntr);

@@ -338,7 +338,7 @@ def test_512_thread_bundle_kernel_against_the_oracle_at_config4_size(bundles):
     n = nsrc * nper
     ref = _oracle_receiver_times(nx, pv, u, nrec, n, workers=24)
     e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
-    e.set_option("bundle", 1)                  # automatic: must pick 8 members, 512 threads
+    e.set_option("bundle", 8)                  # eight members per bundle; beyond 1500 nodes per side the kernel is k_fim_bundle<8, 512> (Engine::bundle_threads)
     t = e.traveltimes(**u).reshape(n, nrec)
     st = e.stats()
     assert st["bundles"] == nsrc and st["bundle_size"] == 8 and st["bundled_units"] == n

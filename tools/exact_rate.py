@@ -28,6 +28,6 @@ for l in lds:
               f'{st["exact_pops"]/st["ms_exact"]/1e3:.1f} M accepts/s, {st["ms_exact"]*1e3/(st["exact_pops"]/n):.3f} us per accept per unit', flush=True)
         c = e.debug_counters()
         if c[:8].sum() > 0:          # probe build -DDSA_X_CLOCKS: cycles per phase of the accept step, summed over the wavefronts' first lanes
-            names = ["root+coords", "indices+fetch issue", "pop", "slot fix-up + fetch wait", "paths + candidates", "second-look loop + last", "store loop"]
+            names = ["root+coords", "indices+fetch issue", "pop", "slot fix-up + fetch wait", "paths + candidates", "votes + stores (+ sequential way)", "-"]
             steps = st["exact_pops"] / n * (n / 4.0)
-            print("    cycles per step: " + ", ".join(f"{nm} {c[i]/steps:.0f}" for i, nm in enumerate(names)) + f" | total {c[:7].sum()/steps:.0f} | steps with a second look {c[7]/steps:.3f}", flush=True)
+            print("    cycles per step: " + ", ".join(f"{nm} {c[i]/steps:.0f}" for i, nm in enumerate(names)) + f" | total {c[:7].sum()/steps:.0f} | steps the sequential way {c[7]/steps:.3f}", flush=True)
