@@ -265,6 +265,8 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
     // seven loads per lane in flight while the root leaves the tree: the quadrant's stencil, the neighbour's slowness and status
     const XRec vj = m.F[idj], vj2 = m.F[idj2], vk = m.F[idk], vk2 = m.F[idk2];
     const int st_pre = m.F[mid].st;
+    // (the tree's last entry but one: the entry the NEXT removal sinks, unless this step adds nodes or writes that slot -- see the step's end)
+    const XEntry spare = xg_get(m, m.ntr > 1 ? m.ntr - 1 : 1);
     const float slown = m.slow[mid], risti = m.risti[in ? mx0 : 0];
     DSA_XCLK(1)
     const int ntr_old = m.ntr;
@@ -343,8 +345,16 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
         // the node itself where it stops
         XEntry w = pq;
         if (r4 == up) w = XEntry{ trial, mid };
-        xg_put(m, st != 0 && r4 <= up, sq >> r4, w);
+        const bool wr = st != 0 && r4 <= up;
+        xg_put(m, wr, sq >> r4, w);
         m.ntr += __popc(newq);
+        // the tree's last entry for the next step, without a load behind these stores: it is what this step wrote there (a new node's chain
+        // ends at the last slot; else an update's or the removal's move may have), or else the entry fetched at the step's start
+        const bool h1 = wr && (sq >> r4) == m.ntr, h2 = L.gl <= P.moves && P.to == m.ntr;
+        const unsigned v1 = xg_vote16(h1, lane), v2 = xg_vote16(h2, lane);
+        const int src = L.base + 4 * (__builtin_ctz((v1 ? v1 : v2) | 0x10000u) & 15);
+        const int lk = xg_from_lane(src, __float_as_int(h1 ? w.key : P.mine.key)), li = xg_from_lane(src, h1 ? w.id : P.mine.id);
+        m.last = (v1 | v2) ? XEntry{ __int_as_float(lk), li } : spare;
     } else {
         // the sequential way (reference order, each neighbour reading its path after the one before has stored): lane 4 q of the group
         // holds neighbour q's values
@@ -367,9 +377,9 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
             idq = id_b; id_b = id_c; id_c = id_d;
             trq = tr_b; tr_b = tr_c; tr_c = tr_d;
         }
+        if (m.ntr > 0) m.last = xg_get(m, m.ntr);
     }
     DSA_XCLK(5)
-    if (m.ntr > 0) m.last = xg_get(m, m.ntr);
     m.pops += 1u;
 }
 
