@@ -41,6 +41,11 @@ typedef __attribute__((address_space(1))) float BGF32;
 typedef __attribute__((address_space(1))) const float BGCF32;
 typedef float __attribute__((ext_vector_type(4))) BV4;
 typedef __attribute__((address_space(1))) BV4 BGV4;
+typedef float __attribute__((ext_vector_type(2))) BV2;
+// the MPL members a lane carries (round 4: four, or two -- half the live values per lane, twice the lanes per node)
+template <int MPL> struct BMem;
+template <> struct BMem<4> { typedef BV4 V; typedef __attribute__((address_space(1))) BV4 GV; };
+template <> struct BMem<2> { typedef BV2 V; typedef __attribute__((address_space(1))) BV2 GV; };
 
 // OR over the lanes of a node (CH consecutive lanes): quad permutes
 template <int CH>
@@ -48,6 +53,7 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 {
     if (CH >= 2) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
     if (CH >= 4) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    if (CH >= 8) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);     // row_half_mirror: the other quad of the eight
     return v;
 }
 
@@ -60,12 +66,14 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 #endif
 // NT = 256 threads per workgroup up to 1500 nodes per side (128: -1.7 %, 512: -13 % at 1025^2), 512 beyond: a 4097^2 front has ~2700 ready
 // nodes per round, four times what 256 threads and their 2 x 1024 ready slots take
-template <int G, int NT>
+template <int G, int NT, int MPL = 4>
 __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
 {
     constexpr int NW = NT / 64;
-    constexpr int CH = G / 4;                  // lanes per node in pass B, four members each
+    constexpr int CH = G / MPL;                // lanes per node in pass B, MPL (four, or two) members each
+    typedef typename BMem<MPL>::V BV;
+    typedef typename BMem<MPL>::GV BGV;
     constexpr int NPW = 64 / CH;               // nodes per wave trip
     constexpr unsigned GB = G * 4u;            // bytes per node
     extern __shared__ unsigned dyn_lds[];
@@ -219,10 +227,10 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
     unsigned evals = 0, nchanged = 0;                        // member evaluations of this lane
     // pass B: this lane's node slot, member chunk, member maps
     const int sub = lane % CH, nslot = lane / CH;
-    const unsigned sub_b = (unsigned)sub * 16u;
-    unsigned mp[4], vmask = 0u;                               // (bit m: member sub * 4 + m exists)
+    const unsigned sub_b = (unsigned)sub * (4u * MPL);
+    unsigned mp[MPL], vmask = 0u;                             // (bit m: member sub * MPL + m exists)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { mp[m] = (unsigned)s_map[sub * 4 + m] * 4u; if (sub * 4 + m < nmem) vmask |= 1u << m; }
+    for (int m = 0; m < MPL; ++m) { mp[m] = (unsigned)s_map[sub * MPL + m] * 4u; if (sub * MPL + m < nmem) vmask |= 1u << m; }
 
 #ifdef DSA_BUNDLE_CLOCKS      // probe: where a round's wall clock goes (thread 0: pass A incl. its barrier, even half, odd half, bookkeeping), into clocks[0..3] of the pilot
     unsigned long long bt[4] = { 0, 0, 0, 0 }, bt0 = wall_clock64();
@@ -432,27 +440,27 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 in[3] = act && iz + 1 < nnz;    in_outer[3] = act && iz + 2 < nnz;
                 int nid[8];
                 rec_stencil(nbz, id, nid);
-                const BV4 inf4 = { kInf, kInf, kInf, kInf };
-                BV4 vn[4], vo[4];
+                BV infv, vown, sl;
+#pragma unroll
+                for (int m = 0; m < MPL; ++m) { infv[m] = kInf; vown[m] = -1.0f; sl[m] = 1.0f; }          // (inactive lanes read as pinned)
+                BV vn[4], vo[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    vn[q] = in[q] ? *(BGV4*)(Bb + (unsigned)nid[q] * GB + sub_b) : inf4;
-                    vo[q] = in_outer[q] ? *(BGV4*)(Bb + (unsigned)nid[4 + q] * GB + sub_b) : inf4;
+                    vn[q] = in[q] ? *(BGV*)(Bb + (unsigned)nid[q] * GB + sub_b) : infv;
+                    vo[q] = in_outer[q] ? *(BGV*)(Bb + (unsigned)nid[4 + q] * GB + sub_b) : infv;
                 }
-                BV4 vown = { -1.0f, -1.0f, -1.0f, -1.0f };          // inactive lanes read as pinned
-                BV4 sl = { 1.0f, 1.0f, 1.0f, 1.0f };
                 if (act) {
-                    vown = *(BGV4*)(Bb + (unsigned)id * GB + sub_b);
+                    vown = *(BGV*)(Bb + (unsigned)id * GB + sub_b);
                     const unsigned sb = (unsigned)id * npb;
-                    sl.x = *(BGCF32*)(slowb + sb + mp[0]); sl.y = *(BGCF32*)(slowb + sb + mp[1]);
-                    sl.z = *(BGCF32*)(slowb + sb + mp[2]); sl.w = *(BGCF32*)(slowb + sb + mp[3]);
+#pragma unroll
+                    for (int m = 0; m < MPL; ++m) sl[m] = *(BGCF32*)(slowb + sb + mp[m]);
                 }
                 const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
                 __builtin_amdgcn_s_setprio(0);
-                BV4 outv = vown;
+                BV outv = vown;
                 unsigned wm = 0u;                                    // dependents some member wants activated: bit q near, bit 4 + q outer
                 bool any_changed = false;
-                const int key0 = id * G + sub * 4;
+                const int key0 = id * G + sub * MPL;
                 // four copies of the member body with fixed vector components (default), or -DDSA_BUNDLE_ROTATE: one body, the vectors rotating
                 // by a component per trip (18 KB less code, 37 moves more per member: 616 -> 587 ms per headline launch for the copies,
                 // profiles/r03_bundle_sizes.log)
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
 #define DSA_BM(v) (v).x
 #pragma nounroll
 #endif
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MPL; ++m) {
                     Hood h;
                     bool flagged = false;
 #pragma unroll
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                     if (!valid) t_old = -1.0f;
                     flagged = flagged || (valid && __builtin_signbit(raw));
                     if (flagged) {          // exceptional nodes in this member's neighbourhood: tau (and pinned) from the table
-                        const int mo = sub * 4 + m;
+                        const int mo = sub * MPL + m;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             bool pin;
@@ -515,6 +523,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                     outv[m] = newv;
 #else
                     // next member of this lane: rotate the vectors
+                    static_assert(MPL == 4, "DSA_BUNDLE_ROTATE is a four-members-per-lane build variant");
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         vn[q] = BV4{ vn[q].y, vn[q].z, vn[q].w, vn[q].x };
@@ -528,8 +537,8 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
 #undef DSA_BM
                 __builtin_amdgcn_s_setprio(1);
                 if (any_changed) {
-                    *(BGV4*)(Bb + (unsigned)id * GB + sub_b) = outv;
-                    if (sub == 0) *(BGF32*)(Pb + ((unsigned)id << 2)) = outv.x;       // the pilot's shadow copy (unchanged pilots rewrite their value)
+                    *(BGV*)(Bb + (unsigned)id * GB + sub_b) = outv;
+                    if (sub == 0) *(BGF32*)(Pb + ((unsigned)id << 2)) = outv[0];       // the pilot's shadow copy (unchanged pilots rewrite their value)
                 }
                 // dependents: the members' OR, one lane per node issues the activations (fim_kernel.hip: the mask bits are constant shifts
                 // of the node's own bit)
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 // the node, and the window returns to the front.
                 {
                     const unsigned chg = node_or<CH>(any_changed ? 1u : 0u);
-                    const float pt = outv.x;                                     // (lane sub == 0: the pilot's value at this node, new or unchanged)
+                    const float pt = outv[0];                                   // (lane sub == 0: the pilot's value at this node, new or unchanged)
                     if (sub == 0 && chg && !__builtin_signbit(pt) && pt < stale) smin_lane = fminf(smin_lane, pt);
                 }
                 if (sub == 0 && wm) {
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         if (any_dst)
             for (int i = tid; i < ntile * kTileRecs; i += NT) {
 #pragma unroll
-                for (int c4 = 0; c4 < CH; ++c4) {
+                for (int c4 = 0; c4 < G / 4; ++c4) {
                     const BV4 v = *(BGV4*)(Bb + (unsigned)i * GB + (unsigned)c4 * 16u);
                     BGF32* d;
                     if ((d = (BGF32*)s_dst[4 * c4 + 0])) d[i] = fabsf(v.x);
@@ -676,16 +685,19 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
 
 size_t bundle_lds_bytes(int tile_words) { return (size_t)tile_words * 4; }
 
-void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int threads, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream)
+void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int threads, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream, int members_per_lane)
 {
     if (nbundles <= 0) return;
     const size_t lds = bundle_lds_bytes(tile_words);
 #define DSA_LAUNCH_BUNDLE(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
-    if (threads == 512) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 512); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 512); else DSA_LAUNCH_BUNDLE(4, 512); }
+#define DSA_LAUNCH_BUNDLE2(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT, 2>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
+    if (members_per_lane == 2 && threads == 256) { if (G == 16) DSA_LAUNCH_BUNDLE2(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE2(8, 256); else DSA_LAUNCH_BUNDLE2(4, 256); }
+    else if (threads == 512) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 512); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 512); else DSA_LAUNCH_BUNDLE(4, 512); }
     else if (threads == 64) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 64); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 64); else DSA_LAUNCH_BUNDLE(4, 64); }
     else if (threads == 128) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 128); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 128); else DSA_LAUNCH_BUNDLE(4, 128); }
     else { if (G == 16) DSA_LAUNCH_BUNDLE(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 256); else DSA_LAUNCH_BUNDLE(4, 256); }
 #undef DSA_LAUNCH_BUNDLE
+#undef DSA_LAUNCH_BUNDLE2
 }
 
 // slowI[id * np + m] = slow_all[m * field_stride + id]: the maps' slowness, member-minor

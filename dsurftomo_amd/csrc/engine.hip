@@ -565,7 +565,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipEventRecord(events[4], stream));
         if (exact_ties != 2) {
             launch_fim(prob_c.p, nsolo, sc, stream, ends_c.p);
-            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream);
+            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl);
         }
         HIP_TRY(this, hipEventRecord(events[5], stream));
         if (exact_ties) {
@@ -1161,6 +1161,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "bundle_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
+    if (n == "bundle_members_per_lane" && (value == 4 || value == 2)) { en->bundle_mpl = (int)value; return 0; }
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }

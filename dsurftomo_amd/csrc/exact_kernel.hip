@@ -180,6 +180,26 @@ __device__ __forceinline__ XPop xg_pop_root(XG& m, int gl)
     int tpp = 1, tpc = 2, level = 0, mydst = 0, myold = 0;
     XEntry mine = e;
     const int lim = m.ntr < m.lcap ? m.ntr : m.lcap;
+    // two levels per LDS round trip while the four grandchildren exist and lie in LDS: the pair of children and both pairs under them are
+    // read together, the second level picks its pair by the first level's choice
+    while (2 * tpc + 3 <= lim) {
+        const xf4 c = *(DSA_LDS const xf4*)(m.hl + tpc), g0 = *(DSA_LDS const xf4*)(m.hl + 2 * tpc), g1 = *(DSA_LDS const xf4*)(m.hl + 2 * tpc + 2);
+        const bool r1 = c.x > c.z;
+        const float k1 = r1 ? c.z : c.x;
+        const int i1 = __float_as_int(r1 ? c.w : c.y), c1 = tpc + (r1 ? 1 : 0);
+        const bool mv1 = k1 < e.key;
+        const xf4 gp = r1 ? g1 : g0;
+        const bool r2 = gp.x > gp.z;
+        const float k2 = r2 ? gp.z : gp.x;
+        const int i2 = __float_as_int(r2 ? gp.w : gp.y), c2 = 2 * c1 + (r2 ? 1 : 0);
+        const bool mv2 = mv1 && k2 < e.key;
+        const bool cap1 = mv1 && gl == level, cap2 = mv2 && gl == level + 1;
+        mine.key = cap1 ? k1 : cap2 ? k2 : mine.key; mine.id = cap1 ? i1 : cap2 ? i2 : mine.id;
+        mydst = cap1 ? tpp : cap2 ? c1 : mydst; myold = cap1 ? c1 : cap2 ? c2 : myold;
+        level += (mv1 ? 1 : 0) + (mv2 ? 1 : 0);
+        tpp = mv2 ? c2 : mv1 ? c1 : tpp;
+        tpc = mv2 ? 2 * c2 : m.ntr + 1;
+    }
     while (tpc < lim) DSA_XG_LEVEL(*(DSA_LDS const xf4*)(m.hl + tpc), )
     if (tpc == m.ntr && tpc <= m.lcap) {                      // (an only child, in LDS)
         const XEntry a = xg_entry(*(DSA_LDS const xf2*)(m.hl + tpc));

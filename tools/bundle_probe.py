@@ -38,6 +38,7 @@ for G in sizes:
     e.set_option('bundle', G)
     if os.environ.get('DSA_PROBE_BTHREADS'): e.set_option('bundle_threads', int(os.environ['DSA_PROBE_BTHREADS']))
     if os.environ.get('DSA_PROBE_BPOOL'): e.set_option('bundle_pool', int(os.environ['DSA_PROBE_BPOOL']))
+    if os.environ.get('DSA_PROBE_MPL'): e.set_option('bundle_members_per_lane', int(os.environ['DSA_PROBE_MPL']))
     if os.environ.get('DSA_PROBE_BWINDOW'): e.set_option('bundle_window_cells', float(os.environ['DSA_PROBE_BWINDOW']))
     if what == "check": e.set_option('field_pool', -1)
     e.plan(**u)
