@@ -359,3 +359,29 @@ def test_512_thread_bundle_kernel_against_the_oracle_at_config4_size(bundles):
     # stay inside the same bounds, and no further from the oracle than a small multiple of the unit-by-unit solve
     assert d.max() <= 1.2e-3 and (d > TOL).sum() <= 0.08 * d.size
     assert (d > TOL).sum() <= 2 * (ds > TOL).sum() + 8
+
+
+def test_two_members_per_lane_variant_equals_four(bundles):
+    """option bundle_members_per_lane = 2 (k_fim_bundle<G, 256, 2>: half the live values per lane, twice the lanes per node; measured 6 %
+    slower at equal occupancy, kept as a build the occupancy experiments start from): same receiver times and fields, bit for bit"""
+    e = bundles
+    nx, nsrc, nper, nrec = 33, 6, 16, 8
+    pv = mixed_maps(nx, nper)
+    u = ragged_units(nx, nsrc, nper, nrec, [16, 9, 5, 2, 1])
+    n = len(u["map_index"])
+    e.set_option("field_pool", -1)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    out = {}
+    try:
+        for mpl in (4, 2):
+            e.set_option("bundle_members_per_lane", mpl)
+            for G in (16, 8, 4):
+                e.set_option("bundle", G)
+                t = e.traveltimes(**u)
+                out[(mpl, G)] = (t, np.stack([e.field(k) for k in range(n)]))
+    finally:
+        e.set_option("bundle_members_per_lane", 4)
+    for G in (16, 8, 4):
+        assert np.array_equal(bits(out[(2, G)][0]), bits(out[(4, G)][0])), G
+        assert np.array_equal(bits(out[(2, G)][1]), bits(out[(4, G)][1])), G
+    parity_log.add(f"bundles, two members per lane: {n} units (ragged period sets), sizes 16 / 8 / 4: receiver times and all {out[(2, 16)][1].size} field nodes identical to four members per lane")

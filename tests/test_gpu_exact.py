@@ -129,3 +129,32 @@ def test_tie_detector_and_exact_redo_at_headline_size(exact, kind, nsrc):
     # a statistical statement (profiles/r03_exact_probe_*.log: 0-1 of 4096 such units on the checkerboard end with a receiver beyond
     # 1e-4 s, worst 1.4e-4 s): assert the scale of the tie noise, report the measured worst above
     assert d[~exact_u].max() <= 3e-4 if (~exact_u).any() else True
+
+
+def test_literal_march_in_batches_with_times_from_the_marched_fields(exact):
+    """exact_ties = 2 with more units than the marching pool holds (option exact_pool) and more than the compact field slots (field_pool):
+    the batches write their units' receiver times themselves (k_xreceivers: no compact copy of a field is made), the fields are then
+    reported as gone -- and the times are those of a call that keeps every field, bit for bit"""
+    from dsurftomo_amd.engine import EngineError
+    e = exact
+    nx, nsrc, nper, nrec = 35, 40, 2, 6
+    u = synth.units(nx, nsrc, nper, nrec)
+    pv = np.stack([synth.medium(nx, k, p) for p, k in enumerate(("checker4", "rough"))])
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("exact_ties", 2)
+    try:
+        t_all = e.traveltimes(**u)
+        e.field(2 * nsrc - 1)
+        e.set_option("exact_pool", 28)           # three batches (28 + 26 + 26: equal sizes)
+        e.set_option("field_pool", 16)
+        e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        t_b = e.traveltimes(**u)
+        st = e.stats()
+        with pytest.raises(EngineError):
+            e.field(0)
+    finally:
+        e.set_option("exact_pool", 0)
+        e.set_option("field_pool", 0)
+    assert st["exact_units"] == 2 * nsrc
+    assert np.isfinite(t_all).all() and np.array_equal(bits(t_b), bits(t_all))
+    parity_log.add(f"exact mode in batches: {2 * nsrc} units through a marching pool of 28 and 16 compact slots: receiver times from the marched fields = those of the resident call")
