@@ -59,15 +59,18 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 
 }  // namespace
 
-#ifdef DSA_BUNDLE_WAVES      // experiments: waves per SIMD the register allocation aims at (default: what 256 threads allow, 2 at 207 VGPRs)
-#define DSA_BUNDLE_OCC __attribute__((amdgpu_waves_per_eu(DSA_BUNDLE_WAVES, DSA_BUNDLE_WAVES)))
+// Waves per SIMD the register allocation aims at.  Round 4: with TWO members per lane and the irregular members out of the trip (the slow
+// queue of pass B) the kernel fits 168 VGPRs without a spill: three workgroups of 256 threads per CU instead of two.  Four members per lane
+// stay at two (204 VGPRs; forced to 168 they spill 30).  -DDSA_BUNDLE_WAVES=n overrides both for experiments.
+#ifdef DSA_BUNDLE_WAVES
+#define DSA_BUNDLE_OCC(MPL) __attribute__((amdgpu_waves_per_eu(DSA_BUNDLE_WAVES, DSA_BUNDLE_WAVES)))
 #else
-#define DSA_BUNDLE_OCC
+#define DSA_BUNDLE_OCC(MPL) __attribute__((amdgpu_waves_per_eu((MPL) == 2 ? 3 : 1, (MPL) == 2 ? 3 : 2)))
 #endif
 // NT = 256 threads per workgroup up to 1500 nodes per side (128: -1.7 %, 512: -13 % at 1025^2), 512 beyond: a 4097^2 front has ~2700 ready
 // nodes per round, four times what 256 threads and their 2 x 1024 ready slots take
 template <int G, int NT, int MPL = 4>
-__global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
+__global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(MPL) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
 {
     constexpr int NW = NT / 64;
@@ -85,6 +88,8 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
     constexpr int rhalf = NT < 256 ? 1024 : NT * 4;      // ready nodes of one colour a round can take (the rest keep their bits)
     __shared__ int ready[2 * rhalf];
     __shared__ int s_member[kBundleMax], s_map[kBundleMax];
+    constexpr int kSlowQ = 1024;                          // entries of a wave's slow queue (pass B)
+    __shared__ int slowq[NW * kSlowQ];
 
     const FimBundle* const bd = bundles + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -219,6 +224,102 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
         __syncthreads();
         if (sc[BC_OVERFLOW]) dead = true;
     }
+
+    // dependents of node id: the mask bits are constant shifts of the node's own bit (fim_kernel.hip); wm: bit q near, bit 4 + q outer neighbour q
+    auto activate_node = [&](int id, unsigned wm, int half) {
+        const int own_tile = id >> 6;
+        const unsigned long long b = 1ull << (id & 63);
+        auto sel = [](unsigned w, unsigned long long v) -> unsigned long long { return w ? v : 0ull; };
+        const unsigned long long own_bits =
+            sel(wm & 1u, b >> 8) | sel(wm & 16u, b >> 16) | sel(wm & 2u, b << 8) | sel(wm & 32u, b << 16) |
+            sel(wm & 4u, (b >> 1) & 0x7f7f7f7f7f7f7f7full) | sel(wm & 64u, (b >> 2) & 0x3f3f3f3f3f3f3f3full) |
+            sel(wm & 8u, (b << 1) & 0xfefefefefefefefeull) | sel(wm & 128u, (b << 2) & 0xfcfcfcfcfcfcfcfcull);
+        const unsigned long long fxm = sel(wm & 1u, b << 56) | sel(wm & 16u, b << 48);
+        const unsigned long long fxp = sel(wm & 2u, b >> 56) | sel(wm & 32u, b >> 48);
+        const unsigned long long fzm = sel(wm & 4u, (b << 7) & 0x8080808080808080ull) | sel(wm & 64u, (b << 6) & 0xc0c0c0c0c0c0c0c0ull);
+        const unsigned long long fzp = sel(wm & 8u, (b >> 7) & 0x0101010101010101ull) | sel(wm & 128u, (b >> 6) & 0x0303030303030303ull);
+        auto activate = [&](int tile, unsigned long long bits) {
+            if (bits) {
+                atomicOr((unsigned long long*)(mask_at(tile) + half), bits);
+                atomicOr(&tb[tile >> 5], 1u << (tile & 31));
+            }
+        };
+        activate(own_tile - nbz, fxm);
+        activate(own_tile + nbz, fxp);
+        activate(own_tile - 1, fzm);
+        activate(own_tile + 1, fzp);
+        activate(own_tile, own_bits);
+    };
+    // one member (index mo of the bundle) of node id, from memory: the slow pass of pass B
+    auto slow_member = [&](int id, int mo, int half, float stale, unsigned& evals, unsigned& nchanged, unsigned& hv_lane, float& kmin_lane, float& smin_lane) {
+        if (mo >= nmem) return;
+        int iz, ix;
+        coords(id, &iz, &ix);
+        int nid[8];
+        rec_stencil(nbz, id, nid);
+        const unsigned mb = (unsigned)mo * 4u;
+        Hood h;
+        h.in[0] = ix > 0;          h.in_outer[0] = ix > 1;
+        h.in[1] = ix + 1 < nnx;    h.in_outer[1] = ix + 2 < nnx;
+        h.in[2] = iz > 0;          h.in_outer[2] = iz > 1;
+        h.in[3] = iz + 1 < nnz;    h.in_outer[3] = iz + 2 < nnz;
+        // the nine values of the member's neighbourhood and, for the exceptional ones (sign bit), their acceptance times from the table: ONE
+        // copy of the look-up, the nine positions rotated through it (nine inlined copies kept ~20 more registers alive, and this loop -- not
+        // the regular members' bodies -- decided the kernel's register count)
+        float val[9], tau[9];
+        int kid[9];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            val[q] = h.in[q] ? *(BGF32*)(Bb + (unsigned)nid[q] * GB + mb) : kInf;
+            val[4 + q] = h.in_outer[q] ? *(BGF32*)(Bb + (unsigned)nid[4 + q] * GB + mb) : kInf;
+            kid[q] = nid[q]; kid[4 + q] = nid[4 + q];
+        }
+        val[8] = *(BGF32*)(Bb + (unsigned)id * GB + mb);
+        kid[8] = id;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) tau[q] = val[q];
+#pragma nounroll
+        for (int it = 0; it < 9; ++it) {
+            float v = val[0], t = tau[0];
+            if (__builtin_signbit(v)) { bool pin; t = exc_lookup(kid[0] * G + mo, &pin); v = pin ? v : -v; }
+            const int k0 = kid[0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { val[j] = val[j + 1]; tau[j] = tau[j + 1]; kid[j] = kid[j + 1]; }
+            val[8] = v; tau[8] = t; kid[8] = k0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h.near_[q] = val[q]; h.near_tau[q] = tau[q]; h.outer[q] = val[4 + q]; h.outer_tau[q] = tau[4 + q]; }
+        const float t_old = val[8], k_old = tau[8];
+        const int key = id * G + mo;
+        if (t_pinned(t_old)) return;
+        float k = kInf;
+        const float slown = *(BGCF32*)(slowb + (unsigned)id * npb + (unsigned)s_map[mo] * 4u);
+        const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
+        const float c = solve_node_t<false>(h, slown, geom, &k, nullptr);
+        ++evals;
+        if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return;
+        float newv = c;
+        if (bf2u(c) != bf2u(k)) { if (!exc_upsert(key, k)) { p.info[2] = -2; sc[BC_OVERFLOW] = 1; } newv = -c; }
+        *(BGF32*)(Bb + (unsigned)id * GB + mb) = newv;
+        if (mo == 0) { *(BGF32*)(Pb + ((unsigned)id << 2)) = newv; kmin_lane = fminf(kmin_lane, k); }
+        ++nchanged;
+        hv_lane += ((unsigned)key * 2654435761u) ^ (bf2u(c) * 40503u) ^ (bf2u(k) * 2246822519u);
+        {   // (a change far behind the front: see pass B)
+            const float pt = mo == 0 ? newv : pv(id);
+            if (!__builtin_signbit(pt) && pt < stale) smin_lane = fminf(smin_lane, pt);
+        }
+        unsigned wm = 0u;
+        const float t_lo = fminf(t_value(t_old), c), k_lo = fminf(k_old, k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float ky = h.near_tau[q];
+            if (h.in[q] && !t_pinned(h.near_[q]) && k_lo <= ky) wm |= 1u << q;
+            if (h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) && t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q]) wm |= 16u << q;
+        }
+        if (wm) activate_node(id, wm, half);
+    };
+    int* const wq = slowq + wave * kSlowQ;              // the wave's queue of (node << 4 | member) left to the slow pass
+    int qn = 0;
 
     int rounds = 0, stall = 0, freezes = 0, sm_same = 0;
     float sm_prev = kInf, sm_prev2 = kInf;
@@ -461,84 +562,69 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                 unsigned wm = 0u;                                    // dependents some member wants activated: bit q near, bit 4 + q outer
                 bool any_changed = false;
                 const int key0 = id * G + sub * MPL;
-                // four copies of the member body with fixed vector components (default), or -DDSA_BUNDLE_ROTATE: one body, the vectors rotating
-                // by a component per trip (18 KB less code, 37 moves more per member: 616 -> 587 ms per headline launch for the copies,
-                // profiles/r03_bundle_sizes.log)
-#ifndef DSA_BUNDLE_ROTATE
-#define DSA_BM(v) (v)[m]
+                // Round 4: the member bodies below are the REGULAR case only -- no exceptional node (a pinned one, or one whose acceptance time
+                // differs from its value: ~0.2 % of the evaluations) in the member's neighbourhood, and a result that is causal (tau = T).  A member
+                // that is not regular is left for the slow pass behind the store (bit m of `slow`), which evaluates it from memory with the
+                // exception table at hand.  What this buys is registers: the table look-ups and the table insert, inlined into every member
+                // body, kept ~30 more VGPRs alive (profiles/r04_bundle_vgprs.txt), and 168 is the line for a third workgroup per CU.
+                unsigned slow = 0u;
 #pragma unroll
-#else
-#define DSA_BM(v) (v).x
-#pragma nounroll
-#endif
                 for (int m = 0; m < MPL; ++m) {
                     Hood h;
                     bool flagged = false;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float a = DSA_BM(vn[q]), b = DSA_BM(vo[q]);
+                        const float a = vn[q][m], b = vo[q][m];
                         h.in[q] = in[q]; h.in_outer[q] = in_outer[q];
                         h.near_[q] = a; h.near_tau[q] = a; h.outer[q] = b; h.outer_tau[q] = b;
-                        flagged = flagged || __builtin_signbit(a) || __builtin_signbit(b);
+                        flagged = flagged | __builtin_signbit(a) | __builtin_signbit(b);
                     }
-                    const float raw = DSA_BM(vown);
+                    const float raw = vown[m];
                     const bool valid = act && ((vmask >> m) & 1u);
-                    float t_old = raw, k_old = raw;
-                    if (!valid) t_old = -1.0f;
-                    flagged = flagged || (valid && __builtin_signbit(raw));
-                    if (flagged) {          // exceptional nodes in this member's neighbourhood: tau (and pinned) from the table
-                        const int mo = sub * MPL + m;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            bool pin;
-                            if (__builtin_signbit(h.near_[q])) { const float v = h.near_[q]; h.near_tau[q] = exc_lookup(nid[q] * G + mo, &pin); h.near_[q] = pin ? v : -v; }
-                            if (__builtin_signbit(h.outer[q])) { const float v = h.outer[q]; h.outer_tau[q] = exc_lookup(nid[4 + q] * G + mo, &pin); h.outer[q] = pin ? v : -v; }
-                        }
-                        if (valid && __builtin_signbit(raw)) { bool pin; k_old = exc_lookup(key0 + m, &pin); t_old = pin ? raw : -raw; }
-                    }
+                    flagged = flagged | __builtin_signbit(raw);
+                    float c = 0.0f, k = kInf;
                     bool changed = false;
-                    float c = 0.0f, k = kInf, newv = raw;
-                    if (!t_pinned(t_old)) {
-                        const float slown = DSA_BM(sl);
+                    if (valid && !flagged) {
+                        const float slown = sl[m];
                         c = solve_node_t<false>(h, slown, geom, &k, nullptr);
-                        ++evals;
-                        changed = bf2u(c) != bf2u(t_old) || bf2u(k) != bf2u(k_old);
+                        if (bf2u(c) != bf2u(k)) flagged = true;                       // (a non-causal result: the table's business)
+                        else { ++evals; changed = bf2u(c) != bf2u(raw); }
                     }
+                    if (valid && flagged) slow |= 1u << m;
                     if (changed) {
-                        if (bf2u(c) == bf2u(k)) newv = c;
-                        else { if (!exc_upsert(key0 + m, k)) { p.info[2] = -2; sc[BC_OVERFLOW] = 1; } newv = -c; }
+                        outv[m] = c;
                         ++nchanged;
                         any_changed = true;
                         hv_lane += ((unsigned)(key0 + m) * 2654435761u) ^ (bf2u(c) * 40503u) ^ (bf2u(k) * 2246822519u);
                         if (sub == 0 && m == 0) kmin_lane = fminf(kmin_lane, k);                 // the pilot's changes hold the window back
-                        const float t_lo = fminf(t_value(t_old), c), k_lo = fminf(k_old, k);
+                        const float t_lo = fminf(raw, c), k_lo = t_lo;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float ky = h.near_tau[q];
-                            if (h.in[q] && !t_pinned(h.near_[q]) && k_lo <= ky) wm |= 1u << q;
-                            if (h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) && t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q]) wm |= 16u << q;
+                            if (h.in[q] && k_lo <= ky) wm |= 1u << q;
+                            if (h.in_outer[q] && ky < kInf && h.near_[q] > t_lo && k_lo < h.outer_tau[q]) wm |= 16u << q;
                         }
                     }
-#ifndef DSA_BUNDLE_ROTATE
-                    outv[m] = newv;
-#else
-                    // next member of this lane: rotate the vectors
-                    static_assert(MPL == 4, "DSA_BUNDLE_ROTATE is a four-members-per-lane build variant");
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        vn[q] = BV4{ vn[q].y, vn[q].z, vn[q].w, vn[q].x };
-                        vo[q] = BV4{ vo[q].y, vo[q].z, vo[q].w, vo[q].x };
-                    }
-                    vown = BV4{ vown.y, vown.z, vown.w, vown.x };
-                    sl = BV4{ sl.y, sl.z, sl.w, sl.x };
-                    outv = BV4{ outv.y, outv.z, outv.w, newv };
-#endif
                 }
-#undef DSA_BM
                 __builtin_amdgcn_s_setprio(1);
                 if (any_changed) {
                     *(BGV*)(Bb + (unsigned)id * GB + sub_b) = outv;
                     if (sub == 0) *(BGF32*)(Pb + ((unsigned)id << 2)) = outv[0];       // the pilot's shadow copy (unchanged pilots rewrite their value)
+                }
+                // the members left out above go to the wave's queue (node, member of the bundle); a full queue (it holds the pinned neighbourhood of
+                // the first rounds several times over) puts the node back on its tile's mask instead: it is listed again next round
+                if (__any(slow != 0u)) {
+                    bool again = false;
+#pragma unroll
+                    for (int m = 0; m < MPL; ++m) {
+                        const bool push = ((slow >> m) & 1u) != 0u;
+                        const unsigned long long bal = __ballot(push);
+                        const int pos = qn + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (push && pos < kSlowQ) wq[pos] = (id << 4) | (sub * MPL + m);
+                        again = again || (push && pos >= kSlowQ);
+                        qn += __popcll(bal);
+                    }
+                    if (again) { atomicOr((unsigned long long*)(mask_at(id >> 6) + half), 1ull << (id & 63)); atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31)); }
                 }
                 // dependents: the members' OR, one lane per node issues the activations (fim_kernel.hip: the mask bits are constant shifts
                 // of the node's own bit)
@@ -555,31 +641,16 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC void k_fim_bundle(const FimBundl
                     const float pt = outv[0];                                   // (lane sub == 0: the pilot's value at this node, new or unchanged)
                     if (sub == 0 && chg && !__builtin_signbit(pt) && pt < stale) smin_lane = fminf(smin_lane, pt);
                 }
-                if (sub == 0 && wm) {
-                    const int own_tile = id >> 6;
-                    const unsigned long long b = 1ull << (id & 63);
-                    auto sel = [](unsigned w, unsigned long long v) -> unsigned long long { return w ? v : 0ull; };
-                    const unsigned long long own_bits =
-                        sel(wm & 1u, b >> 8) | sel(wm & 16u, b >> 16) | sel(wm & 2u, b << 8) | sel(wm & 32u, b << 16) |
-                        sel(wm & 4u, (b >> 1) & 0x7f7f7f7f7f7f7f7full) | sel(wm & 64u, (b >> 2) & 0x3f3f3f3f3f3f3f3full) |
-                        sel(wm & 8u, (b << 1) & 0xfefefefefefefefeull) | sel(wm & 128u, (b << 2) & 0xfcfcfcfcfcfcfcfcull);
-                    const unsigned long long fxm = sel(wm & 1u, b << 56) | sel(wm & 16u, b << 48);
-                    const unsigned long long fxp = sel(wm & 2u, b >> 56) | sel(wm & 32u, b >> 48);
-                    const unsigned long long fzm = sel(wm & 4u, (b << 7) & 0x8080808080808080ull) | sel(wm & 64u, (b << 6) & 0xc0c0c0c0c0c0c0c0ull);
-                    const unsigned long long fzp = sel(wm & 8u, (b >> 7) & 0x0101010101010101ull) | sel(wm & 128u, (b >> 6) & 0x0303030303030303ull);
-                    auto activate = [&](int tile, unsigned long long bits) {
-                        if (bits) {
-                            atomicOr((unsigned long long*)(mask_at(tile) + half), bits);
-                            atomicOr(&tb[tile >> 5], 1u << (tile & 31));
-                        }
-                    };
-                    activate(own_tile - nbz, fxm);
-                    activate(own_tile + nbz, fxp);
-                    activate(own_tile - 1, fzm);
-                    activate(own_tile + 1, fzp);
-                    activate(own_tile, own_bits);
-                }
+                if (sub == 0 && wm) activate_node(id, wm, half);
             }
+            // the wave's slow queue: one thread per (node, member), the member body of round 3 whole -- exception table look-ups, a result
+            // whose acceptance time differs from its value into the table -- on values read from memory, with its own activations
+            qn = qn < kSlowQ ? qn : kSlowQ;
+            for (int base = 0; base < qn; base += 64) {
+                const int e = base + lane < qn ? wq[base + lane] : -1;
+                if (e >= 0) slow_member(e >> 4, e & 15, half, stale, evals, nchanged, hv_lane, kmin_lane, smin_lane);
+            }
+            qn = 0;
             if (half == 1) {
                 const unsigned hv = wave_sum(hv_lane);
                 const float kmin = wave_min(kmin_lane), smin = wave_min(smin_lane);

@@ -83,7 +83,8 @@ struct Engine {
                                        // (measured at 1025^2, 16 members: 0.4 / 0.5 / 0.6 / 0.8 / 1.25 cells -> 24.4 / 24.6 / 24.4 / 23.9 / 22.7 k solves/s)
     int bundle_threads_opt = 0;        // option bundle_threads: workgroup size of the bundle kernel (0 = by grid size: 256, 512 beyond 1500 nodes per side)
     int bundle_max_rounds = 0;         // option bundle_max_rounds (tests): > 0 = round limit of the bundles; a bundle that hits it sends its chunk to the unit-by-unit solve
-    int bundle_mpl = 4;                // option bundle_members_per_lane: 4, or 2 (k_fim_bundle<G, 256, 2>)
+    int bundle_mpl = 0;                // option bundle_members_per_lane: 0 = automatic, 4, or 2 (k_fim_bundle<G, 256, 2>: 168 VGPRs, three workgroups per CU)
+    int bundle_mpl_now = 4;            // ... what the current launch uses
     int bundle_pool_opt = 0;           // option bundle_pool: bundle field slots (0 = up to 1024; fewer than the bundles of a launch: recycled like the unit slots)
     DevBuf<float> slowI, B_pool;       // member-minor slowness of all maps; bundle field slots
     bool slowI_ready = false;
@@ -98,6 +99,7 @@ struct Engine {
     size_t bundle_room(size_t free_b) const;
     bool grow_unit_pool();
     int bundle_threads() const;
+    size_t bundles_resident() const;
     int choose_bundle_size(int step, long* solo_units = nullptr);
     int plan_bundles(int first, int n, int G, int* nsolo, int* nbundles);
     size_t lists_stride = 0;

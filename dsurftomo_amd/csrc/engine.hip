@@ -446,6 +446,13 @@ size_t Engine::solve_stage_bytes() const
            b(info) + b(clocks) + b(tieinfo) + b(xinfo) + b(x_units) + b(B_pool) + b(exc_b) + b(lists_b) + b(bpool_gen) + b(bundles_d) + b(member_flag);
 }
 
+// bundles the chip holds at a time: one workgroup of 512 threads per CU, two of 256 (four members per lane: 204 VGPRs) or three (two
+// members per lane: 168 VGPRs, round 4)
+size_t Engine::bundles_resident() const
+{
+    return (size_t)256 * (bundle_threads() == 512 ? 1 : (bundle_threads() == 256 && bundle_mpl_now == 2) ? 3 : 2);
+}
+
 // workgroup size of the bundle kernel (bundle_kernel.hip)
 int Engine::bundle_threads() const
 {
@@ -565,7 +572,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipEventRecord(events[4], stream));
         if (exact_ties != 2) {
             launch_fim(prob_c.p, nsolo, sc, stream, ends_c.p);
-            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl);
+            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
         }
         HIP_TRY(this, hipEventRecord(events[5], stream));
         if (exact_ties) {
@@ -722,7 +729,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
         if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
         const long nb = std::min<long>(bundles_with(G), (long)step);
-        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), bundle_threads() == 512 ? 288 : 576);      // (bundles resident at a time, and a few more)
+        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), (long)(bundles_resident() + bundles_resident() / 8));      // (bundles resident at a time, and a few more)
         return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.7 * (double)free_b);      // (what plan_bundles allows itself)
     };
     if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) {
@@ -749,7 +756,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         if (nb == 0 || !fits(G)) continue;
         const double frac = (double)covered / (double)h_src.size();                  // units that end up in bundles ...
         const double fill = (double)covered / ((double)nb * G);                       // ... and how full the bundles are
-        const double est = frac * rate[k] * fill * std::min(1.0, (double)std::min<long>(nb, (long)step) / (bundle_threads() == 512 ? 280.0 : 560.0)) + (1.0 - frac) * 10.4 * std::min(1.0, n_units / 1100.0);
+        const double est = frac * rate[k] * fill * std::min(1.0, (double)std::min<long>(nb, (long)step) / (1.1 * (double)bundles_resident())) + (1.0 - frac) * 10.4 * std::min(1.0, n_units / 1100.0);
         if (est > best) { best = est; pick = G; if (solo_units) *solo_units = (long)h_src.size() - covered; }
     }
     return pick;
@@ -789,6 +796,9 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     const int nsolo = (int)solo.size(), nb = (int)pieces.size();
     *nsolo_out = nsolo; *nbundles_out = nb;
     if (nb == 0) return 0;
+    // members per lane: four (two workgroups per CU), or two -- three workgroups per CU, +29 % on a launch of 2 000 bundles, but nothing on
+    // 1 000, whose last 232 bundles then run one to a CU (profiles/r04_bundle_occupancy.log): automatic from 1 500 bundles on
+    bundle_mpl_now = bundle_mpl ? bundle_mpl : (bundle_threads() == 256 && nb >= 1500 ? 2 : 4);
     h_launch_rank.assign((size_t)n, 0);
     for (int r = 0; r < nsolo; ++r) h_launch_rank[(size_t)solo[(size_t)r].second] = r;
     const int lg = G == 16 ? 4 : G == 8 ? 3 : 2;
@@ -802,7 +812,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
     // field slots: one per bundle, or -- more bundles than the chip holds at a time -- as many as can be resident and a few more; a bundle
     // claims a free one when it starts (FimBundle::slot_busy)
-    const size_t resident = bundle_threads() == 512 ? 256 : 512;
+    const size_t resident = bundles_resident();
     bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (int)(resident + resident / 8)), room });
     const size_t BS = (size_t)bundle_slots;
     const size_t b_stride = (size_t)(G + 1) * nrec_c;
@@ -1161,7 +1171,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "bundle_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
-    if (n == "bundle_members_per_lane" && (value == 4 || value == 2)) { en->bundle_mpl = (int)value; return 0; }
+    if (n == "bundle_members_per_lane" && (value == 0 || value == 4 || value == 2)) { en->bundle_mpl = (int)value; return 0; }
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }

@@ -380,7 +380,7 @@ def test_two_members_per_lane_variant_equals_four(bundles):
                 t = e.traveltimes(**u)
                 out[(mpl, G)] = (t, np.stack([e.field(k) for k in range(n)]))
     finally:
-        e.set_option("bundle_members_per_lane", 4)
+        e.set_option("bundle_members_per_lane", 0)
     for G in (16, 8, 4):
         assert np.array_equal(bits(out[(2, G)][0]), bits(out[(4, G)][0])), G
         assert np.array_equal(bits(out[(2, G)][1]), bits(out[(4, G)][1])), G
