@@ -85,6 +85,9 @@ struct Engine {
     int bundle_max_rounds = 0;         // option bundle_max_rounds (tests): > 0 = round limit of the bundles; a bundle that hits it sends its chunk to the unit-by-unit solve
     int bundle_mpl = 0;                // option bundle_members_per_lane: 0 = automatic, 4, or 2 (k_fim_bundle<G, 256, 2>: 168 VGPRs, three workgroups per CU)
     int bundle_mpl_now = 4;            // ... what the current launch uses
+    int bundles_a = 0, bundles_b = 0, bundle_Gb = 0;      // the launch's bundles: whole ones, and (plan_bundles) the last ones cut in halves of bundle_Gb members on a second stream
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
     int bundle_pool_opt = 0;           // option bundle_pool: bundle field slots (0 = up to 1024; fewer than the bundles of a launch: recycled like the unit slots)
     DevBuf<float> slowI, B_pool;       // member-minor slowness of all maps; bundle field slots
     bool slowI_ready = false;

@@ -90,6 +90,7 @@ Engine::~Engine()
     rel(Srow); rel(sen_vs); rel(sen_vp); rel(sen_rho); rel(vels_d); rel(trace_ids); rel(vlist); rel(nvv); rel(counts); rel(offsets);
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
+    if (stream2) { (void)hipStreamDestroy(stream2); (void)hipEventDestroy(ev_b0); (void)hipEventDestroy(ev_b1); stream2 = nullptr; }
     rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(X_pool); rel(X_heap); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
@@ -572,7 +573,16 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipEventRecord(events[4], stream));
         if (exact_ties != 2) {
             launch_fim(prob_c.p, nsolo, sc, stream, ends_c.p);
-            if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
+            if (nbundles && bundles_b > 0) {
+                // the bundles cut in halves on a second stream beside the whole ones: both wait for the stages before, the stream after waits for both
+                if (!stream2) { HIP_TRY(this, hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking)); HIP_TRY(this, hipEventCreateWithFlags(&ev_b0, hipEventDisableTiming)); HIP_TRY(this, hipEventCreateWithFlags(&ev_b1, hipEventDisableTiming)); }
+                HIP_TRY(this, hipEventRecord(ev_b0, stream));
+                launch_fim_bundles(bundles_d.p, bundles_a, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
+                HIP_TRY(this, hipStreamWaitEvent(stream2, ev_b0, 0));
+                launch_fim_bundles(bundles_d.p + bundles_a, bundles_b, bundle_Gb, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream2, bundle_mpl_now);
+                HIP_TRY(this, hipEventRecord(ev_b1, stream2));
+                HIP_TRY(this, hipStreamWaitEvent(stream, ev_b1, 0));
+            } else if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
         }
         HIP_TRY(this, hipEventRecord(events[5], stream));
         if (exact_ties) {
@@ -745,18 +755,42 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     // (bundle_threads(): half as many bundles fill the chip).  Grids below 400 nodes per side stay unit by unit: their solves are short.
     if (std::min(g.nnx, g.nnz) < 400) return 0;
     const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
-    double best = 10.4 * std::min(1.0, n_units / 1100.0) * 1.05;
+    const double solo_rate = 10.4 * std::min(1.0, n_units / 1100.0);          // k solves/s
+    double best = solo_rate * 1.05;
     int pick = 0;
-    const double rate[3] = { 24.5, 20.4, 15.5 };
     const int sizes[3] = { 16, 8, 4 };
+    // Round 4 (256-thread kernel): a launch's time from the measured time of ONE bundle at one / two / three workgroups per CU at 1025^2 (ms;
+    // the ratios hold at other sizes: only ratios decide) -- a bundle takes what its rounds take, whatever shares the chip with it, so a
+    // launch of nb <= 768 bundles takes one bundle's time at that occupancy, a longer one whole generations plus a last partial one that
+    // costs at least 45 % of a generation (profiles/r04_bundle_occupancy.log: 768 bundles of 16 340 ms, 1 000 571, 1 600 839; 1 000 of 8
+    // 331); between 768 and 1 500 bundles plan_bundles cuts the last ones in halves (1 000 bundles of 16: 487 ms)
+    const double t_one[3][3] = { { 277.0, 290.0, 340.0 }, { 177.0, 198.0, 209.0 }, { 140.0, 147.0, 170.0 } };
+    const double rate512[3] = { 24.5, 20.4, 15.5 };                             // (512-thread kernel, one workgroup per CU: round 3's table)
     for (int k = 0; k < 3; ++k) {
         const int G = sizes[k];
         long nb = 0, covered = 0;
         for (auto& kv : count) { nb += kv.second / G; covered += (kv.second / G) * G; if (kv.second % G >= 2) { ++nb; covered += kv.second % G; } }
         if (nb == 0 || !fits(G)) continue;
+        nb = std::min<long>(nb, (long)step);
         const double frac = (double)covered / (double)h_src.size();                  // units that end up in bundles ...
         const double fill = (double)covered / ((double)nb * G);                       // ... and how full the bundles are
-        const double est = frac * rate[k] * fill * std::min(1.0, (double)std::min<long>(nb, (long)step) / (1.1 * (double)bundles_resident())) + (1.0 - frac) * 10.4 * std::min(1.0, n_units / 1100.0);
+        double est;
+        if (bundle_threads() == 512) est = frac * rate512[k] * fill * std::min(1.0, (double)nb / 280.0) + (1.0 - frac) * solo_rate;
+        else {
+            const double occ = (double)nb / 256.0;
+            double ms;
+            if (occ <= 1.0) ms = t_one[k][0];
+            else if (occ <= 2.0) ms = t_one[k][0] + (t_one[k][1] - t_one[k][0]) * (occ - 1.0);
+            else if (occ <= 3.0) ms = t_one[k][1] + (t_one[k][2] - t_one[k][1]) * (occ - 2.0);
+            else {
+                const double gens = std::floor((double)nb / 768.0), rem = (double)nb / 768.0 - gens;
+                ms = t_one[k][2] * (gens + (rem > 0.0 ? 0.45 + 0.55 * rem : 0.0));
+                if (G >= 8 && nb > 768 && nb < 1500) ms *= 0.87;                    // (the halved last bundles)
+            }
+            // k solves/s (= units per ms) of the whole launch: the bundles in `ms` (less when they are not full), the rest unit by unit behind them
+            const double units_s = n_units * (1.0 - frac);
+            est = n_units / (ms * (0.35 + 0.65 * fill) + units_s / std::max(solo_rate, 1e-9));
+        }
         if (est > best) { best = est; pick = G; if (solo_units) *solo_units = (long)h_src.size() - covered; }
     }
     return pick;
@@ -793,55 +827,91 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     std::vector<std::pair<float, int>> solo;
     for (int u = 0; u < n; ++u) if (!h_member_flag[(size_t)u]) solo.push_back({ farness(u), u });
     std::stable_sort(solo.begin(), solo.end());
-    const int nsolo = (int)solo.size(), nb = (int)pieces.size();
+    const int nsolo = (int)solo.size();
+    int nb = (int)pieces.size();
     *nsolo_out = nsolo; *nbundles_out = nb;
+    bundles_a = nb; bundles_b = 0; bundle_Gb = 0;
     if (nb == 0) return 0;
-    // members per lane: four (two workgroups per CU), or two -- three workgroups per CU, +29 % on a launch of 2 000 bundles, but nothing on
-    // 1 000, whose last 232 bundles then run one to a CU (profiles/r04_bundle_occupancy.log): automatic from 1 500 bundles on
-    bundle_mpl_now = bundle_mpl ? bundle_mpl : (bundle_threads() == 256 && nb >= 1500 ? 2 : 4);
+    // Members per lane and workgroups per CU (round 4, profiles/r04_bundle_occupancy.log).  Four members per lane: 204 VGPRs, two workgroups
+    // of 256 threads per CU, 512 bundles resident.  Two: 168 VGPRs, three per CU, 768 resident -- a bundle then takes 340 ms instead of 290
+    // at the headline size, but a CU finishes 28 % more of them per second: 768 bundles 340 ms (two generations at two per CU: ~450), 2 000
+    // bundles 977 ms against 1 261.  The catch is a last generation that is nearly empty: 1 000 bundles = 768 + 232 run 571 ms against 556
+    // at two per CU.  So, automatic mode: up to 512 bundles four members per lane; up to 768 two; beyond 1 500 two; and in between the
+    // first 768 (the longest) as they are and the REST CUT IN HALVES -- bundles of G / 2 on a second stream, which fill the CUs the first
+    // launch frees one by one (464 bundles of 8: 185 ms by themselves).
+    const bool auto_mpl = bundle_mpl == 0 && bundle_threads() == 256;
+    const int res3 = 768;
+    bundle_mpl_now = bundle_mpl ? bundle_mpl : (auto_mpl && nb > 512 ? 2 : 4);
+    std::vector<std::pair<float, std::vector<int>>> tail;
+    if (auto_mpl && bundle_opt == 1 && G >= 8 && nb > res3 && nb < 1500) {
+        std::vector<std::pair<float, std::vector<int>>> keep(pieces.begin(), pieces.begin() + res3);
+        for (size_t k = (size_t)res3; k < pieces.size(); ++k) {
+            const std::vector<int>& v = pieces[k].second;
+            if ((int)v.size() >= G / 2 + 2) {
+                tail.push_back({ pieces[k].first, std::vector<int>(v.begin(), v.begin() + G / 2) });
+                tail.push_back({ pieces[k].first, std::vector<int>(v.begin() + G / 2, v.end()) });
+            } else keep.push_back(pieces[k]);
+        }
+        pieces.swap(keep);
+        bundles_a = (int)pieces.size(); bundles_b = (int)tail.size(); bundle_Gb = G / 2;
+        nb = bundles_a + bundles_b;
+        *nbundles_out = nb;
+    }
     h_launch_rank.assign((size_t)n, 0);
     for (int r = 0; r < nsolo; ++r) h_launch_rank[(size_t)solo[(size_t)r].second] = r;
-    const int lg = G == 16 ? 4 : G == 8 ? 3 : 2;
-    const int xlog_b = exc_log2cap + lg;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
     free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;
     free_b = bundle_room(free_b);
-    const size_t slot_b = (size_t)(G + 1) * nrec_c * 4 + ((size_t)8 << xlog_b) + lists_c_stride * 4;
-    const size_t room = (size_t)(0.7 * (double)free_b) / slot_b;
-    if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
-    // field slots: one per bundle, or -- more bundles than the chip holds at a time -- as many as can be resident and a few more; a bundle
-    // claims a free one when it starts (FimBundle::slot_busy)
+    // field slots per group of bundles: one per bundle, or -- more bundles than the chip holds at a time -- as many as can be resident and a
+    // few more; a bundle claims a free one when it starts (FimBundle::slot_busy)
+    struct Group { int G, count, slots, xlog; size_t b_stride, b_off, exc_off, slot0; };
+    Group gr[2] = { { G, bundles_a, 0, 0, 0, 0, 0, 0 }, { bundle_Gb, bundles_b, 0, 0, 0, 0, 0, 0 } };
     const size_t resident = bundles_resident();
-    bundle_slots = (int)std::min<size_t>({ (size_t)nb, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (int)(resident + resident / 8)), room });
-    const size_t BS = (size_t)bundle_slots;
-    const size_t b_stride = (size_t)(G + 1) * nrec_c;
-    if (ensure(B_pool, BS * b_stride) || ensure(exc_b, BS << xlog_b) || ensure(lists_b, BS * lists_c_stride) || ensure(bpool_gen, BS) ||
+    size_t b_total = 0, exc_total = 0, slots_total = 0;
+    for (int q = 0; q < 2; ++q) {
+        Group& r = gr[q];
+        if (r.count == 0) continue;
+        const int lg = r.G == 16 ? 4 : r.G == 8 ? 3 : 2;
+        r.xlog = exc_log2cap + lg;
+        r.b_stride = (size_t)(r.G + 1) * nrec_c;
+        const size_t slot_b = r.b_stride * 4 + ((size_t)8 << r.xlog) + lists_c_stride * 4;
+        const size_t room = (size_t)(0.7 * (double)free_b) / slot_b / (bundles_b ? 2 : 1);
+        if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
+        r.slots = (int)std::min<size_t>({ (size_t)r.count, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (int)(resident + resident / 8)), room });
+        r.b_off = b_total; r.exc_off = exc_total; r.slot0 = slots_total;
+        b_total += (size_t)r.slots * r.b_stride; exc_total += (size_t)r.slots << r.xlog; slots_total += (size_t)r.slots;
+    }
+    bundle_slots = gr[0].slots;
+    if (ensure(B_pool, b_total) || ensure(exc_b, exc_total) || ensure(lists_b, slots_total * lists_c_stride) || ensure(bpool_gen, slots_total) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
     if (!slowI_ready) { launch_interleave_maps(slow.p, nrec_c, nmaps, slowI.p, stream); slowI_ready = true; }
     h_bundles.assign((size_t)nb, FimBundle{});
     int rank = nsolo;
     for (int k = 0; k < nb; ++k) {
+        const Group& r = gr[k < bundles_a ? 0 : 1];
+        const std::vector<int>& mem = k < bundles_a ? pieces[(size_t)k].second : tail[(size_t)(k - bundles_a)].second;
+        const int kk = k < bundles_a ? k : k - bundles_a;
         FimBundle& bd = h_bundles[(size_t)k];
-        bd.B = B_pool.p; bd.b_stride = b_stride; bd.p_offset = (size_t)G * nrec_c;
-        bd.exc = exc_b.p; bd.exc_stride = (size_t)1 << xlog_b; bd.exc_log2cap = xlog_b;
-        bd.lists = lists_b.p; bd.lists_stride = lists_c_stride;
-        bd.slot_busy = bundle_slots < nb ? bpool_gen.p : nullptr; bd.nslots = bundle_slots; bd.slot = bundle_slots < nb ? 0 : k;
+        bd.B = B_pool.p + r.b_off; bd.b_stride = r.b_stride; bd.p_offset = (size_t)r.G * nrec_c;
+        bd.exc = exc_b.p + r.exc_off; bd.exc_stride = (size_t)1 << r.xlog; bd.exc_log2cap = r.xlog;
+        bd.lists = lists_b.p + r.slot0 * lists_c_stride; bd.lists_stride = lists_c_stride;
+        bd.slot_busy = r.slots < r.count ? bpool_gen.p + r.slot0 : nullptr; bd.nslots = r.slots; bd.slot = r.slots < r.count ? 0 : kk;
         bd.slowI = slowI.p; bd.np = nmaps;
-        bd.nmem = (int)pieces[(size_t)k].second.size();
+        bd.nmem = (int)mem.size();
         for (int m = 0; m < kBundleMax; ++m) { bd.member[m] = 0; bd.map[m] = 0; }
         for (int m = 0; m < bd.nmem; ++m) {
-            const int u = pieces[(size_t)k].second[(size_t)m];
+            const int u = mem[(size_t)m];
             h_launch_rank[(size_t)u] = rank;
             bd.member[m] = rank++;
             bd.map[m] = h_src[(size_t)(first + u)].period;
         }
     }
-    HIP_TRY(this, hipMemsetAsync(bpool_gen.p, 0, BS * sizeof(int), stream));
+    HIP_TRY(this, hipMemsetAsync(bpool_gen.p, 0, slots_total * sizeof(int), stream));
     HIP_TRY(this, hipMemcpyAsync(bundles_d.p, h_bundles.data(), (size_t)nb * sizeof(FimBundle), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(member_flag.p, h_member_flag.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(launch_rank.p, h_launch_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
-    stats[DSA_STAT_BUNDLE_SLOTS] = bundle_slots;
+    stats[DSA_STAT_BUNDLE_SLOTS] = (double)slots_total;
     return 0;
 }
 
