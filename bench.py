@@ -275,6 +275,8 @@ def spawn_ranks(args):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
+        if args.no_secondary:
+            cmd.append("--no-secondary")
         procs.append(subprocess.Popen(cmd, env=env))
     # poll: when one rank dies (build error, bad device, out of memory) the others would sit in the rendezvous or the
     # collective until the backend's timeout -- end them and fail at once; an overall limit covers a silent hang
@@ -307,6 +309,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only (the counter passes of tools/profile_bench.sh)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -441,7 +444,10 @@ def main():
                        "parallelism": "sources (all their periods) sharded over %d rank(s) on %d GPU(s), %s all-gather of receiver times" % (world, min(world, ndev), "gloo (shared devices)" if shared else "RCCL")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": ("k_fim_bundle<%d> (coarse fixed-point solve, the %d periods of a source per workgroup)" % (int(st.get("bundle_size", 0)), int(st.get("bundle_size", 0)))
+                         "kernel": (("k_fim_bundle<%d,...> (coarse fixed-point solve, the %d periods of a source per workgroup" % (int(st.get("bundle_size", 0)), int(st.get("bundle_size", 0)))
+                                     + ("; the last bundles of the launch are cut in halves and run as k_fim_bundle<%d,...> on a second stream beside the whole ones: "
+                                        "avg_launch_ms spans the pair, as the counters of profiles/pmc_latest.json do)" % (int(st.get("bundle_size", 0)) // 2)
+                                        if st.get("bundles", 0) * st.get("bundle_size", 0) > st.get("bundled_units", 0) + 0.5 * st.get("bundle_size", 0) else ")"))
                                     if st.get("bundle_size", 0) else "k_fim_sorted<256, compact> (coarse fixed-point solve)"), "bytes_per_solve": bps,
                          "launches": int(acc["launches_fim_coarse"]),
                          "avg_launch_ms": round(acc["ms_fim_coarse"] / launches, 3),
@@ -480,6 +486,8 @@ def main():
         line["secondary"] = {}
         for name, leg in (("exact_mode", lambda: exact_secondary(eng, with_reference=not args.no_cpu_baseline)), ("bundling_on_unrelated_maps", lambda: bundling_secondary(eng)),
                           ("rays", lambda: rays_secondary(eng)), ("dispersion", lambda: dispersion_secondary(eng))):
+            if args.no_secondary:
+                break
             try:
                 line["secondary"][name] = leg()
             except Exception as ex:

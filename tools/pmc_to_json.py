@@ -36,10 +36,11 @@ def counters(dbdir, kernel_substr):
                 continue
             cols = [r[1] for r in cur.execute("pragma table_info(%s)" % cc[0])]
             name_col = "kernel_name" if "kernel_name" in cols else "name"
-            # per dispatch of the dominant kernel: the largest one is the coarse solve (the refined launch is ~3 % of it)
-            q = "select counter_name, max(value), count(*) from %s where %s like ? group by counter_name" % (cc[0], name_col)
-            for c, v, n in cur.execute(q, ("%" + kernel_substr + "%",)):
-                out[c] = {"max_per_dispatch": v, "dispatches": n}
+            # per dispatch of the dominant kernel: the largest one is the coarse solve (the refined launch is ~3 % of it); `sum` is for a
+            # step that takes several launches of it (the bundle kernel: whole bundles, then the halves of the last ones)
+            q = "select counter_name, max(value), count(*), sum(value) from %s where %s like ? group by counter_name" % (cc[0], name_col)
+            for c, v, n, t in cur.execute(q, ("%" + kernel_substr + "%",)):
+                out[c] = {"max_per_dispatch": v, "dispatches": n, "sum": t}
     return out
 
 
@@ -70,8 +71,13 @@ def main():
         return dispersion(sys.argv[2], float(sys.argv[3]), sys.argv[4])
     d, solves, dst = sys.argv[1], float(sys.argv[2]), sys.argv[3]
     kernel = sys.argv[4] if len(sys.argv) > 4 else "k_fim"
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # > 0: the counters of ALL launches of `kernel`, over `steps` steps
     import bench
     c = counters(d, kernel)
+    if steps > 0:
+        for k in c:
+            c[k]["max_per_dispatch"] = c[k]["sum"] / steps          # (per step: what the per-solve figures below divide)
+            c[k]["per"] = "step (all launches of the kernel in it)"
     cal_path = os.path.join(ROOT, "profiles", "fetch_calibration.json")
     cf = cw = 1.0
     cal = "uncalibrated (profiles/fetch_calibration.json absent)"

@@ -12,13 +12,13 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r -- python3 bench
 for g in "fetch FETCH_SIZE" "write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "busy SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
          "insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "wait SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES"; do
   set -- $g; n=$1; shift
-  timeout 900 rocprofv3 --pmc "$@" -d $OUT/pmc/$n -o r -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $OUT/$n.log 2>&1
+  timeout 900 rocprofv3 --pmc "$@" -d $OUT/pmc/$n -o r -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > $OUT/$n.log 2>&1
 done
 {
   echo "== kernel trace (rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline)"; grep '"metric"' $OUT/trace.log | cut -c1-600
   python3 tools/rocpd_summary.py $(find $OUT/trace -name "*.db" | head -1)
-  for n in fetch write busy insts wait; do echo "== pmc $n"; grep '"metric"' $OUT/$n.log | cut -c1-200; python3 tools/rocpd_pmc.py $(find $OUT/pmc/$n -name "*.db" | head -1) | grep "k_fim"; done
+  for n in fetch write busy insts wait; do echo "== pmc $n"; grep '"metric"' $OUT/$n.log | cut -c1-200; python3 tools/rocpd_pmc.py $(find $OUT/pmc/$n -name "*.db" | head -1) | grep "k_fim\|k_x"; done
   echo "== pmc_latest.json"
-  python3 tools/pmc_to_json.py $OUT/pmc 16000 $OUT/pmc_latest.json
+  python3 tools/pmc_to_json.py $OUT/pmc 16000 $OUT/pmc_latest.json k_fim_bundle ${DSA_PMC_STEPS:-1}
 } > $OUT/summary.txt 2>&1
 tail -30 $OUT/summary.txt
