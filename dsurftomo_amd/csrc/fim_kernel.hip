@@ -397,14 +397,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     // (the largest field, 513^2 tiles of 512 B, is 135 MB).
     typedef __attribute__((address_space(1))) char GChar;
     // COMPACT (coarse problems): one float per node plus the exception table (eikonal_core.h); else (T, tau) records
-    GChar* const Fb = COMPACT ? (GChar*)p.Tc : (GChar*)p.F;
-    GChar* const excb = (GChar*)p.exc;
+    GChar* Fb = COMPACT ? (GChar*)p.Tc : (GChar*)p.F;       // (a claimed field slot replaces the three slot pointers below)
+    GChar* excb = (GChar*)p.exc;
     const int xlog = p.exc_log2cap;
     GChar* const slowb = (GChar*)p.slow;
     GCF32* const risti = (GCF32*)p.risti;
     const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
     const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
-    GChar* const maskb = (GChar*)p.lists;                    // ntile node masks
+    GChar* maskb = (GChar*)p.lists;                          // ntile node masks
     auto rec = [&](int id) -> GRec* { return (GRec*)(Fb + ((unsigned)id << 3)); };
     auto slow_at = [&](int id) -> float { return *(GCF32*)(slowb + ((unsigned)id << 2)); };
     constexpr bool kOddR = DSA_ODD_CLEAR != 0;
@@ -460,24 +460,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
     };
 
     bool dead = false;                                       // an error before the first round: skip the rounds, still hand the slot on
+    int my_slot = -1;                                        // (the claimed field slot, when the launch recycles slots)
     if (COMPACT && ends) {
         // The field slot (FimEnds): wait for its previous user, then every node unreached, the exception table empty, and the nodes the
         // serial prologue pinned (window records) into both.  All by this workgroup, in this order.
         const FimEnds* const E = ends + blockIdx.x;
-        int* const pg = E->pool_gen;
-        if (pg) {
-            // (the slot's previous user is workgroup blockIdx.x - pool of this launch: dispatched earlier, so done or running -- an assumption
-            // about dispatch order the hardware does not promise; a wait that outlasts any solve therefore gives up: the unit
-            // reports -3 and the engine fails loudly instead of hanging the device.  The bundle slots are claimed, not assigned: no such wait.)
-            __shared__ int s_slot_ok;
+        if (E->slot_busy) {
+            // Fewer field slots than units in the launch: thread 0 claims the first free one at or after blockIdx.x % pool by compare-and-swap
+            // (as the bundle kernel does) and frees it at the very end.  No assumption about the order workgroups are dispatched in: a
+            // workgroup only ever waits for RUNNING workgroups to finish (ADVICE r03 / VERDICT r03 item 5; before: "slot r % pool once
+            // workgroup r - pool is done").  The wait is still bounded so that a corrupted flag array fails loudly (-3) instead of hanging.
             if (tid == 0) {
-                const int want = E->gen;
-                long long spins = 0;
-                while (__hip_atomic_load(pg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want && spins < (1ll << 26)) { __builtin_amdgcn_s_sleep(64); ++spins; }
-                s_slot_ok = spins < (1ll << 26) ? 1 : 0;
+                const int P = E->nslots;
+                int q = (int)(blockIdx.x % (unsigned)P), tries = 0;
+                long long sweeps = 0;
+                for (;;) {
+                    if (atomicCAS(&E->slot_busy[q], 0, 1) == 0) break;
+                    q = q + 1 == P ? 0 : q + 1;
+                    if (++tries == P) { tries = 0; if (++sweeps >= (1ll << 24)) { q = -1; break; } __builtin_amdgcn_s_sleep(64); }
+                }
+                __threadfence();                        // (what the slot's previous user wrote is behind us)
+                sc[0] = q;
             }
             __syncthreads();
-            if (!s_slot_ok) { if (tid == 0) { p.info[2] = -3; p.info[0] = 0; } return; }
+            my_slot = sc[0];
+            __syncthreads();
+            if (my_slot < 0) { if (tid == 0) { p.info[2] = -3; p.info[0] = 0; } return; }
+            Fb = (GChar*)(E->Tc_pool + (size_t)my_slot * ntile * kTileRecs);
+            excb = (GChar*)(E->exc_pool + ((size_t)my_slot << xlog));
+            maskb = (GChar*)(E->lists_pool + (size_t)my_slot * E->lists_stride);
         }
         typedef float __attribute__((ext_vector_type(4))) V4;
         typedef __attribute__((address_space(1))) V4 GV4;
@@ -1182,14 +1193,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 const RayDesc rd = E->rays[r];
                 if (!(rd.flags & kRayTime)) continue;
                 float t;
-                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)p.Tc, E->veln, E->dpl, &t)) atomicExch(E->err, E->ray0 + r + 1);
+                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)Fb, E->veln, E->dpl, &t)) atomicExch(E->err, E->ray0 + r + 1);
                 E->out[rd.data] = t;
             }
         }
-        if (E->pool_gen) {
+        if (E->slot_busy) {
             __threadfence();
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(E->pool_gen, E->gen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(&E->slot_busy[my_slot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid == 0) {

@@ -50,8 +50,12 @@ struct FimProblem {
 struct FimEnds {
     const Rec* W;            // window records, (cwnz, cwnx) column-major
     int cwz0, cwx0, cwnz, cwnx;
-    int* pool_gen;           // the slot's use counter; null: the slot is this unit's alone
-    int gen;                 // the slot is free for this unit when *pool_gen == gen; gen + 1 is stored when the unit is done
+    int* slot_busy;          // recycled field slots: the pool's busy flags (the workgroup claims a free slot by compare-and-swap and
+    int nslots;              // clears the flag when done); null: the slot named in the FimProblem is this unit's alone
+    float* Tc_pool;          // the pool's arrays: slot q at Tc_pool + q * (tile records of the grid), exc_pool + (q << exc_log2cap),
+    unsigned long long* exc_pool;      // lists_pool + q * lists_stride
+    int* lists_pool;
+    unsigned lists_stride;
     const RayDesc* rays;     // the unit's receivers; null: the receiver kernel (k_srtimes) runs after the launch
     int nrays, ray0;         // ray0: index of the first of them in the plan (error reporting)
     const float* veln;       // row-major velocity grid of the unit's period
@@ -152,7 +156,7 @@ struct BatchPtrs {
     int* lists; size_t lists_stride;   // active-list scratch of the refined solve, per unit
     int* lists_c; size_t lists_c_stride;   // tile records of the coarse solve, per field slot
     // field slots of the coarse solve: T_c / exc_c / lists_c hold `pool` slots; pool >= units of the launch: unit s owns slot s for the whole
-    // chunk; fewer: workgroup r of the launch takes slot r % pool after workgroup r - pool has finished (slot counters pool_gen)
+    // chunk; fewer: a workgroup of the launch claims a free slot (busy flags pool_gen) and frees it when its unit is done
     int pool;
     int* pool_gen;
 };

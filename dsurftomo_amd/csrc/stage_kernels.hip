@@ -334,7 +334,8 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     if (ends_c) {
         FimEnds e;
         e.W = b.W_c + (size_t)s * kCWinMax * kCWinMax; e.cwz0 = sd.cwz0; e.cwx0 = sd.cwx0; e.cwnz = sd.cwnz; e.cwnx = sd.cwnx;
-        e.pool_gen = recycled && !member ? b.pool_gen + slot : nullptr; e.gen = recycled && !member ? rank / b.pool : 0;
+        e.slot_busy = recycled && !member ? b.pool_gen : nullptr; e.nslots = b.pool;
+        e.Tc_pool = b.T_c; e.exc_pool = b.exc_c; e.lists_pool = b.lists_c; e.lists_stride = (unsigned)b.lists_c_stride;
         e.rays = rays ? rays + sd.first_ray : nullptr; e.nrays = sd.nrec; e.ray0 = sd.first_ray;
         e.veln = veln_all + (size_t)sd.period * veln_stride; e.scx = sd.scx; e.scz = sd.scz; e.dpl = dpl; e.out = out; e.err = err; e.g = g;
         ends_c[rank] = e;

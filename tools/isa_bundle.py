@@ -1,21 +1,23 @@
-"""Static instruction mix of the bundle kernel k_fim_bundle<16> (gfx950, the tree's flags): whole kernel and the loop nest around the solver
+"""Static instruction mix of the bundle kernel k_fim_bundle<G, threads, members per lane> (default <16, 256, 2>; gfx950, the tree's flags): whole kernel and the loop nest around the solver
 (member loop inside node-trip loop inside half-round loop inside round loop), from the compiler's own assembly.
-   python3 tools/isa_bundle.py > profiles/r03_isa_bundle_kernel.txt      (CPU only: hipcc cross-compiles)"""
+   python3 tools/isa_bundle.py [G [threads [members per lane]]] > profiles/r04_isa_bundle_kernel.txt      (CPU only: hipcc cross-compiles)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dsurftomo_amd import build
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+NT = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+MPL = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 with tempfile.TemporaryDirectory() as td:
     cmd = [build.hipcc()] + build.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-save-temps", "-c", os.path.join(ROOT, "dsurftomo_amd", "csrc", "bundle_kernel.hip"), "-o", os.path.join(td, "b.o")]
     r = subprocess.run(cmd, cwd=td, capture_output=True, text=True)
     asm = open([os.path.join(td, f) for f in os.listdir(td) if f.endswith("gfx950.s")][0]).read()
     remarks = r.stderr
-name = "_ZN3dsa12k_fim_bundleILi%dEEEvPKNS_9FimBundleEPKNS_10FimProblemEPKNS_7FimEndsE" % G
-print("k_fim_bundle<%d>: %s" % (G, " ".join(cmd[1:-5])))
+name = re.search(r"_ZN3dsa12k_fim_bundleILi%dELi%dELi%dEEEv\w+" % (G, NT, MPL), asm).group(0)
+print("k_fim_bundle<%d, %d, %d>: %s" % (G, NT, MPL, " ".join(cmd[1:-5])))
 blk = remarks[remarks.index("Function Name: " + name):]
 for key in ("VGPRs:", "AGPRs:", "SGPRs:", "ScratchSize", "Occupancy", "SGPRs Spill", "VGPRs Spill", "LDS Size"):
-    m = re.search(r"remark:\s+(%s[^\[]*)" % re.escape(key), blk)
+    m = re.search(r"\s(%s[^\n]*?)\s\[-Rpass" % re.escape(key), blk)
     if m: print("   ", m.group(1).strip())
 a = asm.index(name + ":"); b = asm.index(".Lfunc_end", a)
 lines = asm[a:b].split("\n")
