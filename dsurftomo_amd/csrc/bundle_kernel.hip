@@ -568,16 +568,15 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(MPL) void k_fim_bundle(const Fim
                 // exception table at hand.  What this buys is registers: the table look-ups and the table insert, inlined into every member
                 // body, kept ~30 more VGPRs alive (profiles/r04_bundle_vgprs.txt), and 168 is the line for a third workgroup per CU.
                 unsigned slow = 0u;
+                const bool interior = in[0] && in[1] && in[2] && in[3];      // (a node on the grid's edge: the general walk's business)
 #pragma unroll
                 for (int m = 0; m < MPL; ++m) {
-                    Hood h;
-                    bool flagged = false;
+                    float tn[4], t2[4];
+                    bool flagged = !interior;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float a = vn[q][m], b = vo[q][m];
-                        h.in[q] = in[q]; h.in_outer[q] = in_outer[q];
-                        h.near_[q] = a; h.near_tau[q] = a; h.outer[q] = b; h.outer_tau[q] = b;
-                        flagged = flagged | __builtin_signbit(a) | __builtin_signbit(b);
+                        tn[q] = vn[q][m]; t2[q] = vo[q][m];
+                        flagged = flagged | __builtin_signbit(tn[q]) | __builtin_signbit(t2[q]);
                     }
                     const float raw = vown[m];
                     const bool valid = act && ((vmask >> m) & 1u);
@@ -585,9 +584,12 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(MPL) void k_fim_bundle(const Fim
                     float c = 0.0f, k = kInf;
                     bool changed = false;
                     if (valid && !flagged) {
-                        const float slown = sl[m];
-                        c = solve_node_t<false>(h, slown, geom, &k, nullptr);
-                        if (bf2u(c) != bf2u(k)) flagged = true;                       // (a non-causal result: the table's business)
+                        // (round 4) the walk written out for the regular neighbourhood: straight-line code, about half the instructions of
+                        // solve_node_t's loop; where it does not apply (a third neighbour taken in, the opposite neighbour second: ~1 % of
+                        // the evaluations) it says so and the member goes to the slow pass like an exceptional one
+                        bool ok;
+                        c = solve_regular(tn, t2, sl[m], geom, &k, &ok);
+                        if (!ok || bf2u(c) != bf2u(k)) flagged = true;               // (a non-causal result: the table's business)
                         else { ++evals; changed = bf2u(c) != bf2u(raw); }
                     }
                     if (valid && flagged) slow |= 1u << m;
@@ -600,9 +602,9 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(MPL) void k_fim_bundle(const Fim
                         const float t_lo = fminf(raw, c), k_lo = t_lo;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float ky = h.near_tau[q];
-                            if (h.in[q] && k_lo <= ky) wm |= 1u << q;
-                            if (h.in_outer[q] && ky < kInf && h.near_[q] > t_lo && k_lo < h.outer_tau[q]) wm |= 16u << q;
+                            const float ky = tn[q];
+                            if (k_lo <= ky) wm |= 1u << q;                               // (interior: the four near neighbours exist)
+                            if (in_outer[q] && ky < kInf && ky > t_lo && k_lo < t2[q]) wm |= 16u << q;
                         }
                     }
                 }

@@ -488,6 +488,71 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
     *tau_out = (c > tnow) ? c : tnow;
     return c;
 }
+// Round 4: the walk of solve_node_t written out for the REGULAR neighbourhood -- all four near neighbours inside the grid, no pinned
+// value among the eight, every acceptance time equal to its value (tau = T: the compact field's rule for every node that has no entry
+// in the exception table).  tn[q] / t2[q]: the near and outer values in Hood's order (+inf: not reached; outer outside the grid: +inf).
+//
+// What the general form spends on generality -- a sorting network over (key, index), the alive set as a bit mask, a loop whose trip
+// count differs from lane to lane with every candidate behind a select -- collapses here:
+//   * the walk takes the neighbours in the order of their values, the lower index first on a tie, so its first two are the smaller
+//     one of each direction ("upwind") unless the second-smallest is the first one's opposite neighbour;
+//   * with tau = T the second-order switch of a neighbour, (outer alive at the clock) && tn > t2, is just t2 < tn, at every step of the
+//     walk: the one-sided candidate of the first neighbour is the same number at step one and step two;
+//   * at step two exactly one quadrant has both neighbours alive, and both one-sided candidates exist (the opposite neighbours are
+//     inside the grid and not alive).
+// Step one: c1 = one-sided(first); the walk stops there when the second key is +inf or c1 <= it.  Step two: c2 = min(one-sided x,
+// one-sided z, the quadrant's two-sided value); it stops when the third key is +inf or c2 <= it.  Anything else -- a third neighbour
+// taken in, the opposite neighbour second -- returns *ok = false and the caller uses solve_node_t.  Every operation is the one
+// solve_node_t performs on the same operands (tests/test_hostcheck.py: 2e7 random regular neighbourhoods and whole solves, bit for bit).
+DSA_HD float solve_regular(const float* tn, const float* t2, float slown, const NodeGeom& g, float* tau_out, bool* ok)
+{
+    const bool x1 = tn[1] < tn[0], z1 = tn[3] < tn[2];
+    const float tx = x1 ? tn[1] : tn[0], ox = x1 ? tn[0] : tn[1], tx2 = x1 ? t2[1] : t2[0];
+    const float tz = z1 ? tn[3] : tn[2], oz = z1 ? tn[2] : tn[3], tz2 = z1 ? t2[3] : t2[2];
+    const bool xf = tx <= tz;                                   // the x neighbour leads (lower index on a tie)
+    const bool std2 = xf ? (tz < ox) : (tx <= oz);              // the second of the walk is the other direction's upwind neighbour
+    const float k0 = xf ? tx : tz;
+    const float k1 = xf ? (std2 ? tz : ox) : (std2 ? tx : oz);
+    const float k2 = ox < oz ? ox : oz;
+    const float s2 = sq(slown);
+    const float A = sq(g.ri * g.dnx), B = sq(g.risti * g.dnz);
+    const float s2A = A * s2, s2B = B * s2;
+    const bool sx = tx2 < tx, sz = tz2 < tz;                    // second order towards x / z
+    const float Px = fmaf(4.0f, tx, -tx2), Pz = fmaf(4.0f, tz, -tz2);
+    const float rx = sqrt_pos(sx ? 4.0f * s2A : s2 * sq(g.ri) * sq(g.dnx));
+    const float rz = sqrt_pos(sz ? 4.0f * s2B : s2 * sq(g.risti) * sq(g.dnz));
+    const float onex = sx ? div3(Px + rx) : tx + rx;
+    const float onez = sz ? div3(Pz + rz) : tz + rz;
+    const float c1 = xf ? onex : onez;
+    const bool stop1 = !(k1 < kInf && c1 > k1);
+    // step two: the quadrant (x upwind, z upwind); operand table of solve_node_t
+    const bool both = sx && sz, one = sx != sz;
+    const float p = sx ? (sz ? Px : 3.0f * tz) : (sz ? 3.0f * tx : tz);
+    const float q_ = (sx && !sz) ? 4.0f * tx : (sz ? 4.0f * tz : tx);
+    const float r = sz ? tz2 : (sx ? tx2 : 0.0f);
+    const float U = (sx && !sz) ? B : A;
+    const float S = (sx && !sz) ? 4.0f * s2A : (sz ? 4.0f * s2B : s2B);
+    const float a00 = A + B;
+    const float a = sx ? (sz ? 4.0f * a00 : 4.0f * A + 9.0f * B) : (sz ? 4.0f * B + 9.0f * A : a00);
+    const float tref = sx ? (sz ? Px : tz) : tx;
+    const float em = (p - q_) + r;
+    const float b = (both ? 8.0f : (one ? 1.0f : -2.0f)) * (((one ? 6.0f : 1.0f) * em) * U);
+    const float cc = (both ? 4.0f : 1.0f) * (U * (sq(em) - S));
+    float rd1 = sq(b) - 4.0f * a * cc;
+    if (rd1 < 0.0f) rd1 = 0.0f;
+    const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+    float trav = tref + tdsh;
+    if (both) trav = div3(trav);
+    float c2 = onex < kInf ? onex : kInf;
+    c2 = onez < c2 ? onez : c2;
+    c2 = trav < c2 ? trav : c2;
+    const bool stop2 = !(k2 < kInf && c2 > k2);
+    *ok = stop1 || (std2 && stop2);
+    const float c = stop1 ? c1 : c2, tnow = stop1 ? k0 : k1;
+    *tau_out = (c > tnow) ? c : tnow;
+    return c;
+}
+
 DSA_HD float solve_node(const Hood& h, float slown, const NodeGeom& g, float* tau_out)
 {
 #ifdef DSA_LEDGER

@@ -347,7 +347,7 @@ int hc_depthkernel(int ncol, int nz, const float* vels, const float* depz, float
 // rule; the ready set is evaluated from the old states), used to study convergence on the CPU.
 // Interface arrays are row-major (nnz fastest); storage inside is tiled like on the device.
 // mode 0: all ready nodes at once; mode 1: two sub-passes by node parity (even first).
-extern "C" { int g_prune = 1; }
+extern "C" { int g_prune = 1; long g_regular_stats[8] = {}; long* hc_regular_stats() { return g_regular_stats; } }
 extern "C" long hc_device_schedule(int nnx, int nnz, float* Tio, float* tauio, const float* slow_rm, const float* risti,
                                    float ri, float dnx, float dnz, float window, int mode, int max_rounds,
                                    long* out /* rounds, evals, last list size, freezes */, int* cyc_ids, int ncyc)
@@ -396,6 +396,27 @@ extern "C" long hc_device_schedule(int nnx, int nnz, float* Tio, float* tauio, c
                 int iz0, ix0; rec_coords(nbz, sub[k], &iz0, &ix0);
                 const Hood h = load_hood(f, iz0 + 1, ix0 + 1); const NodeGeom g = { ri, risti[ix0], dnx, dnz };
                 nT[k] = solve_node(h, slow[sub[k]], g, &nK[k]); ++evals;
+                // (round 4) the regular-neighbourhood form of the walk beside it: where it applies and says ok, the same bits
+                {
+                    bool regular = true;
+                    float tn[4], t2[4];
+                    for (int q = 0; q < 4; ++q) {
+                        regular = regular && h.in[q] && !std::signbit(h.near_[q]) && std::memcmp(&h.near_[q], &h.near_tau[q], 4) == 0;
+                        if (h.in_outer[q]) regular = regular && !std::signbit(h.outer[q]) && std::memcmp(&h.outer[q], &h.outer_tau[q], 4) == 0;
+                        tn[q] = h.near_[q]; t2[q] = h.in_outer[q] ? h.outer[q] : kInf;
+                    }
+                    ++g_regular_stats[0];
+                    if (regular) {
+                        ++g_regular_stats[1];
+                        float kr; bool ok;
+                        const float cr = solve_regular(tn, t2, slow[sub[k]], g, &kr, &ok);
+                        if (ok) {
+                            ++g_regular_stats[2];
+                            if (std::memcmp(&cr, &nT[k], 4) || std::memcmp(&kr, &nK[k], 4)) ++g_regular_stats[3];
+                            if (std::memcmp(&cr, &kr, 4)) ++g_regular_stats[4];          // (ok but not causal: the caller's slow path)
+                        }
+                    }
+                }
             }
             for (size_t k = 0; k < sub.size(); ++k) {
                 const int id = sub[k];
@@ -517,6 +538,60 @@ extern "C" long hc_solve_node_compare(unsigned long long seed, long n, long* sta
     return bad;
 }
 
+
+// solve_regular (round 4: the walk written out for neighbourhoods without pinned / late-accepted / missing near neighbours) against
+// solve_node on n random regular neighbourhoods.  Returns the number of cases where it said ok and its (T, tau) bits differ;
+// stat[0] = cases it accepted, stat[1] = those that stopped after one neighbour (coverage).
+extern "C" long hc_solve_regular_compare(unsigned long long seed, long n, long* stat)
+{
+    unsigned long long st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(st >> 33); };
+    auto uni = [&]() { return (float)(rnd() & 0xffffff) / 16777216.0f; };
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        NodeGeom g;
+        g.ri = 6371.0f - 40.0f * uni();
+        g.risti = g.ri * sinf(0.3f + 1.2f * uni());
+        g.dnx = 5e-5f + 6e-4f * uni();
+        g.dnz = (rnd() & 3) ? g.dnx * (0.7f + 0.6f * uni()) : g.dnx;
+        const float slown = 1.0f / (1.5f + 3.5f * uni());
+        const float hx = g.ri * g.dnx * slown, hz = g.risti * g.dnz * slown;
+        const float t0 = (rnd() & 7) ? 300.0f * uni() : 2.0f * uni();
+        const int mode = rnd() & 15;
+        Hood h;
+        float tn[4], t2[4];
+        for (int q = 0; q < 4; ++q) {
+            const float hq = q < 2 ? hx : hz;
+            const unsigned r = rnd();
+            h.in[q] = true;
+            h.in_outer[q] = ((r >> 5) & 15) != 0;
+            float t = t0 + hq * (2.4f * uni() - 1.2f);
+            if (mode == 1) t = t0;                                               // all equal
+            if (mode == 2 && (q & 1)) t = t0 + hq * 0.25f;                       // pairs equal
+            if (mode == 4) t = t0 + (float)(rnd() % 3) * hq * 0.5f;             // ties across the directions
+            if (t < 0.0f) t = 0.0f;
+            if (((r >> 11) & 7) == 0) t = kInf;                                  // not reached
+            float o = t + hq * (1.6f * uni() - 1.1f);
+            if (mode == 3) o = t;                                                // tn == t2: first order
+            if (o < 0.0f) o = 0.0f;
+            if (((r >> 23) & 15) == 0) o = 0.0f;
+            if (((r >> 27) & 7) == 0 || t == kInf) o = kInf;
+            h.near_[q] = t; h.near_tau[q] = t;
+            h.outer[q] = h.in_outer[q] ? o : kInf; h.outer_tau[q] = h.outer[q];
+            tn[q] = t; t2[q] = h.outer[q];
+        }
+        float ka, kb; bool ok;
+        const float a = solve_node(h, slown, g, &ka);
+        const float b = solve_regular(tn, t2, slown, g, &kb, &ok);
+        if (!ok) continue;
+        if (stat) { stat[0] += 1; if (!(ka > 0.0f) || std::memcmp(&a, &ka, 4) == 0) stat[1] += 0; }
+        if (std::memcmp(&a, &b, 4) != 0 || std::memcmp(&ka, &kb, 4) != 0) {
+            if (bad < 5) std::fprintf(stderr, "solve_regular differs at case %ld: T %.9g vs %.9g, tau %.9g vs %.9g\n", i, (double)a, (double)b, (double)ka, (double)kb);
+            ++bad;
+        }
+    }
+    return bad;
+}
 
 // Exact mode (csrc/exact_march.h) on the CPU: the CPU model of the device's march (same order of events per accept step, same quadrant
 // arithmetic), sequenced like the device's launches

@@ -36,6 +36,9 @@ def H():
     h.hc_device_schedule.restype = C.c_long
     h.hc_solve_node_compare.argtypes = [C.c_ulonglong, C.c_long, L.vp]
     h.hc_solve_node_compare.restype = C.c_long
+    h.hc_solve_regular_compare.argtypes = [C.c_ulonglong, C.c_long, L.vp]
+    h.hc_solve_regular_compare.restype = C.c_long
+    h.hc_regular_stats.restype = C.POINTER(C.c_long)
     h.hc_depthkernel.argtypes = [L.i32, L.i32, L.vp, L.vp, L.f32, L.i32, L.i32, L.i32, L.vp, L.i32, L.vp, L.vp, L.vp, L.vp]
     h.hc_quads_compare.argtypes = [C.c_ulonglong, C.c_long]
     h.hc_quads_compare.restype = C.c_long
@@ -55,6 +58,36 @@ def test_solve_node_equals_the_step_by_step_form(H):
     assert bad == 0
     assert stat[1] > 1e5 and stat[2] > 1e6 and stat[3] > 1e5, stat      # the walk really takes one, two, three and more neighbours
     assert stat[5] > 100 and stat[6] > 20, stat                        # the tie detector (same (T, tau) with it) met ties, some with influence
+
+
+def test_regular_form_of_the_walk_equals_solve_node(H):
+    """solve_regular (round 4: the walk written out for neighbourhoods with four near neighbours, nothing pinned, tau = T -- what the bundle
+    kernel's member bodies evaluate) gives solve_node's (T, tau) bit for bit wherever it says ok: 2e7 random regular neighbourhoods, and
+    every evaluation of whole emulated solves on three media, where it must also cover nearly all of them"""
+    stat = np.zeros(8, np.int64)
+    assert H.hc_solve_regular_compare(20261003, 20_000_000, L.ptr(stat)) == 0
+    assert stat[0] > 5e6, stat                                         # (the random cases are adversarial: it takes under half of them)
+    nx = 35
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+    N = g.nnx
+    sx, sz = synth.sources(nx, 8)
+    rs = H.hc_regular_stats()
+    for kind, src in (("rough", 1), ("checker4", 5), ("smooth", 2)):
+        for k in range(8):
+            rs[k] = 0
+        pv = synth.medium(nx, kind)
+        T = np.zeros((N, N), np.float32); tau = np.zeros((N, N), np.float32); slow = np.zeros((N, N), np.float32)
+        ris = np.zeros(N, np.float32); geom = np.zeros(4, np.float32)
+        assert H.hc_coarse_problem(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8, L.ptr(pv), sx[src], sz[src], L.ptr(T),
+                                   L.ptr(tau), L.ptr(slow), L.ptr(ris), L.ptr(geom)) == 0
+        out = np.zeros(4, np.int64); cyc = np.zeros(4, np.int32)
+        assert H.hc_device_schedule(N, N, L.ptr(T), L.ptr(tau), L.ptr(slow), L.ptr(ris), geom[0], geom[1], geom[2],
+                                    np.float32(0.6 * geom[3]), 1, 20000, L.ptr(out), L.ptr(cyc), 4) == 0
+        evals, regular, ok, differ, noncausal = (int(rs[k]) for k in range(5))
+        print("%s: %d evaluations, %d regular neighbourhoods, %d taken by solve_regular (%.2f %%), %d of them non-causal, %d differ"
+              % (kind, evals, regular, ok, 100.0 * ok / evals, noncausal, differ))
+        assert differ == 0
+        assert ok > 0.93 * evals, (kind, evals, regular, ok)
 
 
 def test_stencil_bitwise_against_oracle(H):
