@@ -59,18 +59,22 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 
 }  // namespace
 
-// Waves per SIMD the register allocation aims at.  Round 4: with TWO members per lane and the irregular members out of the trip (the slow
-// queue of pass B) the kernel fits 168 VGPRs without a spill: three workgroups of 256 threads per CU instead of two.  Four members per lane
-// stay at two (204 VGPRs; forced to 168 they spill 30).  -DDSA_BUNDLE_WAVES=n overrides both for experiments.
+// Waves per SIMD the register allocation aims at (256-thread workgroups; three waves per SIMD = three workgroups per CU, 168 VGPRs).
+// Round 4: with the irregular members out of the trip (the slow queue of pass B) and the walk of the regular ones written out
+// (solve_regular) TWO members per lane fit 168 VGPRs without a spill, four members per lane with two spilled registers (179 left alone).
+// Measured at three per CU, 768 bundles at 1025^2 (profiles/r04_bundle_occupancy.log): bundles of 16 -- four per lane 240.9 ms, two per
+// lane 256.4; bundles of 8 -- four per lane 194.9, two per lane 187.2.  So: 16 members four per lane, 8 and 4 members two per lane when
+// the launch fills more than two workgroups per CU (four per lane, two per CU, below that).  512-thread workgroups (grids beyond 1500
+// nodes per side) stay at two waves per SIMD.  -DDSA_BUNDLE_WAVES=n overrides for experiments.
 #ifdef DSA_BUNDLE_WAVES
-#define DSA_BUNDLE_OCC(MPL) __attribute__((amdgpu_waves_per_eu(DSA_BUNDLE_WAVES, DSA_BUNDLE_WAVES)))
+#define DSA_BUNDLE_OCC(G, NT, MPL) __attribute__((amdgpu_waves_per_eu(DSA_BUNDLE_WAVES, DSA_BUNDLE_WAVES)))
 #else
-#define DSA_BUNDLE_OCC(MPL) __attribute__((amdgpu_waves_per_eu((MPL) == 2 ? 3 : 1, (MPL) == 2 ? 3 : 2)))
+#define DSA_BUNDLE_OCC(G, NT, MPL) __attribute__((amdgpu_waves_per_eu(((NT) == 256 && ((MPL) == 2 || (G) == 16)) ? 3 : 1, ((NT) == 256 && ((MPL) == 2 || (G) == 16)) ? 3 : 2)))
 #endif
 // NT = 256 threads per workgroup up to 1500 nodes per side (128: -1.7 %, 512: -13 % at 1025^2), 512 beyond: a 4097^2 front has ~2700 ready
 // nodes per round, four times what 256 threads and their 2 x 1024 ready slots take
 template <int G, int NT, int MPL = 4>
-__global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(MPL) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
+__global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
 {
     constexpr int NW = NT / 64;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(MPL) void k_fim_bundle(const Fim
         s_slot = slot;
     }
     __syncthreads();
-    const int my_slot = s_slot;
+    const int my_slot = __builtin_amdgcn_readfirstlane(s_slot);
     float* const Bslot = bd->B + (size_t)my_slot * bd->b_stride;
     BGChar* const Bb = (BGChar*)Bslot;
     BGChar* const excb = (BGChar*)(bd->exc + (size_t)my_slot * bd->exc_stride);
@@ -766,8 +770,6 @@ void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int thr
 #define DSA_LAUNCH_BUNDLE2(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT, 2>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
     if (members_per_lane == 2 && threads == 256) { if (G == 16) DSA_LAUNCH_BUNDLE2(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE2(8, 256); else DSA_LAUNCH_BUNDLE2(4, 256); }
     else if (threads == 512) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 512); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 512); else DSA_LAUNCH_BUNDLE(4, 512); }
-    else if (threads == 64) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 64); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 64); else DSA_LAUNCH_BUNDLE(4, 64); }
-    else if (threads == 128) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 128); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 128); else DSA_LAUNCH_BUNDLE(4, 128); }
     else { if (G == 16) DSA_LAUNCH_BUNDLE(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 256); else DSA_LAUNCH_BUNDLE(4, 256); }
 #undef DSA_LAUNCH_BUNDLE
 #undef DSA_LAUNCH_BUNDLE2

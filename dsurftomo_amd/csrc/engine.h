@@ -83,8 +83,8 @@ struct Engine {
                                        // (measured at 1025^2, 16 members: 0.4 / 0.5 / 0.6 / 0.8 / 1.25 cells -> 24.4 / 24.6 / 24.4 / 23.9 / 22.7 k solves/s)
     int bundle_threads_opt = 0;        // option bundle_threads: workgroup size of the bundle kernel (0 = by grid size: 256, 512 beyond 1500 nodes per side)
     int bundle_max_rounds = 0;         // option bundle_max_rounds (tests): > 0 = round limit of the bundles; a bundle that hits it sends its chunk to the unit-by-unit solve
-    int bundle_mpl = 0;                // option bundle_members_per_lane: 0 = automatic, 4, or 2 (k_fim_bundle<G, 256, 2>: 168 VGPRs, three workgroups per CU)
-    int bundle_mpl_now = 4;            // ... what the current launch uses
+    int bundle_mpl = 0;                // option bundle_members_per_lane: 0 = automatic (bundle_mpl_of), 4, or 2
+    int bundle_mpl_now = 4, bundle_mpl_b = 2;      // ... what the current launch uses (whole bundles; the halved last ones)
     int bundles_a = 0, bundles_b = 0, bundle_Gb = 0;      // the launch's bundles: whole ones, and (plan_bundles) the last ones cut in halves of bundle_Gb members on a second stream
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
@@ -102,7 +102,8 @@ struct Engine {
     size_t bundle_room(size_t free_b) const;
     bool grow_unit_pool();
     int bundle_threads() const;
-    size_t bundles_resident() const;
+    size_t bundles_resident(int G, int mpl) const;
+    int bundle_mpl_of(int G, long nb) const;
     int choose_bundle_size(int step, long* solo_units = nullptr);
     int plan_bundles(int first, int n, int G, int* nsolo, int* nbundles);
     size_t lists_stride = 0;

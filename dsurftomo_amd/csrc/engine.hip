@@ -449,15 +449,27 @@ size_t Engine::solve_stage_bytes() const
 
 // bundles the chip holds at a time: one workgroup of 512 threads per CU, two of 256 (four members per lane: 204 VGPRs) or three (two
 // members per lane: 168 VGPRs, round 4)
-size_t Engine::bundles_resident() const
+size_t Engine::bundles_resident(int G, int mpl) const
 {
-    return (size_t)256 * (bundle_threads() == 512 ? 1 : (bundle_threads() == 256 && bundle_mpl_now == 2) ? 3 : 2);
+#ifdef DSA_BUNDLE_WAVES          // (probe builds: bundle_kernel.hip compiled for that many waves per SIMD whatever the members per lane)
+    if (bundle_threads() == 256) return (size_t)256 * DSA_BUNDLE_WAVES;
+#endif
+    // (bundle_kernel.hip: DSA_BUNDLE_OCC -- three workgroups of 256 threads per CU with two members per lane and for bundles of 16)
+    return (size_t)256 * (bundle_threads() == 512 ? 1 : (mpl == 2 || G == 16) ? 3 : 2);
 }
 
-// workgroup size of the bundle kernel (bundle_kernel.hip)
+// Members per lane of a launch of nb bundles of G: the option, or 16 members four per lane; 8 and 4 members two per lane (three workgroups
+// per CU) when the launch holds more than the 512 bundles that two per CU take, else four
+int Engine::bundle_mpl_of(int G, long nb) const
+{
+    if (bundle_mpl) return bundle_mpl;
+    if (bundle_threads() != 256 || G == 16) return 4;
+    return nb > 512 ? 2 : 4;
+}
+
 int Engine::bundle_threads() const
 {
-    if (bundle_threads_opt == 64 || bundle_threads_opt == 128 || bundle_threads_opt == 256 || bundle_threads_opt == 512) return bundle_threads_opt;
+    if (bundle_threads_opt == 256 || bundle_threads_opt == 512) return bundle_threads_opt;
     return std::max(g.nnx, g.nnz) > 1500 ? 512 : 256;
 }
 
@@ -579,7 +591,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                 HIP_TRY(this, hipEventRecord(ev_b0, stream));
                 launch_fim_bundles(bundles_d.p, bundles_a, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
                 HIP_TRY(this, hipStreamWaitEvent(stream2, ev_b0, 0));
-                launch_fim_bundles(bundles_d.p + bundles_a, bundles_b, bundle_Gb, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream2, bundle_mpl_now);
+                launch_fim_bundles(bundles_d.p + bundles_a, bundles_b, bundle_Gb, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream2, bundle_mpl_b);
                 HIP_TRY(this, hipEventRecord(ev_b1, stream2));
                 HIP_TRY(this, hipStreamWaitEvent(stream, ev_b1, 0));
             } else if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
@@ -739,7 +751,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
         if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
         const long nb = std::min<long>(bundles_with(G), (long)step);
-        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), (long)(bundles_resident() + bundles_resident() / 8));      // (bundles resident at a time, and a few more)
+        const size_t want = (size_t)std::min<long>(std::max<long>(nb, 1), (long)(bundles_resident(G, bundle_mpl_of(G, nb)) * 9 / 8));      // (bundles resident at a time, and a few more)
         return want * slot_bytes(G) + (size_t)nmaps * nrec_c * 4 < (size_t)(0.7 * (double)free_b);      // (what plan_bundles allows itself)
     };
     if (bundle_opt == 4 || bundle_opt == 8 || bundle_opt == 16) {
@@ -755,16 +767,16 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     // (bundle_threads(): half as many bundles fill the chip).  Grids below 400 nodes per side stay unit by unit: their solves are short.
     if (std::min(g.nnx, g.nnz) < 400) return 0;
     const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
-    const double solo_rate = 10.4 * std::min(1.0, n_units / 1100.0);          // k solves/s
+    const double solo_rate = 10.0 * std::min(1.0, n_units / 1100.0);          // k solves/s
     double best = solo_rate * 1.05;
     int pick = 0;
     const int sizes[3] = { 16, 8, 4 };
     // Round 4 (256-thread kernel): a launch's time from the measured time of ONE bundle at one / two / three workgroups per CU at 1025^2 (ms;
     // the ratios hold at other sizes: only ratios decide) -- a bundle takes what its rounds take, whatever shares the chip with it, so a
     // launch of nb <= 768 bundles takes one bundle's time at that occupancy, a longer one whole generations plus a last partial one that
-    // costs at least 45 % of a generation (profiles/r04_bundle_occupancy.log: 768 bundles of 16 340 ms, 1 000 571, 1 600 839; 1 000 of 8
-    // 331); between 768 and 1 500 bundles plan_bundles cuts the last ones in halves (1 000 bundles of 16: 487 ms)
-    const double t_one[3][3] = { { 277.0, 290.0, 340.0 }, { 177.0, 198.0, 209.0 }, { 140.0, 147.0, 170.0 } };
+    // costs at least 45 % of a generation (profiles/r04_bundle_occupancy.log); between 768 and 1 500 bundles plan_bundles cuts the last
+    // ones in halves (1 000 bundles of 16: 383 ms)
+    const double t_one[3][3] = { { 189.5, 210.0, 241.0 }, { 130.8, 151.7, 187.2 }, { 104.8, 125.4, 164.3 } };
     const double rate512[3] = { 24.5, 20.4, 15.5 };                             // (512-thread kernel, one workgroup per CU: round 3's table)
     for (int k = 0; k < 3; ++k) {
         const int G = sizes[k];
@@ -785,7 +797,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
             else {
                 const double gens = std::floor((double)nb / 768.0), rem = (double)nb / 768.0 - gens;
                 ms = t_one[k][2] * (gens + (rem > 0.0 ? 0.45 + 0.55 * rem : 0.0));
-                if (G >= 8 && nb > 768 && nb < 1500) ms *= 0.87;                    // (the halved last bundles)
+                if (G >= 8 && nb > 768 && nb < 1500) ms *= 0.98;                    // (the halved last bundles)
             }
             // k solves/s (= units per ms) of the whole launch: the bundles in `ms` (less when they are not full), the rest unit by unit behind them
             const double units_s = n_units * (1.0 - frac);
@@ -832,16 +844,16 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     *nsolo_out = nsolo; *nbundles_out = nb;
     bundles_a = nb; bundles_b = 0; bundle_Gb = 0;
     if (nb == 0) return 0;
-    // Members per lane and workgroups per CU (round 4, profiles/r04_bundle_occupancy.log).  Four members per lane: 204 VGPRs, two workgroups
-    // of 256 threads per CU, 512 bundles resident.  Two: 168 VGPRs, three per CU, 768 resident -- a bundle then takes 340 ms instead of 290
-    // at the headline size, but a CU finishes 28 % more of them per second: 768 bundles 340 ms (two generations at two per CU: ~450), 2 000
-    // bundles 977 ms against 1 261.  The catch is a last generation that is nearly empty: 1 000 bundles = 768 + 232 run 571 ms against 556
-    // at two per CU.  So, automatic mode: up to 512 bundles four members per lane; up to 768 two; beyond 1 500 two; and in between the
-    // first 768 (the longest) as they are and the REST CUT IN HALVES -- bundles of G / 2 on a second stream, which fill the CUs the first
-    // launch frees one by one (464 bundles of 8: 185 ms by themselves).
+    // Members per lane and workgroups per CU (round 4, profiles/r04_bundle_occupancy.log; bundle_mpl_of, bundle_kernel.hip: DSA_BUNDLE_OCC):
+    // bundles of 16 run three workgroups per CU (768 resident), bundles of 8 / 4 too when the launch has more than 512 of them.  A bundle
+    // takes longer with two neighbours on its CU than with one (768 bundles of 16: 241 ms; 500: 210; 250: 190), but a CU finishes more of
+    // them per second.  The catch is a last generation that is nearly empty -- 1 000 bundles = 768 + 232 -- so, automatic mode, between 768
+    // and 1 500 bundles: the first 768 (the longest) as they are and the REST CUT IN HALVES -- bundles of G / 2, two members per lane, on a
+    // second stream, which fill the CUs the first launch frees one by one (1 000 sources x 16 periods: 383 ms against ~430 uncut).
     const bool auto_mpl = bundle_mpl == 0 && bundle_threads() == 256;
     const int res3 = 768;
-    bundle_mpl_now = bundle_mpl ? bundle_mpl : (auto_mpl && nb > 512 ? 2 : 4);
+    bundle_mpl_now = bundle_mpl_of(G, nb);
+    bundle_mpl_b = bundle_mpl ? bundle_mpl : 2;
     std::vector<std::pair<float, std::vector<int>>> tail;
     if (auto_mpl && bundle_opt == 1 && G >= 8 && nb > res3 && nb < 1500) {
         std::vector<std::pair<float, std::vector<int>>> keep(pieces.begin(), pieces.begin() + res3);
@@ -867,7 +879,6 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     // few more; a bundle claims a free one when it starts (FimBundle::slot_busy)
     struct Group { int G, count, slots, xlog; size_t b_stride, b_off, exc_off, slot0; };
     Group gr[2] = { { G, bundles_a, 0, 0, 0, 0, 0, 0 }, { bundle_Gb, bundles_b, 0, 0, 0, 0, 0, 0 } };
-    const size_t resident = bundles_resident();
     size_t b_total = 0, exc_total = 0, slots_total = 0;
     for (int q = 0; q < 2; ++q) {
         Group& r = gr[q];
@@ -878,6 +889,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         const size_t slot_b = r.b_stride * 4 + ((size_t)8 << r.xlog) + lists_c_stride * 4;
         const size_t room = (size_t)(0.7 * (double)free_b) / slot_b / (bundles_b ? 2 : 1);
         if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
+        const size_t resident = bundles_resident(r.G, q == 0 ? bundle_mpl_now : bundle_mpl_b);
         r.slots = (int)std::min<size_t>({ (size_t)r.count, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (int)(resident + resident / 8)), room });
         r.b_off = b_total; r.exc_off = exc_total; r.slot0 = slots_total;
         b_total += (size_t)r.slots * r.b_stride; exc_total += (size_t)r.slots << r.xlog; slots_total += (size_t)r.slots;
@@ -1238,7 +1250,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
     if (n == "bundle_window_cells" && value > 0) { en->bundle_window_cells = (float)value; return 0; }
-    if (n == "bundle_threads" && (value == 0 || value == 64 || value == 128 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
+    if (n == "bundle_threads" && (value == 0 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
     if (n == "bundle_members_per_lane" && (value == 0 || value == 4 || value == 2)) { en->bundle_mpl = (int)value; return 0; }

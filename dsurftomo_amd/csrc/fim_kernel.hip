@@ -475,15 +475,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                 int q = (int)(blockIdx.x % (unsigned)P), tries = 0;
                 long long sweeps = 0;
                 for (;;) {
-                    if (atomicCAS(&E->slot_busy[q], 0, 1) == 0) break;
+                    // (look before the compare-and-swap: thousands of waiting workgroups polling with atomics slow the running ones down)
+                    if (__hip_atomic_load(&E->slot_busy[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && atomicCAS(&E->slot_busy[q], 0, 1) == 0) break;
                     q = q + 1 == P ? 0 : q + 1;
-                    if (++tries == P) { tries = 0; if (++sweeps >= (1ll << 24)) { q = -1; break; } __builtin_amdgcn_s_sleep(64); }
+                    if (++tries >= P || tries >= 64) { tries = 0; if (++sweeps >= (1ll << 24)) { q = -1; break; } __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
                 }
                 __threadfence();                        // (what the slot's previous user wrote is behind us)
                 sc[0] = q;
             }
             __syncthreads();
-            my_slot = sc[0];
+            my_slot = __builtin_amdgcn_readfirstlane(sc[0]);       // (uniform: the slot's arrays are addressed from scalar registers, as the assigned ones were)
             __syncthreads();
             if (my_slot < 0) { if (tid == 0) { p.info[2] = -3; p.info[0] = 0; } return; }
             Fb = (GChar*)(E->Tc_pool + (size_t)my_slot * ntile * kTileRecs);
