@@ -61,12 +61,13 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  * curve = 2^shift, 0 = one lane per curve, -1 default = 8 lanes up to 4096 curves, 4 up to 32768), "lsmr_device_vectors"
  * (dsa_lsmr: 0 default = ordered reductions on the host, 1 = all vectors on the device; same results), "field_pool" (field slots of
  * the coarse solve: 0 default = four times the workgroups the GPU holds at once -- a dsa_solve over more units than that recycles the
- * slots, each workgroup resetting its slot, solving, and writing its unit's receiver times before it hands the slot on; -1 = one slot per
+ * slots, each workgroup claiming a free slot (compare-and-swap, no assumption about dispatch order), resetting it, solving, and writing its unit's receiver times before it frees the slot; -1 = one slot per
  * unit; > 0 = that many.  Fields stay readable (dsa_get_field) only when the units of the call fit the slots; rows / exact mode / keep_fields
  * calls never recycle), "bundle" (the units of one source -- its periods -- solved side by side by one workgroup under one shared round
  * schedule: 1 default = automatic -- 16 / 8 / 4 members per bundle, whichever the measured rates promise most for the call's sources and
  * periods, on grids of at least 400 nodes per side when the bundles fill the GPU and their field slots fit the memory, else none; 0 = off; 4 / 8 / 16 = that size whatever the count.  Same travel times as unit by unit -- the fixed point does not
- * depend on the schedule; default mode only, i.e. exact_ties = 0; "bundle_window_cells" = causal window of the bundles, default 0.6; "bundle_threads" = workgroup size of the bundle kernel, 0 default = 256, 512 beyond 1500 nodes per side (64 / 128 for experiments); "bundle_max_rounds" = round limit of the bundles, 0 default = the solver's own (a bundle that hits it sends its chunk to the unit-by-unit solve; used by the tests of that fallback); "bundle_pool" = bundle field slots, 0 default = as many as bundles can be resident at a time and an eighth more (576 / 288), claimed by the bundles as they start), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
+ * depend on the schedule; where a field has exact ties (two self-consistent states) the two can settle differently: measured
+ * identical on the headline and checkerboard media, 4 of 262 144 receiver times apart by up to 4.2e-5 s on unrelated random maps; default mode only, i.e. exact_ties = 0; "bundle_window_cells" = causal window of the bundles, default 0.6; "bundle_threads" = workgroup size of the bundle kernel, 0 default = 256, 512 beyond 1500 nodes per side; "bundle_members_per_lane" = 0 default (bundles of 16 four members per lane, bundles of 8 / 4 two per lane when the launch holds more than 512 of them), 4 or 2; "bundle_max_rounds" = round limit of the bundles, 0 default = the solver's own (a bundle that hits it sends its chunk to the unit-by-unit solve; used by the tests of that fallback); "bundle_pool" = bundle field slots, 0 default = as many as bundles can be resident at a time and an eighth more (864 at three 256-thread workgroups per CU / 288 for 512-thread ones; within the memory budget), claimed by the bundles as they start), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
  * Grid size limit: the coarse solve keeps one bit per 8x8-node tile in LDS (36 KB): up to about 4340 nodes per side (nx <= 545 at dicing 8);
  * dsa_plan returns DSA_ERR_ARGUMENT beyond. */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
@@ -204,9 +205,13 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  * bit-equal times of two neighbouring narrow-band nodes, where the reference's own answer depends on the layout of its binary
  * tree (CalSurfG.f90:417-485, :768-921).  Option "exact_ties": 0 (default) fixed point only; 1 = the solve kernel detects such
  * ties (option "tie_threshold", seconds: the influence on the node's value a tie must have to count; default 2e-5, 0 = any tie) and the
- * units that met one are solved again by the reference's march itself, replayed on the device one wavefront per unit -- their
- * fields are then bit-identical to the reference's; 2 = every unit by the literal march.  Options "exact_lds_slots" (tree slots
- * in LDS per marching unit; default 0 = chosen by the number of units that march: 768 for thousands, up to 16384 for a few hundred) and "exact_pool" (units marching at a time, 0 = by free memory).
+ * units that met one are solved again by the reference's march itself, replayed on the device four units per wavefront -- their
+ * fields are then bit-identical to the reference's; 2 = every unit by the literal march (1 950 solves/s at 1025^2 with 16 000 units in
+ * flight).  Options "exact_lds_slots" (tree slots in LDS per marching unit, the rest of the tree in global memory: 64 ..
+ * 4991, made odd; default 0 = what lets every wavefront of a batch be resident: 148 KB of a CU's LDS divided among them), "exact_pool"
+ * (units marching at a time, 0 = by free memory: 8 bytes per node and unit, at most "exact_pool_max", default 16384).  The march's tree
+ * holds at most 65 534 nodes per unit (16-bit slots): a narrow band longer than that returns DSA_ERR_INTERNAL (grids beyond ~8000
+ * nodes per side; the grid size limit below is lower).
  * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: met a tie, bit 1: solved by the literal march) and the largest
  * tie influence in seconds (either array may be NULL). */
 int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence);
