@@ -84,6 +84,7 @@ struct Engine {
     int bundle_threads_opt = 0;        // option bundle_threads: workgroup size of the bundle kernel (0 = by grid size: 256, 512 beyond 1500 nodes per side)
     int bundle_max_rounds = 0;         // option bundle_max_rounds (tests): > 0 = round limit of the bundles; a bundle that hits it sends its chunk to the unit-by-unit solve
     int bundle_mpl = 0;                // option bundle_members_per_lane: 0 = automatic (bundle_mpl_of), 4, or 2
+    bool bundle_wide = false;          // this call's bundles run 512 threads wide on a small grid (choose_bundle_size: a CU per bundle)
     int bundle_mpl_now = 4, bundle_mpl_b = 2;      // ... what the current launch uses (whole bundles; the halved last ones)
     int bundles_a = 0, bundles_b = 0, bundle_Gb = 0;      // the launch's bundles: whole ones, and (plan_bundles) the last ones cut in halves of bundle_Gb members on a second stream
     hipStream_t stream2 = nullptr;

@@ -467,10 +467,15 @@ int Engine::bundle_mpl_of(int G, long nb) const
     return nb > 512 ? 2 : 4;
 }
 
+// Workgroup size of the bundle kernel: the option; 512 beyond 1500 nodes per side (a 4097^2 front does not fit the ready lists of 256
+// threads); else 256 -- unless choose_bundle_size found the launch so small that every bundle gets a CU to itself (bundle_wide: at most
+// 256 bundles), where eight waves per bundle finish a round sooner than four (round 4: 125 sources x 16 periods as 250 bundles of 8,
+// 102 ms with 512 threads against 131 with 256; profiles/r04_bundle_occupancy.log)
 int Engine::bundle_threads() const
 {
     if (bundle_threads_opt == 256 || bundle_threads_opt == 512) return bundle_threads_opt;
-    return std::max(g.nnx, g.nnz) > 1500 ? 512 : 256;
+    if (std::max(g.nnx, g.nnz) > 1500) return 512;
+    return bundle_wide ? 512 : 256;
 }
 
 BatchPtrs Engine::batch() const
@@ -736,6 +741,7 @@ size_t Engine::bundle_room(size_t free_b) const
 int Engine::choose_bundle_size(int step, long* solo_units)
 {
     if (solo_units) *solo_units = (long)h_src.size();
+    bundle_wide = false;
     if (bundle_opt == 0 || h_src.empty() || (bundles_failed && bundle_opt == 1)) return 0;
     // units per source (same coordinates bit for bit), in planned order
     std::map<std::pair<uint32_t, uint32_t>, int> count;
@@ -778,6 +784,8 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     // ones in halves (1 000 bundles of 16: 383 ms)
     const double t_one[3][3] = { { 189.5, 210.0, 241.0 }, { 130.8, 151.7, 187.2 }, { 104.8, 125.4, 164.3 } };
     const double rate512[3] = { 24.5, 20.4, 15.5 };                             // (512-thread kernel, one workgroup per CU: round 3's table)
+    const double t_wide[3] = { 119.0, 90.0, 78.0 };                             // (512 threads at 1025^2, a CU per bundle: ms of one bundle of 16 / 8 / 4)
+    bool pick_wide = false;
     for (int k = 0; k < 3; ++k) {
         const int G = sizes[k];
         long nb = 0, covered = 0;
@@ -803,8 +811,16 @@ int Engine::choose_bundle_size(int step, long* solo_units)
             const double units_s = n_units * (1.0 - frac);
             est = n_units / (ms * (0.35 + 0.65 * fill) + units_s / std::max(solo_rate, 1e-9));
         }
-        if (est > best) { best = est; pick = G; if (solo_units) *solo_units = (long)h_src.size() - covered; }
+        bool wide = false;
+        if (bundle_threads_opt == 0 && bundle_threads() == 256 && nb <= 256) {
+            // ... or a CU per bundle with 512 threads (one bundle's time at that width, nearly flat in the number of bundles)
+            const double ms_w = t_wide[k] + 12.0 * (double)nb / 256.0;
+            const double est_w = n_units / (ms_w * (0.35 + 0.65 * fill) + n_units * (1.0 - frac) / std::max(solo_rate, 1e-9));
+            if (est_w > est) { est = est_w; wide = true; }
+        }
+        if (est > best) { best = est; pick = G; pick_wide = wide; if (solo_units) *solo_units = (long)h_src.size() - covered; }
     }
+    bundle_wide = pick_wide;
     return pick;
 }
 
@@ -924,6 +940,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     HIP_TRY(this, hipMemcpyAsync(member_flag.p, h_member_flag.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(launch_rank.p, h_launch_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
     stats[DSA_STAT_BUNDLE_SLOTS] = (double)slots_total;
+    stats[DSA_STAT_BUNDLE_THREADS] = (double)bundle_threads();
     return 0;
 }
 

@@ -228,7 +228,7 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_RAYS_CLAMPED, DSA_STAT_MS_RAYS, DSA_STAT_MS_ROWS, DSA_STAT_NAR, DSA_STAT_MS_DISPERSION,
        DSA_STAT_CURVES, DSA_STAT_CHANGES_TOTAL, DSA_STAT_TIE_UNITS, DSA_STAT_EXACT_UNITS, DSA_STAT_EXACT_POPS,
        DSA_STAT_MS_EXACT, DSA_STAT_FIELD_SLOTS, DSA_STAT_FOOTPRINT_MB, DSA_STAT_BUNDLE_SIZE, DSA_STAT_BUNDLES,
-       DSA_STAT_BUNDLED_UNITS, DSA_STAT_BUNDLE_SLOTS, DSA_STAT_COUNT };
+       DSA_STAT_BUNDLED_UNITS, DSA_STAT_BUNDLE_SLOTS, DSA_STAT_BUNDLE_THREADS, DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */

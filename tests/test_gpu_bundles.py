@@ -312,16 +312,22 @@ def test_bundled_receivers_on_tie_prone_media_against_the_oracle(bundles, kind, 
     ref = _oracle_receiver_times(nx, pv, u, nrec, n)
     e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     res = {}
-    for G in (0, 16):
+    for G in (0, 16, 1):
         e.set_option("bundle", G)
         t = e.traveltimes(**u).reshape(n, nrec)
         st = e.stats()
-        assert st["bundles"] == (nsrc if G else 0)
+        if G != 1:
+            assert st["bundles"] == (nsrc if G else 0)
+            if G: assert st["bundle_threads"] == 256
+        else:
+            # automatic: a launch this small gives every bundle a CU to itself and runs them 512 threads wide (Engine::choose_bundle_size)
+            assert st["bundles"] > 0 and st["bundled_units"] == n and st["bundle_threads"] == 512, st
         d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
         res[G] = (float(d.max()), int((d > TOL).sum()), int((bits(t) != bits(ref)).sum()))
     parity_log.add(f"bundles vs oracle N=1025 {kind}: {n} units x {nrec} receivers | bundles of 16: max |dt| {res[16][0]:.3g} s, beyond 1e-4 s {res[16][1]}, not bit-identical {res[16][2]} | "
-                   f"unit by unit: max |dt| {res[0][0]:.3g} s, beyond {res[0][1]}, not bit-identical {res[0][2]}")
-    for G in (0, 16):
+                   f"unit by unit: max |dt| {res[0][0]:.3g} s, beyond {res[0][1]}, not bit-identical {res[0][2]} | automatic (512 threads wide): max |dt| {res[1][0]:.3g} s, beyond {res[1][1]}, not bit-identical {res[1][2]}")
+    e.set_option("bundle", 1)
+    for G in (0, 16, 1):
         assert res[G][1] == 0 and res[G][0] <= worst_allowed, (G, res[G])
 
 
