@@ -807,15 +807,15 @@ int Engine::choose_bundle_size(int step, long* solo_units)
                 ms = t_one[k][2] * (gens + (rem > 0.0 ? 0.45 + 0.55 * rem : 0.0));
                 if (G >= 8 && nb > 768 && nb < 1500) ms *= 0.98;                    // (the halved last bundles)
             }
-            // k solves/s (= units per ms) of the whole launch: the bundles in `ms` (less when they are not full), the rest unit by unit behind them
+            // k solves/s (= units per ms) of the whole launch: the bundles in `ms` (a little less when they are not full: idle member lanes save no trips), the rest unit by unit behind them
             const double units_s = n_units * (1.0 - frac);
-            est = n_units / (ms * (0.35 + 0.65 * fill) + units_s / std::max(solo_rate, 1e-9));
+            est = n_units / (ms * (0.65 + 0.35 * fill) + units_s / std::max(solo_rate, 1e-9));
         }
         bool wide = false;
         if (bundle_threads_opt == 0 && bundle_threads() == 256 && nb <= 256) {
             // ... or a CU per bundle with 512 threads (one bundle's time at that width, nearly flat in the number of bundles)
             const double ms_w = t_wide[k] + 12.0 * (double)nb / 256.0;
-            const double est_w = n_units / (ms_w * (0.35 + 0.65 * fill) + n_units * (1.0 - frac) / std::max(solo_rate, 1e-9));
+            const double est_w = n_units / (ms_w * (0.65 + 0.35 * fill) + n_units * (1.0 - frac) / std::max(solo_rate, 1e-9));
             if (est_w > est) { est = est_w; wide = true; }
         }
         if (est > best) { best = est; pick = G; pick_wide = wide; if (solo_units) *solo_units = (long)h_src.size() - covered; }

@@ -169,6 +169,28 @@ def test_headline_size_bundles_equal_unit_by_unit(bundles):
     parity_log.add(f"bundles at N=1025 (headline medium): {out[0].size} receiver times of {nsrc * nper} units, 16 and 8 members: bit-identical to unit by unit")
 
 
+def test_last_partial_generation_of_bundles_cut_in_halves(bundles):
+    """round 4: a launch of 768 .. 1 500 bundles keeps the first 768 (three workgroups per CU) whole and runs the rest as bundles of half
+    the size on a second stream beside them (Engine::plan_bundles).  800 sources x 16 periods on a 401^2 grid in automatic mode: 768
+    bundles of 16 + 64 halves of 8 -- every receiver time the unit-by-unit solve's, bit for bit"""
+    e = bundles
+    nx, nsrc, nper, nrec = 53, 800, 16, 4
+    pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 41)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("bundle", 0)
+    ref = e.traveltimes(**u)
+    e.set_option("bundle", 1)
+    t = e.traveltimes(**u)
+    st = e.stats()
+    assert st["bundle_size"] == 16 and st["bundled_units"] == nsrc * nper, st
+    assert st["bundles"] == 768 + 2 * (nsrc - 768), st                  # the 32 bundles beyond the first generation: two halves each
+    nbad = int((bits(t) != bits(ref)).sum())
+    parity_log.add(f"bundles at N={e.nnx}, {nsrc} sources x {nper} periods, automatic: {int(st['bundles'])} bundles (768 of 16 + {2 * (nsrc - 768)} halves of 8 on the second stream): "
+                   f"{nbad} of {t.size} receiver times differ from unit by unit")
+    assert nbad == 0
+
+
 @pytest.mark.parametrize("nx,nsrc,nper,G", [(257, 3, 8, 8), (513, 2, 4, 4)])
 def test_big_grids_use_the_512_thread_bundle_kernel(bundles, nx, nsrc, nper, G):
     """beyond 1500 nodes per side the bundle kernel runs 512 threads wide (2 x 2048 ready nodes per round): 2033^2 and 4081^2 against unit by unit"""
