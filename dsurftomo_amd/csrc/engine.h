@@ -79,7 +79,8 @@ struct Engine {
     // round schedule.  Option `bundle`: 0 = off, 1 = automatic (default: 16, 8 or 4 members by the sources' unit counts and the memory),
     // 4 / 8 / 16 = that many members per bundle.  Default mode only (the tie detector and the literal march work per unit).
     int bundle_opt = 1;
-    float bundle_window_cells = 0.6f;  // causal window of the bundles: a round's fixed costs are shared by the members, so fewer evaluations per round pay
+    float bundle_window_opt = 0.0f;    // option bundle_window_cells: causal window of the bundles, 0 = automatic (bundle_window(): 0.6 cells -- a round's fixed costs are shared by the members, so fewer evaluations per round pay; 1.25 for small wide launches)
+    int bundle_G_now = 0;              // members per bundle of the current solve
                                        // (measured at 1025^2, 16 members: 0.4 / 0.5 / 0.6 / 0.8 / 1.25 cells -> 24.4 / 24.6 / 24.4 / 23.9 / 22.7 k solves/s)
     int bundle_threads_opt = 0;        // option bundle_threads: workgroup size of the bundle kernel (0 = by grid size: 256, 512 beyond 1500 nodes per side)
     int bundle_max_rounds = 0;         // option bundle_max_rounds (tests): > 0 = round limit of the bundles; a bundle that hits it sends its chunk to the unit-by-unit solve
@@ -103,6 +104,7 @@ struct Engine {
     size_t bundle_room(size_t free_b) const;
     bool grow_unit_pool();
     int bundle_threads() const;
+    float bundle_window() const;
     size_t bundles_resident(int G, int mpl) const;
     int bundle_mpl_of(int G, long nb) const;
     int choose_bundle_size(int step, long* solo_units = nullptr);

@@ -467,6 +467,15 @@ int Engine::bundle_mpl_of(int G, long nb) const
     return nb > 512 ? 2 : 4;
 }
 
+// Causal window of the bundles in cells: the option (default 0.6: at full occupancy the evaluations are what costs); a small launch of
+// small bundles, 512 threads wide with a CU per bundle, is bound by the length of its rounds' chain instead: 1.25 cells there (24 % fewer
+// rounds, 15 % more evaluations: 250 bundles of 8 at 1025^2 102.2 -> 96.8 ms; bundles of 16 show no difference; profiles/r04_bundle_occupancy.log)
+float Engine::bundle_window() const
+{
+    if (bundle_window_opt > 0.0f) return bundle_window_opt;
+    return (bundle_wide && bundle_G_now > 0 && bundle_G_now < 16) ? 1.25f : 0.6f;
+}
+
 // Workgroup size of the bundle kernel: the option; 512 beyond 1500 nodes per side (a 4097^2 front does not fit the ready lists of 256
 // threads); else 256 -- unless choose_bundle_size found the launch so small that every bundle gets a CU to itself (bundle_wide: at most
 // 256 bundles), where eight waves per bundle finish a round sooner than four (round 4: 125 sources x 16 periods as 250 bundles of 8,
@@ -538,6 +547,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     HIP_TRY(this, hipMemsetAsync(err.p, 0, 4 * sizeof(int32_t), stream));
     const int bundle_G = exact_ties == 0 ? choose_bundle_size(step) : 0;
     stats[DSA_STAT_BUNDLE_SIZE] = bundle_G;
+    bundle_G_now = bundle_G;
     if (bundle_G == 0 && !grow_unit_pool()) return status;      // (plan() shrank the unit pool for bundles this call will not use)
     HIP_TRY(this, hipEventRecord(events[0], stream));
     std::vector<int32_t> h_info, h_flags;
@@ -575,7 +585,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         }
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
                              detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p,
-                             nbundles ? member_flag.p : nullptr, bundle_window_cells * cell_c, bundle_max_rounds, stream);
+                             nbundles ? member_flag.p : nullptr, bundle_window() * cell_c, bundle_max_rounds, stream);
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         FimLaunch sr = shape_r, sc = shape_c;
         sr.tie = sc.tie = detect ? 1 : 0;
@@ -784,7 +794,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     // ones in halves (1 000 bundles of 16: 383 ms)
     const double t_one[3][3] = { { 189.5, 210.0, 241.0 }, { 130.8, 151.7, 187.2 }, { 104.8, 125.4, 164.3 } };
     const double rate512[3] = { 24.5, 20.4, 15.5 };                             // (512-thread kernel, one workgroup per CU: round 3's table)
-    const double t_wide[3] = { 119.0, 90.0, 78.0 };                             // (512 threads at 1025^2, a CU per bundle: ms of one bundle of 16 / 8 / 4)
+    const double t_wide[3] = { 119.0, 85.0, 74.0 };                             // (512 threads at 1025^2, a CU per bundle: ms of one bundle of 16 / 8 / 4)
     bool pick_wide = false;
     for (int k = 0; k < 3; ++k) {
         const int G = sizes[k];
@@ -1266,7 +1276,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
-    if (n == "bundle_window_cells" && value > 0) { en->bundle_window_cells = (float)value; return 0; }
+    if (n == "bundle_window_cells" && value >= 0) { en->bundle_window_opt = (float)value; return 0; }
     if (n == "bundle_threads" && (value == 0 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
