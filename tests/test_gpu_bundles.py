@@ -191,6 +191,31 @@ def test_last_partial_generation_of_bundles_cut_in_halves(bundles):
     assert nbad == 0
 
 
+def test_small_launch_on_a_rectangular_grid_runs_wide_and_equals_unit_by_unit(bundles):
+    """round 4: the member bodies evaluate regular neighbourhoods with solve_regular (different steps in x and z here: 401 x 537 nodes,
+    dvz = 1.3 dvx), and a launch of at most 256 bundles runs them 512 threads wide.  40 sources x 8 periods, smooth maps: automatic
+    (wide) and forced bundles of 8 (256 threads) both give the unit-by-unit receiver times bit for bit"""
+    e = bundles
+    nx, ny, nsrc, nper, nrec = 53, 70, 40, 8, 6
+    i = np.arange(nx, dtype=np.float64)[None, :]; j = np.arange(ny, dtype=np.float64)[:, None]
+    pv = np.stack([np.ascontiguousarray(((2.8 + 0.05 * p) * (1.0 + 0.10 * np.sin(4 * np.pi * i / nx) * np.cos(3 * np.pi * j / ny))).reshape(-1)) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 51)          # (sources and receivers inside the 401-node square: inside the rectangle too)
+    e.set_maps(nx, ny, synth.GOXD, synth.GOZD, synth.DVD, np.float32(1.3) * np.float32(synth.DVD), pv)
+    assert (e.nnx, e.nnz) == (401, 537)
+    out = {}
+    for G in (0, 1, 8):
+        e.set_option("bundle", G)
+        out[G] = e.traveltimes(**u)
+        st = e.stats()
+        if G == 1: assert st["bundles"] > 0 and st["bundled_units"] == nsrc * nper and st["bundle_threads"] == 512, st
+        if G == 8: assert st["bundles"] == nsrc and st["bundle_threads"] == 256, st
+    e.set_option("bundle", 1)
+    for G in (1, 8):
+        nbad = int((bits(out[G]) != bits(out[0])).sum())
+        parity_log.add(f"bundles on a 401 x 537 grid ({'automatic, 512 threads wide' if G == 1 else 'bundles of 8, 256 threads'}): {nbad} of {out[G].size} receiver times differ from unit by unit")
+        assert np.isfinite(out[G]).all() and nbad == 0, G
+
+
 @pytest.mark.parametrize("nx,nsrc,nper,G", [(257, 3, 8, 8), (513, 2, 4, 4)])
 def test_big_grids_use_the_512_thread_bundle_kernel(bundles, nx, nsrc, nper, G):
     """beyond 1500 nodes per side the bundle kernel runs 512 threads wide (2 x 2048 ready nodes per round): 2033^2 and 4081^2 against unit by unit"""
