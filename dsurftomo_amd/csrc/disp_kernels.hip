@@ -26,7 +26,7 @@ template <int IFUNC>
 __global__ __launch_bounds__(64) DSA_DISP_OCC void k_dispersion(const LayerGeom* __restrict__ G, const float* __restrict__ vels, int ncol,
                                                    int npert, int igr, int kmax, const double* __restrict__ t,
                                                    float* __restrict__ ws, size_t nlanes, double* __restrict__ curves, int layers_in_lds,
-                                                   int gshift, unsigned long long* __restrict__ diag)
+                                                   int gshift, unsigned long long* __restrict__ diag, unsigned long long* __restrict__ fail_list, int fail_cap)
 {
     // gshift > 0 (few curves): 2^gshift neighbouring lanes share one curve -- see Layers::gsize.  A curve is one
     // dependent chain of ~20 000 layer matrices; with one lane per curve a call with 324 columns keeps a quarter of the
@@ -71,14 +71,15 @@ __global__ __launch_bounds__(64) DSA_DISP_OCC void k_dispersion(const LayerGeom*
     const int kfail = dispersion_curve<IFUNC>(m, igr, kmax, t, curves + (size_t)p * kmax * ncol + c, (size_t)ncol);
     // diagnostics of the boundary (surfdisp96.f:308-339): how many curves ended without a root, and the first of them (by curve number)
     if (kfail && diag && (gshift == 0 || (threadIdx.x & ((1u << gshift) - 1u)) == 0u)) {
-        atomicAdd(diag, 1ull);
+        const unsigned long long slot = atomicAdd(diag, 1ull);
         atomicMin(diag + 1, ((unsigned long long)tid << 16) | (unsigned long long)kfail);
+        if (fail_list && slot < (unsigned long long)fail_cap) fail_list[slot] = ((unsigned long long)tid << 8) | (unsigned long long)kfail;
     }
 }
 
 void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
                        const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, int gshift,
-                       unsigned long long* d_diag, hipStream_t stream)
+                       unsigned long long* d_diag, unsigned long long* d_fail_list, int fail_cap, hipStream_t stream)
 {
     const size_t n = ((size_t)ncol * npert) << gshift;
     if (n == 0) return;
@@ -86,8 +87,36 @@ void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, 
     const int per = 64 >> gshift;
     size_t lds = layers_in_lds ? (size_t)4 * rmax * per * sizeof(float) : 0;
     if (gshift > 0) lds += 8 + (size_t)64 * 15 * sizeof(double);
-    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift, d_diag);
-    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift, d_diag);
+    if (iwave == 1) hipLaunchKernelGGL(k_dispersion<1>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift, d_diag, d_fail_list, fail_cap);
+    else hipLaunchKernelGGL(k_dispersion<2>, grid, block, lds, stream, d_geom, d_vels, ncol, npert, igr, kmax, d_t, d_ws, nlanes, d_curves, layers_in_lds, gshift, d_diag, d_fail_list, fail_cap);
+}
+
+// Host replay of one curve (kernels.h): the kernel's set-up of the column and its perturbation, the same layer table, the loop-nest form of the
+// curve (the state machine of the Rayleigh kernel gives the same bits, dispersion_core.h) with the trace the reference's unit-66 block prints.
+int disp_replay_failure(const LayerGeom& G, const float* vs_in, int pert, int iwave, int igr, int kmax, const double* t,
+                        int* mmax, float* table, double* cc_cm_c1, double* c)
+{
+    float vs[kMaxDepths], vp[kMaxDepths], rho[kMaxDepths];
+    for (int k = 0; k < G.nz; ++k) { vs[k] = vs_in[k]; brocher_vp_rho(vs[k], &vp[k], &rho[k]); }
+    if (pert > 0) {
+        const int idx = pert - 1, i = idx / 6, q = (idx % 6) >> 1, sgn = idx & 1;
+        float* arr = q == 0 ? vs : (q == 1 ? vp : rho);
+        const float base = arr[i];
+        const float dln = 0.01f;
+        arr[i] = sgn ? base + 0.5f * dln * base : base - 0.5f * dln * base;
+    }
+    Layers m;
+    m.d = table; m.a = table + kMaxLayers; m.b = table + 2 * kMaxLayers; m.rho = table + 3 * kMaxLayers;
+    m.stride = 1;
+    double cg[kMaxPeriods];
+    DispTrace tr{};
+    int kfail;
+    if (iwave == 1) { build_layers<1>(G, vs, vp, rho, m); kfail = dispersion_curve_nested<1>(m, igr, kmax, t, cg, 1, &tr); }
+    else { build_layers<2>(G, vs, vp, rho, m); kfail = dispersion_curve_nested<2>(m, igr, kmax, t, cg, 1, &tr); }
+    *mmax = m.mmax;
+    cc_cm_c1[0] = tr.cc; cc_cm_c1[1] = tr.cm; cc_cm_c1[2] = tr.c1;
+    for (int k = 0; k < kMaxPeriods; ++k) c[k] = k < kfail - 1 ? tr.c[k] : 0.0;
+    return kfail;
 }
 
 // pv(c, k) = curve 0; sen_q(c, slot0 + k, i) = (cg(+) - cg(-)) / dble(dln * base_q(i)), CalSurfG.f90:76-150

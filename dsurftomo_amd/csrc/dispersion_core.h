@@ -750,8 +750,13 @@ DSA_HD int dispersion_curve_states(const Layers& m, int igr, int kmax, const dou
 // The reference's own loop nest (kept for Love waves, see dispersion_curve).  Returns 0, or -- when no zero of the secular function was found for a period (the reference's "improper initial value in disper -
 // no zero found" block on unit 66, surfdisp96.f:308-339, after which it zero-fills the rest of the curve, :342-348) -- the 1-based
 // index k of that period.
+// What the reference's unit-66 block prints about a curve that ended without a root (surfdisp96.f:327-337): the starting phase velocity
+// and floor (cc, cm), the phase velocity the failed search stopped at (c1), and the roots of the periods before (c(1..k-1)).  Filled by
+// the loop nest below when asked (the host's replay of a failing curve, Engine::dispersion_failure); the device passes none.
+struct DispTrace { double cc, cm, c1; double c[kMaxPeriods]; };
+
 template <int IFUNC>
-DSA_HD int dispersion_curve_nested(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride)
+DSA_HD int dispersion_curve_nested(const Layers& m, int igr, int kmax, const double* t, double* cg, size_t cstride, DispTrace* tr = nullptr)
 {
     const int mmax = m.mmax;
     const float ddc = 0.005f, h = 0.005f;
@@ -792,9 +797,10 @@ DSA_HD int dispersion_curve_nested(const Layers& m, int igr, int kmax, const dou
         if (k == 1) { c1 = cc; clow = cc; ifirst = 1; }
         else { ifirst = 0; c1 = cprev - onea * dc; clow = cm; }
         int iret = getsol<IFUNC>(m, t1, &c1, clow, dc, cm, betmx, ifirst, &del1st);
-        if (iret == -1) { failed = true; break; }
+        if (iret == -1) { failed = true; if (tr) { tr->cc = cc; tr->cm = cm; tr->c1 = c1; } break; }
         const double ck = c1;
         cprev = ck;
+        if (tr) tr->c[k - 1] = ck;
         if (igr > 0) {
             t1 = (double)t1b;
             clow = 0.0 + one * dc;               // cb(k) is still zero here

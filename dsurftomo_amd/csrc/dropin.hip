@@ -51,6 +51,7 @@ int engine()
         if (const char* s = getenv("DSA_WINDOW_CELLS")) dsa_set_option(e, "window_cells", atof(s));
         if (const char* s = getenv("DSA_EXACT_TIES")) dsa_set_option(e, "exact_ties", atof(s));       // exact mode for an unchanged Fortran host
         if (const char* s = getenv("DSA_TIE_THRESHOLD")) dsa_set_option(e, "tie_threshold", atof(s));
+        if (const char* s = getenv("DSA_DISP_FAILURE_LOG")) dsa_set_option(e, "disp_failure_log", atof(s));   // per-call unit-66 blocks (dsa_dropin_dispersion_failure)
         if (const char* s = getenv("DSA_BUNDLE")) dsa_set_option(e, "bundle", atof(s));               // 0 off, 1 automatic (default), 4 / 8 / 16 members
         g_pool.push_back(e);
     }
@@ -318,6 +319,13 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     *nar = (int)n;
     remember(L, *nx * *ny, true);
     return 0;
+}
+
+int dsa_dropin_dispersion_failure(int index, int* info, double* vals, float* table, double* c)
+{
+    dsa_engine* e = dsa_dropin_engine();          // (every engine of a multi-device call runs the whole dispersion stage: the first one's log)
+    if (!e) return DSA_ERR_STATE;
+    return dsa_dispersion_failure(e, index, info, vals, table, c);
 }
 
 int dsa_dropin_diagnostics(int* rbint_notes, long long* disp_count, int* disp_first, double* disp_period)

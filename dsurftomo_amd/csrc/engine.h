@@ -164,6 +164,15 @@ struct Engine {
     long long disp_fail_count = 0;     // dispersion curves that ended with "no zero found" (surfdisp96.f:308-339)
     int disp_fail_first[5] = {};       // first of them in call order: iwave, igr, column (1-based), perturbation (0 = the model itself), period index k
     double disp_fail_period = 0.0;
+    // option disp_failure_log: keep up to that many of the curves without a root, in the reference's call order (column, then
+    // perturbation, wave type by wave type), so that a host can print the reference's unit-66 block per failing surfdisp96 call
+    // (dsa_dispersion_failure replays the curve on the host for the numbers and the layer table)
+    int disp_failure_log = 0;
+    struct DispFailRec { int iwave, igr, nper, column, pert, k; double t[60]; };
+    std::vector<DispFailRec> disp_failures;
+    std::vector<float> h_vels;         // the model of dsa_dispersion_begin (ncol * nz): the replay's input
+    DevBuf<unsigned long long> disp_fail_list;
+    int dispersion_failure(int index, int* info, double* vals, float* table, double* c) const;
     long long rays_clamped = 0;        // traced rays that were clamped at the model boundary (reference rbint, CalSurfG.f90:2082-2101)
     int first_clamped_unit = -1;       // planned unit of the first of them
     int disp_group_shift = -1;         // lanes per Rayleigh curve = 2^shift; -1 = by the number of curves, 0 = one lane per curve

@@ -181,6 +181,8 @@ int Engine::dispersion_begin(int nx, int ny, int nz, const float* vels, const fl
     HIP_TRY(this, hipStreamSynchronize(stream));
     disp_ready = true;
     disp_fail_count = 0;
+    disp_failures.clear();
+    h_vels.assign(vels, vels + ncol * nz);
     have_sens = false;
     stats[DSA_STAT_MS_DISPERSION] = 0.0;
     stats[DSA_STAT_CURVES] = 0.0;
@@ -213,7 +215,9 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
         if (disp_group_shift > 0) gshift = disp_group_shift;
         else gshift = nlanes <= 4096 ? 3 : nlanes <= 32768 ? 2 : 0;      // measured: 324 curves 21.6 -> 7.8 ms, 17 820 curves 22.7 -> 16.9 ms, 944 k curves 166 -> 285 ms
     }
-    launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, h_geom.rmax, in_lds, gshift, disp_diag.p, stream);
+    if (disp_failure_log > 0 && ensure(disp_fail_list, (size_t)disp_failure_log)) return status;
+    launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, h_geom.rmax, in_lds, gshift, disp_diag.p,
+                      disp_failure_log > 0 ? disp_fail_list.p : nullptr, disp_failure_log, stream);
     launch_depth_kernels(vels_d.p, ncol, disp_nz, nper, curves.p, with_kernels, pvstore.p + (size_t)map_first * ncol, sen_vs.p, sen_vp.p, sen_rho.p,
                          disp_kmax_total, sen_slot, stream);
     HIP_TRY(this, hipEventRecord(events[2], stream));
@@ -234,8 +238,44 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
             disp_fail_period = k >= 1 && k <= nper ? t[k - 1] : 0.0;
         }
         disp_fail_count += (long long)diag[0];
+        if (disp_failure_log > 0) {
+            // the failing curves of this run in the reference's call order: column by column, the model itself, then its perturbations
+            // (CalSurfG.f90:44-150 on one thread; the device reports them in any order)
+            const size_t nl = (size_t)std::min<unsigned long long>(diag[0], (unsigned long long)disp_failure_log);
+            std::vector<unsigned long long> list(nl);
+            HIP_TRY(this, hipMemcpy(list.data(), disp_fail_list.p, nl * 8, hipMemcpyDeviceToHost));
+            std::vector<DispFailRec> recs;
+            for (unsigned long long v : list) {
+                const unsigned long long curve = v >> 8;
+                DispFailRec r{};
+                r.iwave = iwave; r.igr = igr; r.nper = nper; r.k = (int)(v & 0xffull);
+                r.column = (int)(curve % (unsigned long long)ncol) + 1; r.pert = (int)(curve / (unsigned long long)ncol);
+                for (int q = 0; q < nper && q < 60; ++q) r.t[q] = t[q];
+                recs.push_back(r);
+            }
+            std::sort(recs.begin(), recs.end(), [](const DispFailRec& a, const DispFailRec& b) { return a.column != b.column ? a.column < b.column : a.pert < b.pert; });
+            for (const DispFailRec& r : recs) if ((int)disp_failures.size() < disp_failure_log) disp_failures.push_back(r);
+        }
     }
     return 0;
+}
+
+// One logged failure (option disp_failure_log), replayed on the host: info = { iwave, igr, column, perturbation, k, periods of the call,
+// layers, failures logged }, vals = { t(k), cc, cm, c1 }, table = d, a, b, rho of the flattened layers (4 x 200 floats), c = the roots of
+// the periods before k (60 doubles; c[k-1] on: 0 -- the reference prints an element of its array it never assigned there)
+int Engine::dispersion_failure(int index, int* info, double* vals, float* table, double* c) const
+{
+    if (index < 0 || index >= (int)disp_failures.size() || !info || !vals || !table || !c) return DSA_ERR_ARGUMENT;
+    const DispFailRec& r = disp_failures[(size_t)index];
+    const size_t ncol = (size_t)disp_nx * disp_ny;
+    float vs[64];
+    for (int k = 0; k < disp_nz; ++k) vs[k] = h_vels[(size_t)k * ncol + (size_t)(r.column - 1)];
+    int mmax = 0;
+    double ccc[3] = { 0.0, 0.0, 0.0 };
+    const int k = disp_replay_failure(h_geom, vs, r.pert, r.iwave, r.igr, r.nper, r.t, &mmax, table, ccc, c);
+    info[0] = r.iwave; info[1] = r.igr; info[2] = r.column; info[3] = r.pert; info[4] = r.k; info[5] = r.nper; info[6] = mmax; info[7] = (int)disp_failures.size();
+    vals[0] = r.k >= 1 && r.k <= r.nper ? r.t[r.k - 1] : 0.0; vals[1] = ccc[0]; vals[2] = ccc[1]; vals[3] = ccc[2];
+    return k == r.k ? 0 : DSA_ERR_INTERNAL;          // (the replay must fail where the device did)
 }
 
 int Engine::dispersion_copy_map(int from, int to, int n)
@@ -1284,6 +1324,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
+    if (n == "disp_failure_log" && value >= 0 && value <= 65536) { en->disp_failure_log = (int)value; return 0; }
     if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4991))) { en->exact_lds_slots = (int)value; return 0; }
     if (n == "exact_pool" && value >= 0) { en->exact_pool = (int)value; return 0; }
     if (n == "exact_pool_max" && value >= 4 && value <= 32768) { en->exact_pool_max = (size_t)value; return 0; }
@@ -1463,6 +1504,12 @@ int dsa_debug_counters(const dsa_engine* e, double* out24)
     if (!e || !out24) return DSA_ERR_ARGUMENT;
     for (int q = 0; q < 24; ++q) out24[q] = reinterpret_cast<const Engine*>(e)->phase_ticks[8 + q];
     return 0;
+}
+
+int dsa_dispersion_failure(const dsa_engine* e, int index, int* info, double* vals, float* table, double* c)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    return reinterpret_cast<const Engine*>(e)->dispersion_failure(index, info, vals, table, c);
 }
 
 int dsa_dispersion_diagnostics(const dsa_engine* e, long long* count, int* first, double* period)

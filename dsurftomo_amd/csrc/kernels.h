@@ -227,9 +227,17 @@ void launch_scan(const int* d_counts, int n, long long* d_offsets, hipStream_t s
 // dispersion (disp_kernels.hip) ---------------------------------------------------------------------
 struct LayerGeom;
 // curves: (npert, kmax, ncol) fp64; ws: 4 * rmax * nlanes floats of layer workspace; iwave 1 Love, 2 Rayleigh
+// d_fail_list (or null): the curves without a root, slot by slot as they report (curve << 8 | period index, up to fail_cap of them)
 void launch_dispersion(int iwave, const LayerGeom* d_geom, const float* d_vels, int ncol, int npert, int igr, int kmax,
                        const double* d_t, float* d_ws, size_t nlanes, double* d_curves, int rmax, int layers_in_lds, int gshift,
-                       unsigned long long* d_diag /* [0] curves without a root, [1] min of (curve << 16 | period index) */, hipStream_t stream);
+                       unsigned long long* d_diag /* [0] curves without a root, [1] min of (curve << 16 | period index) */,
+                       unsigned long long* d_fail_list, int fail_cap, hipStream_t stream);
+// One curve once more on the host, with what the reference's unit-66 block prints about a curve that ended without a root
+// (surfdisp96.f:327-337): vs = the column's nz grid values, pert = the perturbation index of k_dispersion (0 = the model itself).
+// table: 4 x 200 floats (d, a, b, rho of the flattened layers), c: 60 doubles (roots of the periods before k).  Returns the period index
+// k the curve failed at (0: it did not fail).
+int disp_replay_failure(const LayerGeom& G, const float* vs, int pert, int iwave, int igr, int kmax, const double* t,
+                        int* mmax, float* table, double* cc_cm_c1, double* c);
 void launch_depth_kernels(const float* d_vels, int ncol, int nz, int kmax, const double* d_curves, int with_kernels, double* d_pv,
                           double* d_sen_vs, double* d_sen_vp, double* d_sen_rho, int kmax_total, int slot0, hipStream_t stream);
 void launch_to_float(const double* d_in, float* d_out, size_t n, hipStream_t stream);

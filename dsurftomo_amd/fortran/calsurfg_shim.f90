@@ -45,6 +45,13 @@ module dsa_bindings
       integer(c_long_long) :: disp_count
       real(c_double) :: disp_period
     end function
+    integer(c_int) function dsa_dropin_dispersion_failure(index, info, vals, table, c) bind(C, name='dsa_dropin_dispersion_failure')
+      import :: c_int, c_double, c_float
+      integer(c_int), value :: index
+      integer(c_int) :: info(8)
+      real(c_double) :: vals(4), c(60)
+      real(c_float) :: table(200,4)
+    end function
     function dsa_dropin_error() bind(C, name='dsa_dropin_error') result(p)
       import :: c_ptr
       type(c_ptr) :: p
@@ -93,15 +100,19 @@ end subroutine
 !  * unit 6, CalSurfG.f90:1447-1454: the six-line note about a ray tracked along the model boundary, once after every (period,
 !    source) iteration from the first such ray on -- the count comes from the engine.
 !  * unit 66 (the host program's log file, main.f90:156), surfdisp96.f:308-339: "improper initial value in disper - no zero found".
-!    The reference writes the block once per failing surfdisp96 call together with that call's layer table; here it is written once
-!    per CalSurfG call for the first failing curve, followed by the number of curves that ended this way (the layer tables stay on
-!    the device).
+!    The reference writes the block once per failing surfdisp96 call together with that call's layer table.  With DSA_DISP_FAILURE_LOG=N
+!    in the environment the engine keeps the first N failing calls in the reference's single-thread call order and this routine writes
+!    the reference's block for each of them, line by line, layer table included (dsa_dropin_dispersion_failure replays the curve on
+!    the host for the numbers); the last list holds c(1..k-1) and 0 for c(k), an element the reference prints without ever having
+!    assigned it.  Without the variable (default): the text once per CalSurfG call for the first failing curve, followed by the number
+!    of curves that ended this way.
 subroutine dsa_report()
   use dsa_bindings
   implicit none
-  integer :: notes, first(5), rc, i
+  integer :: notes, first(5), rc, i, j, nlog, info(8), ifunc, k, is, ie, mmax
   integer(c_long_long) :: ndisp
-  real*8 :: period
+  real*8 :: period, vals(4), c(60), cc, cm, c1
+  real*4 :: table(200,4)
   rc = dsa_dropin_diagnostics(notes, ndisp, first, period)
   if (rc /= 0) return
   do i = 1, notes
@@ -112,7 +123,40 @@ subroutine dsa_report()
     WRITE(6,*)'that you adjust the dimensions of your grid'
     WRITE(6,*)'to prevent this from occurring.'
   enddo
+  ! the failing calls one by one, as the reference writes them (surfdisp96.f:308-339), when the engine kept a log
+  nlog = 0
   if (ndisp > 0) then
+    rc = dsa_dropin_dispersion_failure(0, info, vals, table, c)
+    if (rc == 0) nlog = info(8)
+  endif
+  do j = 1, nlog
+    rc = dsa_dropin_dispersion_failure(j - 1, info, vals, table, c)
+    if (rc /= 0) exit
+    ifunc = info(1); k = info(5); is = 1; ie = info(6); mmax = info(7)
+    cc = vals(2); cm = vals(3); c1 = vals(4)
+    write(66,*)'improper initial value in disper - no zero found'
+    write(66,*)'in fundamental mode '
+    write(66,*)'This may be due to low velocity zone '
+    write(66,*)'causing reverse phase velocity dispersion, '
+    write(66,*)'and mode jumping.'
+    write(66,*)'due to looking for Love waves in a halfspace'
+    write(66,*)'which is OK if there are Rayleigh data.'
+    write(66,*)'If reverse dispersion is the problem,'
+    write(66,*)'Get present model using OPTION 28, edit sobs.d,'
+    write(66,*)'Rerun with onel large than 2'
+    write(66,*)'which is the default '
+    write(66,*)'ifunc = ',ifunc ,' (1=L, 2=R)'
+    write(66,*)'mode  = ',0
+    write(66,*)'period= ',vals(1), ' for k,is,ie=',k,is,ie
+    write(66,*)'cc,cm = ',cc,cm
+    write(66,*)'c1    = ',c1
+    write(66,*)'d,a,b,rho (d(mmax)=control ignore)'
+    write(66,'(4f15.5)')(table(i,1),table(i,2),table(i,3),table(i,4),i=1,mmax)
+    write(66,*)' c(i),i=1,k (NOTE may be part)'
+    write(66,*)(c(i),i=1,k)
+  enddo
+  if (nlog > 0 .and. ndisp > nlog) write(66,*)'curves of this call that ended this way: ',ndisp,' (the first ',nlog,' written above)'
+  if (ndisp > 0 .and. nlog == 0) then
     write(66,*)'improper initial value in disper - no zero found'
     write(66,*)'in fundamental mode '
     write(66,*)'This may be due to low velocity zone '

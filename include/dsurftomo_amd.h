@@ -199,6 +199,14 @@ int dsa_debug_field(dsa_engine* e, int unit, int which, float* out);
  * rays: traced rays of the last dsa_solve_rows that were clamped at the model boundary (reference rbint, CalSurfG.f90:2082-2101,
  *   reported by the note of :1447-1454), and the planned unit of the first of them (-1: none). */
 int dsa_dispersion_diagnostics(const dsa_engine* e, long long* count, int* first, double* period);
+/* The failing curves one by one (reference surfdisp96.f:308-339 writes its block, with the call's layer table, once per failing
+ * surfdisp96 call).  Option "disp_failure_log" = N > 0 keeps the first N of them in the reference's single-thread call order (wave type
+ * by wave type; column by column, the model itself, then its depth-kernel perturbations: CalSurfG.f90:44-150); dsa_dispersion_failure
+ * replays curve `index` (0-based) on the host and returns what the block prints: info[8] = { ifunc (1 L, 2 R), igr, column
+ * (jj-1)*nx+ii, perturbation, k, ie (periods of the call; is = 1), mmax, failures logged }, vals[4] = { t(k), cc, cm, c1 },
+ * table[800] = d, a, b, rho of the flattened layers (200 each, mmax used), c[60] = the roots of the periods before k (the reference
+ * also prints c(k), an element it never assigned: 0 here).  DSA_ERR_ARGUMENT beyond the logged ones. */
+int dsa_dispersion_failure(const dsa_engine* e, int index, int* info, double* vals, float* table, double* c);
 int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit);
 
 /* Exact time ties: the fixed-point solve lands on the reference's Fast-Marching travel times except downstream of
@@ -286,6 +294,9 @@ int dsa_dropin_velocity_maps(const int* which, double* pv);
  *   disp_count / disp_first[5] / disp_period: see dsa_dispersion_diagnostics (the reference writes its block to unit 66).
  * The C level prints nothing itself; dsurftomo_amd/fortran/calsurfg_shim.f90 writes the reference's texts. */
 int dsa_dropin_diagnostics(int* rbint_notes, long long* disp_count, int* disp_first, double* disp_period);
+/* dsa_dispersion_failure of the last dsa_calsurfg call (environment DSA_DISP_FAILURE_LOG = N switches the log on): the shim then writes
+ * the reference's unit-66 block once per failing surfdisp96 call, layer table included */
+int dsa_dropin_dispersion_failure(int index, int* info, double* vals, float* table, double* c);
 
 /* text of the last error of the process-wide engine used by the drop-in level */
 const char* dsa_dropin_error(void);

@@ -255,6 +255,20 @@ def test_fortran_shim_prints_the_reference_diagnostics(tmp_path):
         assert rr.returncode == 0, rr.stderr[-800:]
         assert rr.stdout.count("Note that at least one two-point ray path") == notes
         assert (refdir / "fort.66").read_text().count("improper initial value in disper - no zero found") == ncurves[0]
+        # round 4 (missing 5): with DSA_DISP_FAILURE_LOG the shim writes the reference's block once per failing surfdisp96
+        # call, layer table and all -- the reference's unit-66 file of the same call on one thread, character for character
+        ref1 = tmp_path / "ref1"
+        ref1.mkdir()
+        rr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(ref1), env=dict(os.environ, OMP_NUM_THREADS="1"))
+        assert rr.returncode == 0, rr.stderr[-800:]
+        logdir = tmp_path / "log"
+        logdir.mkdir()
+        r2 = subprocess.run([exe, fin, str(logdir / "out.bin")], capture_output=True, text=True, timeout=300, cwd=str(logdir), env=dict(os.environ, DSA_DISP_FAILURE_LOG="16"))
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+        ours, theirs = (logdir / "fort.66").read_text(), (ref1 / "fort.66").read_text()
+        assert "d,a,b,rho (d(mmax)=control ignore)" in ours and ours.count("improper initial value") == REF_BLOCKS
+        assert ours == theirs, "unit 66 differs from the reference's:\n" + "\n".join(a + "   |   " + b for a, b in zip(ours.splitlines(), theirs.splitlines()) if a != b)[:2000]
+        parity_log.add(f"unit 66 with DSA_DISP_FAILURE_LOG: {ours.count('improper initial value')} blocks of {len(ours.splitlines()) // max(ours.count('improper initial value'), 1)} lines (layer tables included), identical to the reference's file of the same call: {ours == theirs}")
 
 
 def test_fortran_shim(tmp_path):
