@@ -113,14 +113,16 @@ def cpu_baseline(budget_units=96):
 
 
 def exact_secondary(eng, with_reference=True):
-    """The in-tolerance mode on the tie-prone medium: configs[2]'s grid with configs[4]'s checkerboard, 512 sources x 16
-    periods = 8192 units x 32 receivers (the march fills the chip from ~8000 units on: 4096 units run at ~880, 16 000 at ~1740 solves/s).  exact_ties = 2 -- the reference's Fast Marching replayed on the device (csrc/exact_kernel.hip) --
+    """The in-tolerance mode on the tie-prone medium: configs[2]'s grid and unit count with configs[4]'s checkerboard,
+    1000 sources x 16 periods = 16 000 units x 32 receivers, all marching at once (the march is bound by the memory system's latency: its
+    rate grows with the units in flight -- 4096 units ~880, 8192 ~1700, 16 000 ~1950 solves/s).  exact_ties = 2 -- the reference's Fast
+    Marching replayed on the device (csrc/exact_kernel.hip) --
     timed with the engine's HIP events over the whole call, and checked bit for bit against the reference on 16 of the units; exact_ties = 1
     -- tie detector, literal march for the flagged units -- with the flagged fraction and the worst receiver of the units it left alone
     (against the exact_ties = 2 times, which ARE the reference's)."""
     import numpy as np
     import synth
-    nsrc = 512
+    nsrc = NSRC
     units = synth.units(NX, nsrc, NPER, NREC, seed=synth.SEED + 41)
     n = nsrc * NPER
     pv = np.stack([synth.medium(NX, "checker", p) for p in range(NPER)])

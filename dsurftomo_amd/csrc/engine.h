@@ -120,7 +120,8 @@ struct Engine {
     int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each, made odd); 0 = by the number of units marching (.. 4799)
     int exact_pool = 0;                // units marching at a time (0 = by free memory, at most exact_pool_max)
     size_t exact_pool_max = 16384;     // option exact_pool_max: four units per wavefront, sixteen wavefronts per CU (measured at 1025^2: 10 240 units 1 500, 12 288 1 600, 16 384 1 700 solves/s)
-    DevBuf<unsigned long long> X_pool, X_heap;   // per marching unit: (T, status) records of the whole grid; tree slots beyond the LDS part
+    DevBuf<unsigned> X_pool;                     // per marching unit: one packed word per node of the whole grid (exact_kernel.hip)
+    DevBuf<unsigned long long> X_heap;           // ... and the tree slots beyond the LDS part
     DevBuf<int> x_units, x_nstart;
     DevBuf<unsigned long long> x_starts;         // the coarse stage's starting tree per marching unit (kernels.h: exact_start_bytes)
     DevBuf<int32_t> xinfo, tieinfo;

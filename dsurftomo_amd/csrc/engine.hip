@@ -1002,14 +1002,15 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
     (void)n;
     // (a tree holds at most 65 535 nodes -- sixteen levels, one per lane of a unit's group; narrow bands are a few times nnx + nnz)
     const int gcap_max = std::min(16 * (g.nnx + g.nnz) + 4096, 65534);
-    const size_t per = nrec_c * 8 + (size_t)gcap_max * 8 + exact_start_bytes() + 4;
+    const size_t per = nrec_c * 4 + (size_t)gcap_max * 8 + exact_start_bytes() + 4;      // (one packed word per node, exact_kernel.hip)
     size_t pool = (size_t)exact_pool;
     if (!pool) {
-        // units marching at a time: as many as 65 % of the free memory holds, at most exact_pool_max (four units per wavefront)
+        // units marching at a time: as many as 80 % of the free memory holds, at most exact_pool_max (four units per wavefront; at 4097^2 the
+        // rate is the units in flight: 1 536 units 28 solves/s, 2 688 43, 3 456 52 -- profiles/r04_exact_rates.log)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
-        const size_t have = X_pool.cap * 8 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4;
-        pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.65 * (double)(free_b + have)) / per));
+        const size_t have = X_pool.cap * 4 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4;
+        pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.80 * (double)(free_b + have)) / per));
     }
     pool = std::min(pool, xl.size());
     {   // batches of equal size (10 240 + 6 144 units take as long as two full batches)

@@ -54,7 +54,9 @@ struct XStart { int id; float T; };          // one node of the coarse stage's s
 #define DSA_GLB
 #endif
 struct XG {                                  // the march of one unit; every lane of its group holds the same values
-    DSA_GLB XRec* F; DSA_GLB const float* slow; DSA_GLB const float* risti;
+    DSA_GLB XRec* F;                         // refined boxes: (T, status) records
+    DSA_GLB unsigned* P;                     // propagation grid: ONE word per node (packed records, below)
+    DSA_GLB const float* slow; DSA_GLB const float* risti;
     int nbz, nnx, nnz; unsigned nbz_inv;
     float ri, dnx, dnz;
     DSA_LDS XEntry* hl; DSA_GLB XEntry* hg;
@@ -64,6 +66,26 @@ struct XG {                                  // the march of one unit; every lan
     unsigned pops;
     XEntry last;                             // tree[ntr], fetched at the end of the step before: the entry the next removal of the root sinks
 };
+
+// Records of the propagation grid, round 4: one 32-bit word per node instead of (T, status) -- far 0xffffffff; alive the value's bits (a
+// travel time: sign bit clear); in the tree 0x80000000 | slot.  A node in the tree needs no value of its own in the field: its trial value
+// is its tree entry's key (fouds2 reads alive nodes only, and overwrites a trial value without looking at it, :758), and the node being
+// accepted hands its value over in a register (XLane::rootj / rootk).  Half the bytes per unit: twice the units in flight where memory
+// bounds them (4097^2: 67 MB per unit instead of 134), half the sectors behind a tile of neighbours.  PK = false: the refined boxes'
+// (T, status) records, whose trial values the hand-off's snapshot wants (reference ttnr holds them, :1287).
+constexpr unsigned kXFar = 0xffffffffu, kXInTree = 0x80000000u;
+__device__ __forceinline__ XRec xg_unpack(unsigned w)
+{
+    XRec r;
+    r.T = __uint_as_float(w);
+    r.st = w == kXFar ? -1 : (int)w >= 0 ? 0 : (int)(w & 0xffffu);
+    return r;
+}
+template <bool PK> __device__ __forceinline__ XRec xg_load(const XG& m, int id) { if (PK) return xg_unpack(m.P[id]); return m.F[id]; }
+template <bool PK> __device__ __forceinline__ int xg_status(const XG& m, int id) { if (PK) return xg_unpack(m.P[id]).st; return m.F[id].st; }
+template <bool PK> __device__ __forceinline__ void xg_set_alive(XG& m, int id, float T) { if (PK) m.P[id] = __float_as_uint(T); else m.F[id].st = 0; }
+template <bool PK> __device__ __forceinline__ void xg_set_slot(XG& m, int id, int s) { if (PK) m.P[id] = kXInTree | (unsigned)s; else m.F[id].st = s; }
+template <bool PK> __device__ __forceinline__ void xg_set_trial(XG& m, int id, float T) { if (!PK) m.F[id].T = T; }
 
 // Tree entries move as 8- / 16-byte vectors through pointers of an EXPLICIT address space.  (Copying an XEntry struct goes through its
 // implicit copy constructor, i.e. through a generic reference: the compiler then folds "slot in LDS ? LDS read : global read" into ONE flat
@@ -89,14 +111,14 @@ __device__ __forceinline__ void xg_put_tree(XG& m, bool on, int s, XEntry e)
     if (on && s > m.lcap) *(DSA_GLB xf2*)(m.hg + (s - m.lcap - 1)) = xg_vec(e);
 }
 // ... and the node's status (reference nsts: its slot)
-__device__ __forceinline__ void xg_put_status(XG& m, bool on, int s, XEntry e)
+template <bool PK> __device__ __forceinline__ void xg_put_status(XG& m, bool on, int s, XEntry e)
 {
-    if (on) m.F[e.id].st = s;
+    if (on) xg_set_slot<PK>(m, e.id, s);
 }
-__device__ __forceinline__ void xg_put(XG& m, bool on, int s, XEntry e)
+template <bool PK> __device__ __forceinline__ void xg_put(XG& m, bool on, int s, XEntry e)
 {
     xg_put_tree(m, on, s, e);
-    xg_put_status(m, on, s, e);
+    xg_put_status<PK>(m, on, s, e);
 }
 // the sixteen bits of a group in a wavefront-wide vote
 __device__ __forceinline__ unsigned xg_vote16(bool c, int lane) { return (unsigned)(__ballot(c) >> (lane & 48)) & 0xffffu; }
@@ -116,7 +138,7 @@ __device__ __forceinline__ XEntry xg_path(const XG& m, int s, bool check, int gl
     return xg_get(m, have ? a : 1);
 }
 // (one attempt with the path entries p: false when lane 15 found another node at slot s -- nothing is stored then; *moved: entries went down)
-__device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e, int s, bool check, XEntry p, int gl, int lane, bool* moved)
+template <bool PK> __device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e, int s, bool check, XEntry p, int gl, int lane, bool* moved)
 {
     const int a = gl < 15 ? (s >> (gl + 1)) : s;
     const bool have = a >= 1 && (gl < 15 || check);
@@ -127,24 +149,24 @@ __device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e, int s, bool check
     const int moves = __builtin_ctz(~b);
     XEntry w = p;
     if (gl == moves) w = e;
-    xg_put(m, gl <= moves, s >> gl, w);
+    xg_put<PK>(m, gl <= moves, s >> gl, w);
     *moved = moves > 0;
     return true;
 }
-__device__ __forceinline__ void xg_sift_up(XG& m, XEntry e, int s, bool check, int gl, int lane)
+template <bool PK> __device__ __forceinline__ void xg_sift_up(XG& m, XEntry e, int s, bool check, int gl, int lane)
 {
     bool moved;
-    if (!xg_sift_apply(m, e, s, check, xg_path(m, s, check, gl), gl, lane, &moved)) {
+    if (!xg_sift_apply<PK>(m, e, s, check, xg_path(m, s, check, gl), gl, lane, &moved)) {
         // (rare: the node was pushed down a level by an earlier neighbour of this step; its status says where to)
-        s = m.F[e.id].st;
-        (void)xg_sift_apply(m, e, s, false, xg_path(m, s, false, gl), gl, lane, &moved);
+        s = xg_status<PK>(m, e.id);
+        (void)xg_sift_apply<PK>(m, e, s, false, xg_path(m, s, false, gl), gl, lane, &moved);
     }
 }
-__device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lane)
+template <bool PK> __device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lane)
 {
     if (m.ntr + 1 > m.lcap + m.gcap) { m.err = 1; return; }
     m.ntr += 1;
-    xg_sift_up(m, XEntry{ key, id }, m.ntr, false, gl, lane);
+    xg_sift_up<PK>(m, XEntry{ key, id }, m.ntr, false, gl, lane);
 }
 // reference downtree (:800-858): the last entry replaces the root and sinks; of two children with equal keys the left one is taken
 // (`>`), a child moves up only when strictly smaller.  The walk down reads one 16-byte pair of children per level (lcap is odd: the
@@ -266,7 +288,7 @@ __device__ __forceinline__ int xg_rec(int nbz, int iz0, int ix0)
 #else
 #define DSA_XCLK(k)
 #endif
-__device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int ix0, const XLane& L, int lane
+template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int ix0, const XLane& L, int lane
 #ifdef DSA_X_CLOCKS
                                                , unsigned long long* xc, unsigned long long& xt
 #endif
@@ -283,8 +305,13 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
     const int idj = inj ? xg_rec(m.nbz, mz0, xj) : root.id, idj2 = inj2 ? xg_rec(m.nbz, mz0, xj2) : root.id;
     const int idk = ink ? xg_rec(m.nbz, zk, mx0) : root.id, idk2 = ink2 ? xg_rec(m.nbz, zk2, mx0) : root.id;
     // seven loads per lane in flight while the root leaves the tree: the quadrant's stencil, the neighbour's slowness and status
-    const XRec vj = m.F[idj], vj2 = m.F[idj2], vk = m.F[idk], vk2 = m.F[idk2];
-    const int st_pre = m.F[mid].st;
+    XRec vj = xg_load<PK>(m, idj), vk = xg_load<PK>(m, idk);
+    const XRec vj2 = xg_load<PK>(m, idj2), vk2 = xg_load<PK>(m, idk2);
+    const int st_pre = xg_status<PK>(m, mid);
+    if (PK) {          // (packed records: the node being accepted is still "in the tree" in the field; its value is the root's key)
+        vj.T = L.rootj ? root.key : vj.T;
+        vk.T = L.rootk ? root.key : vk.T;
+    }
     // (the tree's last entry but one: the entry the NEXT removal sinks, unless this step adds nodes or writes that slot -- see the step's end)
     const XEntry spare = xg_get(m, m.ntr > 1 ? m.ntr - 1 : 1);
     const float slown = m.slow[mid], risti = m.risti[in ? mx0 : 0];
@@ -357,16 +384,16 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
     // the neighbours' trial values (fouds2 overwrites them unconditionally, :758: the first lane of each neighbour's four stores it) ...
     // (the paths fetched above are waited for HERE, before the first store: a wait further down would also cover the stores)
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
-    if (lead) m.F[root.id].st = 0;
-    xg_put_status(m, L.gl <= P.moves, P.to, P.mine);
-    if (r4 == 0 && st != 0) m.F[mid].T = trial;
+    if (lead) xg_set_alive<PK>(m, root.id, root.key);
+    xg_put_status<PK>(m, L.gl <= P.moves, P.to, P.mine);
+    if (r4 == 0 && st != 0) xg_set_trial<PK>(m, mid, trial);
     if (!sequential) {
         // ... and the neighbours' updates, one store pass for the four: lane r < up its ancestor's entry a level down (slot s >> r), lane `up`
         // the node itself where it stops
         XEntry w = pq;
         if (r4 == up) w = XEntry{ trial, mid };
         const bool wr = st != 0 && r4 <= up;
-        xg_put(m, wr, sq >> r4, w);
+        xg_put<PK>(m, wr, sq >> r4, w);
         m.ntr += __popc(newq);
         // the tree's last entry for the next step, without a load behind these stores: it is what this step wrote there (a new node's chain
         // ends at the last slot; else an update's or the removal's move may have), or else the entry fetched at the step's start
@@ -391,7 +418,7 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
             if (stq != 0) {
                 const bool fresh = stq < 0;
                 m.ntr += fresh ? 1 : 0;
-                xg_sift_up(m, XEntry{ trq, idq }, fresh ? m.ntr : m.F[idq].st, !fresh, L.gl, lane);
+                xg_sift_up<PK>(m, XEntry{ trq, idq }, fresh ? m.ntr : xg_status<PK>(m, idq), !fresh, L.gl, lane);
             }
             stq = st_b; st_b = st_c; st_c = st_d; st_d = 0;
             idq = id_b; id_b = id_c; id_c = id_d;
@@ -408,7 +435,7 @@ __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int 
 // test of :396-407 -- marks that node alive and stops.  Otherwise: travel(urg = 2) on the propagation grid from the hand-off's tree
 template <bool REFINED>
 __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const int* __restrict__ units, int n, const float* __restrict__ slow_all,
-                                               size_t field_stride, const float* __restrict__ risti_c, XRec* pool, size_t pool_stride,
+                                               size_t field_stride, const float* __restrict__ risti_c, unsigned* pool, size_t pool_stride,
                                                XEntry* heap_pool, int gcap, int lcap, const XStart* __restrict__ starts, const int* __restrict__ nstart,
                                                int32_t* xinfo, unsigned long long* clk)
 {
@@ -424,6 +451,8 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
     m.last = XEntry{ 0.0f, 0 };
     m.lcap = lcap; m.hg = (DSA_GLB XEntry*)(heap_pool + (size_t)(live ? slot : 0) * gcap); m.gcap = gcap;
     m.ntr = 0; m.err = 0; m.pops = 0u; m.ri = g.earth;
+    m.F = nullptr; m.P = nullptr;
+    constexpr bool PK = !REFINED;
     int rnx = 0, rnz = 0, oxl = 0, oxh = 0, ozl = 0, ozh = 0;
     if (REFINED) {
         const SourceDesc* sd = b.src + s;
@@ -444,17 +473,17 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
                     const float t = 2.0f * ds / (vss[i - 1][j - 1] + vsrc);
                     const int id = rec_index(m.nbz, isz - 2 + j, isx - 2 + i);
                     if (lead) m.F[id].T = t;
-                    xg_add(m, id, t, lane & 15, lane);
+                    xg_add<PK>(m, id, t, lane & 15, lane);
                 }
         }
     } else {
         const SourceDesc* sd = b.src + s;
-        m.F = (DSA_GLB XRec*)(pool + (size_t)(live ? slot : 0) * pool_stride); m.slow = (DSA_GLB const float*)(slow_all + (size_t)sd->period * field_stride); m.risti = (DSA_GLB const float*)risti_c;
+        m.P = (DSA_GLB unsigned*)(pool + (size_t)(live ? slot : 0) * pool_stride); m.slow = (DSA_GLB const float*)(slow_all + (size_t)sd->period * field_stride); m.risti = (DSA_GLB const float*)risti_c;
         x_set_grid(m, g.nbz, g.nnx, g.nnz); m.dnx = g.dnx; m.dnz = g.dnz;
         if (live) {
             const int cnt = nstart[slot];
             const XStart* st = starts + (size_t)slot * kXStage;
-            for (int q = 0; q < cnt; ++q) { const XStart e = st[q]; xg_add(m, e.id, e.T, lane & 15, lane); }
+            for (int q = 0; q < cnt; ++q) { const XStart e = st[q]; xg_add<PK>(m, e.id, e.T, lane & 15, lane); }
         }
     }
     const XLane L = xg_lane(lane);
@@ -475,11 +504,11 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
                 const int iz = iz0 + 1, ix = ix0 + 1;
                 stop = (ix == 1 && oxl) || (ix == rnx && oxh) || (iz == 1 && ozl) || (iz == rnz && ozh);
             }
-            if (stop) { if (lead) m.F[root.id].st = 0; active = false; }
+            if (stop) { if (lead) xg_set_alive<PK>(m, root.id, root.key); active = false; }
 #ifdef DSA_X_CLOCKS
-            else { DSA_XCLK(0) xg_accept_root(m, root, iz0, ix0, L, lane, xc, xt); }
+            else { DSA_XCLK(0) xg_accept_root<PK>(m, root, iz0, ix0, L, lane, xc, xt); }
 #else
-            else xg_accept_root(m, root, iz0, ix0, L, lane);
+            else xg_accept_root<PK>(m, root, iz0, ix0, L, lane);
 #endif
         }
     }
@@ -493,22 +522,23 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
 }
 
 // every record far, value 0 (the reference's nsts = -1): the refined boxes of the batch's units and their pool slots
-__global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restrict__ units, XRec* pool, size_t pool_stride, int nrec)
+__global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restrict__ units, unsigned* pool, size_t pool_stride, int nrec)
 {
     const int slot = blockIdx.y;
     const int s = units[slot];
     const uint4 v = { 0u, 0xffffffffu, 0u, 0xffffffffu };              // two records {0.0f, -1}
+    const uint4 far4 = { kXFar, kXFar, kXFar, kXFar };                 // four packed records
     uint4* const Fr = (uint4*)(b.F_r + (size_t)s * kRefRecs);
     uint4* const Fc = (uint4*)(pool + (size_t)slot * pool_stride);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = t; i < (size_t)kRefRecs / 2; i += step) Fr[i] = v;
-    for (size_t i = t; i < (size_t)nrec / 2; i += step) Fc[i] = v;
+    for (size_t i = t; i < (size_t)nrec / 4; i += step) Fc[i] = far4;
 }
 
 // between the two marches, one workgroup per unit: the snapshot the ray tracer reads (reference ttnr / nstsr, :1287-1288), every sgdl-th
 // refined node -- status and, for status >= 0, value -- onto the propagation grid (:1293-1303), alive nodes that touch a far node back
 // into the narrow band (:1332-1349), and the starting tree's nodes in the reference's scan order (:341-347)
-__global__ __launch_bounds__(64) void k_xhandoff(GridDesc g, BatchPtrs b, const int* __restrict__ units, XRec* pool, size_t pool_stride,
+__global__ __launch_bounds__(64) void k_xhandoff(GridDesc g, BatchPtrs b, const int* __restrict__ units, unsigned* pool, size_t pool_stride,
                                                  XStart* starts, int* nstart)
 {
     __shared__ int stage_st[kXStage];
@@ -552,7 +582,7 @@ __global__ __launch_bounds__(64) void k_xhandoff(GridDesc g, BatchPtrs b, const 
     __syncthreads();
     for (int q = lane, t = 0; q < bxn * bzn; q += 64, ++t) if ((promote >> t) & 1u) stage_st[q] = 1;
     __syncthreads();
-    XRec* const Fc = pool + (size_t)slot * pool_stride;
+    unsigned* const Fc = pool + (size_t)slot * pool_stride;
     XStart* const out = starts + (size_t)slot * kXStage;
     int count = 0;
     for (int q0 = 0; q0 < bxn * bzn; q0 += 64) {
@@ -562,37 +592,34 @@ __global__ __launch_bounds__(64) void k_xhandoff(GridDesc g, BatchPtrs b, const 
         const int bx = have ? q / bzn : 0, bz = have ? q - bx * bzn : 0;
         const int id = rec_index(g.nbz, sd.vnt + bz - 1, sd.vnl + bx - 1);
         const float tq = have ? stage_T[q] : 0.0f;
-        if (st == 0) Fc[id] = XRec{ tq, 0 };
+        if (st == 0) Fc[id] = __float_as_uint(tq);
         const unsigned long long mask = __ballot(st > 0);
-        if (st > 0) {
-            Fc[id].T = tq;
-            out[count + __popcll(mask & ((1ull << lane) - 1ull))] = XStart{ id, tq };
-        }
+        if (st > 0) out[count + __popcll(mask & ((1ull << lane) - 1ull))] = XStart{ id, tq };      // (its word in the field: set when the march adds it to the tree)
         count += __popcll(mask);
     }
     if (lane == 0) nstart[slot] = count;
 }
 
 // the unit's compact coarse field: plain values, no exceptional nodes (every node was accepted once, in order)
-__global__ __launch_bounds__(256) void k_xfinish(GridDesc g, BatchPtrs b, const int* __restrict__ units, const XRec* pool, size_t pool_stride, int nrec)
+__global__ __launch_bounds__(256) void k_xfinish(GridDesc g, BatchPtrs b, const int* __restrict__ units, const unsigned* pool, size_t pool_stride, int nrec)
 {
     const int slot = blockIdx.y;
     const int s = units[slot];
-    const XRec* const Fc = pool + (size_t)slot * pool_stride;
+    const unsigned* const Fc = pool + (size_t)slot * pool_stride;
     float* const T_c = b.T_c + (size_t)s * nrec;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)nrec; i += (size_t)gridDim.x * blockDim.x) {
-        const XRec r = Fc[i];
-        T_c[i] = r.st == 0 ? r.T : kInf;
+        const unsigned w = Fc[i];
+        T_c[i] = (int)w >= 0 ? __uint_as_float(w) : kInf;
     }
 }
 
 // the batch's receiver times straight from the marched fields (reference srtimes, receiver_core.h): a call that wants nothing but times
 // needs no compact copy of its units' fields -- at 4097^2 that copy is 67 MB per unit
 struct MarchFieldT {
-    const XRec* F;
-    __device__ __forceinline__ float operator()(int id) const { const XRec r = F[id]; return r.st == 0 ? r.T : kInf; }
+    const unsigned* F;
+    __device__ __forceinline__ float operator()(int id) const { const unsigned w = F[id]; return (int)w >= 0 ? __uint_as_float(w) : kInf; }
 };
-__global__ __launch_bounds__(64) void k_xreceivers(GridDesc g, BatchPtrs b, const int* __restrict__ units, const XRec* pool, size_t pool_stride,
+__global__ __launch_bounds__(64) void k_xreceivers(GridDesc g, BatchPtrs b, const int* __restrict__ units, const unsigned* pool, size_t pool_stride,
                                                    const RayDesc* __restrict__ rays, const float* __restrict__ veln_all, size_t veln_stride, float dpl,
                                                    float* __restrict__ out, int32_t* __restrict__ err)
 {
@@ -625,15 +652,15 @@ void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int
     }
     const int nrec = g.nbx * g.nbz * kTileRecs;
     const int fill_blocks = (int)std::min<size_t>(((size_t)nrec / 2 + 255) / 256, 64);
-    hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (XRec*)d_pool, pool_stride, nrec);
+    hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (unsigned*)d_pool, pool_stride, nrec);
     const int waves = (n + 3) / 4;
-    hipLaunchKernelGGL(k_xmarch<true>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (XRec*)d_pool, pool_stride,
+    hipLaunchKernelGGL(k_xmarch<true>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
                        (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks);
-    hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (XRec*)d_pool, pool_stride, (XStart*)d_starts, d_nstart);
-    hipLaunchKernelGGL(k_xmarch<false>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (XRec*)d_pool, pool_stride,
+    hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (unsigned*)d_pool, pool_stride, (XStart*)d_starts, d_nstart);
+    hipLaunchKernelGGL(k_xmarch<false>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
                        (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks);
-    if (compact_copy) hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const XRec*)d_pool, pool_stride, nrec);
-    if (rc) hipLaunchKernelGGL(k_xreceivers, dim3(n), dim3(64), 0, stream, g, b, d_units, (const XRec*)d_pool, pool_stride, rc->rays, rc->veln_all, rc->veln_stride,
+    if (compact_copy) hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, nrec);
+    if (rc) hipLaunchKernelGGL(k_xreceivers, dim3(n), dim3(64), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, rc->rays, rc->veln_all, rc->veln_stride,
                                rc->dpl, rc->out, rc->err);
 }
 
