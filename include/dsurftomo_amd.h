@@ -214,10 +214,10 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  * tree (CalSurfG.f90:417-485, :768-921).  Option "exact_ties": 0 (default) fixed point only; 1 = the solve kernel detects such
  * ties (option "tie_threshold", seconds: the influence on the node's value a tie must have to count; default 2e-5, 0 = any tie) and the
  * units that met one are solved again by the reference's march itself, replayed on the device four units per wavefront -- their
- * fields are then bit-identical to the reference's; 2 = every unit by the literal march (1 950 solves/s at 1025^2 with 16 000 units in
+ * fields are then bit-identical to the reference's; 2 = every unit by the literal march (2 100 solves/s at 1025^2 with 16 000 units in
  * flight).  Options "exact_lds_slots" (tree slots in LDS per marching unit, the rest of the tree in global memory: 64 ..
  * 4991, made odd; default 0 = what lets every wavefront of a batch be resident: 148 KB of a CU's LDS divided among them), "exact_pool"
- * (units marching at a time, 0 = by free memory: 80 % of it at 4 bytes per node and unit -- 43 solves/s at 4097^2 --, at most "exact_pool_max", default 16384).  The march's tree
+ * (units marching at a time, 0 = by free memory: 80 % of it at 4 bytes per node and unit -- 50 solves/s at 4097^2 --, at most "exact_pool_max", default 16384).  The march's tree
  * holds at most 65 534 nodes per unit (16-bit slots): a narrow band longer than that returns DSA_ERR_INTERNAL (grids beyond ~8000
  * nodes per side; the grid size limit below is lower).
  * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: met a tie, bit 1: solved by the literal march) and the largest
