@@ -69,7 +69,7 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 #ifdef DSA_BUNDLE_WAVES
 #define DSA_BUNDLE_OCC(G, NT, MPL) __attribute__((amdgpu_waves_per_eu(DSA_BUNDLE_WAVES, DSA_BUNDLE_WAVES)))
 #else
-#define DSA_BUNDLE_OCC(G, NT, MPL) __attribute__((amdgpu_waves_per_eu(((NT) == 256 && ((MPL) == 2 || (G) == 16)) ? 3 : 1, ((NT) == 256 && ((MPL) == 2 || (G) == 16)) ? 3 : 2)))
+#define DSA_BUNDLE_OCC(G, NT, MPL) __attribute__((amdgpu_waves_per_eu((((NT) == 256 && ((MPL) == 2 || (G) == 16)) || (NT) == 768) ? 3 : 1, (((NT) == 256 && ((MPL) == 2 || (G) == 16)) || (NT) == 768) ? 3 : 2)))
 #endif
 // NT = 256 threads per workgroup up to 1500 nodes per side (128: -1.7 %, 512: -13 % at 1025^2), 512 beyond: a 4097^2 front has ~2700 ready
 // nodes per round, four times what 256 threads and their 2 x 1024 ready slots take
@@ -89,10 +89,10 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     __shared__ int wbuf[NW * kWaveBuf];
     __shared__ int wtile[NW * kTileBuf];
     __shared__ unsigned wclr[NW * kTileBuf * kClrWords];
-    constexpr int rhalf = NT < 256 ? 1024 : NT * 4;      // ready nodes of one colour a round can take (the rest keep their bits)
+    constexpr int rhalf = NT < 256 ? 1024 : NT > 512 ? 2048 : NT * 4;      // ready nodes of one colour a round can take (the rest keep their bits)
     __shared__ int ready[2 * rhalf];
     __shared__ int s_member[kBundleMax], s_map[kBundleMax];
-    constexpr int kSlowQ = 1024;                          // entries of a wave's slow queue (pass B)
+    constexpr int kSlowQ = NT > 512 ? 512 : 1024;         // entries of a wave's slow queue (pass B)
     __shared__ int slowq[NW * kSlowQ];
 
     const FimBundle* const bd = bundles + blockIdx.x;
@@ -770,6 +770,7 @@ void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int thr
 #define DSA_LAUNCH_BUNDLE2(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT, 2>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
     if (members_per_lane == 2 && threads == 256) { if (G == 16) DSA_LAUNCH_BUNDLE2(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE2(8, 256); else DSA_LAUNCH_BUNDLE2(4, 256); }
     else if (threads == 512) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 512); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 512); else DSA_LAUNCH_BUNDLE(4, 512); }
+    else if (threads == 768) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 768); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 768); else DSA_LAUNCH_BUNDLE(4, 768); }
     else { if (G == 16) DSA_LAUNCH_BUNDLE(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 256); else DSA_LAUNCH_BUNDLE(4, 256); }
 #undef DSA_LAUNCH_BUNDLE
 #undef DSA_LAUNCH_BUNDLE2

@@ -82,10 +82,10 @@ struct Engine {
     float bundle_window_opt = 0.0f;    // option bundle_window_cells: causal window of the bundles, 0 = automatic (bundle_window(): 0.6 cells -- a round's fixed costs are shared by the members, so fewer evaluations per round pay; 1.25 for small wide launches)
     int bundle_G_now = 0;              // members per bundle of the current solve
                                        // (measured at 1025^2, 16 members: 0.4 / 0.5 / 0.6 / 0.8 / 1.25 cells -> 24.4 / 24.6 / 24.4 / 23.9 / 22.7 k solves/s)
-    int bundle_threads_opt = 0;        // option bundle_threads: workgroup size of the bundle kernel (0 = by grid size: 256, 512 beyond 1500 nodes per side)
+    int bundle_threads_opt = 0;        // option bundle_threads: workgroup size of the bundle kernel (0 = automatic: 256; 768 beyond 1500 nodes per side and for small launches)
     int bundle_max_rounds = 0;         // option bundle_max_rounds (tests): > 0 = round limit of the bundles; a bundle that hits it sends its chunk to the unit-by-unit solve
     int bundle_mpl = 0;                // option bundle_members_per_lane: 0 = automatic (bundle_mpl_of), 4, or 2
-    bool bundle_wide = false;          // this call's bundles run 512 threads wide on a small grid (choose_bundle_size: a CU per bundle)
+    bool bundle_wide = false;          // this call's bundles run 768 threads wide on a small grid (choose_bundle_size: a CU per bundle)
     int bundle_mpl_now = 4, bundle_mpl_b = 2;      // ... what the current launch uses (whole bundles; the halved last ones)
     int bundles_a = 0, bundles_b = 0, bundle_Gb = 0;      // the launch's bundles: whole ones, and (plan_bundles) the last ones cut in halves of bundle_Gb members on a second stream
     hipStream_t stream2 = nullptr;

@@ -495,7 +495,7 @@ size_t Engine::bundles_resident(int G, int mpl) const
     if (bundle_threads() == 256) return (size_t)256 * DSA_BUNDLE_WAVES;
 #endif
     // (bundle_kernel.hip: DSA_BUNDLE_OCC -- three workgroups of 256 threads per CU with two members per lane and for bundles of 16)
-    return (size_t)256 * (bundle_threads() == 512 ? 1 : (mpl == 2 || G == 16) ? 3 : 2);
+    return (size_t)256 * (bundle_threads() >= 512 ? 1 : (mpl == 2 || G == 16) ? 3 : 2);
 }
 
 // Members per lane of a launch of nb bundles of G: the option, or 16 members four per lane; 8 and 4 members two per lane (three workgroups
@@ -508,7 +508,7 @@ int Engine::bundle_mpl_of(int G, long nb) const
 }
 
 // Causal window of the bundles in cells: the option (default 0.6: at full occupancy the evaluations are what costs); a small launch of
-// small bundles, 512 threads wide with a CU per bundle, is bound by the length of its rounds' chain instead: 1.25 cells there (24 % fewer
+// small bundles, wide with a CU per bundle, is bound by the length of its rounds' chain instead: 1.25 cells there (24 % fewer
 // rounds, 15 % more evaluations: 250 bundles of 8 at 1025^2 102.2 -> 96.8 ms; bundles of 16 show no difference; profiles/r04_bundle_occupancy.log)
 float Engine::bundle_window() const
 {
@@ -516,15 +516,17 @@ float Engine::bundle_window() const
     return (bundle_wide && bundle_G_now > 0 && bundle_G_now < 16) ? 1.25f : 0.6f;
 }
 
-// Workgroup size of the bundle kernel: the option; 512 beyond 1500 nodes per side (a 4097^2 front does not fit the ready lists of 256
-// threads); else 256 -- unless choose_bundle_size found the launch so small that every bundle gets a CU to itself (bundle_wide: at most
-// 256 bundles), where eight waves per bundle finish a round sooner than four (round 4: 125 sources x 16 periods as 250 bundles of 8,
-// 102 ms with 512 threads against 131 with 256; profiles/r04_bundle_occupancy.log)
+// Workgroup size of the bundle kernel: the option; 256 threads, three workgroups per CU, as a rule.  Where a bundle has a CU to itself
+// anyway it runs 768 threads WIDE -- twelve waves, three per SIMD, share a round's node trips instead of four: beyond 1500 nodes per
+// side (a 4097^2 front does not fit the ready lists of 256 threads, and a bundle's field slot is so large that a CU's worth of them
+// fills the memory), and on smaller grids when choose_bundle_size found the launch so small that every bundle gets a CU (bundle_wide:
+// at most 256 bundles).  Round 4, profiles/r04_bundle_occupancy.log: 250 bundles of 8 at 1025^2 131 ms with 256 threads, 102 with 512,
+// 95 with 768; 256 bundles of 8 at 4097^2 1 229 ms with 512, 1 122 with 768.
 int Engine::bundle_threads() const
 {
-    if (bundle_threads_opt == 256 || bundle_threads_opt == 512) return bundle_threads_opt;
-    if (std::max(g.nnx, g.nnz) > 1500) return 512;
-    return bundle_wide ? 512 : 256;
+    if (bundle_threads_opt == 256 || bundle_threads_opt == 512 || bundle_threads_opt == 768) return bundle_threads_opt;
+    if (std::max(g.nnx, g.nnz) > 1500) return 768;
+    return bundle_wide ? 768 : 256;
 }
 
 BatchPtrs Engine::batch() const
@@ -833,8 +835,8 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     // costs at least 45 % of a generation (profiles/r04_bundle_occupancy.log); between 768 and 1 500 bundles plan_bundles cuts the last
     // ones in halves (1 000 bundles of 16: 383 ms)
     const double t_one[3][3] = { { 189.5, 210.0, 241.0 }, { 130.8, 151.7, 187.2 }, { 104.8, 125.4, 164.3 } };
-    const double rate512[3] = { 24.5, 20.4, 15.5 };                             // (512-thread kernel, one workgroup per CU: round 3's table)
-    const double t_wide[3] = { 119.0, 85.0, 74.0 };                             // (512 threads at 1025^2, a CU per bundle: ms of one bundle of 16 / 8 / 4)
+    const double rate512[3] = { 24.5, 20.4, 15.5 };                             // (large grids, one wide workgroup per CU: round 3's table; only the ratios decide)
+    const double t_wide[3] = { 106.0, 77.0, 69.0 };                             // (768 threads at 1025^2, a CU per bundle: ms of one bundle of 16 / 8 / 4)
     bool pick_wide = false;
     for (int k = 0; k < 3; ++k) {
         const int G = sizes[k];
@@ -845,7 +847,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         const double frac = (double)covered / (double)h_src.size();                  // units that end up in bundles ...
         const double fill = (double)covered / ((double)nb * G);                       // ... and how full the bundles are
         double est;
-        if (bundle_threads() == 512) est = frac * rate512[k] * fill * std::min(1.0, (double)nb / 280.0) + (1.0 - frac) * solo_rate;
+        if (bundle_threads() >= 512) est = frac * rate512[k] * fill * std::min(1.0, (double)nb / 280.0) + (1.0 - frac) * solo_rate;
         else {
             const double occ = (double)nb / 256.0;
             double ms;
@@ -863,7 +865,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         }
         bool wide = false;
         if (bundle_threads_opt == 0 && bundle_threads() == 256 && nb <= 256) {
-            // ... or a CU per bundle with 512 threads (one bundle's time at that width, nearly flat in the number of bundles)
+            // ... or a CU per bundle, 768 threads wide (one bundle's time at that width, nearly flat in the number of bundles)
             const double ms_w = t_wide[k] + 12.0 * (double)nb / 256.0;
             const double est_w = n_units / (ms_w * (0.65 + 0.35 * fill) + n_units * (1.0 - frac) / std::max(solo_rate, 1e-9));
             if (est_w > est) { est = est_w; wide = true; }
@@ -1318,7 +1320,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
     if (n == "bundle_window_cells" && value >= 0) { en->bundle_window_opt = (float)value; return 0; }
-    if (n == "bundle_threads" && (value == 0 || value == 256 || value == 512)) { en->bundle_threads_opt = (int)value; return 0; }
+    if (n == "bundle_threads" && (value == 0 || value == 256 || value == 512 || value == 768)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
     if (n == "bundle_members_per_lane" && (value == 0 || value == 4 || value == 2)) { en->bundle_mpl = (int)value; return 0; }

@@ -193,7 +193,7 @@ def test_last_partial_generation_of_bundles_cut_in_halves(bundles):
 
 def test_small_launch_on_a_rectangular_grid_runs_wide_and_equals_unit_by_unit(bundles):
     """round 4: the member bodies evaluate regular neighbourhoods with solve_regular (different steps in x and z here: 401 x 537 nodes,
-    dvz = 1.3 dvx), and a launch of at most 256 bundles runs them 512 threads wide.  40 sources x 8 periods, smooth maps: automatic
+    dvz = 1.3 dvx), and a launch of at most 256 bundles runs them 768 threads wide.  40 sources x 8 periods, smooth maps: automatic
     (wide) and forced bundles of 8 (256 threads) both give the unit-by-unit receiver times bit for bit"""
     e = bundles
     nx, ny, nsrc, nper, nrec = 53, 70, 40, 8, 6
@@ -207,18 +207,18 @@ def test_small_launch_on_a_rectangular_grid_runs_wide_and_equals_unit_by_unit(bu
         e.set_option("bundle", G)
         out[G] = e.traveltimes(**u)
         st = e.stats()
-        if G == 1: assert st["bundles"] > 0 and st["bundled_units"] == nsrc * nper and st["bundle_threads"] == 512, st
+        if G == 1: assert st["bundles"] > 0 and st["bundled_units"] == nsrc * nper and st["bundle_threads"] == 768, st
         if G == 8: assert st["bundles"] == nsrc and st["bundle_threads"] == 256, st
     e.set_option("bundle", 1)
     for G in (1, 8):
         nbad = int((bits(out[G]) != bits(out[0])).sum())
-        parity_log.add(f"bundles on a 401 x 537 grid ({'automatic, 512 threads wide' if G == 1 else 'bundles of 8, 256 threads'}): {nbad} of {out[G].size} receiver times differ from unit by unit")
+        parity_log.add(f"bundles on a 401 x 537 grid ({'automatic, 768 threads wide' if G == 1 else 'bundles of 8, 256 threads'}): {nbad} of {out[G].size} receiver times differ from unit by unit")
         assert np.isfinite(out[G]).all() and nbad == 0, G
 
 
 @pytest.mark.parametrize("nx,nsrc,nper,G", [(257, 3, 8, 8), (513, 2, 4, 4)])
-def test_big_grids_use_the_512_thread_bundle_kernel(bundles, nx, nsrc, nper, G):
-    """beyond 1500 nodes per side the bundle kernel runs 512 threads wide (2 x 2048 ready nodes per round): 2033^2 and 4081^2 against unit by unit"""
+def test_big_grids_use_the_wide_bundle_kernel(bundles, nx, nsrc, nper, G):
+    """beyond 1500 nodes per side the bundle kernel runs 768 threads wide (2 x 2048 ready nodes per round; round 3: 512): 2033^2 and 4081^2 against unit by unit"""
     e = bundles
     pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
     u = synth.units(nx, nsrc, nper, 16)
@@ -231,7 +231,7 @@ def test_big_grids_use_the_512_thread_bundle_kernel(bundles, nx, nsrc, nper, G):
         assert st["bundles"] == (0 if g == 0 else nsrc * nper // G)
     d = np.abs(out[G] - out[0])
     nbad = int((bits(out[G]) != bits(out[0])).sum())
-    parity_log.add(f"bundles at N={e.nnx} (512-thread kernel), {nsrc * nper} units in bundles of {G}: {nbad} of {d.size} receiver times differ from unit by unit (max |dt| {float(d.max()):.3g} s)")
+    parity_log.add(f"bundles at N={e.nnx} (wide kernel, 768 threads), {nsrc * nper} units in bundles of {G}: {nbad} of {d.size} receiver times differ from unit by unit (max |dt| {float(d.max()):.3g} s)")
     assert np.isfinite(out[G]).all() and d.max() <= 1e-4
 
 
@@ -367,19 +367,19 @@ def test_bundled_receivers_on_tie_prone_media_against_the_oracle(bundles, kind, 
             assert st["bundles"] == (nsrc if G else 0)
             if G: assert st["bundle_threads"] == 256
         else:
-            # automatic: a launch this small gives every bundle a CU to itself and runs them 512 threads wide (Engine::choose_bundle_size)
-            assert st["bundles"] > 0 and st["bundled_units"] == n and st["bundle_threads"] == 512, st
+            # automatic: a launch this small gives every bundle a CU to itself and runs them 768 threads wide (Engine::choose_bundle_size)
+            assert st["bundles"] > 0 and st["bundled_units"] == n and st["bundle_threads"] == 768, st
         d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
         res[G] = (float(d.max()), int((d > TOL).sum()), int((bits(t) != bits(ref)).sum()))
     parity_log.add(f"bundles vs oracle N=1025 {kind}: {n} units x {nrec} receivers | bundles of 16: max |dt| {res[16][0]:.3g} s, beyond 1e-4 s {res[16][1]}, not bit-identical {res[16][2]} | "
-                   f"unit by unit: max |dt| {res[0][0]:.3g} s, beyond {res[0][1]}, not bit-identical {res[0][2]} | automatic (512 threads wide): max |dt| {res[1][0]:.3g} s, beyond {res[1][1]}, not bit-identical {res[1][2]}")
+                   f"unit by unit: max |dt| {res[0][0]:.3g} s, beyond {res[0][1]}, not bit-identical {res[0][2]} | automatic (768 threads wide): max |dt| {res[1][0]:.3g} s, beyond {res[1][1]}, not bit-identical {res[1][2]}")
     e.set_option("bundle", 1)
     for G in (0, 16, 1):
         assert res[G][1] == 0 and res[G][0] <= worst_allowed, (G, res[G])
 
 
-def test_512_thread_bundle_kernel_against_the_oracle_at_config4_size(bundles):
-    """VERDICT r03 item 1 of "what's missing": at 4097^2 the engine picks k_fim_bundle<8,512>.  configs[4]'s grid and medium (checkerboard
+def test_wide_bundle_kernel_against_the_oracle_at_config4_size(bundles):
+    """VERDICT r03 item 1 of "what's missing": at 4097^2 the engine picks the wide bundle kernel (k_fim_bundle<8, 768>; round 3: <8, 512>).  configs[4]'s grid and medium (checkerboard
     +-8 %, 16-vertex squares), 8 sources x 8 periods = 64 units in 8 bundles of 8, 16 receivers each, against the oracle's Fast Marching.
     The medium is the named tie case of the fixed-point solve: the bundled times must be the unit-by-unit solve's class of
     result -- within the tie noise measured for this medium (tests/test_gpu_fullsize.py KNOWN) -- and the exact mode on the same units the
@@ -391,7 +391,7 @@ def test_512_thread_bundle_kernel_against_the_oracle_at_config4_size(bundles):
     n = nsrc * nper
     ref = _oracle_receiver_times(nx, pv, u, nrec, n, workers=24)
     e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
-    e.set_option("bundle", 8)                  # eight members per bundle; beyond 1500 nodes per side the kernel is k_fim_bundle<8, 512> (Engine::bundle_threads)
+    e.set_option("bundle", 8)                  # eight members per bundle; beyond 1500 nodes per side the kernel is k_fim_bundle<8, 768> (Engine::bundle_threads)
     t = e.traveltimes(**u).reshape(n, nrec)
     st = e.stats()
     assert st["bundles"] == nsrc and st["bundle_size"] == 8 and st["bundled_units"] == n
@@ -404,7 +404,7 @@ def test_512_thread_bundle_kernel_against_the_oracle_at_config4_size(bundles):
         tx = e.traveltimes(**u).reshape(n, nrec)
     finally:
         e.set_option("exact_ties", 0)
-    parity_log.add(f"k_fim_bundle<8,512> vs oracle, configs[4] medium N=4097: {n} units x {nrec} receivers in {nsrc} bundles of 8: max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())} of {d.size}, "
+    parity_log.add(f"k_fim_bundle<8,768> vs oracle, configs[4] medium N=4097: {n} units x {nrec} receivers in {nsrc} bundles of 8: max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())} of {d.size}, "
                    f"not bit-identical {int((bits(t) != bits(ref)).sum())} | unit by unit: max |dt| {ds.max():.3g} s, beyond {int((ds > TOL).sum())} | bundled vs unit by unit: {int((bits(t) != bits(ts)).sum())} differ, "
                    f"max {np.abs(t - ts).max():.3g} s | exact mode: not bit-identical {int((bits(tx) != bits(ref)).sum())}")
     assert (bits(tx) != bits(ref)).sum() == 0
