@@ -91,7 +91,7 @@ Engine::~Engine()
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
     if (stream2) { (void)hipStreamDestroy(stream2); (void)hipEventDestroy(ev_b0); (void)hipEventDestroy(ev_b1); stream2 = nullptr; }
-    rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(X_pool); rel(X_heap); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
+    rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(disp_fail_list); rel(X_pool); rel(X_heap); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
