@@ -73,7 +73,10 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 #endif
 // NT = 256 threads per workgroup up to 1500 nodes per side (128: -1.7 %, 512: -13 % at 1025^2), 512 beyond: a 4097^2 front has ~2700 ready
 // nodes per round, four times what 256 threads and their 2 x 1024 ready slots take
-template <int G, int NT, int MPL = 4>
+// TIE: the engine's tie detector (option exact_ties = 1; fim_kernel.hip does the same unit by unit): a member evaluation whose walk stops at
+// an exact tie goes through the slow pass, where solve_node_t<true> measures the tie's influence on the node; influences above the unit's
+// threshold are counted into the unit's tie record (count, largest influence).
+template <int G, int NT, int MPL = 4, bool TIE = false>
 __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
 {
@@ -299,8 +302,13 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         float k = kInf;
         const float slown = *(BGCF32*)(slowb + (unsigned)id * npb + (unsigned)s_map[mo] * 4u);
         const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
-        const float c = solve_node_t<false>(h, slown, geom, &k, nullptr);
+        float ti = -1.0f;
+        const float c = solve_node_t<TIE>(h, slown, geom, &k, TIE ? &ti : nullptr);
         ++evals;
+        if (TIE && ti >= 0.0f) {
+            const FimProblem* const pm = problems + s_member[mo];
+            if (pm->tie && ti > pm->tie_threshold) { atomicAdd((unsigned*)pm->tie, 1u); atomicMax((unsigned*)pm->tie + 1, bf2u(ti)); }
+        }
         if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return;
         float newv = c;
         if (bf2u(c) != bf2u(k)) { if (!exc_upsert(key, k)) { p.info[2] = -2; sc[BC_OVERFLOW] = 1; } newv = -c; }
@@ -591,9 +599,9 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         // (round 4) the walk written out for the regular neighbourhood: straight-line code, about half the instructions of
                         // solve_node_t's loop; where it does not apply (a third neighbour taken in, the opposite neighbour second: ~1 % of
                         // the evaluations) it says so and the member goes to the slow pass like an exceptional one
-                        bool ok;
-                        c = solve_regular(tn, t2, sl[m], geom, &k, &ok);
-                        if (!ok || bf2u(c) != bf2u(k)) flagged = true;               // (a non-causal result: the table's business)
+                        bool ok, tie = false;
+                        c = solve_regular(tn, t2, sl[m], geom, &k, &ok, TIE ? &tie : nullptr);
+                        if (!ok || (TIE && tie) || bf2u(c) != bf2u(k)) flagged = true;               // (a non-causal result: the table's business; a tie: the detector's)
                         else { ++evals; changed = bf2u(c) != bf2u(raw); }
                     }
                     if (valid && flagged) slow |= 1u << m;
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         const FimEnds* const E = ends + s_member[m];
         const FimProblem* const pm = problems + s_member[m];
         if (tid == 0) {
-            pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = m == 0 ? freezes : 0;
+            pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = (m == 0 || TIE) ? freezes : 0;      // (TIE: a frozen cycle flags every member of the bundle -- whose it was is not known)
             if (failed && pm->info[2] != -2) pm->info[2] = -1;
             if (sc[BC_OVERFLOW]) pm->info[2] = -2;
         }
@@ -762,18 +770,20 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
 
 size_t bundle_lds_bytes(int tile_words) { return (size_t)tile_words * 4; }
 
-void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int threads, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream, int members_per_lane)
+void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int threads, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream, int members_per_lane, bool tie)
 {
     if (nbundles <= 0) return;
     const size_t lds = bundle_lds_bytes(tile_words);
-#define DSA_LAUNCH_BUNDLE(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
-#define DSA_LAUNCH_BUNDLE2(GG, TT) hipLaunchKernelGGL((k_fim_bundle<GG, TT, 2>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
-    if (members_per_lane == 2 && threads == 256) { if (G == 16) DSA_LAUNCH_BUNDLE2(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE2(8, 256); else DSA_LAUNCH_BUNDLE2(4, 256); }
-    else if (threads == 512) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 512); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 512); else DSA_LAUNCH_BUNDLE(4, 512); }
-    else if (threads == 768) { if (G == 16) DSA_LAUNCH_BUNDLE(16, 768); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 768); else DSA_LAUNCH_BUNDLE(4, 768); }
-    else { if (G == 16) DSA_LAUNCH_BUNDLE(16, 256); else if (G == 8) DSA_LAUNCH_BUNDLE(8, 256); else DSA_LAUNCH_BUNDLE(4, 256); }
+#define DSA_LAUNCH_BUNDLE_T(GG, TT, MM, TIE_) hipLaunchKernelGGL((k_fim_bundle<GG, TT, MM, TIE_>), dim3(nbundles), dim3(TT), lds, stream, d_bundles, d_problems, d_ends)
+#define DSA_LAUNCH_BUNDLE_G(TT, MM, TIE_) { if (G == 16) DSA_LAUNCH_BUNDLE_T(16, TT, MM, TIE_); else if (G == 8) DSA_LAUNCH_BUNDLE_T(8, TT, MM, TIE_); else DSA_LAUNCH_BUNDLE_T(4, TT, MM, TIE_); }
+#define DSA_LAUNCH_BUNDLE(TT, MM) { if (tie) DSA_LAUNCH_BUNDLE_G(TT, MM, true) else DSA_LAUNCH_BUNDLE_G(TT, MM, false) }
+    if (members_per_lane == 2 && threads == 256) DSA_LAUNCH_BUNDLE(256, 2)
+    else if (threads == 512) DSA_LAUNCH_BUNDLE(512, 4)
+    else if (threads == 768) DSA_LAUNCH_BUNDLE(768, 4)
+    else DSA_LAUNCH_BUNDLE(256, 4)
+#undef DSA_LAUNCH_BUNDLE_T
+#undef DSA_LAUNCH_BUNDLE_G
 #undef DSA_LAUNCH_BUNDLE
-#undef DSA_LAUNCH_BUNDLE2
 }
 
 // slowI[id * np + m] = slow_all[m * field_stride + id]: the maps' slowness, member-minor

@@ -504,7 +504,9 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
 // one-sided z, the quadrant's two-sided value); it stops when the third key is +inf or c2 <= it.  Anything else -- a third neighbour
 // taken in, the opposite neighbour second -- returns *ok = false and the caller uses solve_node_t.  Every operation is the one
 // solve_node_t performs on the same operands (tests/test_hostcheck.py: 2e7 random regular neighbourhoods and whole solves, bit for bit).
-DSA_HD float solve_regular(const float* tn, const float* t2, float slown, const NodeGeom& g, float* tau_out, bool* ok)
+// `tie` (optional): the walk stopped at an exact tie -- its value equal, bit for bit, to the next neighbour's time: what solve_node_t<true>
+// takes one more trip for (the engine's tie detector); the caller then evaluates the node with that form.
+DSA_HD float solve_regular(const float* tn, const float* t2, float slown, const NodeGeom& g, float* tau_out, bool* ok, bool* tie = nullptr)
 {
     const bool x1 = tn[1] < tn[0], z1 = tn[3] < tn[2];
     const float tx = x1 ? tn[1] : tn[0], ox = x1 ? tn[0] : tn[1], tx2 = x1 ? t2[1] : t2[0];
@@ -548,6 +550,7 @@ DSA_HD float solve_regular(const float* tn, const float* t2, float slown, const 
     c2 = trav < c2 ? trav : c2;
     const bool stop2 = !(k2 < kInf && c2 > k2);
     *ok = stop1 || (std2 && stop2);
+    if (tie) *tie = stop1 ? (k1 < kInf && c1 == k1) : (std2 && stop2 && k2 < kInf && c2 == k2);
     const float c = stop1 ? c1 : c2, tnow = stop1 ? k0 : k1;
     *tau_out = (c > tnow) ? c : tnow;
     return c;

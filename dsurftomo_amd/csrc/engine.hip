@@ -587,7 +587,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     // the refined boxes are small (129^2): a wider window there costs nothing and saves rounds
     const float window_r = std::max(window_cells, 1.5f) * cell_c / (float)kSgdl;
     HIP_TRY(this, hipMemsetAsync(err.p, 0, 4 * sizeof(int32_t), stream));
-    const int bundle_G = exact_ties == 0 ? choose_bundle_size(step) : 0;
+    const int bundle_G = exact_ties != 2 ? choose_bundle_size(step) : 0;      // (exact_ties = 1: the bundle kernel's tie-detector variant)
     stats[DSA_STAT_BUNDLE_SIZE] = bundle_G;
     bundle_G_now = bundle_G;
     if (bundle_G == 0 && !grow_unit_pool()) return status;      // (plan() shrank the unit pool for bundles this call will not use)
@@ -646,12 +646,12 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                 // the bundles cut in halves on a second stream beside the whole ones: both wait for the stages before, the stream after waits for both
                 if (!stream2) { HIP_TRY(this, hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking)); HIP_TRY(this, hipEventCreateWithFlags(&ev_b0, hipEventDisableTiming)); HIP_TRY(this, hipEventCreateWithFlags(&ev_b1, hipEventDisableTiming)); }
                 HIP_TRY(this, hipEventRecord(ev_b0, stream));
-                launch_fim_bundles(bundles_d.p, bundles_a, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
+                launch_fim_bundles(bundles_d.p, bundles_a, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now, detect);
                 HIP_TRY(this, hipStreamWaitEvent(stream2, ev_b0, 0));
-                launch_fim_bundles(bundles_d.p + bundles_a, bundles_b, bundle_Gb, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream2, bundle_mpl_b);
+                launch_fim_bundles(bundles_d.p + bundles_a, bundles_b, bundle_Gb, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream2, bundle_mpl_b, detect);
                 HIP_TRY(this, hipEventRecord(ev_b1, stream2));
                 HIP_TRY(this, hipStreamWaitEvent(stream, ev_b1, 0));
-            } else if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now);
+            } else if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now, detect);
         }
         HIP_TRY(this, hipEventRecord(events[5], stream));
         if (exact_ties) {

@@ -121,8 +121,9 @@ struct FimBundle {
 };
 size_t bundle_lds_bytes(int tile_words);
 // G = 16, 8 or 4 members per bundle slot (members beyond nmem idle)
-void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int threads /* 256 or 512 */, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream,
-                        int members_per_lane = 4 /* 4, or 2 (256 threads): half the live values per lane, twice the lanes per node */);
+void launch_fim_bundles(const FimBundle* d_bundles, int nbundles, int G, int threads /* 256, 512 or 768 */, const FimProblem* d_problems, const FimEnds* d_ends, int tile_words, hipStream_t stream,
+                        int members_per_lane = 4 /* 4, or 2 (256 threads): half the live values per lane, twice the lanes per node */,
+                        bool tie = false /* the tie detector's variant (exact_ties = 1) */);
 // slowI[id * np + m] = slow_all[m * field_stride + id]
 void launch_interleave_maps(const float* d_slow_all, size_t field_stride, int np, float* d_slowI, hipStream_t stream);
 
