@@ -580,10 +580,16 @@ extern "C" long hc_solve_regular_compare(unsigned long long seed, long n, long* 
             h.outer[q] = h.in_outer[q] ? o : kInf; h.outer_tau[q] = h.outer[q];
             tn[q] = t; t2[q] = h.outer[q];
         }
-        float ka, kb; bool ok;
+        float ka, kb; bool ok, tie = false;
         const float a = solve_node(h, slown, g, &ka);
-        const float b = solve_regular(tn, t2, slown, g, &kb, &ok);
+        const float b = solve_regular(tn, t2, slown, g, &kb, &ok, &tie);
         if (!ok) continue;
+        {   // the tie it reports is the tie solve_node_t<true> probes (the engine's detector routes such evaluations to that form)
+            float kt, ti;
+            (void)solve_node_t<true>(h, slown, g, &kt, &ti);
+            if (stat) { stat[2] += tie ? 1 : 0; }
+            if (tie != (ti >= 0.0f)) { if (bad < 5) std::fprintf(stderr, "solve_regular tie flag differs at case %ld: %d vs influence %g\n", i, (int)tie, (double)ti); ++bad; }
+        }
         if (stat) { stat[0] += 1; if (!(ka > 0.0f) || std::memcmp(&a, &ka, 4) == 0) stat[1] += 0; }
         if (std::memcmp(&a, &b, 4) != 0 || std::memcmp(&ka, &kb, 4) != 0) {
             if (bad < 5) std::fprintf(stderr, "solve_regular differs at case %ld: T %.9g vs %.9g, tau %.9g vs %.9g\n", i, (double)a, (double)b, (double)ka, (double)kb);

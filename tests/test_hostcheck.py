@@ -67,6 +67,7 @@ def test_regular_form_of_the_walk_equals_solve_node(H):
     stat = np.zeros(8, np.int64)
     assert H.hc_solve_regular_compare(20261003, 20_000_000, L.ptr(stat)) == 0
     assert stat[0] > 5e6, stat                                         # (the random cases are adversarial: it takes under half of them)
+    assert stat[2] > 1e4, stat                                         # ... ties among them: its tie flag = solve_node_t<true>'s probe (counted in the return value)
     nx = 35
     g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
     N = g.nnx
