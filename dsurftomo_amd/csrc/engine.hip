@@ -817,13 +817,14 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         if (solo_units) { long cov = 0; for (auto& kv : count) { cov += (kv.second / bundle_opt) * bundle_opt; if (kv.second % bundle_opt >= 2) cov += kv.second % bundle_opt; } *solo_units = (long)h_src.size() - cov; }
         return bundle_opt;
     }
-    // automatic: a bundle is one workgroup where its members would have been G, so it pays only while the bundles still fill the chip
-    // (512 resident workgroups).  Estimated solves/s from the rates measured at 1025^2 with the chip full (unit by unit 10.4 k, bundles of
-    // 4 / 8 / 16: 15.5 k / 20.4 k / 24.5 k; profiles/r03_bundle_sizes.log) times the fill; the best estimate wins.  The ratios hold from 497^2
-    // (40 k unit by unit, 64 k in bundles of 16) to 2033^2 (2.4 k against 4.75 k in bundles of 8) and 4081^2 (0.57 k against 1.1-1.4 k in
-    // bundles of 8); beyond 1500 nodes per side the bundle kernel runs 512 threads wide with 2 x 2048 ready slots, one workgroup per CU
-    // (bundle_threads(): half as many bundles fill the chip).  Grids below 400 nodes per side stay unit by unit: their solves are short.
-    if (std::min(g.nnx, g.nnz) < 400) return 0;
+    // automatic: a bundle is one workgroup where its members would have been G, so it pays only while the bundles still fill the chip.
+    // The best of the estimates below wins: a launch-time model from times measured at 1025^2 (only the ratios decide; they hold from 129^2
+    // to 4097^2: profiles/r03_bundle_sizes.log, r04_bundle_occupancy.log).  Beyond 1500 nodes per side the bundle kernel runs wide (768
+    // threads, one workgroup per CU: a third as many bundles fill the chip); round 3's table of rates serves there.
+    // Grid size: round 3 kept grids below 400 nodes per side unit by unit.  With round 4's kernel the bundles win there too when the call
+    // has the sources (16 periods x 1000 sources: 385^2 66 k -> 141 k solves/s, 257^2 119 k -> 200 k, 129^2 232 k -> 288 k; 200 sources at
+    // 257^2: 101 k -> 116 k; profiles/r04_bundle_occupancy.log), so the floor is 120 nodes per side.
+    if (std::min(g.nnx, g.nnz) < 120) return 0;
     const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
     const double solo_rate = 10.0 * std::min(1.0, n_units / 1100.0);          // k solves/s
     double best = solo_rate * 1.05;
