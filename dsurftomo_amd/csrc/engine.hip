@@ -825,6 +825,10 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     // has the sources (16 periods x 1000 sources: 385^2 66 k -> 141 k solves/s, 257^2 119 k -> 200 k, 129^2 232 k -> 288 k; 200 sources at
     // 257^2: 101 k -> 116 k; profiles/r04_bundle_occupancy.log), so the floor is 120 nodes per side.
     if (std::min(g.nnx, g.nnz) < 120) return 0;
+    // ... but only for launches that fill the chip: below 400 nodes per side a solve is a few hundred short rounds, many unit-by-unit
+    // workgroups share a CU, and a handful of bundles -- the Taipei example: 34 bundles for 449 units at 137^2 -- take longer than the
+    // units by themselves (coarse solves 2.9 -> 7.0 ms); there a size needs 384 bundles of at least 8 members and the wide variant stays off
+    const bool small_grid = std::min(g.nnx, g.nnz) < 400;
     const double n_units = (double)std::min<size_t>(h_src.size(), (size_t)step);
     const double solo_rate = 10.0 * std::min(1.0, n_units / 1100.0);          // k solves/s
     double best = solo_rate * 1.05;
@@ -845,6 +849,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
         for (auto& kv : count) { nb += kv.second / G; covered += (kv.second / G) * G; if (kv.second % G >= 2) { ++nb; covered += kv.second % G; } }
         if (nb == 0 || !fits(G)) continue;
         nb = std::min<long>(nb, (long)step);
+        if (small_grid && (nb < 384 || G < 8)) continue;      // (bundles of 4 lose there: 100 sources x 16 at 257^2 73 k against 93 k unit by unit)
         const double frac = (double)covered / (double)h_src.size();                  // units that end up in bundles ...
         const double fill = (double)covered / ((double)nb * G);                       // ... and how full the bundles are
         double est;
@@ -865,7 +870,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
             est = n_units / (ms * (0.65 + 0.35 * fill) + units_s / std::max(solo_rate, 1e-9));
         }
         bool wide = false;
-        if (bundle_threads_opt == 0 && bundle_threads() == 256 && nb <= 256) {
+        if (bundle_threads_opt == 0 && bundle_threads() == 256 && nb <= 256 && !small_grid) {
             // ... or a CU per bundle, 768 threads wide (one bundle's time at that width, nearly flat in the number of bundles)
             const double ms_w = t_wide[k] + 12.0 * (double)nb / 256.0;
             const double est_w = n_units / (ms_w * (0.65 + 0.35 * fill) + n_units * (1.0 - frac) / std::max(solo_rate, 1e-9));

@@ -65,7 +65,7 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  * unit; > 0 = that many.  Fields stay readable (dsa_get_field) only when the units of the call fit the slots; rows / exact mode / keep_fields
  * calls never recycle), "bundle" (the units of one source -- its periods -- solved side by side by one workgroup under one shared round
  * schedule: 1 default = automatic -- 16 / 8 / 4 members per bundle, whichever the measured rates promise most for the call's sources and
- * periods, on grids of at least 120 nodes per side when the bundles fill the GPU and their field slots fit the memory, else none; 0 = off; 4 / 8 / 16 = that size whatever the count.  Same travel times as unit by unit -- the fixed point does not
+ * periods, on grids of at least 120 nodes per side (below 400: only launches of at least 384 bundles of 8 or 16) when the bundles fill the GPU and their field slots fit the memory, else none; 0 = off; 4 / 8 / 16 = that size whatever the count.  Same travel times as unit by unit -- the fixed point does not
  * depend on the schedule; where a field has exact ties (two self-consistent states) the two can settle differently: measured
  * identical on the headline and checkerboard media, 4 of 262 144 receiver times apart by up to 4.2e-5 s on unrelated random maps; exact_ties = 0 and 1 (the tie detector runs inside the bundles), not 2; "bundle_window_cells" = causal window of the bundles, 0 default = 0.6 (1.25 for launches of at most 256 bundles of 8 or 4, which run 768 threads wide); "bundle_threads" = workgroup size of the bundle kernel, 0 default = 256 (three workgroups per CU) -- 768 (one per CU, twelve waves sharing a round) beyond 1500 nodes per side and for launches of at most 256 bundles --, or 256 / 512 / 768; "bundle_members_per_lane" = 0 default (bundles of 16 four members per lane, bundles of 8 / 4 two per lane when the launch holds more than 512 of them), 4 or 2; "bundle_max_rounds" = round limit of the bundles, 0 default = the solver's own (a bundle that hits it sends its chunk to the unit-by-unit solve; used by the tests of that fallback); "bundle_pool" = bundle field slots, 0 default = as many as bundles can be resident at a time and an eighth more (864 at three 256-thread workgroups per CU / 288 for the wide ones; within the memory budget), claimed by the bundles as they start), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
  * Grid size limit: the coarse solve keeps one bit per 8x8-node tile in LDS (36 KB): up to about 4340 nodes per side (nx <= 545 at dicing 8);
