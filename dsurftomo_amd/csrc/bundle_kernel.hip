@@ -47,6 +47,20 @@ template <int MPL> struct BMem;
 template <> struct BMem<4> { typedef BV4 V; typedef __attribute__((address_space(1))) BV4 GV; };
 template <> struct BMem<2> { typedef BV2 V; typedef __attribute__((address_space(1))) BV2 GV; };
 
+// Round 5: the outer neighbours a node trip fetches.  The regular walk (eikonal_core.h: solve_regular) uses the outer value of ONE
+// neighbour per direction -- the upwind one, the smaller of the two near values -- so the two downwind outer vectors of a trip were 128
+// fetched bytes each that no member read.  Pass A has the pilot's four near times of every listed node in registers anyway: it says
+// which outer neighbours are worth fetching (bit q of a 4-bit code in the top bits of the ready-list entry; record indices stay below
+// 2^28: Engine::choose_bundle_size / fits), pass B fetches those, and a member whose own upwind side is not among them (fronts that
+// collide right there) goes through the slow queue, which reads everything.  A direction whose two near times are both unreached, or
+// closer than a quarter of the causal window (the members' fronts may order them differently), keeps both sides.
+constexpr int kFarShift = 28;
+__device__ __forceinline__ unsigned far_sides(float lo, float hi, float margin)
+{
+    if (!(fabsf(lo - hi) > margin)) return 3u;              // both unreached (inf - inf = NaN), or too close to call
+    return hi < lo ? 2u : 1u;
+}
+
 // OR over the lanes of a node (CH consecutive lanes): quad permutes
 template <int CH>
 __device__ __forceinline__ unsigned node_or(unsigned v)
@@ -73,9 +87,13 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 #endif
 // NT = 256 threads per workgroup up to 1500 nodes per side (128: -1.7 %, 512: -13 % at 1025^2), 512 beyond: a 4097^2 front has ~2700 ready
 // nodes per round, four times what 256 threads and their 2 x 1024 ready slots take
-// TIE: the engine's tie detector (option exact_ties = 1; fim_kernel.hip does the same unit by unit): a member evaluation whose walk stops at
-// an exact tie goes through the slow pass, where solve_node_t<true> measures the tie's influence on the node; influences above the unit's
-// threshold are counted into the unit's tie record (count, largest influence).
+// TIE: the engine's tie detector (options exact_ties / tie_detect).  Round 4 sent every member evaluation whose walk stopped at an exact tie
+// through the slow pass (+10 % kernel time on a medium without a single tie that matters, and transient ties of the iteration were counted
+// like final ones).  Round 5: the detector is a CENSUS OF THE CONVERGED FIELD behind the round loop -- a node's walk stops at a tie exactly
+// when one of its four near neighbours carries its value bit for bit, so one streaming pass over the bundle's field compares every node with
+// its x+ and z+ neighbours (the members of a node side by side in one 16-byte vector), and only the tied (node, member) pairs are evaluated once
+// more, by solve_node_t<true>, for the tie's influence on the node; influences above the unit's threshold go into the unit's tie record
+// (count, largest influence).  The round loop of TIE = true is that of TIE = false.
 template <int G, int NT, int MPL = 4, bool TIE = false>
 __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
@@ -85,7 +103,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     typedef typename BMem<MPL>::V BV;
     typedef typename BMem<MPL>::GV BGV;
     constexpr int NPW = 64 / CH;               // nodes per wave trip
-    constexpr unsigned GB = G * 4u;            // bytes per node
+    constexpr unsigned GB = G * 4u * DSA_BSTRIDE;            // bytes per node (DSA_BSTRIDE = 2, probe builds: every node's segment alone in its 128-byte line -- more fetched bytes, the same instructions)
     extern __shared__ unsigned dyn_lds[];
     __shared__ int sc[BC_COUNT];
     constexpr int kWaveBuf = 256, kTileBuf = NT > 256 ? 128 : 256, kClrWords = 4;      // (512 threads: the per-tile scratch of eight waves has to fit the static LDS)
@@ -129,6 +147,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     BGChar* const slowb = (BGChar*)bd->slowI;
     const unsigned npb = (unsigned)bd->np * 4u;         // bytes of slowness per node
     BGCF32* const risti = (BGCF32*)p.risti;
+    const float far_margin = bd->far_all ? kInf : 0.25f * p.window;
     const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
     const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
     BGChar* const maskb = (BGChar*)(bd->lists + (size_t)my_slot * bd->lists_stride);
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     bool dead = false;
     {
         const BV4 inf4 = { kInf, kInf, kInf, kInf };
-        for (int i = tid; i < ntile * (kTileRecs * G / 4); i += NT) ((BGV4*)Bb)[i] = inf4;
+        for (int i = tid; i < ntile * (kTileRecs * G / 4) * DSA_BSTRIDE; i += NT) ((BGV4*)Bb)[i] = inf4;
         for (int i = tid; i < ntile * (kTileRecs / 4); i += NT) ((BGV4*)Pb)[i] = inf4;
         for (int i = tid; i < (1 << xlog); i += NT) *exc_at((unsigned)i) = kExcEmpty;
         for (int i = tid; i < (ntile << (kMaskShift - 3)); i += NT) *(BGU64*)(maskb + ((size_t)i << 3)) = 0ull;
@@ -257,15 +276,11 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         activate(own_tile + 1, fzp);
         activate(own_tile, own_bits);
     };
-    // one member (index mo of the bundle) of node id, from memory: the slow pass of pass B
-    auto slow_member = [&](int id, int mo, int half, float stale, unsigned& evals, unsigned& nchanged, unsigned& hv_lane, float& kmin_lane, float& smin_lane) {
-        if (mo >= nmem) return;
-        int iz, ix;
-        coords(id, &iz, &ix);
+    // the neighbourhood of one member (index mo of the bundle) of node id from memory, exception table included; returns the node's own state
+    auto load_hood = [&](int id, int mo, int ix, int iz, Hood& h, float* t_old, float* k_old) {
         int nid[8];
         rec_stencil(nbz, id, nid);
         const unsigned mb = (unsigned)mo * 4u;
-        Hood h;
         h.in[0] = ix > 0;          h.in_outer[0] = ix > 1;
         h.in[1] = ix + 1 < nnx;    h.in_outer[1] = ix + 2 < nnx;
         h.in[2] = iz > 0;          h.in_outer[2] = iz > 1;
@@ -296,19 +311,24 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { h.near_[q] = val[q]; h.near_tau[q] = tau[q]; h.outer[q] = val[4 + q]; h.outer_tau[q] = tau[4 + q]; }
-        const float t_old = val[8], k_old = tau[8];
+        *t_old = val[8]; *k_old = tau[8];
+    };
+    // one member of node id, from memory: the slow pass of pass B
+    auto slow_member = [&](int id, int mo, int half, float stale, unsigned& evals, unsigned& nchanged, unsigned& hv_lane, float& kmin_lane, float& smin_lane) {
+        if (mo >= nmem) return;
+        int iz, ix;
+        coords(id, &iz, &ix);
+        const unsigned mb = (unsigned)mo * 4u;
+        Hood h;
+        float t_old, k_old;
+        load_hood(id, mo, ix, iz, h, &t_old, &k_old);
         const int key = id * G + mo;
         if (t_pinned(t_old)) return;
         float k = kInf;
         const float slown = *(BGCF32*)(slowb + (unsigned)id * npb + (unsigned)s_map[mo] * 4u);
         const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
-        float ti = -1.0f;
-        const float c = solve_node_t<TIE>(h, slown, geom, &k, TIE ? &ti : nullptr);
+        const float c = solve_node_t<false>(h, slown, geom, &k, nullptr);
         ++evals;
-        if (TIE && ti >= 0.0f) {
-            const FimProblem* const pm = problems + s_member[mo];
-            if (pm->tie && ti > pm->tie_threshold) { atomicAdd((unsigned*)pm->tie, 1u); atomicMax((unsigned*)pm->tie + 1, bf2u(ti)); }
-        }
         if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return;
         float newv = c;
         if (bf2u(c) != bf2u(k)) { if (!exc_upsert(key, k)) { p.info[2] = -2; sc[BC_OVERFLOW] = 1; } newv = -c; }
@@ -330,6 +350,23 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         }
         if (wm) activate_node(id, wm, half);
     };
+    // the tie census' second look (TIE): member mo of node id in the converged field, evaluated once more with the detector's walk
+    auto tie_member = [&](int id, int mo) {
+        if (mo >= nmem) return;
+        int iz, ix;
+        coords(id, &iz, &ix);
+        if (ix >= nnx || iz >= nnz) return;
+        Hood h;
+        float t_old, k_old;
+        load_hood(id, mo, ix, iz, h, &t_old, &k_old);
+        if (t_pinned(t_old)) return;
+        float k = kInf, ti = -1.0f;
+        const float slown = *(BGCF32*)(slowb + (unsigned)id * npb + (unsigned)s_map[mo] * 4u);
+        const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
+        (void)solve_node_t<true>(h, slown, geom, &k, &ti);
+        const FimProblem* const pm = problems + s_member[mo];
+        if (ti >= 0.0f && pm->tie && ti > pm->tie_threshold) { atomicAdd((unsigned*)pm->tie, 1u); atomicMax((unsigned*)pm->tie + 1, bf2u(ti)); }
+    };
     int* const wq = slowq + wave * kSlowQ;              // the wave's queue of (node << 4 | member) left to the slow pass
     int qn = 0;
 
@@ -344,6 +381,17 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     unsigned mp[MPL], vmask = 0u;                             // (bit m: member sub * MPL + m exists)
 #pragma unroll
     for (int m = 0; m < MPL; ++m) { mp[m] = (unsigned)s_map[sub * MPL + m] * 4u; if (sub * MPL + m < nmem) vmask |= 1u << m; }
+    // (round 5) the lane's members on consecutive maps, the first one a multiple of MPL (the periods of a source in order: the usual
+    // case): their slowness values are one aligned vector of the member-minor copy -- one load instead of MPL
+    bool sl_vec = (bd->np % MPL) == 0;
+    {
+        const int base = sub * MPL < nmem ? s_map[sub * MPL] : 0;
+        sl_vec = sl_vec && (base % MPL) == 0 && base + MPL <= bd->np;
+#pragma unroll
+        for (int m = 1; m < MPL; ++m) if (sub * MPL + m < nmem && s_map[sub * MPL + m] != base + m) sl_vec = false;
+        if (sl_vec) mp[0] = (unsigned)base * 4u;
+    }
+    sl_vec = __all(sl_vec);                                   // (one path per wave)
 
 #ifdef DSA_BUNDLE_CLOCKS      // probe: where a round's wall clock goes (thread 0: pass A incl. its barrier, even half, odd half, bookkeeping), into clocks[0..3] of the pilot
     unsigned long long bt[4] = { 0, 0, 0, 0 }, bt0 = wall_clock64();
@@ -411,9 +459,10 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                 int id[kI], par[kI], slot[kI];
                 float lb[kI], own[kI];
                 bool ppin[kI];
+                unsigned far_code[kI];                                   // (round 5) which outer neighbours pass B fetches: see kFarShift
 #pragma unroll
                 for (int i = 0; i < kI; ++i) {
-                    id[i] = -1; par[i] = 0; slot[i] = 0; lb[i] = kInf; own[i] = kInf; ppin[i] = false;
+                    id[i] = -1; par[i] = 0; slot[i] = 0; lb[i] = kInf; own[i] = kInf; ppin[i] = false; far_code[i] = 15u;
                     if (i * 64 >= nn) continue;
                     const bool have = i * 64 + lane < nn;
                     const int e = have ? nbuf[i * 64 + lane] : 0;
@@ -437,6 +486,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                             if (__builtin_signbit(own[i])) { own[i] = exc_lookup(id[i] * G, &pin); ppin[i] = pin; }
                         }
                         lb[i] = fminf(fminf(a, b2), fminf(c2, d2));
+                        far_code[i] = far_sides(a, b2, far_margin) | (far_sides(c2, d2, far_margin) << 2);
                     }
                 }
                 __builtin_amdgcn_s_setprio(2);
@@ -470,7 +520,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                     const int pe = base_e + __popcll(be[i] & below), po = base_o + __popcll(bo[i] & below);
                     base_e += __popcll(be[i]); base_o += __popcll(bo[i]);
                     const bool got = (want_e && pe < rhalf) || (want_o && po < rhalf);
-                    if (got) ready[want_o ? rhalf + po : pe] = id[i];
+                    if (got) ready[want_o ? rhalf + po : pe] = (int)((unsigned)id[i] | (far_code[i] << kFarShift));
                     if ((got && !want_o) || frozen[i]) atomicOr(&clr[kClrWords * slot[i] + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));
                     if (got && want_o) atomicOr(&clr[kClrWords * slot[i] + 2 + ((id[i] >> 5) & 1)], 1u << (id[i] & 31));     // evaluated by this round's odd half
                     if (have && !frozen[i] && !got) tmin_lane = fminf(tmin_lane, lb[i]);
@@ -542,7 +592,9 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             for (int j0 = wave * NPW; j0 < nready; j0 += NW * NPW) {
                 const int j = j0 + nslot;
                 const bool act = j < nready;
-                const int id = act ? ready[half ? rhalf + j : j] : 0;
+                const unsigned ent = act ? (unsigned)ready[half ? rhalf + j : j] : 0u;
+                const int id = (int)(ent & ((1u << kFarShift) - 1u));
+                const unsigned farc = ent >> kFarShift;                      // outer neighbours to fetch (pass A)
                 int iz, ix;
                 __builtin_amdgcn_s_setprio(3);
                 coords(id, &iz, &ix);
@@ -553,20 +605,25 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                 in[3] = act && iz + 1 < nnz;    in_outer[3] = act && iz + 2 < nnz;
                 int nid[8];
                 rec_stencil(nbz, id, nid);
-                BV infv, vown, sl;
+                BV infv, nanv, vown, sl;
 #pragma unroll
-                for (int m = 0; m < MPL; ++m) { infv[m] = kInf; vown[m] = -1.0f; sl[m] = 1.0f; }          // (inactive lanes read as pinned)
+                for (int m = 0; m < MPL; ++m) { infv[m] = kInf; nanv[m] = __builtin_nanf(""); vown[m] = -1.0f; sl[m] = 1.0f; }          // (inactive lanes read as pinned)
                 BV vn[4], vo[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     vn[q] = in[q] ? *(BGV*)(Bb + (unsigned)nid[q] * GB + sub_b) : infv;
-                    vo[q] = in_outer[q] ? *(BGV*)(Bb + (unsigned)nid[4 + q] * GB + sub_b) : infv;
+                    // (an outer neighbour that exists but is not fetched reads as NaN: solve_regular refuses a member whose upwind side it is, and
+                    // the pruning below counts it as "later than this node", i.e. activates: the conservative side)
+                    vo[q] = !in_outer[q] ? infv : ((farc >> q) & 1u) ? *(BGV*)(Bb + (unsigned)nid[4 + q] * GB + sub_b) : nanv;
                 }
                 if (act) {
                     vown = *(BGV*)(Bb + (unsigned)id * GB + sub_b);
                     const unsigned sb = (unsigned)id * npb;
+                    if (sl_vec) sl = *(BGV*)(slowb + sb + mp[0]);
+                    else {
 #pragma unroll
-                    for (int m = 0; m < MPL; ++m) sl[m] = *(BGCF32*)(slowb + sb + mp[m]);
+                        for (int m = 0; m < MPL; ++m) sl[m] = *(BGCF32*)(slowb + sb + mp[m]);
+                    }
                 }
                 const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
                 __builtin_amdgcn_s_setprio(0);
@@ -599,9 +656,9 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         // (round 4) the walk written out for the regular neighbourhood: straight-line code, about half the instructions of
                         // solve_node_t's loop; where it does not apply (a third neighbour taken in, the opposite neighbour second: ~1 % of
                         // the evaluations) it says so and the member goes to the slow pass like an exceptional one
-                        bool ok, tie = false;
-                        c = solve_regular(tn, t2, sl[m], geom, &k, &ok, TIE ? &tie : nullptr);
-                        if (!ok || (TIE && tie) || bf2u(c) != bf2u(k)) flagged = true;               // (a non-causal result: the table's business; a tie: the detector's)
+                        bool ok;
+                        c = solve_regular(tn, t2, sl[m], geom, &k, &ok);
+                        if (!ok || bf2u(c) != bf2u(k)) flagged = true;               // (a non-causal result: the table's business)
                         else { ++evals; changed = bf2u(c) != bf2u(raw); }
                     }
                     if (valid && flagged) slow |= 1u << m;
@@ -616,7 +673,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         for (int q = 0; q < 4; ++q) {
                             const float ky = tn[q];
                             if (k_lo <= ky) wm |= 1u << q;                               // (interior: the four near neighbours exist)
-                            if (in_outer[q] && ky < kInf && ky > t_lo && k_lo < t2[q]) wm |= 16u << q;
+                            if (in_outer[q] && ky < kInf && ky > t_lo && !(k_lo >= t2[q])) wm |= 16u << q;      // (t2 NaN: not fetched, see above)
                         }
                     }
                 }
@@ -721,11 +778,76 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     }
     __threadfence_block();
     __syncthreads();
+    if (TIE && !failed && !sc[BC_OVERFLOW]) {
+        // ---- tie census of the converged field (see the head of the kernel): a wave takes every NW-th tile, 64 / (G/4) nodes per trip, a lane
+        // four members of its node -- the node against its x+ and z+ neighbours, so that every pair of neighbours is looked at once
+        constexpr int LPN = G / 4, NPI = 64 / LPN;
+        const int csub = lane % LPN, cnode = lane / LPN;
+        const BV4 inf4 = { kInf, kInf, kInf, kInf };
+        int cq = 0;
+        bool lost = false;                     // (a trip with more ties than the queue holds: every member of the bundle counts as tied)
+        auto census_flush = [&]() {
+            lost = lost || cq > kSlowQ;
+            cq = cq < kSlowQ ? cq : kSlowQ;
+            for (int base = 0; base < cq; base += 64) {
+                const int e = base + lane < cq ? wq[base + lane] : -1;
+                if (e >= 0) tie_member(e >> 4, e & 15);
+            }
+            cq = 0;
+        };
+        for (int tile = wave; tile < ntile; tile += NW) {
+#pragma unroll 2
+            for (int r0 = 0; r0 < kTileRecs; r0 += NPI) {
+                const int id = (tile << 6) + r0 + cnode;
+                int iz, ix;
+                coords(id, &iz, &ix);
+                const bool here = ix < nnx && iz < nnz;
+                int nid[8];
+                rec_stencil(nbz, id, nid);
+                const BV4 own = here ? *(BGV4*)(Bb + (unsigned)id * GB + (unsigned)csub * 16u) : inf4;
+                const BV4 vx = (here && ix + 1 < nnx) ? *(BGV4*)(Bb + (unsigned)nid[1] * GB + (unsigned)csub * 16u) : inf4;
+                const BV4 vz = (here && iz + 1 < nnz) ? *(BGV4*)(Bb + (unsigned)nid[3] * GB + (unsigned)csub * 16u) : inf4;
+                unsigned tm = 0u;              // bit m: member m ties with the x+ neighbour, bit 4 + m: with the z+ neighbour
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float a = fabsf(own[m]);
+                    if (a < kInf) { if (a == fabsf(vx[m])) tm |= 1u << m; if (a == fabsf(vz[m])) tm |= 16u << m; }
+                }
+                if (__any(tm != 0u)) {
+                    if (cq + 3 * 4 * 64 > kSlowQ) census_flush();
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        // (the node itself, then the partner of each tie)
+                        const bool p0 = ((tm >> m) & 0x11u) != 0u, p1 = ((tm >> m) & 1u) != 0u, p2 = ((tm >> (4 + m)) & 1u) != 0u;
+                        const int mo = csub * 4 + m;
+                        unsigned long long bal = __ballot(p0);
+                        int pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (p0 && pos < kSlowQ) wq[pos] = (id << 4) | mo;
+                        cq += __popcll(bal);
+                        bal = __ballot(p1);
+                        pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (p1 && pos < kSlowQ) wq[pos] = (nid[1] << 4) | mo;
+                        cq += __popcll(bal);
+                        bal = __ballot(p2);
+                        pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (p2 && pos < kSlowQ) wq[pos] = (nid[3] << 4) | mo;
+                        cq += __popcll(bal);
+                    }
+                }
+            }
+        }
+        census_flush();
+        if (lost && lane < nmem) {
+            const FimProblem* const pm = problems + s_member[lane];
+            if (pm->tie) { atomicAdd((unsigned*)pm->tie, 1u); atomicMax((unsigned*)pm->tie + 1, bf2u(kInf)); }
+        }
+        __syncthreads();
+    }
     for (int m = 0; m < nmem; ++m) {
         const FimEnds* const E = ends + s_member[m];
         const FimProblem* const pm = problems + s_member[m];
         if (tid == 0) {
-            pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = (m == 0 || TIE) ? freezes : 0;      // (TIE: a frozen cycle flags every member of the bundle -- whose it was is not known)
+            pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = m == 0 ? freezes : 0;      // (a statistic: a frozen 2-cycle sits an ulp or two from a tie state, which the census below sees or not by its own rule)
             if (failed && pm->info[2] != -2) pm->info[2] = -1;
             if (sc[BC_OVERFLOW]) pm->info[2] = -2;
         }
@@ -735,7 +857,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                 const RayDesc rd = E->rays[r];
                 if (!(rd.flags & kRayTime)) continue;
                 float t;
-                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)Bslot + m, E->veln, E->dpl, &t, G)) atomicExch(E->err, E->ray0 + r + 1);
+                if (!receiver_time(g, E->scx, E->scz, rd, (const float*)Bslot + m, E->veln, E->dpl, &t, G * DSA_BSTRIDE)) atomicExch(E->err, E->ray0 + r + 1);
                 E->out[rd.data] = t;
             }
         }

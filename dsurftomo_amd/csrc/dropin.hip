@@ -84,6 +84,17 @@ Layout make_layout(int kRc, int kRg, int kLc, int kLg, int kmax, bool clobber)
     return L;
 }
 
+long long g_tie_units = 0, g_tie_left = 0, g_tie_marched = 0;      // tie census of the last drop-in call (dsa_dropin_tie_diagnostics)
+float g_tie_influence = 0.0f;
+void tie_reset() { g_tie_units = g_tie_left = g_tie_marched = 0; g_tie_influence = 0.0f; }
+void tie_collect(dsa_engine* e)
+{
+    double st[DSA_STAT_COUNT + 8];
+    if (dsa_get_stats(e, st) != 0) return;
+    g_tie_units += (long long)st[DSA_STAT_TIE_UNITS]; g_tie_left += (long long)st[DSA_STAT_TIE_UNITS_LEFT]; g_tie_marched += (long long)st[DSA_STAT_EXACT_UNITS];
+    g_tie_influence = std::max(g_tie_influence, (float)st[DSA_STAT_TIE_INFLUENCE_MAX]);
+}
+
 int g_rbint_notes = 0;                // diagnostics of the last dsa_calsurfg call (dsa_dropin_diagnostics)
 long long g_disp_count = 0;
 int g_disp_first[5] = { 0, 0, 0, 0, 0 };
@@ -192,6 +203,7 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     else if (const char* s = getenv("DSA_MAXNAR")) cap = atoll(s);
     *nar = 0;
     g_rbint_notes = 0; g_disp_count = 0;
+    tie_reset();
 
     // Every engine runs the dispersion stage for the whole model (it is small next to the solves) and then its share of the unit
     // list.  Round 3: the share is a set of SOURCES with all their units -- the engine solves the periods of a source side by side
@@ -289,6 +301,7 @@ int dsa_calsurfg(const int* nx, const int* ny, const int* nz, const int* nparpi,
     int first_clamped = -1;
     for (int k = 0; k < ne; ++k) {
         if (part[k].rc != 0) { g_dropin_error = part[k].err; return part[k].rc; }
+        if (ne == 1 || !part[k].units.empty()) tie_collect(g_pool[(size_t)k]);
         n += part[k].n;
         if (part[k].first_clamped >= 0 && (first_clamped < 0 || part[k].first_clamped < first_clamped)) first_clamped = part[k].first_clamped;
     }
@@ -326,6 +339,18 @@ int dsa_dropin_dispersion_failure(int index, int* info, double* vals, float* tab
     dsa_engine* e = dsa_dropin_engine();          // (every engine of a multi-device call runs the whole dispersion stage: the first one's log)
     if (!e) return DSA_ERR_STATE;
     return dsa_dispersion_failure(e, index, info, vals, table, c);
+}
+
+// Tie census of the last dsa_calsurfg / dsa_synthetic call (all its engines): units that hold an exact time tie with an influence above the
+// threshold, how many of them were left to the fixed point (exact_ties = 0: their travel times may differ from the reference's Fast Marching by
+// more than 1e-4 s) and how many were solved again by the reference's march (exact_ties = 1), and the largest influence met.
+int dsa_dropin_tie_diagnostics(long long* flagged_units, long long* left_to_fixed_point, long long* marched_units, float* largest_influence)
+{
+    if (flagged_units) *flagged_units = g_tie_units;
+    if (left_to_fixed_point) *left_to_fixed_point = g_tie_left;
+    if (marched_units) *marched_units = g_tie_marched;
+    if (largest_influence) *largest_influence = g_tie_influence;
+    return 0;
 }
 
 int dsa_dropin_diagnostics(int* rbint_notes, long long* disp_count, int* disp_first, double* disp_period)
@@ -444,7 +469,9 @@ int dsa_synthetic(const int* nx, const int* ny, const int* nz, const int* nparpi
     if ((rc = make_units(L, false, *nsrcsurf, *nrcf, wavetype, igrt, periods, nrc1, nsrcsurf1, scxf, sczf, rcxf, rczf, U)) != 0) return rc;
     if ((rc = dsa_plan_units(e, (int)U.map.size(), U.map.data(), U.sx.data(), U.sz.data(), U.nrec.data(), U.rx.data(), U.rz.data(),
                              U.mode.data(), nullptr, U.data.data())) != 0) return fail(rc);
+    tie_reset();
     if ((rc = dsa_solve(e, obst)) != 0) return fail(rc);
+    tie_collect(e);
     // obst = t + t * gaussian() * noiselevel (:2840).  The reference draws from the compiler's unseeded
     // random_number; the Fortran shim calls this entry with noiselevel 0 and adds the reference's own
     // gaussian() on its side.  Called directly with a non-zero level, a private generator is used.

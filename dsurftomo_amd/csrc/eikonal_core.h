@@ -549,7 +549,10 @@ DSA_HD float solve_regular(const float* tn, const float* t2, float slown, const 
     c2 = onez < c2 ? onez : c2;
     c2 = trav < c2 ? trav : c2;
     const bool stop2 = !(k2 < kInf && c2 > k2);
-    *ok = stop1 || (std2 && stop2);
+    // (round 5, bundle_kernel.hip: an outer value the caller did not fetch arrives as NaN; the walk never reads the downwind ones, and a
+    // member whose UPWIND outer value is missing -- its near neighbour reached -- is not this function's business)
+    const bool missing = (tx2 != tx2 && tx < kInf) || (tz2 != tz2 && tz < kInf);
+    *ok = (stop1 || (std2 && stop2)) && !missing;
     if (tie) *tie = stop1 ? (k1 < kInf && c1 == k1) : (std2 && stop2 && k2 < kInf && c2 == k2);
     const float c = stop1 ? c1 : c2, tnow = stop1 ? k0 : k1;
     *tau_out = (c > tnow) ? c : tnow;

@@ -19,6 +19,16 @@ struct DevBuf {
 
 struct SpmvState;
 
+// Defaults of the tie handling (round 5; DESIGN.md "Modes").  exact_ties = 1: the fixed point, a census of its exact ties, and the units
+// that hold a tie whose influence on its node exceeds tie_threshold solved again by the reference's march itself.  Where nothing is flagged
+// the census costs a few per cent of the solve; a flagged unit costs a march -- one unit's accepts are sequential, 2.3 us each: 35 ms at
+// 121^2, 2.4 s at 1025^2, whatever the number of units marching beside it.  tie_threshold 2e-5 s: below it the ties of a smooth medium
+// (one ulp of a 100 s travel time is 7.6e-6 s) would flag half of the headline's units for differences that stay inside 1e-4 s
+// (profiles/r05_ties_headline.log); it is a heuristic, not a bound -- the guarantee is exact_ties = 2.  exact_ties = 0 opts out
+// (DSA_EXACT_TIES=0 for an unchanged Fortran host); the census still runs (tie_detect) and the call reports what it would have flagged.
+constexpr int kDefaultExactTies = 1;
+constexpr float kDefaultTieThreshold = 2.0e-5f;
+
 struct Engine {
     int device = 0;
     std::string arch;
@@ -87,6 +97,9 @@ struct Engine {
     int bundle_mpl = 0;                // option bundle_members_per_lane: 0 = automatic (bundle_mpl_of), 4, or 2
     bool bundle_wide = false;          // this call's bundles run 768 threads wide on a small grid (choose_bundle_size: a CU per bundle)
     int bundle_mpl_now = 4, bundle_mpl_b = 2;      // ... what the current launch uses (whole bundles; the halved last ones)
+    int bundle_threads_b = 256;                    // workgroup size of the second group of a launch (plan_bundles)
+    int bundle_tail_opt = 0;                       // option bundle_tail: what a launch of 768 .. 1500 bundles does with the ones beyond the first generation: 0 = cut in halves (256 threads), 1 = whole, 768 threads wide
+    int bundle_far_all = 0;                        // option bundle_far_all (A/B): 1 = every node trip fetches all four outer neighbours (round 4's loads)
     int bundles_a = 0, bundles_b = 0, bundle_Gb = 0;      // the launch's bundles: whole ones, and (plan_bundles) the last ones cut in halves of bundle_Gb members on a second stream
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
@@ -105,7 +118,7 @@ struct Engine {
     bool grow_unit_pool();
     int bundle_threads() const;
     float bundle_window() const;
-    size_t bundles_resident(int G, int mpl) const;
+    size_t bundles_resident(int G, int mpl, int threads = 0) const;
     int bundle_mpl_of(int G, long nb) const;
     int choose_bundle_size(int step, long* solo_units = nullptr);
     int plan_bundles(int first, int n, int G, int* nsolo, int* nbundles);
@@ -115,8 +128,9 @@ struct Engine {
     int fim_sorted = 1;                // 1: k_fim_sorted (tile masks, record-order sweep), 0: k_fim (lists); same fixed point
     // exact mode (exact_kernel.hip): 0 off; 1 = units whose fixed-point solve met an exact time tie (or froze a cycle) are solved
     // again by the literal Fast Marching; 2 = every unit by the literal Fast Marching only
-    int exact_ties = 0;
-    float tie_threshold = 2.0e-5f;     // a tie counts when taking the tied neighbour in moves the node's value by more than this (s); 0 = any tie
+    int exact_ties = kDefaultExactTies;
+    float tie_threshold = kDefaultTieThreshold;     // a tie counts when taking the tied neighbour in moves the node's value by more than this (s); 0 = any tie
+    int tie_detect = 1;                // option tie_detect: exact_ties = 0 runs the detector too and reports the units it would have flagged (no second solve)
     int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each, made odd); 0 = by the number of units marching (.. 4799)
     int exact_pool = 0;                // units marching at a time (0 = by free memory, at most exact_pool_max)
     size_t exact_pool_max = 16384;     // option exact_pool_max: four units per wavefront, sixteen wavefronts per CU (measured at 1025^2: 10 240 units 1 500, 12 288 1 600, 16 384 1 700 solves/s)
@@ -196,7 +210,7 @@ struct Engine {
     SpmvState* spmv = nullptr;         // device copy of a COO matrix for dsa_spmv (spmv.hip)
     int lsmr_device_vectors = 0;       // dsa_lsmr: 1 = vectors and ordered reductions on the device, 0 = on the host (lsmr.hip)
 
-    double stats[32] = {};
+    double stats[40] = {};
 
     ~Engine();
     void fail(int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));

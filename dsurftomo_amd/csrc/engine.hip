@@ -215,9 +215,11 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
         if (disp_group_shift > 0) gshift = disp_group_shift;
         else gshift = nlanes <= 4096 ? 3 : nlanes <= 32768 ? 2 : 0;      // measured: 324 curves 21.6 -> 7.8 ms, 17 820 curves 22.7 -> 16.9 ms, 944 k curves 166 -> 285 ms
     }
-    if (disp_failure_log > 0 && ensure(disp_fail_list, (size_t)disp_failure_log)) return status;
+    // (the device lists failing curves in arrival order: room for every curve of the run, so that the FIRST disp_failure_log of the
+    // reference's call order can be picked after the host sort -- a list of disp_failure_log entries kept an arbitrary subset)
+    if (disp_failure_log > 0 && ensure(disp_fail_list, nlanes)) return status;
     launch_dispersion(iwave, geom.p, vels_d.p, ncol, npert, igr, nper, tper.p, disp_ws.p, nlanes, curves.p, h_geom.rmax, in_lds, gshift, disp_diag.p,
-                      disp_failure_log > 0 ? disp_fail_list.p : nullptr, disp_failure_log, stream);
+                      disp_failure_log > 0 ? disp_fail_list.p : nullptr, disp_failure_log > 0 ? (int)std::min<size_t>(nlanes, (size_t)0x7fffffff) : 0, stream);
     launch_depth_kernels(vels_d.p, ncol, disp_nz, nper, curves.p, with_kernels, pvstore.p + (size_t)map_first * ncol, sen_vs.p, sen_vp.p, sen_rho.p,
                          disp_kmax_total, sen_slot, stream);
     HIP_TRY(this, hipEventRecord(events[2], stream));
@@ -241,7 +243,7 @@ int Engine::dispersion_run(int iwave, int igr, int nper, const double* t, int wi
         if (disp_failure_log > 0) {
             // the failing curves of this run in the reference's call order: column by column, the model itself, then its perturbations
             // (CalSurfG.f90:44-150 on one thread; the device reports them in any order)
-            const size_t nl = (size_t)std::min<unsigned long long>(diag[0], (unsigned long long)disp_failure_log);
+            const size_t nl = (size_t)std::min<unsigned long long>(diag[0], (unsigned long long)nlanes);
             std::vector<unsigned long long> list(nl);
             HIP_TRY(this, hipMemcpy(list.data(), disp_fail_list.p, nl * 8, hipMemcpyDeviceToHost));
             std::vector<DispFailRec> recs;
@@ -416,7 +418,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         size_t P = field_pool_opt > 0 ? (size_t)field_pool_opt : std::max<size_t>((size_t)4 * resident, roomy);
         // units that will be solved inside bundles (bundle_kernel.hip) need no slot of their own unless rays follow (solve() grows the
         // pool then): the pool shrinks to what the left-over units can use, and the memory goes to the bundle fields
-        if (field_pool_opt == 0 && !keep_fields && exact_ties == 0) {
+        if (field_pool_opt == 0 && !keep_fields && exact_ties != 2) {
             long solo_units = 0;
             if (choose_bundle_size(nunits, &solo_units) > 0) P = std::min<size_t>(P, (size_t)std::max<long>(256, 2 * solo_units));
         }
@@ -464,7 +466,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
 // crawls (75 k against 186 k solves/s at 121^2).  Returns false on an allocation error.
 bool Engine::grow_unit_pool()
 {
-    if (field_pool_opt != 0 || keep_fields || exact_ties != 0) return true;
+    if (field_pool_opt != 0 || keep_fields || exact_ties == 2) return true;
     const int resident = 256 * std::max(1, std::min(4, 1024 / std::max(shape_c.threads, 1)));
     const size_t roomy = std::min<size_t>(16384, ((size_t)16 << 30) / per_slot_bytes);
     size_t P = std::min<size_t>(std::max<size_t>((size_t)4 * resident, roomy), (size_t)std::max<size_t>(h_src.size(), 1));
@@ -489,13 +491,14 @@ size_t Engine::solve_stage_bytes() const
 
 // bundles the chip holds at a time: one workgroup of 512 threads per CU, two of 256 (four members per lane: 204 VGPRs) or three (two
 // members per lane: 168 VGPRs, round 4)
-size_t Engine::bundles_resident(int G, int mpl) const
+size_t Engine::bundles_resident(int G, int mpl, int threads) const
 {
+    if (threads <= 0) threads = bundle_threads();
 #ifdef DSA_BUNDLE_WAVES          // (probe builds: bundle_kernel.hip compiled for that many waves per SIMD whatever the members per lane)
-    if (bundle_threads() == 256) return (size_t)256 * DSA_BUNDLE_WAVES;
+    if (threads == 256) return (size_t)256 * DSA_BUNDLE_WAVES;
 #endif
     // (bundle_kernel.hip: DSA_BUNDLE_OCC -- three workgroups of 256 threads per CU with two members per lane and for bundles of 16)
-    return (size_t)256 * (bundle_threads() >= 512 ? 1 : (mpl == 2 || G == 16) ? 3 : 2);
+    return (size_t)256 * (threads >= 512 ? 1 : (mpl == 2 || G == 16) ? 3 : 2);
 }
 
 // Members per lane of a launch of nb bundles of G: the option, or 16 members four per lane; 8 and 4 members two per lane (three workgroups
@@ -559,9 +562,13 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
       std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
       stats[DSA_STAT_MS_DISPERSION] = keep_ms; stats[DSA_STAT_CURVES] = keep_n; }
     std::fill(phase_ticks, phase_ticks + kClockSlots, 0.0);
+    std::fill(h_unit_flags.begin(), h_unit_flags.end(), (unsigned char)0);      // (per solve: a unit marched by an earlier call with other options is not "marched")
+    std::fill(h_unit_tie.begin(), h_unit_tie.end(), 0.0f);
     // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
     // the solve (rays and rows, the exact mode, keep_fields) a launch takes one unit per slot
-    const bool may_recycle = !rows && exact_ties == 0 && !keep_fields;
+    // (round 5: exact_ties = 1 runs like exact_ties = 0 -- recycled slots, receiver times from the solve's own field -- and the units the
+    // detector flags are marched afterwards from scratch, their receiver times written again from the marched fields)
+    const bool may_recycle = !rows && exact_ties != 2 && !keep_fields;
     // exact_ties = 2 with nothing wanted but receiver times: every unit the per-unit arrays hold in one launch, times from the marched fields
     const bool exact_fused = exact_ties == 2 && !rows && !keep_fields;
     if (!may_recycle && !exact_fused && field_pool_opt == 0 && pool_slots < std::min(chunk, nunits)) {
@@ -576,7 +583,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         }
     }
     const int step = (may_recycle || exact_fused) ? chunk : std::min(chunk, pool_slots);
-    const bool fused_times = exact_ties == 0;          // the coarse solve writes its unit's receiver times itself
+    const bool fused_times = exact_ties != 2;          // the coarse solve writes its unit's receiver times itself
     stats[DSA_STAT_UNITS] = nunits;
     stats[DSA_STAT_CHUNK] = step;
     stats[DSA_STAT_FIELD_SLOTS] = pool_slots;
@@ -618,7 +625,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             for (int r = 0; r < n; ++r) h_launch_rank[(size_t)far[r].second] = r;
             HIP_TRY(this, hipMemcpyAsync(launch_rank.p, h_launch_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
         }
-        const bool detect = exact_ties == 1;
+        // the tie detector runs in the fixed-point modes (round 5: in exact_ties = 0 too, option tie_detect, so that a call that leaves tie-prone
+        // units to the fixed point can say so: DSA_STAT_TIE_UNITS / DSA_STAT_TIE_UNITS_LEFT, dsa_unit_ties)
+        const bool detect = exact_ties == 1 || (exact_ties == 0 && tie_detect);
         // bundles: the units of one source side by side in one workgroup (bundle_kernel.hip).  Solo units keep the launch ranks
         // 0 .. nsolo-1 (and the field slots those select), the members of the bundles follow, bundle by bundle.
         int nsolo = n, nbundles = 0;
@@ -648,7 +657,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                 HIP_TRY(this, hipEventRecord(ev_b0, stream));
                 launch_fim_bundles(bundles_d.p, bundles_a, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now, detect);
                 HIP_TRY(this, hipStreamWaitEvent(stream2, ev_b0, 0));
-                launch_fim_bundles(bundles_d.p + bundles_a, bundles_b, bundle_Gb, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream2, bundle_mpl_b, detect);
+                launch_fim_bundles(bundles_d.p + bundles_a, bundles_b, bundle_Gb, bundle_threads_b, prob_c.p, ends_c.p, sc.tile_words, stream2, bundle_mpl_b, detect);
                 HIP_TRY(this, hipEventRecord(ev_b1, stream2));
                 HIP_TRY(this, hipStreamWaitEvent(stream, ev_b1, 0));
             } else if (nbundles) launch_fim_bundles(bundles_d.p, nbundles, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now, detect);
@@ -668,14 +677,18 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                     float a, c2;
                     std::memcpy(&a, t + 1, 4); std::memcpy(&c2, t + 3, 4);
                     h_unit_tie[(size_t)(first + u)] = std::max(a, c2);
-                    const bool frozen = h_inf[(size_t)u * 16 + 3] + h_inf[(size_t)u * 16 + 11] > 0;
+                    // (a frozen cycle of a unit-by-unit solve flags its unit; inside a bundle the census of the converged field decides, bundle_kernel.hip)
+                    const bool member = nbundles > 0 && h_member_flag[(size_t)u] != 0;
+                    const bool frozen = h_inf[(size_t)u * 16 + 3] > 0 || (!member && h_inf[(size_t)u * 16 + 11] > 0);
                     if (t[0] > 0 || t[2] > 0 || frozen) { h_unit_flags[(size_t)(first + u)] |= 1; xl.push_back(u); }
                 }
                 stats[DSA_STAT_TIE_UNITS] += (double)xl.size();
             }
             if (!xl.empty()) {
                 const auto w0 = std::chrono::steady_clock::now();
-                if (run_exact(first, n, xl, exact_fused, !exact_fused || n <= pool_slots) != 0) return status;
+                // exact_ties = 1: the flagged units' receiver times once more, from the marched fields; their compact fields into the units'
+                // slots when every unit of the launch has one (rays, keep_fields, small calls)
+                if (run_exact(first, n, xl, exact_fused || exact_ties == 1, exact_ties == 1 ? n <= pool_slots : (!exact_fused || n <= pool_slots)) != 0) return status;
                 stats[DSA_STAT_MS_EXACT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
             }
         }
@@ -687,6 +700,8 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         HIP_TRY(this, hipGetLastError());
         h_info.resize((size_t)n * 16);
         h_flags.resize((size_t)n * 4);
+        std::vector<int32_t> h_tie0;
+        if (exact_ties == 0 && detect) { h_tie0.resize((size_t)n * 4); HIP_TRY(this, hipMemcpyAsync(h_tie0.data(), tieinfo.p, (size_t)n * 16, hipMemcpyDeviceToHost, stream)); }
         HIP_TRY(this, hipMemcpyAsync(h_info.data(), info.p, (size_t)n * 16 * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipMemcpyAsync(h_flags.data(), flags.p, (size_t)n * 4 * 4, hipMemcpyDeviceToHost, stream));
         if (dsurf && r1 > r0) {
@@ -747,7 +762,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         }
         for (int u = 0; u < n; ++u) {
             const int32_t* fi = &h_info[(size_t)u * 16];
-            if (fi[10] == -3) { fail(DSA_ERR_INTERNAL, "unit %d: its field slot was never released by the slot's previous user (recycled slots assume in-order workgroup dispatch; set option field_pool = -1 for a slot per unit)", first + u); return DSA_ERR_INTERNAL; }
+            if (fi[10] == -3) { fail(DSA_ERR_INTERNAL, "unit %d: no free field slot within the wait bound (pool of %d slots, claimed by compare-and-swap: a pool smaller than the resident workgroups on very long solves, or corrupted busy flags; set option field_pool = -1 for a slot per unit)", first + u, pool_slots); return DSA_ERR_INTERNAL; }
             if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
             if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
             stats[DSA_STAT_ROUNDS_MAX] = std::max(stats[DSA_STAT_ROUNDS_MAX], (double)fi[8]);
@@ -760,6 +775,18 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             stats[DSA_STAT_RESCANS] += fi[1] + fi[9];
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
         }
+        if (!h_tie0.empty()) {      // exact_ties = 0: what the detector saw is reported, nothing is solved again
+            for (int u = 0; u < n; ++u) {
+                const int32_t* t = &h_tie0[(size_t)u * 4];
+                float a, c2;
+                std::memcpy(&a, t + 1, 4); std::memcpy(&c2, t + 3, 4);
+                h_unit_tie[(size_t)(first + u)] = std::max(a, c2);
+                const bool member = nbundles > 0 && h_member_flag[(size_t)u] != 0;
+                const bool frozen = h_info[(size_t)u * 16 + 3] > 0 || (!member && h_info[(size_t)u * 16 + 11] > 0);
+                if (t[0] > 0 || t[2] > 0 || frozen) { h_unit_flags[(size_t)(first + u)] |= 1; stats[DSA_STAT_TIE_UNITS] += 1.0; stats[DSA_STAT_TIE_UNITS_LEFT] += 1.0; }
+            }
+        }
+        for (int u = 0; u < n; ++u) stats[DSA_STAT_TIE_INFLUENCE_MAX] = std::max(stats[DSA_STAT_TIE_INFLUENCE_MAX], (double)h_unit_tie[(size_t)(first + u)]);
         last_chunk_first = first;                               // the per-unit arrays (refined snapshots, ...) of this chunk stay resident ...
         last_chunk_n = n;
         fields_resident = n <= pool_slots;                      // ... the coarse fields only when every unit had a slot (recycled slots: gone)
@@ -803,9 +830,10 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
     free_b += B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;          // (what a previous call holds is reused)
     free_b = bundle_room(free_b);
-    auto slot_bytes = [&](int G) { int lg = G == 16 ? 4 : G == 8 ? 3 : 2; return (size_t)(G + 1) * nrec_c * 4 + ((size_t)8 << (exc_log2cap + lg)) + lists_c_stride * 4; };
+    auto slot_bytes = [&](int G) { int lg = G == 16 ? 4 : G == 8 ? 3 : 2; return (size_t)(G * DSA_BSTRIDE + 1) * nrec_c * 4 + ((size_t)8 << (exc_log2cap + lg)) + lists_c_stride * 4; };
     auto fits = [&](int G) {
-        if ((unsigned long long)nrec_c * (unsigned long long)G * 4ull >= (1ull << 32)) return false;          // 32-bit byte offsets inside a bundle field
+        if ((unsigned long long)nrec_c * (unsigned long long)G * 4ull * DSA_BSTRIDE >= (1ull << 32)) return false;          // 32-bit byte offsets inside a bundle field
+        if (nrec_c >= ((size_t)1 << 28)) return false;                                                          // (record indices share the ready-list word with the far-load code)
         if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
         if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
         const long nb = std::min<long>(bundles_with(G), (long)step);
@@ -928,8 +956,16 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     const int res3 = 768;
     bundle_mpl_now = bundle_mpl_of(G, nb);
     bundle_mpl_b = bundle_mpl ? bundle_mpl : 2;
+    bundle_threads_b = bundle_threads();
     std::vector<std::pair<float, std::vector<int>>> tail;
-    if (auto_mpl && bundle_opt == 1 && G >= 8 && nb > res3 && nb < 1500) {
+    if (auto_mpl && bundle_opt == 1 && G >= 8 && nb > res3 && nb < 1500 && bundle_tail_opt == 1 && nb - res3 <= 256) {
+        // Round 5, option bundle_tail = 1: the bundles beyond the first generation stay WHOLE and run 768 threads wide on the second stream, a CU
+        // each as the first generation's workgroups leave (a bundle of 16 alone on a CU: 106 ms wide against 190 with 256 threads)
+        tail.assign(pieces.begin() + res3, pieces.end());
+        pieces.resize((size_t)res3);
+        bundles_a = res3; bundles_b = (int)tail.size(); bundle_Gb = G;
+        bundle_mpl_b = 4; bundle_threads_b = 768;
+    } else if (auto_mpl && bundle_opt == 1 && G >= 8 && nb > res3 && nb < 1500) {
         std::vector<std::pair<float, std::vector<int>>> keep(pieces.begin(), pieces.begin() + res3);
         for (size_t k = (size_t)res3; k < pieces.size(); ++k) {
             const std::vector<int>& v = pieces[k].second;
@@ -959,11 +995,11 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         if (r.count == 0) continue;
         const int lg = r.G == 16 ? 4 : r.G == 8 ? 3 : 2;
         r.xlog = exc_log2cap + lg;
-        r.b_stride = (size_t)(r.G + 1) * nrec_c;
+        r.b_stride = (size_t)(r.G * DSA_BSTRIDE + 1) * nrec_c;
         const size_t slot_b = r.b_stride * 4 + ((size_t)8 << r.xlog) + lists_c_stride * 4;
         const size_t room = (size_t)(0.7 * (double)free_b) / slot_b / (bundles_b ? 2 : 1);
         if (room < 1) { fail(DSA_ERR_DEVICE, "bundles: no room for one bundle field slot (%zu B)", slot_b); return DSA_ERR_DEVICE; }
-        const size_t resident = bundles_resident(r.G, q == 0 ? bundle_mpl_now : bundle_mpl_b);
+        const size_t resident = bundles_resident(r.G, q == 0 ? bundle_mpl_now : bundle_mpl_b, q == 0 ? bundle_threads() : bundle_threads_b);
         r.slots = (int)std::min<size_t>({ (size_t)r.count, (size_t)(bundle_pool_opt > 0 ? bundle_pool_opt : (int)(resident + resident / 8)), room });
         r.b_off = b_total; r.exc_off = exc_total; r.slot0 = slots_total;
         b_total += (size_t)r.slots * r.b_stride; exc_total += (size_t)r.slots << r.xlog; slots_total += (size_t)r.slots;
@@ -979,11 +1015,11 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         const std::vector<int>& mem = k < bundles_a ? pieces[(size_t)k].second : tail[(size_t)(k - bundles_a)].second;
         const int kk = k < bundles_a ? k : k - bundles_a;
         FimBundle& bd = h_bundles[(size_t)k];
-        bd.B = B_pool.p + r.b_off; bd.b_stride = r.b_stride; bd.p_offset = (size_t)r.G * nrec_c;
+        bd.B = B_pool.p + r.b_off; bd.b_stride = r.b_stride; bd.p_offset = (size_t)r.G * DSA_BSTRIDE * nrec_c;
         bd.exc = exc_b.p + r.exc_off; bd.exc_stride = (size_t)1 << r.xlog; bd.exc_log2cap = r.xlog;
         bd.lists = lists_b.p + r.slot0 * lists_c_stride; bd.lists_stride = lists_c_stride;
         bd.slot_busy = r.slots < r.count ? bpool_gen.p + r.slot0 : nullptr; bd.nslots = r.slots; bd.slot = r.slots < r.count ? 0 : kk;
-        bd.slowI = slowI.p; bd.np = nmaps;
+        bd.slowI = slowI.p; bd.np = nmaps; bd.far_all = bundle_far_all;
         bd.nmem = (int)mem.size();
         for (int m = 0; m < kBundleMax; ++m) { bd.member[m] = 0; bd.map[m] = 0; }
         for (int m = 0; m < bd.nmem; ++m) {
@@ -1328,14 +1364,17 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "bundle_window_cells" && value >= 0) { en->bundle_window_opt = (float)value; return 0; }
     if (n == "bundle_threads" && (value == 0 || value == 256 || value == 512 || value == 768)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
+    if (n == "bundle_tail" && (value == 0 || value == 1)) { en->bundle_tail_opt = (int)value; return 0; }
+    if (n == "bundle_far_all" && (value == 0 || value == 1)) { en->bundle_far_all = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
     if (n == "bundle_members_per_lane" && (value == 0 || value == 4 || value == 2)) { en->bundle_mpl = (int)value; return 0; }
     if (n == "bundle" && (value == 0 || value == 1 || value == 4 || value == 8 || value == 16)) { en->planned = false; en->bundle_opt = (int)value; return 0; }
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
+    if (n == "tie_detect" && (value == 0 || value == 1)) { en->tie_detect = (int)value; return 0; }
     if (n == "disp_failure_log" && value >= 0 && value <= 65536) { en->disp_failure_log = (int)value; return 0; }
-    if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4991))) { en->exact_lds_slots = (int)value; return 0; }
-    if (n == "exact_pool" && value >= 0) { en->exact_pool = (int)value; return 0; }
+    if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4975))) { en->exact_lds_slots = (int)value; return 0; }
+    if (n == "exact_pool" && value >= 0 && value <= 65535) { en->exact_pool = (int)value; return 0; }
     if (n == "exact_pool_max" && value >= 4 && value <= 32768) { en->exact_pool_max = (size_t)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }
     en->fail(DSA_ERR_ARGUMENT, "unknown option or bad value: %s=%g", name, value);

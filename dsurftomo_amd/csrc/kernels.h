@@ -98,6 +98,9 @@ struct FimLaunch {
 // (tests/tools/bundle_lab.cpp measures what sharing costs: +4...+9 % evaluations for maps that are multiples of one pattern, +13...+20 % for
 // mixtures of patterns, +56 % for unrelated random maps), so each member's field is the one its own solve produces.
 constexpr int kBundleMax = 16;
+#ifndef DSA_BSTRIDE
+#define DSA_BSTRIDE 1          // probe builds (-DDSA_BSTRIDE=2): the nodes of a bundle field twice as far apart, i.e. one 64-byte segment per 128-byte line (tools/bytes_probe.sh)
+#endif
 struct FimBundle {
     // the pool of bundle field slots (round 3, late: a bundle CLAIMS a free slot when it starts -- `slot_busy`, one flag per slot -- instead
     // of being given one by number: with the bundles launched longest first, "slot = number mod slots" made the second generation wait
@@ -115,6 +118,7 @@ struct FimBundle {
     int nslots, slot;
     const float* slowI;           // member-minor slowness of all maps: slowI[id * np + map]
     int np;
+    int far_all;                  // 1: pass A asks for all four outer neighbours of every node (option bundle_far_all; A/B of round 5's upwind-only loads)
     int nmem;
     int member[kBundleMax];       // indices into the launch's FimProblem / FimEnds arrays (grid, seeds, window records, receivers, info)
     int map[kBundleMax];

@@ -45,6 +45,11 @@ module dsa_bindings
       integer(c_long_long) :: disp_count
       real(c_double) :: disp_period
     end function
+    integer(c_int) function dsa_dropin_tie_diagnostics(flagged, left, marched, influence) bind(C, name='dsa_dropin_tie_diagnostics')
+      import :: c_int, c_long_long, c_float
+      integer(c_long_long) :: flagged, left, marched
+      real(c_float) :: influence
+    end function
     integer(c_int) function dsa_dropin_dispersion_failure(index, info, vals, table, c) bind(C, name='dsa_dropin_dispersion_failure')
       import :: c_int, c_double, c_float
       integer(c_int), value :: index
@@ -94,6 +99,26 @@ subroutine CalSurfG(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf, &
        scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,nar)
   if (rc /= 0) call dsa_stop('CalSurfG')
   call dsa_report()
+  call dsa_report_ties('CalSurfG')
+end subroutine
+
+! Not a message of the reference: one line on unit 6 when a call left travel-time fields with exact time ties to the fixed-point solve
+! (DSA_EXACT_TIES=0 in the environment).  With the default (exact_ties = 1) such fields are solved again by the reference's own march and
+! nothing is written.
+subroutine dsa_report_ties(where)
+  use dsa_bindings
+  implicit none
+  character(len=*), intent(in) :: where
+  integer(c_long_long) :: nflag, nleft, nmarch
+  real(c_float) :: infl
+  integer :: rc
+  rc = dsa_dropin_tie_diagnostics(nflag, nleft, nmarch, infl)
+  if (rc /= 0) return
+  if (nleft > 0) then
+    write(6,'(a,a,a,i0,a,es9.2,a)') ' dsurftomo_amd (', where, '): ', nleft, &
+      ' (period, source) travel-time fields hold exact time ties (largest influence ', infl, &
+      ' s) and were left to the fixed-point solve (DSA_EXACT_TIES=0): they may differ from Fast Marching by more than 1e-4 s'
+  endif
 end subroutine
 
 ! The reference's non-fatal messages, written where and how it writes them.
@@ -202,6 +227,7 @@ subroutine synthetic(nx,ny,nz,nparpi,vels,obst, &
        kmaxRc,kmaxRg,kmaxLc,kmaxLg,tRc,tRg,tLc,tLg,wavetype,igrt,periods,depz,minthk, &
        scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,zero)
   if (rc /= 0) call dsa_stop('synthetic')
+  call dsa_report_ties('synthetic')
   ! the 2-D velocity maps the reference writes for plotting (CalSurfG.f90:2559-2617), same statements
   kper = (/ kmaxRc, kmaxRg, kmaxLc, kmaxLg /)
   fname = (/ 'velmap2dRc.dat  ', 'velmap2dRg.dat  ', 'velmap2dLc.dat  ', 'velmap2dLg.dat  ' /)

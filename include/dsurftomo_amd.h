@@ -236,7 +236,10 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_RAYS_CLAMPED, DSA_STAT_MS_RAYS, DSA_STAT_MS_ROWS, DSA_STAT_NAR, DSA_STAT_MS_DISPERSION,
        DSA_STAT_CURVES, DSA_STAT_CHANGES_TOTAL, DSA_STAT_TIE_UNITS, DSA_STAT_EXACT_UNITS, DSA_STAT_EXACT_POPS,
        DSA_STAT_MS_EXACT, DSA_STAT_FIELD_SLOTS, DSA_STAT_FOOTPRINT_MB, DSA_STAT_BUNDLE_SIZE, DSA_STAT_BUNDLES,
-       DSA_STAT_BUNDLED_UNITS, DSA_STAT_BUNDLE_SLOTS, DSA_STAT_BUNDLE_THREADS, DSA_STAT_COUNT };
+       DSA_STAT_BUNDLED_UNITS, DSA_STAT_BUNDLE_SLOTS, DSA_STAT_BUNDLE_THREADS,
+       DSA_STAT_TIE_UNITS_LEFT,       /* units the tie detector flagged (DSA_STAT_TIE_UNITS, filled in every mode) that stayed with the fixed point: exact_ties = 0 */
+       DSA_STAT_TIE_INFLUENCE_MAX,    /* largest tie influence met (seconds) */
+       DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 
 /* ---- drop-in level -------------------------------------------------------------------------- */
@@ -294,6 +297,11 @@ int dsa_dropin_velocity_maps(const int* which, double* pv);
  *   disp_count / disp_first[5] / disp_period: see dsa_dispersion_diagnostics (the reference writes its block to unit 66).
  * The C level prints nothing itself; dsurftomo_amd/fortran/calsurfg_shim.f90 writes the reference's texts. */
 int dsa_dropin_diagnostics(int* rbint_notes, long long* disp_count, int* disp_first, double* disp_period);
+/* Tie census of the last dsa_calsurfg / dsa_synthetic call (see dsa_unit_ties): units holding an exact time tie whose influence exceeds the
+ * threshold; how many of them stayed with the fixed point (exact_ties = 0 -- their times may differ from the reference's Fast Marching by more
+ * than 1e-4 s; the shim writes one line about it to unit 6) and how many were solved again by the reference's march (exact_ties = 1, the default);
+ * the largest influence met, in seconds.  Any pointer may be NULL. */
+int dsa_dropin_tie_diagnostics(long long* flagged_units, long long* left_to_fixed_point, long long* marched_units, float* largest_influence);
 /* dsa_dispersion_failure of the last dsa_calsurfg call (environment DSA_DISP_FAILURE_LOG = N switches the log on): the shim then writes
  * the reference's unit-66 block once per failing surfdisp96 call, layer table included */
 int dsa_dropin_dispersion_failure(int index, int* info, double* vals, float* table, double* c);

@@ -30,6 +30,21 @@ def pytest_terminal_summary(terminalreporter):
         pass
 
 
+# the product's defaults of the options tests change (csrc/engine.h: kDefaultExactTies, kDefaultTieThreshold); every GPU test starts from them
+PRODUCT_DEFAULTS = (("exact_ties", 1), ("tie_threshold", 2e-5), ("tie_detect", 1), ("bundle", 1), ("bundle_pool", 0), ("field_pool", 0), ("max_chunk", 0),
+                    ("exact_lds_slots", 0), ("exact_pool", 0), ("bundle_members_per_lane", 0), ("bundle_threads", 0), ("bundle_far_all", 0), ("bundle_tail", 0))
+
+
+@pytest.fixture(autouse=True)
+def _product_defaults(request):
+    """a test that takes the session's engine finds it with the product's defaults, whatever the test before it left behind"""
+    if "engine" in request.fixturenames:
+        e = request.getfixturevalue("engine")
+        for k, v in PRODUCT_DEFAULTS:
+            e.set_option(k, v)
+    yield
+
+
 @pytest.fixture(scope="session")
 def engine():
     """One engine per session; fails loudly when the HIP library or the GPU is missing."""

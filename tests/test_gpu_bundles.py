@@ -31,10 +31,8 @@ def bits(a):
 
 @pytest.fixture()
 def bundles(engine):
-    yield engine
-    engine.set_option("bundle", 1)
-    engine.set_option("bundle_pool", 0)
-    engine.set_option("field_pool", 0)
+    engine.set_option("exact_ties", 0)          # the bundle kernel -- the fixed point -- is the subject: no unit is handed to the march behind it
+    yield engine          # (conftest's _product_defaults puts the options back before the next test)
 
 
 def mixed_maps(nx, nper):
@@ -382,7 +380,7 @@ def test_wide_bundle_kernel_against_the_oracle_at_config4_size(bundles):
     """VERDICT r03 item 1 of "what's missing": at 4097^2 the engine picks the wide bundle kernel (k_fim_bundle<8, 768>; round 3: <8, 512>).  configs[4]'s grid and medium (checkerboard
     +-8 %, 16-vertex squares), 8 sources x 8 periods = 64 units in 8 bundles of 8, 16 receivers each, against the oracle's Fast Marching.
     The medium is the named tie case of the fixed-point solve: the bundled times must be the unit-by-unit solve's class of
-    result -- within the tie noise measured for this medium (tests/test_gpu_fullsize.py KNOWN) -- and the exact mode on the same units the
+    result -- within the band of tie noise measured for this medium (tests/test_gpu_fullsize.py BANDS) -- and the exact mode on the same units the
     oracle's bit for bit."""
     e = bundles
     nx, nsrc, nper, nrec = 515, 8, 8, 16
@@ -399,17 +397,21 @@ def test_wide_bundle_kernel_against_the_oracle_at_config4_size(bundles):
     ts = e.traveltimes(**u).reshape(n, nrec)
     d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
     ds = np.abs(ts.astype(np.float64) - ref.astype(np.float64))
-    try:
-        e.set_option("exact_ties", 2)
-        tx = e.traveltimes(**u).reshape(n, nrec)
-    finally:
-        e.set_option("exact_ties", 0)
-    parity_log.add(f"k_fim_bundle<8,768> vs oracle, configs[4] medium N=4097: {n} units x {nrec} receivers in {nsrc} bundles of 8: max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())} of {d.size}, "
+    e.set_option("exact_ties", 2)
+    tx = e.traveltimes(**u).reshape(n, nrec)
+    e.set_option("exact_ties", 1)              # the product's default: the bundle kernel with its tie census, flagged units marched
+    e.set_option("bundle", 8)
+    t1 = e.traveltimes(**u).reshape(n, nrec)
+    st1 = e.stats()
+    d1 = np.abs(t1.astype(np.float64) - ref.astype(np.float64))
+    parity_log.add(f"k_fim_bundle<8,768> vs oracle, configs[4] medium N=4097: {n} units x {nrec} receivers in {nsrc} bundles of 8, fixed point alone [reported]: max |dt| {d.max():.3g} s, beyond 1e-4 s {int((d > TOL).sum())} of {d.size}, "
                    f"not bit-identical {int((bits(t) != bits(ref)).sum())} | unit by unit: max |dt| {ds.max():.3g} s, beyond {int((ds > TOL).sum())} | bundled vs unit by unit: {int((bits(t) != bits(ts)).sum())} differ, "
-                   f"max {np.abs(t - ts).max():.3g} s | exact mode: not bit-identical {int((bits(tx) != bits(ref)).sum())}")
+                   f"max {np.abs(t - ts).max():.3g} s | exact_ties=2: not bit-identical {int((bits(tx) != bits(ref)).sum())} | default mode (census inside the bundles): {int(st1['tie_units'])} of {n} units flagged and marched, "
+                   f"beyond 1e-4 s {int((d1 > TOL).sum())}, max |dt| {d1.max():.3g} s")
     assert (bits(tx) != bits(ref)).sum() == 0
-    # tie noise of this medium at this size (unit by unit: 3.4 % of the receiver times beyond 1e-4 s, worst 6.9e-4 s): the bundled solve must
-    # stay inside the same bounds, and no further from the oracle than a small multiple of the unit-by-unit solve
+    assert (d1 > TOL).sum() == 0                # the default mode holds the bar on configs[4]'s medium through the bundle kernel's census
+    # the fixed point alone: tie noise of this medium at this size (unit by unit: 3.4 % of the receiver times beyond 1e-4 s, worst 6.9e-4 s) --
+    # the bundled solve is reported, bounded by that band, and no further from the oracle than a small multiple of the unit-by-unit solve
     assert d.max() <= 1.2e-3 and (d > TOL).sum() <= 0.08 * d.size
     assert (d > TOL).sum() <= 2 * (ds > TOL).sum() + 8
 

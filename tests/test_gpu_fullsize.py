@@ -26,19 +26,18 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-# (nx, medium, period, field bound, nodes beyond 1e-4 s).  Receivers: 1e-4 s in every case.
-# Generic media: the north_star bar, 1e-4 s, over the whole field.  The checkerboard of configs[4] (homogeneous blocks
-# aligned with the grid) produces exact time ties between neighbouring narrow-band nodes; the reference's answer there
-# depends on which of the two its heap pops first (CalSurfG.f90:417-424, :768-921) and its scheme carries the one-node
-# difference downstream.  Those cases are named here with their MEASURED figures, asserted exactly (the solve is
-# deterministic: a regression from 14 to 15 nodes fails): 1025^2 checkerboard 0.000442504883 s on 14 nodes; 4097^2 checkerboard
-# (T up to 151 s, one ulp = 1.5e-5 s) 0.000732421875 s on 309 090 nodes (1.84 %).  The exact mode removes both (tests/test_gpu_exact.py).
-FULL = [(131, "smooth", 3, 1e-4, 0), (131, "rough", 0, 1e-4, 0), (131, "homog", 0, 1e-4, 0),
-        (131, "checker", 0, "0.000442504883", 14), (259, "checker", 1, 1e-4, 0), (515, "checker", 2, "0.000732421875", 309090)]
+# (nx, medium, period, band of the fixed point alone).  The DEFAULT mode (exact_ties = 1: fixed point, tie census, flagged units by the reference's
+# march) must hold the north_star bar, 1e-4 s, over the whole field and at every receiver in every case.  The checkerboard of configs[4]
+# (homogeneous blocks aligned with the grid) produces exact time ties between neighbouring narrow-band nodes; the reference's answer there depends
+# on which of the two its heap pops first (CalSurfG.f90:417-424, :768-921) and its scheme carries the one-node difference downstream (DESIGN.md
+# "Ties").  For those cases the fixed point alone (exact_ties = 0) is run beside the default and REPORTED, bounded by a band (largest |dT|, share of
+# nodes beyond 1e-4 s) -- measured: 1025^2 4.43e-4 s on 14 nodes; 4097^2 (T up to 151 s, one ulp = 1.5e-5 s) 7.3e-4 s on 1.84 % of the nodes.
+FULL = [(131, "smooth", 3, None), (131, "rough", 0, None), (131, "homog", 0, None),
+        (131, "checker", 0, (8e-4, 1e-4)), (259, "checker", 1, None), (515, "checker", 2, (1.2e-3, 0.03))]
 
 
-@pytest.mark.parametrize("nx,kind,period,ftol,fover", FULL)
-def test_one_unit_against_oracle(engine, nx, kind, period, ftol, fover):
+@pytest.mark.parametrize("nx,kind,period,band", FULL)
+def test_one_unit_against_oracle(engine, nx, kind, period, band):
     """configs[2] (1025^2 smooth) and configs[4] (4097^2 checkerboard +-8 %, 16-vertex squares) media"""
     g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
     pv = synth.medium(nx, kind, period)
@@ -53,17 +52,27 @@ def test_one_unit_against_oracle(engine, nx, kind, period, ftol, fover):
     rz = (g.goz + (0.5 + u[1::2] * (N - 2)).astype(np.float32) * g.dnz).astype(np.float32)
     engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     assert (bits(engine.velocity(0)) != bits(veln)).sum() == 0
-    t = engine.traveltimes([0], [sx], [sz], [32], rx, rz)
     ref = np.array([L.o_srtimes(g, veln, o["T"], sx, sz, rx[k], rz[k]) for k in range(32)], np.float32)
+    t = engine.traveltimes([0], [sx], [sz], [32], rx, rz)          # the default mode
+    flags, infl = engine.unit_ties()
     T = engine.field(0)
     d = np.abs(T - o["T"])
-    parity_log.add(f"full N={N} {kind}: receivers max |dt| {np.abs(t - ref).max():.3g} s (32) | field max {d.max():.9g} s, beyond 1e-4 s {int((d > TOL).sum())} nodes = {100.0 * (d > TOL).mean():.4f} %, "
-                   f"not bit-identical {100.0 * (bits(T) != bits(o['T'])).mean():.3f} %" + (" [named tie case]" if isinstance(ftol, str) else ""))
+    line = (f"full N={N} {kind} [default mode{', unit marched' if flags[0] & 2 else ''}]: receivers max |dt| {np.abs(t - ref).max():.3g} s (32) | field max {d.max():.9g} s, "
+            f"beyond 1e-4 s {int((d > TOL).sum())} nodes, not bit-identical {100.0 * (bits(T) != bits(o['T'])).mean():.3f} %, largest tie influence {infl[0]:.3g} s")
     assert np.abs(t - ref).max() <= TOL
-    if isinstance(ftol, str):          # a named tie case: the measured figures, exactly
-        assert ("%.9g" % d.max(), int((d > TOL).sum())) == (ftol, fover)
-    else:
-        assert d.max() <= ftol and int((d > TOL).sum()) == fover
+    assert d.max() <= TOL and int((d > TOL).sum()) == 0
+    if band is not None:          # a named tie case: the fixed point alone, reported and bounded
+        assert flags[0] & 2, "the tie census must flag this unit"
+        engine.set_option("exact_ties", 0)
+        t0 = engine.traveltimes([0], [sx], [sz], [32], rx, rz)
+        T0 = engine.field(0)
+        d0 = np.abs(T0 - o["T"])
+        st0 = engine.stats()
+        line += (f" | fixed point alone [named tie case]: receivers max |dt| {np.abs(t0 - ref).max():.3g} s, field max {d0.max():.9g} s, beyond 1e-4 s {int((d0 > TOL).sum())} nodes = "
+                 f"{100.0 * (d0 > TOL).mean():.4f} %, census: {int(st0['tie_units'])} unit flagged and left to the fixed point")
+        assert d0.max() <= band[0] and (d0 > TOL).mean() <= band[1]
+        assert st0["tie_units"] == 1 and st0["tie_units_left"] == 1 and st0["exact_units"] == 0
+    parity_log.add(line)
 
 
 def test_config1_homogeneous_256(engine):
@@ -95,6 +104,7 @@ def test_scaling_is_exact_at_headline_size(engine):
     nx = 131
     u = synth.units(nx, 8, 2, 32)
     pv = np.stack([synth.medium(nx, "smooth", p) for p in range(2)])
+    engine.set_option("exact_ties", 0)          # (a property of the fixed point's arithmetic: the tie threshold is in seconds and does not scale with the medium)
     engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     t1 = engine.traveltimes(**u)
     engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 0.5 * pv)
@@ -159,6 +169,7 @@ def test_wild_medium_keeps_the_exception_table_small(engine):
     u = synth.LCG(77).uniform(64)
     rx = (g.gox + (0.5 + u[0::2] * (N - 2)).astype(np.float32) * g.dnx).astype(np.float32)
     rz = (g.goz + (0.5 + u[1::2] * (N - 2)).astype(np.float32) * g.dnz).astype(np.float32)
+    engine.set_option("exact_ties", 0)          # (the fixed point's exception table is the subject)
     engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     t = engine.traveltimes([0], [sx], [sz], [32], rx, rz)
     ref = np.array([L.o_srtimes(g, veln, o["T"], sx, sz, rx[k], rz[k]) for k in range(32)], np.float32)
@@ -193,6 +204,7 @@ def test_recycled_field_slots_give_the_same_times(engine):
     pv = np.stack([synth.medium(nx, k, p) for p, k in enumerate(("checker4", "rough"))])
     out = {}
     engine.set_option("bundle", 0)              # (the unit-by-unit kernel's slot pool is the subject: since round 4 a 257^2 grid would bundle the two periods of a source)
+    engine.set_option("exact_ties", 0)
     try:
         for pool in (-1, 16, 97, 0):
             engine.set_option("field_pool", pool)
@@ -215,19 +227,12 @@ def test_recycled_field_slots_give_the_same_times(engine):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# Known deviation of the fixed-point solve, kept under the driver's eyes: on media that produce exact time ties
-# between neighbouring narrow-band nodes the reference's answer depends on the layout of its binary tree; the default
-# mode (exact_ties = 0) then differs from it by more than 1e-4 s at a few receiver times / nodes.  The runs are deterministic, so the
-# MEASURED figures are asserted exactly (a regression from 5 to 6 bad times fails); the exact mode (exact_ties = 2) is asserted to
-# remove the deviation on the same units, bit for bit.
-KNOWN = {
-    # name: (receiver times beyond 1e-4 s, largest |dt| as printed with 9 digits)
-    "config4_receivers": (139, "0.000686645508"),      # of 4096 receiver times of 128 units at 4097^2 (times up to 217.6 s); measured r03 (profiles/r03_parity_report.txt)
-    # the rough medium is NOT pinned to one figure: its exact ties can settle in either of their two states from run to run (one ulp, "which
-    # wave's store lands first": DESIGN.md 4 "Repeatability", 2-3 of millions of receiver times), so the measured r03 figures -- 35 of 64
-    # fields with a node beyond 1e-4 s, worst node 0.00126647949 s, 643 of 67.2 M nodes -- are asserted as a band
-    "rough1025_fields": ((33, 37), 1.3e-3, 700),
-}
+# Tie-prone media at full size, all three modes (tests of the bar, not pins of a miss).  The DEFAULT mode (exact_ties = 1)
+# must hold 1e-4 s; exact_ties = 2 (every unit by the reference's march) must be bit-identical; exact_ties = 0 (the fixed point alone) differs
+# from the reference where its heap decided an exact tie (DESIGN.md "Ties") and is reported, bounded by a band around what was measured:
+#   configs[4]'s medium at 4097^2, 128 units x 32 receivers: 139 of 4096 times beyond 1e-4 s, worst 6.9e-4 s (times up to 217.6 s);
+#   1025^2 rough, 64 random sources: 33-37 of 64 fields with a node beyond 1e-4 s, worst node 1.27e-3 s, ~640 of 67.2 M nodes.
+BANDS = {"config4_receivers": (1.2e-3, 0.08), "rough1025_fields": (3e-3, 1e-4)}
 
 
 def _oracle_receivers(nx, pv, u, nrec, units):
@@ -243,50 +248,46 @@ def _oracle_receivers(nx, pv, u, nrec, units):
         return np.stack(list(ex.map(one, units)))
 
 
-def test_receivers_at_scale_config4_known_tie_deviation(engine):
+def test_receivers_at_scale_config4(engine):
     """configs[4]'s grid and medium (4097^2, checkerboard +-8 %, 16-vertex squares): 128 units x 32 receivers against the oracle's
-    Fast Marching.  Default mode: the measured tie deviation, asserted exactly.  Exact mode: bit-identical."""
+    Fast Marching.  Default mode: within 1e-4 s.  exact_ties = 2: bit-identical.  exact_ties = 0: reported, inside its band."""
     nx, nsrc, nper, nrec = 515, 64, 2, 32
     u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 11)
     pv = np.stack([synth.medium(nx, "checker", p) for p in range(nper)])
     n = nsrc * nper
     ref = _oracle_receivers(nx, pv, u, nrec, range(n))
-    try:
-        engine.set_option("max_chunk", 256)
-        engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
-        t = engine.traveltimes(**u).reshape(n, nrec)
-        engine.set_option("exact_ties", 2)
-        engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
-        tx = engine.traveltimes(**u).reshape(n, nrec)
-        st = engine.stats()
-        engine.set_option("exact_ties", 1)          # tie detector + literal march for the flagged units
-        engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
-        t1 = engine.traveltimes(**u).reshape(n, nrec)
-        st1 = engine.stats()
-        flags1, _ = engine.unit_ties()
-    finally:
-        engine.set_option("exact_ties", 0)
-        engine.set_option("max_chunk", 0)
+    engine.set_option("max_chunk", 256)
+    engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    t1 = engine.traveltimes(**u).reshape(n, nrec)          # the default mode
+    st1 = engine.stats()
+    flags1, _ = engine.unit_ties()
+    engine.set_option("exact_ties", 2)
+    engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    tx = engine.traveltimes(**u).reshape(n, nrec)
+    st = engine.stats()
+    engine.set_option("exact_ties", 0)
+    engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    t = engine.traveltimes(**u).reshape(n, nrec)
+    st0 = engine.stats()
     d = np.abs(t.astype(np.float64) - ref.astype(np.float64))
     d1 = np.abs(t1.astype(np.float64) - ref.astype(np.float64))
     marched = (flags1 & 2) != 0
     beyond, worst = int((d > TOL).sum()), "%.9g" % d.max()
-    parity_log.add(f"configs[4] medium N=4097, {n} units x {nrec} receivers [known tie deviation]: default mode max |dt| {worst} s, beyond 1e-4 s {beyond} of {d.size}, "
-                   f"not bit-identical {int((bits(t) != bits(ref)).sum())} (times up to {ref.max():.1f} s) | exact mode: not bit-identical {int((bits(tx) != bits(ref)).sum())}, "
-                   f"{st['exact_pops'] / max(st['ms_exact'], 1e-9) / 1e3:.0f} M accepts/s | exact_ties=1: {int(marched.sum())} of {n} units flagged and marched, "
-                   f"receiver times beyond 1e-4 s {int((d1 > TOL).sum())}, max |dt| {d1.max():.3g} s ({st1['exact_pops'] / max(st1['ms_exact'], 1e-9) / 1e3:.0f} M accepts/s)")
-    assert (bits(tx) != bits(ref)).sum() == 0
+    parity_log.add(f"configs[4] medium N=4097, {n} units x {nrec} receivers: default mode (exact_ties=1): {int(marched.sum())} of {n} units flagged and marched, receiver times beyond 1e-4 s "
+                   f"{int((d1 > TOL).sum())}, max |dt| {d1.max():.3g} s ({st1['exact_pops'] / max(st1['ms_exact'], 1e-9) / 1e3:.0f} M accepts/s) | exact_ties=2: not bit-identical "
+                   f"{int((bits(tx) != bits(ref)).sum())}, {st['exact_pops'] / max(st['ms_exact'], 1e-9) / 1e3:.0f} M accepts/s | fixed point alone (exact_ties=0) [reported]: max |dt| {worst} s, "
+                   f"beyond 1e-4 s {beyond} of {d.size}, not bit-identical {int((bits(t) != bits(ref)).sum())} (times up to {ref.max():.1f} s), census: {int(st0['tie_units'])} units flagged, all left")
+    assert (d1 > TOL).sum() == 0                                         # the default mode holds north_star's tolerance on configs[4]'s medium
     assert (bits(t1[marched]) != bits(ref[marched])).sum() == 0          # flagged units: the reference's bits
-    assert (d1 > TOL).sum() == 0                                         # exact_ties = 1 holds north_star's tolerance on configs[4]'s medium
-    assert d.max() <= 1.2e-3 and beyond <= 0.05 * d.size
-    if KNOWN["config4_receivers"] is not None:
-        assert (beyond, worst) == KNOWN["config4_receivers"]
+    assert (bits(tx) != bits(ref)).sum() == 0
+    assert d.max() <= BANDS["config4_receivers"][0] and beyond <= BANDS["config4_receivers"][1] * d.size
+    assert st0["tie_units_left"] == st0["tie_units"] and st0["exact_units"] == 0
 
 
-def test_fields_at_headline_size_rough_known_tie_deviation(engine):
+def test_fields_at_headline_size_rough(engine):
     """1025^2, rough +-10 % medium, 64 random sources (a quarter of them on node lines, as tests/tools/fuzz_parity.py draws them):
-    whole fields against the oracle.  Default mode: how many fields have a node beyond 1e-4 s and the worst node, asserted exactly;
-    exact mode: every field bit-identical."""
+    whole fields against the oracle.  Default mode: every field within 1e-4 s, flagged units bit-identical; exact_ties = 2: every field
+    bit-identical; exact_ties = 0: reported, inside its band."""
     nx, nsrc = 131, 64
     g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
     N = g.nnx
@@ -303,30 +304,26 @@ def test_fields_at_headline_size_rough_known_tie_deviation(engine):
     engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
     rx = np.repeat(sx[::-1], 1).astype(np.float32); rz = np.repeat(sz[::-1], 1).astype(np.float32)
     args = (np.zeros(nsrc, np.int32), sx, sz, np.ones(nsrc, np.int32), rx, rz)
+    ref1 = np.array([L.o_srtimes(g, veln, sols[k], sx[k], sz[k], rx[k], rz[k]) for k in range(nsrc)], np.float32)
+    t1 = engine.traveltimes(*args)                       # the default mode
+    flags1, _ = engine.unit_ties()
+    marched = (flags1 & 2) != 0
+    dm1 = np.array([np.abs(engine.field(k) - sols[k]).max() for k in range(nsrc)])
+    bad1 = sum(int((bits(engine.field(k)) != bits(sols[k])).sum()) for k in range(nsrc) if marched[k])
+    engine.set_option("exact_ties", 2)
+    engine.traveltimes(*args)
+    exact_bad = sum(int((bits(engine.field(k)) != bits(sols[k])).sum()) for k in range(nsrc))
+    engine.set_option("exact_ties", 0)
     engine.traveltimes(*args)
     dm = np.array([np.abs(engine.field(k) - sols[k]).max() for k in range(nsrc)])
     nbeyond = np.array([int((np.abs(engine.field(k) - sols[k]) > TOL).sum()) for k in range(nsrc)])
-    try:
-        engine.set_option("exact_ties", 2)
-        engine.traveltimes(*args)
-        exact_bad = sum(int((bits(engine.field(k)) != bits(sols[k])).sum()) for k in range(nsrc))
-        engine.set_option("exact_ties", 1)
-        t1 = engine.traveltimes(*args)
-        flags1, _ = engine.unit_ties()
-        marched = (flags1 & 2) != 0
-        dm1 = np.array([np.abs(engine.field(k) - sols[k]).max() for k in range(nsrc)])
-        bad1 = sum(int((bits(engine.field(k)) != bits(sols[k])).sum()) for k in range(nsrc) if marched[k])
-    finally:
-        engine.set_option("exact_ties", 0)
-    ref1 = np.array([L.o_srtimes(g, veln, sols[k], sx[k], sz[k], rx[k], rz[k]) for k in range(nsrc)], np.float32)
     fields_bad, worst = int((dm > TOL).sum()), "%.9g" % dm.max()
-    parity_log.add(f"N=1025 rough, {nsrc} random sources [known tie deviation]: default mode {fields_bad} fields with a node beyond 1e-4 s (worst node {worst} s, "
-                   f"{int(nbeyond.sum())} nodes of {nsrc * N * N} beyond) | exact mode: nodes not bit-identical {exact_bad} | exact_ties=1: {int(marched.sum())} of {nsrc} units marched "
-                   f"(nodes not bit-identical in them {bad1}), fields left to the fixed point: worst node {dm1[~marched].max() if (~marched).any() else 0.0:.3g} s, "
-                   f"receiver times beyond 1e-4 s {int((np.abs(t1 - ref1) > TOL).sum())}")
+    parity_log.add(f"N=1025 rough, {nsrc} random sources: default mode (exact_ties=1): {int(marched.sum())} of {nsrc} units flagged and marched (nodes not bit-identical in them {bad1}), "
+                   f"worst node of all fields {dm1.max():.3g} s, of the fields left to the fixed point {dm1[~marched].max() if (~marched).any() else 0.0:.3g} s, receiver times beyond 1e-4 s "
+                   f"{int((np.abs(t1 - ref1) > TOL).sum())} | exact_ties=2: nodes not bit-identical {exact_bad} | fixed point alone (exact_ties=0) [reported]: {fields_bad} fields with a node beyond "
+                   f"1e-4 s (worst node {worst} s, {int(nbeyond.sum())} nodes of {nsrc * N * N} beyond)")
     assert exact_bad == 0
     assert bad1 == 0 and (np.abs(t1 - ref1) > TOL).sum() == 0
-    assert (dm1[~marched] <= TOL).all() if (~marched).any() else True
-    assert dm.max() <= 3e-3 and nbeyond.sum() <= 1e-4 * nsrc * N * N
-    (lo, hi), worst_cap, nodes_cap = KNOWN["rough1025_fields"]
-    assert lo <= fields_bad <= hi and dm.max() <= worst_cap and nbeyond.sum() <= nodes_cap
+    assert (dm1 <= TOL).all()                            # the default mode: every node of every field
+    worst_cap, share_cap = BANDS["rough1025_fields"]
+    assert dm.max() <= worst_cap and nbeyond.sum() <= share_cap * nsrc * N * N

@@ -15,14 +15,14 @@ import synth
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
-# The only field of this file that leaves the 1e-4 s bar, by (nx, medium, dicing, source index): (largest |dT| as printed with 9 digits,
-# nodes beyond 1e-4 s) -- the MEASURED figures, asserted exactly (the solve is deterministic).  It is an exact-tie case: two
-# neighbouring narrow-band nodes carry bit-equal times, the reference pops one of them first (which one is decided by
-# its heap layout, CalSurfG.f90:417-424 / :768-921) and re-evaluates the other against it at the double root of the
-# two-sided quadratic; the fixed-point solve accepts both without using either in the other's stencil.  The exact mode
-# (tests/test_gpu_exact.py) reproduces the reference on this case bit for bit.  Every other (case, source) asserts 1e-4 s over the field.
+# Modes (csrc/engine.h): the DEFAULT is exact_ties = 1 -- fixed point, census of its exact ties, flagged units solved again by the reference's
+# march -- and must hold 1e-4 s on every field of this file.  exact_ties = 0 (the fixed point alone) is run beside it: it holds the bar too except
+# on the one exact-tie case named here: two neighbouring narrow-band nodes carry bit-equal times, the reference pops one of them first (which
+# one is decided by its heap layout, CalSurfG.f90:417-424 / :768-921) and re-evaluates the other against it at the double root of the two-sided
+# quadratic; the fixed-point solve accepts both without using either in the other's stencil.  That field is reported and bounded by a band
+# (measured: 4.13e-4 s on 41 of 66 049 nodes), not pinned.
 TIE_CASES = {
-    (35, "checker4", 8, 3): ("0.000412940979", 41),     # source on the node (5, 7) of a +-13 % checkerboard: 41 of 66 049 nodes
+    (35, "checker4", 8, 3): (6e-4, 80),     # source on the node (5, 7) of a +-13 % checkerboard
 }
 
 
@@ -60,8 +60,10 @@ FRAC = [(0.43, 0.61), (1.4, 0.5), (0.985, 0.99), (5.0, 7.0), (0.93, 3.2), (0.5, 
         (118.517, 70.504), (118.21, 27.555)]
 
 
+@pytest.mark.parametrize("mode", ["default", "fixed_point"])
 @pytest.mark.parametrize("nx,kind,gd", CASES)
-def test_fields_match_oracle(engine, nx, kind, gd):
+def test_fields_match_oracle(engine, nx, kind, gd, mode):
+    engine.set_option("exact_ties", 1 if mode == "default" else 0)
     srcs = positions(nx, gd, FRAC)
     g, pv, veln, sols = oracle_case(nx, kind, gd, srcs)
     engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv, dicing=gd)
@@ -86,14 +88,14 @@ def test_fields_match_oracle(engine, nx, kind, gd):
         over = int((dT > TOL).sum())
         worst = max(worst, d)
         nbad_nodes += int((bits(T) != bits(o["T"])).sum())
-        named = TIE_CASES.get((nx, kind, gd, u))
+        named = TIE_CASES.get((nx, kind, gd, u)) if mode == "fixed_point" else None
         if d > 0:
-            parity_log.add(f"fixture nx={nx} {kind} gd={gd} source {u} {FRAC[u]}: field max |dT| {d:.9g} s, nodes beyond 1e-4 s {over}"
-                           + (" [named tie case]" if (nx, kind, gd, u) in TIE_CASES else ""))
+            parity_log.add(f"fixture nx={nx} {kind} gd={gd} source {u} {FRAC[u]} [{mode}]: field max |dT| {d:.9g} s, nodes beyond 1e-4 s {over}"
+                           + (" [named tie case of the fixed point: reported, bounded]" if named is not None else ""))
         if named is not None:
-            assert ("%.9g" % d, over) == named, (nx, kind, gd, u, d, over)
+            assert d <= named[0] and over <= named[1], (nx, kind, gd, u, d, over)
         else:
-            assert d <= TOL and over == 0, (nx, kind, gd, u, d, over)
+            assert d <= TOL and over == 0, (nx, kind, gd, u, d, over, mode)
         Tr, Sr = engine.refined(u)
         cls_o = np.sign(o["Sr"]).clip(-1, 1)
         # status classes may differ only at exact time ties (symmetric media); values where both alive agree
@@ -104,7 +106,8 @@ def test_fields_match_oracle(engine, nx, kind, gd):
             ref = L.o_srtimes(g, veln, o["T"], src[0], src[1], rcx[u, k], rcz[u, k])
             assert abs(float(t[2 * u + k]) - float(ref)) <= TOL, (u, k, t[2 * u + k], ref)
     total = len(srcs) * g.nnx * g.nnz
-    parity_log.add(f"fixture nx={nx} {kind} gd={gd}: {len(srcs)} sources, worst field |dT| {worst:.3g} s, nodes not bit-identical {nbad_nodes} of {total}")
+    flagged = int(engine.stats()["tie_units"])
+    parity_log.add(f"fixture nx={nx} {kind} gd={gd} [{mode}]: {len(srcs)} sources, worst field |dT| {worst:.3g} s, nodes not bit-identical {nbad_nodes} of {total}, units the census flagged {flagged}")
     assert nbad_nodes <= 0.001 * total
 
 
@@ -115,6 +118,7 @@ def test_sorted_variant_identical(engine):
     pv = np.stack([synth.medium(nx, "checker4"), synth.medium(nx, "smooth")])
     u = synth.units(nx, 12, 2, 6)
     out = []
+    engine.set_option("exact_ties", 0)          # (the two variants of the fixed-point kernel are the subject)
     for v in (0, 1):
         engine.set_option("fim_sorted", v)
         engine.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
