@@ -113,13 +113,13 @@ def cpu_baseline(budget_units=96):
 
 
 def exact_secondary(eng, with_reference=True):
-    """The in-tolerance mode on the tie-prone medium: configs[2]'s grid and unit count with configs[4]'s checkerboard,
-    1000 sources x 16 periods = 16 000 units x 32 receivers, all marching at once (the march is bound by the memory system's latency: its
-    rate grows with the units in flight -- 4096 units ~880, 8192 ~1700, 16 000 ~1950 solves/s).  exact_ties = 2 -- the reference's Fast
-    Marching replayed on the device (csrc/exact_kernel.hip) --
-    timed with the engine's HIP events over the whole call, and checked bit for bit against the reference on 16 of the units; exact_ties = 1
-    -- tie detector, literal march for the flagged units -- with the flagged fraction and the worst receiver of the units it left alone
-    (against the exact_ties = 2 times, which ARE the reference's)."""
+    """The tie-prone medium at the headline size: configs[2]'s grid and unit count with configs[4]'s checkerboard, 1000 sources x 16 periods =
+    16 000 units x 32 receivers.  exact_ties = 2 -- the reference's Fast Marching replayed on the device (csrc/exact_kernel.hip), all units
+    marching at once (the march is bound by the memory system's latency: its rate grows with the units in flight) -- timed with the engine's
+    HIP events over the whole call and checked bit for bit against the reference on 16 of the units; the DEFAULT mode, exact_ties = 1 -- fixed
+    point, census of its exact ties, the march for the flagged units -- with the flagged fraction and the worst receiver of the units it left
+    alone (against the exact_ties = 2 times, which ARE the reference's); and the fixed point alone (exact_ties = 0).  The census is a
+    heuristic (tie_threshold 2e-5 s): a unit left alone beyond 1e-4 s is reported in `note`."""
     import numpy as np
     import synth
     nsrc = NSRC
@@ -152,14 +152,115 @@ def exact_secondary(eng, with_reference=True):
         flags, infl = eng.unit_ties()
         marched = (flags & 2) != 0
         d = np.abs(t1.astype(np.float64) - tx.astype(np.float64)).max(axis=1)
-        out["exact_ties1"] = {"mode": "exact_ties=1: fixed point + tie detector (tie_threshold 2e-5 s), literal march for the flagged units",
-                              "solves_per_s": round(n / (st1["ms_total"] / 1e3), 1), "ms": round(st1["ms_total"], 1),
+        left_beyond = int((d[~marched] > TOL).sum())
+        out["exact_ties1"] = {"mode": "exact_ties=1 (the default): fixed point + census of its exact ties (tie_threshold 2e-5 s), literal march for the flagged units",
+                              "solves_per_s": round(n / (st1["ms_total"] / 1e3), 1), "ms": round(st1["ms_total"], 1), "ms_march": round(st1["ms_exact"], 1),
                               "flagged_fraction": round(float(marched.mean()), 4), "flagged_units": int(marched.sum()),
                               "flagged_not_bit_identical_to_exact": int((t1[marched].view(np.uint32) != tx[marched].view(np.uint32)).sum()),
                               "unflagged_worst_abs_dt_s": float(d[~marched].max()) if (~marched).any() else 0.0,
-                              "unflagged_units_beyond_1e-4_s": int((d[~marched] > TOL).sum())}
-    finally:
+                              "unflagged_units_beyond_1e-4_s": left_beyond}
+        if left_beyond:
+            out["exact_ties1"]["note"] = "the census is a heuristic: %d unit(s) it left to the fixed point end beyond 1e-4 s; exact_ties=2 is the guarantee" % left_beyond
         eng.set_option("exact_ties", 0)
+        eng.plan(**units)
+        eng.solve()
+        t0 = eng.solve().reshape(n, NREC)
+        st0 = eng.stats()
+        d0 = np.abs(t0.astype(np.float64) - tx.astype(np.float64)).max(axis=1)
+        out["exact_ties0"] = {"mode": "exact_ties=0: the fixed point alone (its census reports, nothing is marched)",
+                              "solves_per_s": round(n / (st0["ms_total"] / 1e3), 1), "ms": round(st0["ms_total"], 1),
+                              "census_flagged_units": int(st0["tie_units"]), "units_beyond_1e-4_s": int((d0 > TOL).sum()), "worst_abs_dt_s": float(d0.max())}
+    finally:
+        eng.set_option("exact_ties", 1)
+    return out
+
+
+def tie_modes_headline(eng, units, pv):
+    """what the default's tie handling costs on the headline medium, where nothing is flagged -- the headline call with the
+    fixed point alone and no census (round 4's configuration), with the census reporting only (exact_ties = 0), and the default (exact_ties = 1:
+    census + march of the flagged units); HIP events over the whole call, best of two."""
+    import synth
+    n = len(units["map_index"])
+    out = {"workload": "the headline call: %d units" % n}
+    try:
+        eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        for tag, opts in (("fixed_point_no_census", (("exact_ties", 0), ("tie_detect", 0))), ("fixed_point_census_reports", (("exact_ties", 0), ("tie_detect", 1))),
+                          ("default_exact_ties1", (("exact_ties", 1), ("tie_detect", 1)))):
+            for k, v in opts:
+                eng.set_option(k, v)
+            eng.plan(**units)
+            eng.solve()
+            best = None
+            for _ in range(2):
+                eng.solve()
+                st = eng.stats()
+                if best is None or st["ms_total"] < best["ms_total"]:
+                    best = st
+            out[tag] = {"solves_per_s": round(n / (best["ms_total"] / 1e3), 1), "ms": round(best["ms_total"], 2), "ms_coarse_kernels": round(best["ms_fim_coarse"], 2),
+                        "census_flagged_units": int(best["tie_units"]), "marched_units": int(best["exact_units"]), "largest_tie_influence_s": float(best.get("tie_influence_max", 0.0))}
+        a, b = out["fixed_point_no_census"]["ms"], out["default_exact_ties1"]["ms"]
+        out["default_costs_percent"] = round(100.0 * (b - a) / a, 2)
+    finally:
+        eng.set_option("exact_ties", 1); eng.set_option("tie_detect", 1)
+    return out
+
+
+def config4_share(device_index, with_reference=True):
+    """one GPU's share of configs[4] -- 4097x4097 grid (nx = ny = 515), checkerboard +-8 %, 128 sources x 24 periods = 3072
+    units x 32 receivers -- in the three modes, HIP events over the whole call (engine of its own: the headline's buffers are released first);
+    receiver times against the reference on an 8-unit sample (the C restatement, pinned bit for bit to the reference's Fortran at 1025^2 ... 4097^2
+    sizes by tests/test_oracle_vs_ref.py, one unit per host thread)."""
+    import numpy as np
+    import synth
+    from dsurftomo_amd.engine import Engine
+    nx, nsrc, nper = 515, 128, 24
+    n = nsrc * nper
+    units = synth.units(nx, nsrc, nper, NREC, seed=synth.SEED + 47)
+    pv = np.stack([synth.medium(nx, "checker", p) for p in range(nper)])
+    out = {"workload": "configs[4] share of one GPU: 4097x4097 grid, checkerboard +-8 %% (16-vertex squares), %d sources x %d periods = %d units, %d receivers each" % (nsrc, nper, n, NREC)}
+    e = Engine(device_index)
+    try:
+        e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        times = {}
+        for tag, mode in (("exact_ties0", 0), ("exact_ties2", 2), ("exact_ties1_default", 1)):
+            e.set_option("exact_ties", mode)
+            e.plan(**units)
+            if mode == 0:
+                e.solve()                              # (allocations; the march's legs are too long to repeat)
+            times[tag] = e.solve().reshape(n, NREC)
+            st = e.stats()
+            rec = {"solves_per_s": round(n / (st["ms_total"] / 1e3), 2), "ms": round(st["ms_total"], 1), "timed_with": "HIP events on the engine's stream, whole call"}
+            if mode != 2:
+                rec.update({"ms_coarse_kernels": round(st["ms_fim_coarse"], 1), "bundles": "%d x %d" % (int(st["bundles"]), int(st["bundle_size"])), "census_flagged_units": int(st["tie_units"])})
+            if mode != 0:
+                rec.update({"marched_units": int(st["exact_units"]), "ms_march": round(st["ms_exact"], 1),
+                            "march_accepts_per_s": round(st["exact_pops"] / max(st["ms_exact"], 1e-9) * 1e3, 0)})
+            out[tag] = rec
+        tx = times["exact_ties2"]
+        for tag in ("exact_ties0", "exact_ties1_default"):
+            d = np.abs(times[tag].astype(np.float64) - tx.astype(np.float64))
+            out[tag]["vs_exact_ties2"] = {"receiver_times_beyond_1e-4_s": int((d > TOL).sum()), "of": int(d.size), "worst_abs_dt_s": float(d.max())}
+        if with_reference:
+            import _libs as L
+            from concurrent.futures import ThreadPoolExecutor
+            pick = np.linspace(0, n - 1, 8).astype(int)
+            g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
+            veln = {p: L.o_gridder(g, pv[p]) for p in sorted(set(int(units["map_index"][k]) for k in pick))}
+
+            def one(k):
+                p = int(units["map_index"][k])
+                o = L.o_solve(g, pv[p], veln[p], units["scx"][k], units["scz"][k])
+                return np.array([L.o_srtimes(g, veln[p], o["T"], units["scx"][k], units["scz"][k], units["rcx"][k * NREC + r], units["rcz"][k * NREC + r]) for r in range(NREC)], np.float32)
+
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+                ref = np.stack(list(ex.map(one, pick)))
+            out["reference_sample"] = {"units": int(len(pick)), "receiver_times": int(ref.size), "against": "port (C restatement pinned to the reference's Fortran)", "seconds": round(time.perf_counter() - t0, 1)}
+            for tag in ("exact_ties0", "exact_ties2", "exact_ties1_default"):
+                d = np.abs(times[tag][pick].astype(np.float64) - ref.astype(np.float64))
+                out[tag]["vs_reference_sample"] = {"beyond_1e-4_s": int((d > TOL).sum()), "not_bit_identical": int((times[tag][pick].view(np.uint32) != ref.view(np.uint32)).sum()), "worst_abs_dt_s": float(d.max())}
+    finally:
+        e.close()
     return out
 
 
@@ -172,8 +273,9 @@ def bundling_secondary(eng):
     units = synth.units(NX, nsrc, NPER, NREC, seed=synth.SEED + 43)
     n = nsrc * NPER
     pv = np.stack([synth.medium(NX, "rough", p) for p in range(NPER)])
-    out = {"workload": "1025x1025 grid, +-10 %% random vertices, an unrelated draw per period; %d sources x %d periods = %d units" % (nsrc, NPER, n)}
+    out = {"workload": "1025x1025 grid, +-10 %% random vertices, an unrelated draw per period; %d sources x %d periods = %d units; exact_ties = 0 (the fixed-point kernels are the subject)" % (nsrc, NPER, n)}
     try:
+        eng.set_option("exact_ties", 0)
         eng.set_maps(NX, NX, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
         for tag, opt in (("bundled", 1), ("unit_by_unit", 0)):
             eng.set_option("bundle", opt)
@@ -182,9 +284,12 @@ def bundling_secondary(eng):
             eng.solve()
             st = eng.stats()
             out[tag] = {"solves_per_s": round(n / (st["ms_total"] / 1e3), 1), "bundle_size": int(st.get("bundle_size", 0)),
-                        "evals_per_node": round(st["evals_total"] / n / (eng.nnx * eng.nnz), 3)}
+                        "evals_per_node": round(st["evals_total"] / n / (eng.nnx * eng.nnz), 3), "marched_units": int(st["exact_units"])}
+            if tag == "bundled" and not st.get("bundle_size", 0):
+                out[tag]["note"] = "the engine did not bundle this call (memory budget / bundles that did not converge): this figure is a unit-by-unit solve"
     finally:
         eng.set_option("bundle", 1)
+        eng.set_option("exact_ties", 1)
     return out
 
 
@@ -418,6 +523,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the other ranks are done: their engines' memory goes back before rank 0 runs the secondary legs (ranks sharing a device -- the 1-GPU rehearsal --
+    # had a memory budget each; rank 0's is lifted)
+    if dist is not None:
+        if rank != 0:
+            eng.close()
+        dist.barrier()
+        if rank == 0 and shared and not os.environ.get("DSA_MEM_BUDGET_GB"):
+            eng.set_memory_budget(0)
     if rank == 0:
         solves = total_units * args.steps
         bps = bytes_per_solve(n)
@@ -455,10 +568,12 @@ def main():
                          "avg_launch_ms": round(acc["ms_fim_coarse"] / launches, 3),
                          "solves_per_launch": round(my_units / launches, 1),
                          "valu_issue": valu,
-                         "note": "achieved = algorithmic bytes / kernel launch time (HIP events on the engine's stream). The solve is a dependency chain "
-                                 "of ~2400 rounds per front, so HBM is not what binds it: valu_issue (fraction of the SIMDs' issue cycles spent on VALU "
-                                 "instructions, from rocprofv3 --pmc) is the second roofline; traffic / valu_issue are null when profiles/pmc_latest.json "
-                                 "was not taken from the kernel sources in the tree"},
+                         "note": "achieved = algorithmic bytes / kernel launch time (HIP events on the engine's stream). `traffic` = bytes at the L2's memory side per "
+                                 "launch (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included): an order of magnitude above the algorithmic bytes -- every "
+                                 "evaluation of a node re-fetches its neighbourhood, and 768 fronts in flight leave no cache level a band to hold -- and close to what "
+                                 "the fabric delivers while the kernel runs (DESIGN.md 'What binds the bundle kernel': the two-point experiment); valu_issue (share of "
+                                 "the SIMDs' issue cycles that carried a VALU instruction) is the other co-limiter. traffic / valu_issue are null when "
+                                 "profiles/pmc_latest.json was not taken from the kernel sources in the tree"},
             "kernel_ms_per_step": {"fim_coarse": round(acc["ms_fim_coarse"] / args.steps, 2), "fim_refined": round(acc["ms_fim_refined"] / args.steps, 2),
                                    "stages": round(acc["ms_stages"] / args.steps, 2)},
             "evals_per_node": round(acc["evals_total"] / max(my_units, 1) / (n * n), 3),
@@ -467,6 +582,9 @@ def main():
             "field_slots": int(st.get("field_slots", 0)), "footprint_mb": round(st.get("footprint_mb", 0.0), 1),     # coarse field slots of the launch (recycled when fewer than the units), HBM held by the solve
             "value_incl_setup": round(solves / (dt + setup_ms / 1000.0), 2),
             "max_abs_err": None,
+            "tie_handling": {"mode": "exact_ties=1 (default): fixed point + census of its exact ties (tie_threshold 2e-5 s) + the reference's march for the flagged units",
+                             "census_flagged_units_last_step": int(st.get("tie_units", 0)), "marched_units_last_step": int(st.get("exact_units", 0)),
+                             "largest_tie_influence_s": float(st.get("tie_influence_max", 0.0))},
         }
         if not args.no_cpu_baseline:
             # N = 1: the bounded CPU baseline (its times are the parity reference).  N > 1: no baseline line (contract), but the
@@ -486,8 +604,15 @@ def main():
                               "against": rec["kind"], "tolerance_s": TOL}
         # secondary legs (rank 0, after the timed region; none of them may take the headline line down with it)
         line["secondary"] = {}
-        for name, leg in (("exact_mode", lambda: exact_secondary(eng, with_reference=not args.no_cpu_baseline)), ("bundling_on_unrelated_maps", lambda: bundling_secondary(eng)),
-                          ("rays", lambda: rays_secondary(eng)), ("dispersion", lambda: dispersion_secondary(eng))):
+        full_units = dict(map_index=units["map_index"], scx=units["scx"], scz=units["scz"], nrec=units["nrec"], rcx=units["rcx"], rcz=units["rcz"])
+        legs = [("tie_modes_headline", lambda: tie_modes_headline(eng, full_units, pv)),
+                ("exact_mode", lambda: exact_secondary(eng, with_reference=not args.no_cpu_baseline)), ("bundling_on_unrelated_maps", lambda: bundling_secondary(eng)),
+                ("rays", lambda: rays_secondary(eng)), ("dispersion", lambda: dispersion_secondary(eng)),
+                ("config4_share", lambda: (eng.close(), config4_share(device_index, with_reference=not args.no_cpu_baseline))[1])]
+        if world > 1:          # (the other ranks wait in the closing barrier: the two long legs -- 16 000 and 3 072 marching units -- belong to the N = 1 line)
+            legs = [l for l in legs if l[0] not in ("exact_mode", "config4_share")]
+            line["secondary"]["note"] = "N > 1: exact_mode and config4_share are legs of the N = 1 line"
+        for name, leg in legs:
             if args.no_secondary:
                 break
             try:

@@ -795,23 +795,35 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             }
             cq = 0;
         };
-        for (int tile = wave; tile < ntile; tile += NW) {
-#pragma unroll 2
-            for (int r0 = 0; r0 < kTileRecs; r0 += NPI) {
+        // (kCU trips' loads -- the node, its x+ and its z+ neighbour, 16 bytes per lane each -- are issued before the first comparison: a lone
+        // workgroup's census is bound by the latency of its loads, 23 ms per launch with two trips in flight, profiles/r05_ab_bundle_kernel.log)
+        constexpr int kCU = 4, TPT = kTileRecs / NPI;
+        const int ntrips = ntile * TPT;
+        for (int tb = wave * kCU; tb < ntrips; tb += NW * kCU) {
+            int idv[kCU], nxv[kCU], nzv[kCU];
+            BV4 own[kCU], vx[kCU], vz[kCU];
+#pragma unroll
+            for (int k = 0; k < kCU; ++k) {
+                const int trip = tb + k < ntrips ? tb + k : ntrips - 1;
+                const int tile = trip / TPT, r0 = (trip - tile * TPT) * NPI;
                 const int id = (tile << 6) + r0 + cnode;
                 int iz, ix;
                 coords(id, &iz, &ix);
-                const bool here = ix < nnx && iz < nnz;
+                const bool here = tb + k < ntrips && ix < nnx && iz < nnz;
                 int nid[8];
                 rec_stencil(nbz, id, nid);
-                const BV4 own = here ? *(BGV4*)(Bb + (unsigned)id * GB + (unsigned)csub * 16u) : inf4;
-                const BV4 vx = (here && ix + 1 < nnx) ? *(BGV4*)(Bb + (unsigned)nid[1] * GB + (unsigned)csub * 16u) : inf4;
-                const BV4 vz = (here && iz + 1 < nnz) ? *(BGV4*)(Bb + (unsigned)nid[3] * GB + (unsigned)csub * 16u) : inf4;
+                idv[k] = id; nxv[k] = nid[1]; nzv[k] = nid[3];
+                own[k] = here ? *(BGV4*)(Bb + (unsigned)id * GB + (unsigned)csub * 16u) : inf4;
+                vx[k] = (here && ix + 1 < nnx) ? *(BGV4*)(Bb + (unsigned)nid[1] * GB + (unsigned)csub * 16u) : inf4;
+                vz[k] = (here && iz + 1 < nnz) ? *(BGV4*)(Bb + (unsigned)nid[3] * GB + (unsigned)csub * 16u) : inf4;
+            }
+#pragma unroll
+            for (int k = 0; k < kCU; ++k) {
                 unsigned tm = 0u;              // bit m: member m ties with the x+ neighbour, bit 4 + m: with the z+ neighbour
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const float a = fabsf(own[m]);
-                    if (a < kInf) { if (a == fabsf(vx[m])) tm |= 1u << m; if (a == fabsf(vz[m])) tm |= 16u << m; }
+                    const float a = fabsf(own[k][m]);
+                    if (a < kInf) { if (a == fabsf(vx[k][m])) tm |= 1u << m; if (a == fabsf(vz[k][m])) tm |= 16u << m; }
                 }
                 if (__any(tm != 0u)) {
                     if (cq + 3 * 4 * 64 > kSlowQ) census_flush();
@@ -822,15 +834,15 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         const int mo = csub * 4 + m;
                         unsigned long long bal = __ballot(p0);
                         int pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (p0 && pos < kSlowQ) wq[pos] = (id << 4) | mo;
+                        if (p0 && pos < kSlowQ) wq[pos] = (idv[k] << 4) | mo;
                         cq += __popcll(bal);
                         bal = __ballot(p1);
                         pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (p1 && pos < kSlowQ) wq[pos] = (nid[1] << 4) | mo;
+                        if (p1 && pos < kSlowQ) wq[pos] = (nxv[k] << 4) | mo;
                         cq += __popcll(bal);
                         bal = __ballot(p2);
                         pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (p2 && pos < kSlowQ) wq[pos] = (nid[3] << 4) | mo;
+                        if (p2 && pos < kSlowQ) wq[pos] = (nzv[k] << 4) | mo;
                         cq += __popcll(bal);
                     }
                 }

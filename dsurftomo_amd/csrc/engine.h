@@ -98,7 +98,7 @@ struct Engine {
     bool bundle_wide = false;          // this call's bundles run 768 threads wide on a small grid (choose_bundle_size: a CU per bundle)
     int bundle_mpl_now = 4, bundle_mpl_b = 2;      // ... what the current launch uses (whole bundles; the halved last ones)
     int bundle_threads_b = 256;                    // workgroup size of the second group of a launch (plan_bundles)
-    int bundle_tail_opt = 0;                       // option bundle_tail: what a launch of 768 .. 1500 bundles does with the ones beyond the first generation: 0 = cut in halves (256 threads), 1 = whole, 768 threads wide
+    int bundle_tail_opt = 1;                       // option bundle_tail: what a launch of 768 .. 1500 bundles does with the ones beyond the first generation: 1 (default) = whole and 768 threads wide when they are at most 256 (a CU each), 0 = cut in halves (256 threads; also beyond 256)
     int bundle_far_all = 0;                        // option bundle_far_all (A/B): 1 = every node trip fetches all four outer neighbours (round 4's loads)
     int bundles_a = 0, bundles_b = 0, bundle_Gb = 0;      // the launch's bundles: whole ones, and (plan_bundles) the last ones cut in halves of bundle_Gb members on a second stream
     hipStream_t stream2 = nullptr;

@@ -892,6 +892,9 @@ int Engine::choose_bundle_size(int step, long* solo_units)
                 const double gens = std::floor((double)nb / 768.0), rem = (double)nb / 768.0 - gens;
                 ms = t_one[k][2] * (gens + (rem > 0.0 ? 0.45 + 0.55 * rem : 0.0));
                 if (G >= 8 && nb > 768 && nb < 1500) ms *= 0.98;                    // (the halved last bundles)
+                // (round 5) at most 256 bundles beyond the first generation: whole, 768 threads wide, a CU each as the first generation leaves
+                // (1 000 bundles of 16: 325 ms against 368 with halves, profiles/r05_ab_bundle_kernel.log)
+                if (bundle_tail_opt == 1 && G >= 8 && bundle_mpl == 0 && nb > 768 && nb <= 1024) ms = t_one[k][2] + 0.8 * (t_wide[k] + 12.0 * (double)(nb - 768) / 256.0);
             }
             // k solves/s (= units per ms) of the whole launch: the bundles in `ms` (a little less when they are not full: idle member lanes save no trips), the rest unit by unit behind them
             const double units_s = n_units * (1.0 - frac);
@@ -1055,6 +1058,17 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
         HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
         const size_t have = X_pool.cap * 4 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4;
         pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.80 * (double)(free_b + have)) / per));
+        if (pool < xl.size() && B_pool.cap > 0) {
+            // exact_ties = 1 on a large grid: the bundles have converged and their field slots (164 GB at 4097^2) are what keeps the march
+            // from holding its units side by side -- at 4097^2 the march's rate IS the number of units in flight.  They go back (the next
+            // plan_bundles allocates them again) before the pool is sized.
+            auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
+            HIP_TRY(this, hipStreamSynchronize(stream));
+            if (stream2) HIP_TRY(this, hipStreamSynchronize(stream2));
+            release(B_pool); release(exc_b); release(lists_b);
+            HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+            pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.80 * (double)(free_b + have)) / per));
+        }
     }
     pool = std::min(pool, xl.size());
     {   // batches of equal size (10 240 + 6 144 units take as long as two full batches)
@@ -1095,6 +1109,12 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
         h_unit_flags[(size_t)(first + u)] |= 2;
     }
     stats[DSA_STAT_EXACT_UNITS] += (double)xl.size();
+    if (exact_ties == 1) {
+        // the march's pool was sized from what the fixed point's buffers left (or took their place, above): it goes back, so that the next
+        // call's bundles find the memory this call's found (exact_ties = 2 keeps its pool: nothing else wants the memory there)
+        auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
+        release(X_pool); release(X_heap);
+    }
     return 0;
 }
 

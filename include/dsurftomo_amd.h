@@ -49,25 +49,52 @@ const char* dsa_error_string(const dsa_engine* e);   /* e may be NULL: last crea
 /* memory the engine may use for per-source fields (bytes, 0 = default: 60 % of free HBM, at most 150 GB) */
 int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
 
-/* options: "window_cells" (causal window of the fixed-point solve, in cell travel times, default 1.25),
- * "max_chunk" (cap on sources resident per chunk, 0 = memory budget only), "list_cap" / "ready_cap" (active-list
- * sizes of the list variant of the solve kernel, 0 = derived from the grid), "fim_threads" (workgroup size of the
- * solve kernel: 128, 256, 512 or 1024; 0 default = 128 up to 700 nodes per side, 256 up to 1500, 512 up to 3000, 1024 beyond), "fim_sorted" (1, default = the solve kernel that keeps its active
- * set in tile masks and walks it in record order; 0 = the variant with lists in activation order; same fixed
- * point), "fim_lds_pad" (extra dynamic LDS bytes per workgroup of the solve kernel, limits the workgroups resident
- * per CU), "ray_budget" (bytes of per-ray vertex slabs per launch of the ray tracer, 0 = a third of free HBM up
- * to 40 GB: the tracer runs one lane per ray, so a launch should hold every ray of the call), "ray_path_cap" (points kept per traced ray for dsa_ray_paths, 0 = none), "disp_layers_lds" (layer
- * tables of the dispersion kernel: 1 LDS, 0 global scratch, -1 default = LDS when they fit), "disp_group_shift" (lanes per dispersion
- * curve = 2^shift, 0 = one lane per curve, -1 default = 8 lanes up to 4096 curves, 4 up to 32768), "lsmr_device_vectors"
- * (dsa_lsmr: 0 default = ordered reductions on the host, 1 = all vectors on the device; same results), "field_pool" (field slots of
- * the coarse solve: 0 default = four times the workgroups the GPU holds at once -- a dsa_solve over more units than that recycles the
- * slots, each workgroup claiming a free slot (compare-and-swap, no assumption about dispatch order), resetting it, solving, and writing its unit's receiver times before it frees the slot; -1 = one slot per
- * unit; > 0 = that many.  Fields stay readable (dsa_get_field) only when the units of the call fit the slots; rows / exact mode / keep_fields
- * calls never recycle), "bundle" (the units of one source -- its periods -- solved side by side by one workgroup under one shared round
- * schedule: 1 default = automatic -- 16 / 8 / 4 members per bundle, whichever the measured rates promise most for the call's sources and
- * periods, on grids of at least 120 nodes per side (below 400: only launches of at least 384 bundles of 8 or 16) when the bundles fill the GPU and their field slots fit the memory, else none; 0 = off; 4 / 8 / 16 = that size whatever the count.  Same travel times as unit by unit -- the fixed point does not
- * depend on the schedule; where a field has exact ties (two self-consistent states) the two can settle differently: measured
- * identical on the headline and checkerboard media, 4 of 262 144 receiver times apart by up to 4.2e-5 s on unrelated random maps; exact_ties = 0 and 1 (the tie detector runs inside the bundles), not 2; "bundle_window_cells" = causal window of the bundles, 0 default = 0.6 (1.25 for launches of at most 256 bundles of 8 or 4, which run 768 threads wide); "bundle_threads" = workgroup size of the bundle kernel, 0 default = 256 (three workgroups per CU) -- 768 (one per CU, twelve waves sharing a round) beyond 1500 nodes per side and for launches of at most 256 bundles --, or 256 / 512 / 768; "bundle_members_per_lane" = 0 default (bundles of 16 four members per lane, bundles of 8 / 4 two per lane when the launch holds more than 512 of them), 4 or 2; "bundle_max_rounds" = round limit of the bundles, 0 default = the solver's own (a bundle that hits it sends its chunk to the unit-by-unit solve; used by the tests of that fallback); "bundle_pool" = bundle field slots, 0 default = as many as bundles can be resident at a time and an eighth more (864 at three 256-thread workgroups per CU / 288 for the wide ones; within the memory budget), claimed by the bundles as they start), "exact_ties" / "tie_threshold" / "exact_lds_slots" / "exact_pool" (see dsa_unit_ties).
+/* Options (dsa_set_option; every value is a double).  Defaults in [brackets]; DSA_ERR_ARGUMENT for an unknown name or a value out of range.
+ *
+ *   tie handling (see dsa_unit_ties below)
+ *     exact_ties               [1]     0 fixed point only | 1 fixed point + tie census + the reference's march for the flagged units | 2 the march for every unit
+ *     tie_threshold            [2e-5]  seconds: the influence on its node's value a tie must have to flag its unit; 0 = any tie
+ *     tie_detect               [1]     exact_ties = 0 runs the census too and reports what it would have flagged (DSA_STAT_TIE_UNITS, dsa_unit_ties); 0 = off
+ *     exact_lds_slots          [0]     tree slots kept in LDS per marching unit, 64 .. 4975 (made odd); 0 = what lets every wavefront of a batch be resident
+ *     exact_pool               [0]     units marching at a time, up to 65535; 0 = by free memory, at most exact_pool_max
+ *     exact_pool_max           [16384] 4 .. 32768
+ *
+ *   fixed-point solve, unit by unit (csrc/fim_kernel.hip)
+ *     window_cells             [1.25]  causal window in cell travel times
+ *     fim_threads              [0]     workgroup size 128 | 256 | 512 | 1024; 0 = by grid size (128 up to 700 nodes per side, 256 up to 1500, 512 up to 3000, 1024 beyond)
+ *     fim_sorted               [1]     refined boxes: 1 tile masks walked in record order | 0 lists in activation order (same fixed point)
+ *     fim_lds_pad              [0]     extra dynamic LDS bytes per workgroup (limits the workgroups resident per CU; experiments)
+ *     list_cap, ready_cap      [0]     active-list sizes of the list variant; 0 = from the grid
+ *     field_pool               [0]     coarse field slots: 0 = four times the workgroups the GPU holds (a call with more units recycles them: a workgroup
+ *                                      claims a free slot by compare-and-swap, resets it, solves, writes its unit's receiver times, frees it) | -1 one per
+ *                                      unit | n > 0.  Fields stay readable (dsa_get_field) only when the call's units fit the slots; calls that need the
+ *                                      fields afterwards (rows, exact_ties = 2, keep_fields) never recycle
+ *     exc_log2cap              [0]     log2 of the exception table's entries, 6 .. 24; 0 = from the grid (the table grows by itself when it overflows)
+ *     max_chunk                [0]     cap on units resident per launch; 0 = memory budget only
+ *
+ *   bundles: the periods of one source solved by one workgroup under one shared round schedule (csrc/bundle_kernel.hip).  Same travel times as unit by
+ *   unit -- the fixed point does not depend on the schedule; a field with exact ties has two self-consistent states there and the two solves can settle
+ *   differently (measured: identical on the headline and checkerboard media, 4 of 262 144 times apart by up to 4.2e-5 s on unrelated random maps)
+ *     bundle                   [1]     1 automatic: 16 / 8 / 4 members, whichever the launch-time model promises most for the call's sources and periods,
+ *                                      on grids of at least 120 nodes per side (below 400: only launches of at least 384 bundles of 8 or 16) | 0 off | 4, 8, 16
+ *     bundle_window_cells      [0]     causal window of the bundles; 0 = 0.6 (1.25 for launches of at most 256 bundles of 8 or 4, which run 768 threads wide)
+ *     bundle_threads           [0]     256 | 512 | 768; 0 = 256 (three workgroups per CU), 768 beyond 1500 nodes per side and for launches of at most 256 bundles
+ *     bundle_members_per_lane  [0]     4 | 2; 0 = four for bundles of 16, two for bundles of 8 / 4 in launches of more than 512
+ *     bundle_pool              [0]     bundle field slots; 0 = the bundles resident at a time and an eighth more, within the memory budget
+ *     bundle_tail              [1]     a launch of 768 .. 1500 bundles, the ones beyond the first generation (768 = three workgroups per CU): 1 whole and 768 threads
+ *                                      wide on a second stream, a CU each, when there are at most 256 of them | 0 cut in halves (256 threads; also beyond 256)
+ *     bundle_max_rounds        [0]     round limit of a bundle; 0 = the solver's own.  A bundle that hits it sends its chunk to the unit-by-unit solve (tests)
+ *     bundle_far_all           [0]     1 = every node trip fetches all four outer neighbours (round 4's loads; A/B switch)
+ *
+ *   rays, rows, dispersion, inversion step
+ *     ray_budget               [0]     bytes of per-ray vertex slabs per launch of the tracer; 0 = a third of free HBM, up to 40 GB
+ *     ray_path_cap             [0]     points kept per traced ray for dsa_ray_paths
+ *     rows_on_device           [0]     1 = dsa_solve_rows leaves the COO rows on the device (dsa_iteration_system_device, dsa_lsmr)
+ *     disp_layers_lds          [-1]    layer tables of the dispersion kernel: 1 LDS | 0 global scratch | -1 LDS when they fit
+ *     disp_group_shift         [-1]    lanes per dispersion curve = 2^shift, 0 .. 3; -1 = 8 lanes up to 4096 curves, 4 up to 32768, else 1
+ *     disp_failure_log         [0]     keep the first N curves without a root in the reference's call order (dsa_dispersion_failure)
+ *     lsmr_device_vectors      [0]     dsa_lsmr: 0 ordered reductions on the host | 1 all vectors on the device (same results)
+ *
  * Grid size limit: the coarse solve keeps one bit per 8x8-node tile in LDS (36 KB): up to about 4340 nodes per side (nx <= 545 at dicing 8);
  * dsa_plan returns DSA_ERR_ARGUMENT beyond. */
 int dsa_set_option(dsa_engine* e, const char* name, double value);
@@ -209,18 +236,21 @@ int dsa_dispersion_diagnostics(const dsa_engine* e, long long* count, int* first
 int dsa_dispersion_failure(const dsa_engine* e, int index, int* info, double* vals, float* table, double* c);
 int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit);
 
-/* Exact time ties: the fixed-point solve lands on the reference's Fast-Marching travel times except downstream of
- * bit-equal times of two neighbouring narrow-band nodes, where the reference's own answer depends on the layout of its binary
- * tree (CalSurfG.f90:417-485, :768-921).  Option "exact_ties": 0 (default) fixed point only; 1 = the solve kernel detects such
- * ties (option "tie_threshold", seconds: the influence on the node's value a tie must have to count; default 2e-5, 0 = any tie) and the
- * units that met one are solved again by the reference's march itself, replayed on the device four units per wavefront -- their
- * fields are then bit-identical to the reference's; 2 = every unit by the literal march (2 100 solves/s at 1025^2 with 16 000 units in
- * flight).  Options "exact_lds_slots" (tree slots in LDS per marching unit, the rest of the tree in global memory: 64 ..
- * 4991, made odd; default 0 = what lets every wavefront of a batch be resident: 148 KB of a CU's LDS divided among them), "exact_pool"
- * (units marching at a time, 0 = by free memory: 80 % of it at 4 bytes per node and unit -- 50 solves/s at 4097^2 --, at most "exact_pool_max", default 16384).  The march's tree
- * holds at most 65 534 nodes per unit (16-bit slots): a narrow band longer than that returns DSA_ERR_INTERNAL (grids beyond ~8000
- * nodes per side; the grid size limit below is lower).
- * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: met a tie, bit 1: solved by the literal march) and the largest
+/* Exact time ties (DESIGN.md "Ties").  The fixed-point solve lands on the reference's Fast-Marching travel times except downstream of bit-equal
+ * times of two neighbouring narrow-band nodes, where the reference's own answer depends on the layout of its binary tree (CalSurfG.f90:417-485,
+ * :768-921).  Option "exact_ties":
+ *   1 (default)  fixed point, then a census of the converged fields: a node holds a tie when a near neighbour carries its value bit for bit; the tie's
+ *                influence is what taking the tied neighbour into the node's stencil would change; a unit with an influence above "tie_threshold" is
+ *                solved again by the reference's march itself, replayed on the device four units per wavefront -- its field, refined snapshot and
+ *                receiver times are then the reference's bit for bit.  A heuristic, not a bound: sub-threshold ties can add up along a front.
+ *                Cost: a few per cent where nothing is flagged; a flagged unit costs one march (sequential accepts, ~2.3 us each: 35 ms at 121^2,
+ *                2.4 s at 1025^2, a minute at 4097^2 -- the same for one unit or thousands side by side);
+ *   2            every unit by the march (the guarantee; ~2 000 solves/s at 1025^2 with 16 000 units in flight, ~50 at 4097^2);
+ *   0            the fixed point alone; the census still runs ("tie_detect") and DSA_STAT_TIE_UNITS / DSA_STAT_TIE_UNITS_LEFT / dsa_unit_ties say
+ *                which units a default call would have marched.
+ * The march's tree holds at most 65 534 nodes per unit (16-bit slots): a narrow band longer than that returns DSA_ERR_INTERNAL (grids beyond ~8000
+ * nodes per side; the grid size limit above is lower).
+ * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: holds a tie above the threshold, bit 1: solved by the march) and the largest
  * tie influence in seconds (either array may be NULL). */
 int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence);
 /* rounds the coarse fixed-point solve of each planned unit took in the last dsa_solve (a bundled unit: its bundle's) */

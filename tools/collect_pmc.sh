@@ -39,7 +39,7 @@ IFS=',' read -ra GS <<< "$GROUPS_"
 for g in "${GS[@]}"; do
   c=${SETS[$g]:-}
   if [ -z "$c" ]; then echo "unknown group $g" >> $OUT/rc.txt; continue; fi
-  timeout 600 rocprofv3 --pmc $c -d $OUT/$g -o r -- "${CMD[@]}" > $OUT/$g.log 2>&1
+  timeout 300 rocprofv3 --pmc $c -d $OUT/$g -o r -- "${CMD[@]}" > $OUT/$g.log 2>&1
   echo "$g rc=$?" >> $OUT/rc.txt
 done
 {
