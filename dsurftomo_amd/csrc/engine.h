@@ -139,13 +139,18 @@ struct Engine {
     size_t exact_pool_max = 16384;     // option exact_pool_max: four units per wavefront, sixteen wavefronts per CU (measured at 1025^2: 10 240 units 1 500, 12 288 1 600, 16 384 1 700 solves/s)
     DevBuf<unsigned> X_pool;                     // per marching unit: one packed word per node of the whole grid (exact_kernel.hip)
     DevBuf<unsigned long long> X_heap;           // ... and the tree slots beyond the LDS part
+    // pooled tiles of a times-only march on a large grid (kernels.h XTiles; run_exact)
+    DevBuf<unsigned short> X_tt, X_free;
+    DevBuf<unsigned> X_tp, X_ring, X_pins;
+    int exact_tiles_opt = 0, exact_tile_cap = 0;
+    bool marched_in_tiles = false;
     DevBuf<int> x_units, x_nstart;
     DevBuf<unsigned long long> x_starts;         // the coarse stage's starting tree per marching unit (kernels.h: exact_start_bytes)
     DevBuf<int32_t> xinfo, tieinfo;
     std::vector<unsigned char> h_unit_flags;     // per planned unit after a solve: bit 0 tie met, bit 1 solved by the exact mode
     std::vector<int> h_unit_rounds;               // rounds of the unit's coarse solve (of its bundle's, for a bundled unit)
     std::vector<float> h_unit_tie;               // largest tie influence of the unit (s)
-    int run_exact(int first, int n, const std::vector<int>& local_units, bool receivers, bool compact);
+    int run_exact(int first, int n, const std::vector<int>& local_units, bool receivers, bool compact, bool may_pool_tiles = false);
     DevBuf<int8_t> S_r, cinit;
     DevBuf<int16_t> rst, cst;
     DevBuf<int32_t> heap, flags, info;

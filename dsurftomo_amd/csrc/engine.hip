@@ -92,7 +92,7 @@ Engine::~Engine()
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
     if (stream2) { (void)hipStreamDestroy(stream2); (void)hipEventDestroy(ev_b0); (void)hipEventDestroy(ev_b1); stream2 = nullptr; }
     rel(cand_b);
-    rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(disp_fail_list); rel(X_pool); rel(X_heap); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
+    rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(disp_fail_list); rel(X_pool); rel(X_heap); rel(X_tt); rel(X_tp); rel(X_ring); rel(X_free); rel(X_pins); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -477,10 +477,10 @@ hipError_t Engine::make_stream2()
 // memory for its own fields (at 4097^2 the bundles found none after an exact_ties = 2 call and the solve ran unit by unit, 5.3 s instead of 1.9).
 void Engine::release_march_pool()
 {
-    if (exact_ties == 2 || !X_pool.cap) return;
+    if (exact_ties == 2 || (!X_pool.cap && !X_tp.cap)) return;
     (void)hipStreamSynchronize(stream);
     auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
-    release(X_pool); release(X_heap);
+    release(X_pool); release(X_heap); release(X_tt); release(X_tp); release(X_ring); release(X_free); release(X_pins);
 }
 
 // The unit field pool back to its regular size (four times the resident workgroups, within the plan's budget) when plan() had cut it
@@ -711,7 +711,12 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                 const auto w0 = std::chrono::steady_clock::now();
                 // exact_ties = 1: the flagged units' receiver times once more, from the marched fields; their compact fields into the units'
                 // slots when every unit of the launch has one (rays, keep_fields, small calls)
-                if (run_exact(first, n, xl, exact_fused || exact_ties == 1, exact_ties == 1 ? n <= pool_slots : (!exact_fused || n <= pool_slots)) != 0) return status;
+                // (times-only calls -- no rays, no keep_fields -- may march in pooled tiles: then no compact copy is made and the units' field slots hold nothing)
+                const bool times_only = !rows && !keep_fields;
+                bool compact = exact_ties == 1 ? n <= pool_slots : (!exact_fused || n <= pool_slots);
+                if (times_only && exact_tiles_opt == 1) compact = false;
+                marched_in_tiles = false;
+                if (run_exact(first, n, xl, exact_fused || exact_ties == 1, compact, times_only) != 0) return status;
                 stats[DSA_STAT_MS_EXACT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
             }
         }
@@ -812,7 +817,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         for (int u = 0; u < n; ++u) stats[DSA_STAT_TIE_INFLUENCE_MAX] = std::max(stats[DSA_STAT_TIE_INFLUENCE_MAX], (double)h_unit_tie[(size_t)(first + u)]);
         last_chunk_first = first;                               // the per-unit arrays (refined snapshots, ...) of this chunk stay resident ...
         last_chunk_n = n;
-        fields_resident = n <= pool_slots;                      // ... the coarse fields only when every unit had a slot (recycled slots: gone)
+        fields_resident = n <= pool_slots && !marched_in_tiles;  // ... the coarse fields only when every unit had a slot (recycled slots: gone; marched in pooled tiles: never there)
         if (rows && trace_chunk(first, n, rw, iw, col, cap, nar) != 0) return status;
       } while (redo_chunk);
     }
@@ -1072,19 +1077,42 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
 // literal Fast Marching (exact_kernel.hip) for the chunk-local units `xl` of the resident chunk [first, first + n), in batches of
 // as many units as the pool holds
 // `receivers`: the batches write their units' receiver times themselves; `compact`: the units' compact fields go to their slots (T_c)
-int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receivers, bool compact)
+int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receivers, bool compact, bool may_pool_tiles)
 {
     (void)n;
     // (a tree holds at most 65 535 nodes -- sixteen levels, one per lane of a unit's group; narrow bands are a few times nnx + nnz)
     const int gcap_max = std::min(16 * (g.nnx + g.nnz) + 4096, 65534);
-    const size_t per = nrec_c * 4 + (size_t)gcap_max * 8 + exact_start_bytes() + 4;      // (one packed word per node, exact_kernel.hip)
+    size_t per = nrec_c * 4 + (size_t)gcap_max * 8 + exact_start_bytes() + 4;      // (one packed word per node, exact_kernel.hip)
+    // Pooled tiles (round 5, kernels.h XTiles): a times-only batch whose whole fields would not all fit marches in pooled tiles -- tcap tiles of
+    // 8 x 8 nodes per unit (the band and what lies within a tile of it: a few times the tiles along the grid's perimeter) instead of a word per
+    // node.  At 4097^2: 3.2 MB per unit instead of 67, so the batch is bounded by exact_pool_max, not by memory.  Option exact_tiles: 0 automatic,
+    // 1 always (times-only calls), -1 never; exact_tile_cap: tiles per unit, 0 = 8 (nbx + nbz).
+    const int ntile = g.nbx * g.nbz;
+    const int tcap = exact_tile_cap > 0 ? exact_tile_cap : std::min(65000, std::max(512, 8 * (g.nbx + g.nbz)));
+    const size_t per_tiles = exact_tile_unit_bytes(ntile, tcap) + (size_t)gcap_max * 8 + exact_start_bytes() + 4;
+    bool tiles = false;
+    if (may_pool_tiles && receivers && !compact && exact_tiles_opt >= 0 && tcap < ntile) {
+        if (exact_tiles_opt == 1) tiles = true;
+        else {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+            const size_t have = X_pool.cap * 4 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4 + B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4;
+            const size_t fit_full = (size_t)(0.80 * (double)(free_b + have)) / per;
+            // (the tile table is one more dependent look-up per access and the march is bound by exactly that latency: per accept the pooled march
+            // runs at 55-63 % of the march on whole fields -- 468 against 741 M accepts/s with 3 072 units at 4097^2 -- and wins by the units it
+            // holds side by side: 857 M accepts/s with 9 600.  So: only when the batch would otherwise take three rounds or more.  profiles/r05_exact_pooled_tiles.log)
+            tiles = 2 * fit_full < std::min<size_t>(xl.size(), exact_pool > 0 ? (size_t)exact_pool : exact_pool_max) && per_tiles * 4 < per;
+        }
+    }
+    if (tiles) per = per_tiles;
+    marched_in_tiles = tiles;
     size_t pool = (size_t)exact_pool;
     if (!pool) {
         // units marching at a time: as many as 80 % of the free memory holds, at most exact_pool_max (four units per wavefront; at 4097^2 the
         // rate is the units in flight: 1 536 units 28 solves/s, 2 688 43, 3 456 52 -- profiles/r04_exact_rates.log)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
-        const size_t have = X_pool.cap * 4 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4;
+        const size_t have = X_pool.cap * 4 + X_heap.cap * 8 + x_starts.cap * 8 + x_nstart.cap * 4 + X_tt.cap * 2 + X_tp.cap * 4 + X_ring.cap * 4 + X_free.cap * 2 + X_pins.cap * 4;
         pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.80 * (double)(free_b + have)) / per));
         if (pool < xl.size() && B_pool.cap > 0) {
             // exact_ties = 1 on a large grid: the bundles have converged and their field slots (164 GB at 4097^2) are what keeps the march
@@ -1117,14 +1145,21 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
     lcap = std::max(63, lcap) | 1;
     const int gcap = std::min(gcap_max, 65534 - lcap) & ~1;
     if (exact_lds_bytes(lcap) > 156 * 1024) { fail(DSA_ERR_ARGUMENT, "exact_lds_slots %d needs more than 156 KB of LDS (four units per wavefront)", lcap); return DSA_ERR_ARGUMENT; }
-    if (ensure(X_pool, pool * nrec_c) || ensure(X_heap, pool * (size_t)gcap) || ensure(x_starts, pool * (exact_start_bytes() / 8)) || ensure(x_nstart, pool)) return status;
+    if (ensure(X_heap, pool * (size_t)gcap) || ensure(x_starts, pool * (exact_start_bytes() / 8)) || ensure(x_nstart, pool)) return status;
+    XTiles xt{};
+    if (tiles) {
+        if (ensure(X_tt, pool * exact_tile_table_entries(ntile)) || ensure(X_tp, pool * (size_t)tcap * 64) || ensure(X_ring, pool * (size_t)tcap) || ensure(X_free, pool * (size_t)tcap) ||
+            ensure(X_pins, pool * (((size_t)ntile + 31) / 32)) || ensure(X_pool, 4)) return status;
+        xt = XTiles{ X_tt.p, X_tp.p, X_ring.p, X_free.p, X_pins.p, tcap };
+    } else if (ensure(X_pool, pool * nrec_c)) return status;
+    stats[DSA_STAT_EXACT_POOL] = (double)pool; stats[DSA_STAT_EXACT_TILES] = tiles ? (double)tcap : 0.0;
     HIP_TRY(this, hipMemcpyAsync(x_units.p, xl.data(), xl.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemsetAsync(xinfo.p, 0, (size_t)n * 16, stream));
     for (size_t k = 0; k < xl.size(); k += pool) {
         const int m = (int)std::min(pool, xl.size() - k);
         const XReceivers rc{ rays.p, veln.p, nfield, dpl, out.p, err.p };
         launch_exact(g, batch(), x_units.p + k, m, slow.p, nrec_c, risti_c.p, X_pool.p, nrec_c, X_heap.p, gcap, lcap, x_starts.p, x_nstart.p, xinfo.p, clocks.p,
-                     receivers ? &rc : nullptr, compact, stream);
+                     receivers ? &rc : nullptr, compact, stream, tiles ? &xt : nullptr);
     }
     HIP_TRY(this, hipGetLastError());
     std::vector<int32_t> h_x((size_t)n * 4);
@@ -1132,7 +1167,7 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
     HIP_TRY(this, hipStreamSynchronize(stream));
     for (int u : xl) {
         const int32_t* x = &h_x[(size_t)u * 4];
-        if (x[2]) { fail(DSA_ERR_INTERNAL, "unit %d: exact march guard %d (1: tree capacity %d)", first + u, x[2], lcap + gcap); return DSA_ERR_INTERNAL; }
+        if (x[2]) { fail(DSA_ERR_INTERNAL, "unit %d: exact march guard %d (1: tree capacity %d; 2: tile pool of %d tiles per unit too small: option exact_tile_cap, or exact_tiles = -1; 3: a store into a tile without a slot)", first + u, x[2], lcap + gcap, tcap); return DSA_ERR_INTERNAL; }
         stats[DSA_STAT_EXACT_POPS] += (double)x[0] + (double)x[1];
         h_unit_flags[(size_t)(first + u)] |= 2;
     }
@@ -1141,7 +1176,7 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
         // the march's pool was sized from what the fixed point's buffers left (or took their place, above): it goes back, so that the next
         // call's bundles find the memory this call's found (exact_ties = 2 keeps its pool: nothing else wants the memory there)
         auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
-        release(X_pool); release(X_heap);
+        release(X_pool); release(X_heap); release(X_tt); release(X_tp); release(X_ring); release(X_free); release(X_pins);
     }
     return 0;
 }
@@ -1423,6 +1458,8 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "tie_list" && (value == 0 || value == 1)) { en->tie_list_opt = (int)value; return 0; }
     if (n == "disp_failure_log" && value >= 0 && value <= 65536) { en->disp_failure_log = (int)value; return 0; }
     if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4975))) { en->exact_lds_slots = (int)value; return 0; }
+    if (n == "exact_tiles" && (value == -1 || value == 0 || value == 1)) { en->exact_tiles_opt = (int)value; return 0; }
+    if (n == "exact_tile_cap" && (value == 0 || (value >= 64 && value <= 65000))) { en->exact_tile_cap = (int)value; return 0; }
     if (n == "exact_pool" && value >= 0 && value <= 65535) { en->exact_pool = (int)value; return 0; }
     if (n == "exact_pool_max" && value >= 4 && value <= 32768) { en->exact_pool_max = (size_t)value; return 0; }
     if (n == "fim_threads" && (value == 0 || value == 128 || value == 256 || value == 512 || value == 1024)) { en->planned = false; en->fim_threads = (int)value; return 0; }

@@ -65,6 +65,11 @@ struct XG {                                  // the march of one unit; every lan
     int ntr, err;
     unsigned pops;
     XEntry last;                             // tree[ntr], fetched at the end of the step before: the entry the next removal of the root sinks
+    // pooled tiles (MD = 2; xg_tile_*): tile table, tile pool, the allocated tiles in allocation order (ring of tile numbers), the slots given back
+    // (stack), tiles that must stay (bitmap: a receiver cell's corner lies in them); every lane of the group holds the same counters
+    DSA_GLB unsigned short* tt; DSA_GLB unsigned* tp; DSA_GLB unsigned* ring; DSA_GLB unsigned short* freestk; DSA_GLB const unsigned* pins;
+    int tcap, bump, nfree, rh, rt;           // slots of the pool; next never-used slot; stack size; ring head / tail (monotonic, index mod tcap)
+    int nbx;
 };
 
 // Records of the propagation grid, round 4: one 32-bit word per node instead of (T, status) -- far 0xffffffff; alive the value's bits (a
@@ -81,11 +86,37 @@ __device__ __forceinline__ XRec xg_unpack(unsigned w)
     r.st = w == kXFar ? -1 : (int)w >= 0 ? 0 : (int)(w & 0xffffu);
     return r;
 }
-template <bool PK> __device__ __forceinline__ XRec xg_load(const XG& m, int id) { if (PK) return xg_unpack(m.P[id]); return m.F[id]; }
-template <bool PK> __device__ __forceinline__ int xg_status(const XG& m, int id) { if (PK) return xg_unpack(m.P[id]).st; return m.F[id].st; }
-template <bool PK> __device__ __forceinline__ void xg_set_alive(XG& m, int id, float T) { if (PK) m.P[id] = __float_as_uint(T); else m.F[id].st = 0; }
-template <bool PK> __device__ __forceinline__ void xg_set_slot(XG& m, int id, int s) { if (PK) m.P[id] = kXInTree | (unsigned)s; else m.F[id].st = s; }
-template <bool PK> __device__ __forceinline__ void xg_set_trial(XG& m, int id, float T) { if (!PK) m.F[id].T = T; }
+// MD: 0 = the refined boxes' (T, status) records, 1 = packed words over the whole propagation grid, 2 = packed words in POOLED TILES (round 5):
+// the unit holds only the 8x8-node tiles its narrow band has touched and not yet left behind -- XG::tt maps a tile of the grid to a slot of
+// the unit's tile pool XG::tp (kTNone: never touched, every node far; kTDone: every node alive, the slot given back) -- so that a times-only
+// call on a large grid marches thousands of units where whole fields (67 MB each at 4097^2) let a few hundred march; see xg_tile_* below.
+constexpr unsigned kTNone = 0xffffu, kTDone = 0xfffeu;
+// word index of record id in the unit's tile pool; ~0u: the tile holds no slot
+__device__ __forceinline__ unsigned xg_wa(const XG& m, int id)
+{
+    const unsigned t = m.tt[(unsigned)id >> 6];
+    return t < kTDone ? (t << 6) | ((unsigned)id & 63u) : ~0u;
+}
+template <int MD> __device__ __forceinline__ unsigned xg_word(const XG& m, int id)
+{
+    if (MD == 2) {
+        // (kTNone: every node far.  kTDone: every node alive -- the word's value is gone, and no stencil that is evaluated reads it: a node within
+        // two steps of a node that is not alive lies in a tile that cannot have been given back; status "alive" is all the caller may use)
+        const unsigned t = m.tt[(unsigned)id >> 6];
+        return t < kTDone ? m.tp[(t << 6) | ((unsigned)id & 63u)] : t == kTDone ? 0u : kXFar;
+    }
+    return m.P[id];
+}
+template <int MD> __device__ __forceinline__ XRec xg_load(const XG& m, int id) { if (MD != 0) return xg_unpack(xg_word<MD>(m, id)); return m.F[id]; }
+template <int MD> __device__ __forceinline__ int xg_status(const XG& m, int id) { if (MD != 0) return xg_unpack(xg_word<MD>(m, id)).st; return m.F[id].st; }
+template <int MD> __device__ __forceinline__ void xg_store(XG& m, int id, unsigned w)
+{
+    if (MD == 2) { const unsigned a = xg_wa(m, id); if (a != ~0u) m.tp[a] = w; else m.err = 3; }      // (a store finds its tile allocated: xg_tile_need ran in front of it)
+    else m.P[id] = w;
+}
+template <int MD> __device__ __forceinline__ void xg_set_alive(XG& m, int id, float T) { if (MD != 0) xg_store<MD>(m, id, __float_as_uint(T)); else m.F[id].st = 0; }
+template <int MD> __device__ __forceinline__ void xg_set_slot(XG& m, int id, int s) { if (MD != 0) xg_store<MD>(m, id, kXInTree | (unsigned)s); else m.F[id].st = s; }
+template <int MD> __device__ __forceinline__ void xg_set_trial(XG& m, int id, float T) { if (MD == 0) m.F[id].T = T; }
 
 // Tree entries move as 8- / 16-byte vectors through pointers of an EXPLICIT address space.  (Copying an XEntry struct goes through its
 // implicit copy constructor, i.e. through a generic reference: the compiler then folds "slot in LDS ? LDS read : global read" into ONE flat
@@ -111,14 +142,14 @@ __device__ __forceinline__ void xg_put_tree(XG& m, bool on, int s, XEntry e)
     if (on && s > m.lcap) *(DSA_GLB xf2*)(m.hg + (s - m.lcap - 1)) = xg_vec(e);
 }
 // ... and the node's status (reference nsts: its slot)
-template <bool PK> __device__ __forceinline__ void xg_put_status(XG& m, bool on, int s, XEntry e)
+template <int MD> __device__ __forceinline__ void xg_put_status(XG& m, bool on, int s, XEntry e)
 {
-    if (on) xg_set_slot<PK>(m, e.id, s);
+    if (on) xg_set_slot<MD>(m, e.id, s);
 }
-template <bool PK> __device__ __forceinline__ void xg_put(XG& m, bool on, int s, XEntry e)
+template <int MD> __device__ __forceinline__ void xg_put(XG& m, bool on, int s, XEntry e)
 {
     xg_put_tree(m, on, s, e);
-    xg_put_status<PK>(m, on, s, e);
+    xg_put_status<MD>(m, on, s, e);
 }
 // the sixteen bits of a group in a wavefront-wide vote
 __device__ __forceinline__ unsigned xg_vote16(bool c, int lane) { return (unsigned)(__ballot(c) >> (lane & 48)) & 0xffffu; }
@@ -138,7 +169,7 @@ __device__ __forceinline__ XEntry xg_path(const XG& m, int s, bool check, int gl
     return xg_get(m, have ? a : 1);
 }
 // (one attempt with the path entries p: false when lane 15 found another node at slot s -- nothing is stored then; *moved: entries went down)
-template <bool PK> __device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e, int s, bool check, XEntry p, int gl, int lane, bool* moved)
+template <int MD> __device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e, int s, bool check, XEntry p, int gl, int lane, bool* moved)
 {
     const int a = gl < 15 ? (s >> (gl + 1)) : s;
     const bool have = a >= 1 && (gl < 15 || check);
@@ -149,24 +180,24 @@ template <bool PK> __device__ __forceinline__ bool xg_sift_apply(XG& m, XEntry e
     const int moves = __builtin_ctz(~b);
     XEntry w = p;
     if (gl == moves) w = e;
-    xg_put<PK>(m, gl <= moves, s >> gl, w);
+    xg_put<MD>(m, gl <= moves, s >> gl, w);
     *moved = moves > 0;
     return true;
 }
-template <bool PK> __device__ __forceinline__ void xg_sift_up(XG& m, XEntry e, int s, bool check, int gl, int lane)
+template <int MD> __device__ __forceinline__ void xg_sift_up(XG& m, XEntry e, int s, bool check, int gl, int lane)
 {
     bool moved;
-    if (!xg_sift_apply<PK>(m, e, s, check, xg_path(m, s, check, gl), gl, lane, &moved)) {
+    if (!xg_sift_apply<MD>(m, e, s, check, xg_path(m, s, check, gl), gl, lane, &moved)) {
         // (rare: the node was pushed down a level by an earlier neighbour of this step; its status says where to)
-        s = xg_status<PK>(m, e.id);
-        (void)xg_sift_apply<PK>(m, e, s, false, xg_path(m, s, false, gl), gl, lane, &moved);
+        s = xg_status<MD>(m, e.id);
+        (void)xg_sift_apply<MD>(m, e, s, false, xg_path(m, s, false, gl), gl, lane, &moved);
     }
 }
-template <bool PK> __device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lane)
+template <int MD> __device__ __forceinline__ void xg_add(XG& m, int id, float key, int gl, int lane)
 {
     if (m.ntr + 1 > m.lcap + m.gcap) { m.err = 1; return; }
     m.ntr += 1;
-    xg_sift_up<PK>(m, XEntry{ key, id }, m.ntr, false, gl, lane);
+    xg_sift_up<MD>(m, XEntry{ key, id }, m.ntr, false, gl, lane);
 }
 // reference downtree (:800-858): the last entry replaces the root and sinks; of two children with equal keys the left one is taken
 // (`>`), a child moves up only when strictly smaller.  The walk down reads one 16-byte pair of children per level (lcap is odd: the
@@ -252,6 +283,71 @@ __device__ __forceinline__ XPop xg_pop_root(XG& m, int gl)
 // value of the lane at byte address 4 * lane of the wavefront
 __device__ __forceinline__ int xg_from_lane(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 
+// ---- pooled tiles (MD = 2) ------------------------------------------------------------------------------------------------------------------------
+// A tile can go when no stencil will read it again: fouds2 reads a node's neighbours up to two steps away in x or z, so the alive nodes of tile T
+// are read only by nodes of T and of its four edge neighbours -- when T and those four are alive to the last node (tiles beyond the grid count as
+// alive, nodes of a tile beyond the grid's edge do not count at all), T's slot goes back; a tile that holds a receiver cell's corner stays
+// (k_xreceivers reads it at the end).  Nothing is counted while marching: when the unit needs a slot and has none, it looks at the OLDEST tiles
+// of its ring -- sixteen lanes read a tile's 64 words in one load -- and frees those that qualify; the others go to the ring's tail.
+// tile `t` alive to the last node that lies inside the grid?  (allocated tiles: their words; kTDone: yes; kTNone: no; beyond the grid: yes)
+__device__ __forceinline__ bool xg_tile_all_alive(const XG& m, int tx, int tz, int gl, int lane)
+{
+    if (tx < 0 || tz < 0 || tx >= m.nbx || tz >= m.nbz) return true;
+    const unsigned t = m.tt[tx * m.nbz + tz];
+    if (t == kTDone) return true;
+    if (t == kTNone) return false;
+    const uint4 w = *(DSA_GLB const uint4*)(m.tp + ((size_t)t << 6) + 4 * gl);          // lane gl: records 4 gl .. 4 gl + 3 (row gl / 2 of the tile, four z)
+    const int ix = (tx << 3) + (gl >> 1), iz0 = (tz << 3) + 4 * (gl & 1);
+    const bool inx = ix < m.nnx;
+    bool ok = true;
+    ok = ok && (!(inx && iz0 + 0 < m.nnz) || (int)w.x >= 0);
+    ok = ok && (!(inx && iz0 + 1 < m.nnz) || (int)w.y >= 0);
+    ok = ok && (!(inx && iz0 + 2 < m.nnz) || (int)w.z >= 0);
+    ok = ok && (!(inx && iz0 + 3 < m.nnz) || (int)w.w >= 0);
+    return xg_vote16(!ok, lane) == 0u;
+}
+// look at up to `look` of the oldest tiles; returns with freed slots on the stack (or none: the caller reports the pool as too small)
+__device__ __forceinline__ void xg_tile_collect(XG& m, int look, int gl, int lane)
+{
+    const bool lead = gl == 0;
+    const int n = m.rt - m.rh < look ? m.rt - m.rh : look;
+    for (int k = 0; k < n; ++k) {
+        const unsigned tile = m.ring[(unsigned)m.rh % (unsigned)m.tcap];
+        m.rh += 1;
+        const int tx = (int)(tile / (unsigned)m.nbz), tz = (int)(tile - (unsigned)tx * (unsigned)m.nbz);
+        const bool pinned = (m.pins[tile >> 5] >> (tile & 31u)) & 1u;
+        bool go = !pinned && xg_tile_all_alive(m, tx, tz, gl, lane);
+        go = go && xg_tile_all_alive(m, tx - 1, tz, gl, lane) && xg_tile_all_alive(m, tx + 1, tz, gl, lane);
+        go = go && xg_tile_all_alive(m, tx, tz - 1, gl, lane) && xg_tile_all_alive(m, tx, tz + 1, gl, lane);
+        if (go) {
+            const unsigned slot = m.tt[tile];
+            if (lead) { m.tt[tile] = (unsigned short)kTDone; m.freestk[m.nfree] = (unsigned short)slot; }
+            m.nfree += 1;
+        } else {
+            if (lead) m.ring[(unsigned)m.rt % (unsigned)m.tcap] = tile;
+            m.rt += 1;
+        }
+    }
+}
+// make sure record id's tile has a slot (the group's lanes all pass the same id); the new tile starts far
+__device__ __forceinline__ void xg_tile_need(XG& m, int id, int gl, int lane)
+{
+    const unsigned tile = (unsigned)id >> 6;
+    if (m.tt[tile] < kTDone) return;
+    if (m.nfree == 0 && m.bump >= m.tcap) {
+        // no slot left: the oldest tiles, a few dozen at a time, until one goes (or the whole ring has been looked at twice)
+        for (int tries = 0; m.nfree == 0 && tries < 2 * m.tcap; tries += 32) xg_tile_collect(m, 32, gl, lane);
+        if (m.nfree == 0) { m.err = 2; return; }
+    }
+    unsigned slot;
+    if (m.nfree > 0) { m.nfree -= 1; slot = m.freestk[m.nfree]; }
+    else { slot = (unsigned)m.bump; m.bump += 1; }
+    const uint4 far4 = { kXFar, kXFar, kXFar, kXFar };
+    *(DSA_GLB uint4*)(m.tp + ((size_t)slot << 6) + 4 * gl) = far4;
+    if (gl == 0) { m.tt[tile] = (unsigned short)slot; m.ring[(unsigned)m.rt % (unsigned)m.tcap] = tile; }
+    m.rt += 1;
+}
+
 // what a lane is within its group, fixed for the whole march: lane 4 q + 2 j + k owns quadrant (j: the x- / x+ side, k: the z- / z+ side)
 // of neighbour q (x-, x+, z-, z+) of whatever node is being accepted
 struct XLane {
@@ -288,7 +384,7 @@ __device__ __forceinline__ int xg_rec(int nbz, int iz0, int ix0)
 #else
 #define DSA_XCLK(k)
 #endif
-template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int ix0, const XLane& L, int lane
+template <int MD> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry root, int iz0, int ix0, const XLane& L, int lane
 #ifdef DSA_X_CLOCKS
                                                , unsigned long long* xc, unsigned long long& xt
 #endif
@@ -305,10 +401,15 @@ template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry 
     const int idj = inj ? xg_rec(m.nbz, mz0, xj) : root.id, idj2 = inj2 ? xg_rec(m.nbz, mz0, xj2) : root.id;
     const int idk = ink ? xg_rec(m.nbz, zk, mx0) : root.id, idk2 = ink2 ? xg_rec(m.nbz, zk2, mx0) : root.id;
     // seven loads per lane in flight while the root leaves the tree: the quadrant's stencil, the neighbour's slowness and status
-    XRec vj = xg_load<PK>(m, idj), vk = xg_load<PK>(m, idk);
-    const XRec vj2 = xg_load<PK>(m, idj2), vk2 = xg_load<PK>(m, idk2);
-    const int st_pre = xg_status<PK>(m, mid);
-    if (PK) {          // (packed records: the node being accepted is still "in the tree" in the field; its value is the root's key)
+    XRec vj = xg_load<MD>(m, idj), vk = xg_load<MD>(m, idk);
+    const XRec vj2 = xg_load<MD>(m, idj2), vk2 = xg_load<MD>(m, idk2);
+    unsigned tile_mid = 0u;                    // (pooled tiles: the slot of my neighbour's tile, or kTNone: then its tile has to be allocated before it enters the tree)
+    int st_pre;
+    if (MD == 2) {
+        tile_mid = m.tt[(unsigned)mid >> 6];
+        st_pre = xg_unpack(tile_mid < kTDone ? m.tp[(tile_mid << 6) | ((unsigned)mid & 63u)] : tile_mid == kTDone ? 0u : kXFar).st;
+    } else st_pre = xg_status<MD>(m, mid);
+    if (MD != 0) {     // (packed records: the node being accepted is still "in the tree" in the field; its value is the root's key)
         vj.T = L.rootj ? root.key : vj.T;
         vk.T = L.rootk ? root.key : vk.T;
     }
@@ -317,7 +418,12 @@ template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry 
     const float slown = m.slow[mid], risti = m.risti[in ? mx0 : 0];
     DSA_XCLK(1)
     const int ntr_old = m.ntr;
+    // (pooled tiles: the word addresses the step's stores will need are looked up here, in front of the first store -- a look-up behind a store would
+    // wait for it, and a scattered store into memory no cache holds takes as long as a miss; the root's own word first)
+    unsigned wa_root = 0u, wa_move = 0u;
+    if (MD == 2) wa_root = xg_wa(m, root.id);
     const XPop P = xg_pop_root(m, L.gl);
+    if (MD == 2) wa_move = xg_wa(m, L.gl <= P.moves ? P.mine.id : root.id);
     DSA_XCLK(2)
     // my neighbour's slot after the root's removal: its status was fetched BEFORE it, so if the neighbour is one of the entries the walk
     // moved -- from a slot on the walk's path to that slot's parent, or (the tree's last entry) to where it sank -- the slot follows it.
@@ -345,6 +451,8 @@ template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry 
     const int sq = st == 0 ? 0 : isnew ? m.ntr + 1 + __popc(newq & ((1u << q4) - 1u)) : st;
     const int aq = r4 < 3 ? (sq >> (r4 + 1)) : (isnew ? 0 : sq);
     const XEntry pq = xg_get(m, aq >= 1 ? aq : 1);
+    unsigned wa_pq = 0u;
+    if (MD == 2) wa_pq = xg_wa(m, aq >= 1 ? pq.id : root.id);
     XQuadState s;
     s.ej = inj; s.ek = ink;
     s.aj = inj && (vj.st == 0 || L.rootj);  s.oj = inj2 && vj2.st == 0;
@@ -380,20 +488,42 @@ template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry 
         seq = seq || (L.gl < 6 && se > 0 && sl > 0 && lca >= (reach_e > reach_l ? reach_e : reach_l));
     }
     const bool sequential = xg_vote16(seq, lane) != 0u;
+    if (MD == 2) {
+        // (pooled tiles) a neighbour that enters the tree may lie in a tile the unit has not touched yet: one tile in ~64 steps
+        const unsigned needq = xg_vote16(isnew && r4 == 0 && tile_mid >= kTDone, lane);
+        if (needq) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idq = xg_from_lane(L.base + 16 * q, mid);
+                if ((needq >> (4 * q)) & 1u) xg_tile_need(m, idq, L.gl, lane);
+            }
+            if (m.err) return;
+            tile_mid = m.tt[(unsigned)mid >> 6];
+        }
+    }
     // From here on the step only stores (but for the rare sequential way): the root alive, the statuses of the entries its removal moved,
     // the neighbours' trial values (fouds2 overwrites them unconditionally, :758: the first lane of each neighbour's four stores it) ...
     // (the paths fetched above are waited for HERE, before the first store: a wait further down would also cover the stores)
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
-    if (lead) xg_set_alive<PK>(m, root.id, root.key);
-    xg_put_status<PK>(m, L.gl <= P.moves, P.to, P.mine);
-    if (r4 == 0 && st != 0) xg_set_trial<PK>(m, mid, trial);
+    if (MD == 2) {
+        if (lead) m.tp[wa_root] = __float_as_uint(root.key);
+        if (L.gl <= P.moves) m.tp[wa_move] = kXInTree | (unsigned)P.to;
+    } else {
+        if (lead) xg_set_alive<MD>(m, root.id, root.key);
+        xg_put_status<MD>(m, L.gl <= P.moves, P.to, P.mine);
+    }
+    if (r4 == 0 && st != 0) xg_set_trial<MD>(m, mid, trial);
     if (!sequential) {
         // ... and the neighbours' updates, one store pass for the four: lane r < up its ancestor's entry a level down (slot s >> r), lane `up`
         // the node itself where it stops
         XEntry w = pq;
         if (r4 == up) w = XEntry{ trial, mid };
         const bool wr = st != 0 && r4 <= up;
-        xg_put<PK>(m, wr, sq >> r4, w);
+        if (MD == 2) {
+            xg_put_tree(m, wr, sq >> r4, w);
+            const unsigned wa_w = r4 == up ? ((tile_mid << 6) | ((unsigned)mid & 63u)) : wa_pq;
+            if (wr) m.tp[wa_w] = kXInTree | (unsigned)(sq >> r4);
+        } else xg_put<MD>(m, wr, sq >> r4, w);
         m.ntr += __popc(newq);
         // the tree's last entry for the next step, without a load behind these stores: it is what this step wrote there (a new node's chain
         // ends at the last slot; else an update's or the removal's move may have), or else the entry fetched at the step's start
@@ -418,7 +548,7 @@ template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry 
             if (stq != 0) {
                 const bool fresh = stq < 0;
                 m.ntr += fresh ? 1 : 0;
-                xg_sift_up<PK>(m, XEntry{ trq, idq }, fresh ? m.ntr : xg_status<PK>(m, idq), !fresh, L.gl, lane);
+                xg_sift_up<MD>(m, XEntry{ trq, idq }, fresh ? m.ntr : xg_status<MD>(m, idq), !fresh, L.gl, lane);
             }
             stq = st_b; st_b = st_c; st_c = st_d; st_d = 0;
             idq = id_b; id_b = id_c; id_c = id_d;
@@ -433,11 +563,14 @@ template <bool PK> __device__ __forceinline__ void xg_accept_root(XG& m, XEntry 
 // the marches of up to four units per wavefront, until every tree is empty.  REFINED: travel(urg = 1) on the refined boxes from the four
 // corners of the source cell; the reference's exit -- the root lies on an edge of the box that is not an edge of the model by the literal
 // test of :396-407 -- marks that node alive and stops.  Otherwise: travel(urg = 2) on the propagation grid from the hand-off's tree
-template <bool REFINED>
+// the pooled tiles' arrays of a batch (MD = 2): unit slot j at tt + j * tt_stride etc.
+struct XTilePool { unsigned short* tt; size_t tt_stride; unsigned* tp; unsigned* ring; unsigned short* freestk; unsigned* pins; size_t pins_stride; int tcap; };
+
+template <bool REFINED, bool POOLED = false>
 __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const int* __restrict__ units, int n, const float* __restrict__ slow_all,
                                                size_t field_stride, const float* __restrict__ risti_c, unsigned* pool, size_t pool_stride,
                                                XEntry* heap_pool, int gcap, int lcap, const XStart* __restrict__ starts, const int* __restrict__ nstart,
-                                               int32_t* xinfo, unsigned long long* clk)
+                                               int32_t* xinfo, unsigned long long* clk, XTilePool tpool)
 {
     extern __shared__ unsigned char x_lds[];
     const int lane = threadIdx.x, grp = lane >> 4;
@@ -452,7 +585,8 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
     m.lcap = lcap; m.hg = (DSA_GLB XEntry*)(heap_pool + (size_t)(live ? slot : 0) * gcap); m.gcap = gcap;
     m.ntr = 0; m.err = 0; m.pops = 0u; m.ri = g.earth;
     m.F = nullptr; m.P = nullptr;
-    constexpr bool PK = !REFINED;
+    m.tt = nullptr; m.tp = nullptr; m.ring = nullptr; m.freestk = nullptr; m.pins = nullptr; m.tcap = 0; m.bump = 0; m.nfree = 0; m.rh = 0; m.rt = 0; m.nbx = g.nbx;
+    constexpr int MD = REFINED ? 0 : POOLED ? 2 : 1;
     int rnx = 0, rnz = 0, oxl = 0, oxh = 0, ozl = 0, ozh = 0;
     if (REFINED) {
         const SourceDesc* sd = b.src + s;
@@ -473,17 +607,33 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
                     const float t = 2.0f * ds / (vss[i - 1][j - 1] + vsrc);
                     const int id = rec_index(m.nbz, isz - 2 + j, isx - 2 + i);
                     if (lead) m.F[id].T = t;
-                    xg_add<PK>(m, id, t, lane & 15, lane);
+                    xg_add<MD>(m, id, t, lane & 15, lane);
                 }
         }
     } else {
         const SourceDesc* sd = b.src + s;
-        m.P = (DSA_GLB unsigned*)(pool + (size_t)(live ? slot : 0) * pool_stride); m.slow = (DSA_GLB const float*)(slow_all + (size_t)sd->period * field_stride); m.risti = (DSA_GLB const float*)risti_c;
+        if (POOLED) {
+            const size_t j = live ? (size_t)slot : 0;
+            m.tt = (DSA_GLB unsigned short*)(tpool.tt + j * tpool.tt_stride); m.tp = (DSA_GLB unsigned*)(tpool.tp + j * ((size_t)tpool.tcap << 6));
+            m.ring = (DSA_GLB unsigned*)(tpool.ring + j * (size_t)tpool.tcap); m.freestk = (DSA_GLB unsigned short*)(tpool.freestk + j * (size_t)tpool.tcap);
+            m.pins = (DSA_GLB const unsigned*)(tpool.pins + j * tpool.pins_stride); m.tcap = tpool.tcap;
+        } else m.P = (DSA_GLB unsigned*)(pool + (size_t)(live ? slot : 0) * pool_stride);
+        m.slow = (DSA_GLB const float*)(slow_all + (size_t)sd->period * field_stride); m.risti = (DSA_GLB const float*)risti_c;
         x_set_grid(m, g.nbz, g.nnx, g.nnz); m.dnx = g.dnx; m.dnz = g.dnz;
         if (live) {
             const int cnt = nstart[slot];
             const XStart* st = starts + (size_t)slot * kXStage;
-            for (int q = 0; q < cnt; ++q) { const XStart e = st[q]; xg_add<PK>(m, e.id, e.T, lane & 15, lane); }
+            for (int q = 0; q < cnt; ++q) {
+                const XStart e = st[q];
+                if (POOLED) {
+                    // (the hand-off lists every node it puts on the propagation grid, the alive ones with ~id: their tiles get slots here)
+                    const int id = e.id < 0 ? ~e.id : e.id;
+                    xg_tile_need(m, id, lane & 15, lane);
+                    if (m.err) break;
+                    if (e.id < 0) { if (lead) xg_set_alive<MD>(m, id, e.T); continue; }
+                }
+                xg_add<MD>(m, e.id, e.T, lane & 15, lane);
+            }
         }
     }
     const XLane L = xg_lane(lane);
@@ -504,11 +654,11 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
                 const int iz = iz0 + 1, ix = ix0 + 1;
                 stop = (ix == 1 && oxl) || (ix == rnx && oxh) || (iz == 1 && ozl) || (iz == rnz && ozh);
             }
-            if (stop) { if (lead) xg_set_alive<PK>(m, root.id, root.key); active = false; }
+            if (stop) { if (lead) xg_set_alive<MD>(m, root.id, root.key); active = false; }
 #ifdef DSA_X_CLOCKS
-            else { DSA_XCLK(0) xg_accept_root<PK>(m, root, iz0, ix0, L, lane, xc, xt); }
+            else { DSA_XCLK(0) xg_accept_root<MD>(m, root, iz0, ix0, L, lane, xc, xt); }
 #else
-            else xg_accept_root<PK>(m, root, iz0, ix0, L, lane);
+            else xg_accept_root<MD>(m, root, iz0, ix0, L, lane);
 #endif
         }
     }
@@ -521,25 +671,54 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
     }
 }
 
-// every record far, value 0 (the reference's nsts = -1): the refined boxes of the batch's units and their pool slots
-__global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restrict__ units, unsigned* pool, size_t pool_stride, int nrec)
+// every record far, value 0 (the reference's nsts = -1): the refined boxes of the batch's units and their pool slots (pooled tiles: the
+// tile tables -- no tile touched -- and the bitmaps of the tiles that must stay, filled by k_xpins)
+__global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restrict__ units, unsigned* pool, size_t pool_stride, int nrec, XTilePool tpool)
 {
     const int slot = blockIdx.y;
     const int s = units[slot];
     const uint4 v = { 0u, 0xffffffffu, 0u, 0xffffffffu };              // two records {0.0f, -1}
-    const uint4 far4 = { kXFar, kXFar, kXFar, kXFar };                 // four packed records
+    const uint4 far4 = { kXFar, kXFar, kXFar, kXFar };                 // four packed records (or eight tile-table entries kTNone)
     uint4* const Fr = (uint4*)(b.F_r + (size_t)s * kRefRecs);
-    uint4* const Fc = (uint4*)(pool + (size_t)slot * pool_stride);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = t; i < (size_t)kRefRecs / 2; i += step) Fr[i] = v;
+    if (tpool.tt) {
+        uint4* const tt4 = (uint4*)(tpool.tt + (size_t)slot * tpool.tt_stride);
+        for (size_t i = t; i < tpool.tt_stride / 8; i += step) tt4[i] = far4;
+        unsigned* const pins = tpool.pins + (size_t)slot * tpool.pins_stride;
+        for (size_t i = t; i < tpool.pins_stride; i += step) pins[i] = 0u;
+        return;
+    }
+    uint4* const Fc = (uint4*)(pool + (size_t)slot * pool_stride);
     for (size_t i = t; i < (size_t)nrec / 4; i += step) Fc[i] = far4;
+}
+
+// pooled tiles: the tiles a unit's receivers will read at the end (the four corners of every receiver's cell, receiver_core.h) must keep their slots
+__global__ __launch_bounds__(64) void k_xpins(GridDesc g, BatchPtrs b, const int* __restrict__ units, const RayDesc* __restrict__ rays, XTilePool tpool)
+{
+    const int slot = blockIdx.x;
+    const SourceDesc sd = b.src[units[slot]];
+    unsigned* const pins = tpool.pins + (size_t)slot * tpool.pins_stride;
+    for (int r = threadIdx.x; r < sd.nrec; r += 64) {
+        const RayDesc rd = rays[sd.first_ray + r];
+        if (!(rd.flags & kRayTime)) continue;
+        int irx = (int)((rd.rx - g.gox) / g.dnx) + 1, irz = (int)((rd.rz - g.goz) / g.dnz) + 1;
+        if (irx < 1 || irx > g.nnx || irz < 1 || irz > g.nnz) continue;
+        if (irx == g.nnx) irx -= 1;
+        if (irz == g.nnz) irz -= 1;
+        for (int k = 0; k < 2; ++k)
+            for (int l = 0; l < 2; ++l) {
+                const unsigned tile = (unsigned)rec_index(g.nbz, irz - 1 + l, irx - 1 + k) >> 6;
+                atomicOr(&pins[tile >> 5], 1u << (tile & 31u));
+            }
+    }
 }
 
 // between the two marches, one workgroup per unit: the snapshot the ray tracer reads (reference ttnr / nstsr, :1287-1288), every sgdl-th
 // refined node -- status and, for status >= 0, value -- onto the propagation grid (:1293-1303), alive nodes that touch a far node back
 // into the narrow band (:1332-1349), and the starting tree's nodes in the reference's scan order (:341-347)
 __global__ __launch_bounds__(64) void k_xhandoff(GridDesc g, BatchPtrs b, const int* __restrict__ units, unsigned* pool, size_t pool_stride,
-                                                 XStart* starts, int* nstart)
+                                                 XStart* starts, int* nstart, int pooled)
 {
     __shared__ int stage_st[kXStage];
     __shared__ float stage_T[kXStage];
@@ -592,6 +771,13 @@ __global__ __launch_bounds__(64) void k_xhandoff(GridDesc g, BatchPtrs b, const 
         const int bx = have ? q / bzn : 0, bz = have ? q - bx * bzn : 0;
         const int id = rec_index(g.nbz, sd.vnt + bz - 1, sd.vnl + bx - 1);
         const float tq = have ? stage_T[q] : 0.0f;
+        if (pooled) {
+            // (pooled tiles: the march gives the tiles their slots, so the alive nodes go on the list too, marked ~id, in the same scan order)
+            const unsigned long long mask = __ballot(st >= 0);
+            if (st >= 0) out[count + __popcll(mask & ((1ull << lane) - 1ull))] = XStart{ st == 0 ? ~id : id, tq };
+            count += __popcll(mask);
+            continue;
+        }
         if (st == 0) Fc[id] = __float_as_uint(tq);
         const unsigned long long mask = __ballot(st > 0);
         if (st > 0) out[count + __popcll(mask & ((1ull << lane) - 1ull))] = XStart{ id, tq };      // (its word in the field: set when the march adds it to the tree)
@@ -619,49 +805,77 @@ struct MarchFieldT {
     const unsigned* F;
     __device__ __forceinline__ float operator()(int id) const { const unsigned w = F[id]; return (int)w >= 0 ? __uint_as_float(w) : kInf; }
 };
+struct MarchTilesT {
+    const unsigned short* tt; const unsigned* tp;
+    __device__ __forceinline__ float operator()(int id) const
+    {
+        const unsigned t = tt[(unsigned)id >> 6];
+        if (t >= kTDone) return kInf;                  // (cannot happen for a receiver's corner: k_xpins keeps those tiles)
+        const unsigned w = tp[((size_t)t << 6) | ((unsigned)id & 63u)];
+        return (int)w >= 0 ? __uint_as_float(w) : kInf;
+    }
+};
 __global__ __launch_bounds__(64) void k_xreceivers(GridDesc g, BatchPtrs b, const int* __restrict__ units, const unsigned* pool, size_t pool_stride,
                                                    const RayDesc* __restrict__ rays, const float* __restrict__ veln_all, size_t veln_stride, float dpl,
-                                                   float* __restrict__ out, int32_t* __restrict__ err)
+                                                   float* __restrict__ out, int32_t* __restrict__ err, XTilePool tpool)
 {
     const int slot = blockIdx.x;
     const int s = units[slot];
     const SourceDesc sd = b.src[s];
     const MarchFieldT field{ pool + (size_t)slot * pool_stride };
+    const MarchTilesT tiles{ tpool.tt + (size_t)slot * tpool.tt_stride, tpool.tp + (size_t)slot * ((size_t)tpool.tcap << 6) };
     const float* veln = veln_all + (size_t)sd.period * veln_stride;
     for (int r = threadIdx.x; r < sd.nrec; r += 64) {
         const RayDesc rd = rays[sd.first_ray + r];
         if (!(rd.flags & kRayTime)) continue;
         float t;
-        if (!receiver_time_f(g, sd.scx, sd.scz, rd, field, veln, dpl, &t)) { atomicExch(err, sd.first_ray + r + 1); t = 0.0f; }
+        const bool ok = tpool.tt ? receiver_time_f(g, sd.scx, sd.scz, rd, tiles, veln, dpl, &t) : receiver_time_f(g, sd.scx, sd.scz, rd, field, veln, dpl, &t);
+        if (!ok) { atomicExch(err, sd.first_ray + r + 1); t = 0.0f; }
         out[rd.data] = t;
     }
 }
 
 size_t exact_lds_bytes(int lcap) { return (size_t)4 * (size_t)(lcap + 1 + 16) * sizeof(XEntry); }
 size_t exact_start_bytes() { return (size_t)kXStage * sizeof(XStart); }
+// pooled tiles, per marching unit: the tile table (two bytes per tile of the grid, a multiple of sixteen bytes), tcap tiles of 256 bytes, the ring
+// (four bytes per slot), the stack of free slots (two), the bitmap of the tiles that stay
+size_t exact_tile_table_entries(int ntile) { return ((size_t)ntile + 7) & ~(size_t)7; }
+size_t exact_tile_unit_bytes(int ntile, int tcap) { return exact_tile_table_entries(ntile) * 2 + (size_t)tcap * (256 + 4 + 2) + (((size_t)ntile + 31) / 32) * 4; }
 
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
                   const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
-                  int32_t* d_xinfo, unsigned long long* d_clocks, const XReceivers* rc, bool compact_copy, hipStream_t stream)
+                  int32_t* d_xinfo, unsigned long long* d_clocks, const XReceivers* rc, bool compact_copy, hipStream_t stream, const XTiles* tiles)
 {
     if (n <= 0) return;
     const size_t lds = exact_lds_bytes(lcap);
     if (lds > 48 * 1024) {   // (per device: set every time)
-        (void)hipFuncSetAttribute((const void*)k_xmarch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_xmarch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_xmarch<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_xmarch<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_xmarch<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int nrec = g.nbx * g.nbz * kTileRecs;
+    const int ntile = g.nbx * g.nbz;
+    XTilePool tp{};
+    if (tiles) {
+        tp.tt = (unsigned short*)tiles->tt; tp.tt_stride = exact_tile_table_entries(ntile); tp.tp = (unsigned*)tiles->tp; tp.ring = (unsigned*)tiles->ring;
+        tp.freestk = (unsigned short*)tiles->freestk; tp.pins = (unsigned*)tiles->pins; tp.pins_stride = ((size_t)ntile + 31) / 32; tp.tcap = tiles->tcap;
+    }
     const int fill_blocks = (int)std::min<size_t>(((size_t)nrec / 2 + 255) / 256, 64);
-    hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (unsigned*)d_pool, pool_stride, nrec);
+    hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (unsigned*)d_pool, pool_stride, nrec, tp);
+    if (tiles && rc) hipLaunchKernelGGL(k_xpins, dim3(n), dim3(64), 0, stream, g, b, d_units, rc->rays, tp);
     const int waves = (n + 3) / 4;
-    hipLaunchKernelGGL(k_xmarch<true>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks);
-    hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (unsigned*)d_pool, pool_stride, (XStart*)d_starts, d_nstart);
-    hipLaunchKernelGGL(k_xmarch<false>, dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks);
-    if (compact_copy) hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, nrec);
+    hipLaunchKernelGGL((k_xmarch<true, false>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
+                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp);
+    hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (unsigned*)d_pool, pool_stride, (XStart*)d_starts, d_nstart, tiles ? 1 : 0);
+    if (tiles)
+        hipLaunchKernelGGL((k_xmarch<false, true>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
+                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp);
+    else
+        hipLaunchKernelGGL((k_xmarch<false, false>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
+                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp);
+    if (compact_copy && !tiles) hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, nrec);
     if (rc) hipLaunchKernelGGL(k_xreceivers, dim3(n), dim3(64), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, rc->rays, rc->veln_all, rc->veln_stride,
-                               rc->dpl, rc->out, rc->err);
+                               rc->dpl, rc->out, rc->err, tp);
 }
 
 }  // namespace dsa

@@ -192,12 +192,20 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
 // xinfo[4 u ..]: accepts of the refined / coarse stage, error code (1 tree capacity)
 size_t exact_lds_bytes(int lcap);
 size_t exact_start_bytes();
+// (round 5) POOLED TILES for times-only calls on large grids: a marching unit keeps only the 8x8-node tiles its narrow band has touched and not yet
+// left behind (exact_kernel.hip: xg_tile_*), tcap of them, instead of a word per node of the whole grid -- 2.6 MB instead of 67 MB at 4097^2.  The
+// batch's arrays, unit slot j at offset j * (entries per unit): tt = exact_tile_table_entries(ntile) two-byte entries, tp = tcap * 64 words, ring =
+// tcap words, freestk = tcap two-byte entries, pins = ceil(ntile / 32) words
+struct XTiles { void* tt; void* tp; void* ring; void* freestk; void* pins; int tcap; };
+size_t exact_tile_table_entries(int ntile);
+size_t exact_tile_unit_bytes(int ntile, int tcap);
 // the batch's receiver times from the marched fields themselves (RayDesc::src indexes the resident chunk like d_units does)
 struct XReceivers { const RayDesc* rays; const float* veln_all; size_t veln_stride; float dpl; float* out; int32_t* err; };
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
                   const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
                   int32_t* d_xinfo, unsigned long long* d_clocks /* probe builds (DSA_X_CLOCKS): cycle counts per phase of the accept step */,
-                  const XReceivers* receivers /* null: no receiver times here */, bool compact_copy /* the units' compact fields into BatchPtrs::T_c */, hipStream_t stream);
+                  const XReceivers* receivers /* null: no receiver times here */, bool compact_copy /* the units' compact fields into BatchPtrs::T_c */, hipStream_t stream,
+                  const XTiles* tiles = nullptr /* pooled tiles on the propagation grid (times-only calls: needs `receivers`, no compact copy) */);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
 // RayDesc::src is a global unit index; unit_base is the first unit held by the batch arrays

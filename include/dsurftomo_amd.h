@@ -58,6 +58,9 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *     exact_lds_slots          [0]     tree slots kept in LDS per marching unit, 64 .. 4975 (made odd); 0 = what lets every wavefront of a batch be resident
  *     exact_pool               [0]     units marching at a time, up to 65535; 0 = by free memory, at most exact_pool_max
  *     exact_pool_max           [16384] 4 .. 32768
+ *     exact_tiles              [0]     times-only calls: 0 = the march keeps pooled 8x8-node tiles per unit instead of whole fields when whole fields would bound the
+ *                                      units marching side by side (4097^2: 3 MB per unit instead of 67) | 1 always | -1 never
+ *     exact_tile_cap           [0]     tiles per marching unit, 64 .. 65000; 0 = 8 (tiles per grid side, both sides added)
  *
  *   fixed-point solve, unit by unit (csrc/fim_kernel.hip)
  *     window_cells             [1.25]  causal window in cell travel times
@@ -269,6 +272,8 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_BUNDLED_UNITS, DSA_STAT_BUNDLE_SLOTS, DSA_STAT_BUNDLE_THREADS,
        DSA_STAT_TIE_UNITS_LEFT,       /* units the tie detector flagged (DSA_STAT_TIE_UNITS, filled in every mode) that stayed with the fixed point: exact_ties = 0 */
        DSA_STAT_TIE_INFLUENCE_MAX,    /* largest tie influence met (seconds) */
+       DSA_STAT_EXACT_POOL,           /* units the last march held side by side */
+       DSA_STAT_EXACT_TILES,          /* > 0: it marched in pooled tiles, that many 8x8-node tiles per unit */
        DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 

@@ -193,3 +193,38 @@ def test_literal_march_in_batches_with_times_from_the_marched_fields(exact):
     assert st["exact_units"] == 2 * nsrc
     assert np.isfinite(t_all).all() and np.array_equal(bits(t_b), bits(t_all))
     parity_log.add(f"exact mode in batches: {2 * nsrc} units through a marching pool of 28 and 16 compact slots: receiver times from the marched fields = those of the resident call")
+
+
+@pytest.mark.parametrize("nx,kinds,nsrc,cap,expect_collect", [(35, ("checker4", "rough"), 40, 400, True), (131, ("checker", "smooth"), 24, 0, False), (131, ("rough", "checker"), 16, 1400, True)])
+def test_march_in_pooled_tiles_equals_the_march_on_whole_fields(exact, nx, kinds, nsrc, cap, expect_collect):
+    """Round 5 (csrc/exact_kernel.hip xg_tile_*): a times-only call may march with pooled 8x8-node tiles per unit -- the band and what lies within a
+    tile of it -- instead of a word per node of the whole grid (option exact_tiles; automatic when whole fields would bound the units marching side
+    by side, i.e. at 4097^2).  Same tree, same accepts: the receiver times are those of the march on whole fields, bit for bit -- also with a pool so
+    small that slots must be taken back from the tiles the front has left behind while it marches (exact_tile_cap below the tiles a field touches)."""
+    from dsurftomo_amd.engine import EngineError
+    e = exact
+    nper, nrec = len(kinds), 16
+    u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 81)
+    pv = np.stack([synth.medium(nx, k, p) for p, k in enumerate(kinds)])
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("exact_ties", 2)
+    e.set_option("field_pool", 8)               # (fewer compact slots than units: a times-only call, receiver times from the marched fields)
+    t_full = e.traveltimes(**u)
+    st_full = e.stats()
+    e.set_option("exact_tiles", 1)
+    e.set_option("exact_tile_cap", cap)
+    t_tiles = e.traveltimes(**u)
+    st = e.stats()
+    with pytest.raises(EngineError):
+        e.field(0)
+    assert st_full["exact_tiles"] == 0 and st["exact_tiles"] > 0 and st["exact_units"] == nsrc * nper
+    assert st["exact_pops"] == st_full["exact_pops"]
+    nbad = int((bits(t_tiles) != bits(t_full)).sum())
+    ntile = ((e.nnx + 7) // 8) ** 2
+    parity_log.add(f"march in pooled tiles N={e.nnx} {'/'.join(kinds)}: {nsrc * nper} units, {int(st['exact_tiles'])} tiles per unit of the grid's {ntile}"
+                   f"{' (slots taken back while marching)' if expect_collect else ''}: {nbad} of {t_full.size} receiver times differ from the march on whole fields")
+    assert np.isfinite(t_full).all() and nbad == 0
+    if nx == 35:
+        e.set_option("exact_tile_cap", 64)      # far too few: the march must say so, not return nonsense
+        with pytest.raises(EngineError, match="tile pool"):
+            e.traveltimes(**u)
