@@ -207,9 +207,12 @@ def tie_modes_headline(eng, units, pv):
 
 def config4_share(device_index, with_reference=True):
     """one GPU's share of configs[4] -- 4097x4097 grid (nx = ny = 515), checkerboard +-8 %, 128 sources x 24 periods = 3072
-    units x 32 receivers -- in the three modes, HIP events over the whole call (engine of its own: the headline's buffers are released first);
-    receiver times against the reference on an 8-unit sample (the C restatement, pinned bit for bit to the reference's Fortran at 1025^2 ... 4097^2
-    sizes by tests/test_oracle_vs_ref.py, one unit per host thread)."""
+    units x 32 receivers -- HIP events over the whole call (engine of its own: the headline's buffers are released first).  A march at this size
+    takes a minute whatever the number of units (16.8 M sequential accepts per unit), so the leg runs ONE: the default mode, which flags nearly every
+    unit here -- its march IS exact_ties = 2 on those units (same kernels; tests/test_gpu_fullsize.py::test_receivers_at_scale_config4 checks both
+    bit for bit against the oracle), and `exact_ties2` reports that march's own rate.  DSA_BENCH_FULL=1 adds the separate exact_ties = 2 call.
+    Receiver times against the reference's arithmetic (the C restatement, pinned bit for bit to the reference's Fortran by
+    tests/test_oracle_vs_ref.py, one unit per host thread) on an 8-unit sample and on the units the census left to the fixed point."""
     import numpy as np
     import synth
     from dsurftomo_amd.engine import Engine
@@ -221,8 +224,9 @@ def config4_share(device_index, with_reference=True):
     e = Engine(device_index)
     try:
         e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
-        times = {}
-        for tag, mode in (("exact_ties0", 0), ("exact_ties2", 2), ("exact_ties1_default", 1)):
+        times, marched = {}, None
+        modes = [("exact_ties0", 0), ("exact_ties1_default", 1)] + ([("exact_ties2", 2)] if os.environ.get("DSA_BENCH_FULL") else [])
+        for tag, mode in modes:
             e.set_option("exact_ties", mode)
             e.plan(**units)
             if mode == 0:
@@ -233,17 +237,22 @@ def config4_share(device_index, with_reference=True):
             if mode != 2:
                 rec.update({"ms_coarse_kernels": round(st["ms_fim_coarse"], 1), "bundles": "%d x %d" % (int(st["bundles"]), int(st["bundle_size"])), "census_flagged_units": int(st["tie_units"])})
             if mode != 0:
-                rec.update({"marched_units": int(st["exact_units"]), "ms_march": round(st["ms_exact"], 1),
+                rec.update({"marched_units": int(st["exact_units"]), "ms_march": round(st["ms_exact"], 1), "units_marching_side_by_side": int(st.get("exact_pool", 0)),
                             "march_accepts_per_s": round(st["exact_pops"] / max(st["ms_exact"], 1e-9) * 1e3, 0)})
-            out[tag] = rec
-        tx = times["exact_ties2"]
-        for tag in ("exact_ties0", "exact_ties1_default"):
-            d = np.abs(times[tag].astype(np.float64) - tx.astype(np.float64))
-            out[tag]["vs_exact_ties2"] = {"receiver_times_beyond_1e-4_s": int((d > TOL).sum()), "of": int(d.size), "worst_abs_dt_s": float(d.max())}
+            if mode == 1:
+                fl, _ = e.unit_ties()
+                marched = (fl & 2) != 0
+                out["exact_ties2"] = {"solves_per_s": round(float(marched.sum()) / (st["ms_exact"] / 1e3), 2), "marched_units": int(marched.sum()),
+                                      "note": "the march of the default-mode call above (exact_ties = 2 runs these kernels on every unit): its units over its own time; "
+                                              "DSA_BENCH_FULL=1 times the separate exact_ties = 2 call"}
+            out[tag] = {**out.get(tag, {}), **rec} if tag == "exact_ties2" else rec
+        d = np.abs(times["exact_ties0"].astype(np.float64) - times["exact_ties1_default"].astype(np.float64))[marched]
+        out["exact_ties0"]["vs_the_march_on_the_marched_units"] = {"receiver_times_beyond_1e-4_s": int((d > TOL).sum()), "of": int(d.size), "worst_abs_dt_s": float(d.max()) if d.size else 0.0}
         if with_reference:
             import _libs as L
             from concurrent.futures import ThreadPoolExecutor
-            pick = np.linspace(0, n - 1, 8).astype(int)
+            left = np.nonzero(~marched)[0][:8]
+            pick = np.unique(np.concatenate([np.linspace(0, n - 1, 8).astype(int), left]))
             g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, 8)
             veln = {p: L.o_gridder(g, pv[p]) for p in sorted(set(int(units["map_index"][k]) for k in pick))}
 
@@ -255,10 +264,17 @@ def config4_share(device_index, with_reference=True):
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
                 ref = np.stack(list(ex.map(one, pick)))
-            out["reference_sample"] = {"units": int(len(pick)), "receiver_times": int(ref.size), "against": "port (C restatement pinned to the reference's Fortran)", "seconds": round(time.perf_counter() - t0, 1)}
-            for tag in ("exact_ties0", "exact_ties2", "exact_ties1_default"):
-                d = np.abs(times[tag][pick].astype(np.float64) - ref.astype(np.float64))
-                out[tag]["vs_reference_sample"] = {"beyond_1e-4_s": int((d > TOL).sum()), "not_bit_identical": int((times[tag][pick].view(np.uint32) != ref.view(np.uint32)).sum()), "worst_abs_dt_s": float(d.max())}
+            out["reference_sample"] = {"units": int(len(pick)), "of_which_left_to_the_fixed_point_by_the_default": int(len(left)), "receiver_times": int(ref.size),
+                                       "against": "port (C restatement pinned to the reference's Fortran)", "seconds": round(time.perf_counter() - t0, 1)}
+            for tag in times:
+                dd = np.abs(times[tag][pick].astype(np.float64) - ref.astype(np.float64))
+                out[tag]["vs_reference_sample"] = {"beyond_1e-4_s": int((dd > TOL).sum()), "not_bit_identical": int((times[tag][pick].view(np.uint32) != ref.view(np.uint32)).sum()), "worst_abs_dt_s": float(dd.max())}
+            if len(left):
+                sel = np.isin(pick, left)
+                dl = np.abs(times["exact_ties1_default"][pick][sel].astype(np.float64) - ref[sel].astype(np.float64))
+                out["exact_ties1_default"]["units_left_to_the_fixed_point"] = {"units": int((~marched).sum()), "checked": int(len(left)), "receiver_times_beyond_1e-4_s": int((dl > TOL).sum()), "worst_abs_dt_s": float(dl.max())}
+                if (dl > TOL).any():
+                    out["exact_ties1_default"]["note"] = "the census is a heuristic: a unit it left to the fixed point ends beyond 1e-4 s; exact_ties=2 is the guarantee"
     finally:
         e.close()
     return out

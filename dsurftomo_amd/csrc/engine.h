@@ -120,6 +120,7 @@ struct Engine {
     void release_march_pool();
     int bundle_threads() const;
     float bundle_window() const;
+    float bundle_window_tail() const;
     size_t bundles_resident(int G, int mpl, int threads = 0) const;
     int bundle_mpl_of(int G, long nb) const;
     int choose_bundle_size(int step, long* solo_units = nullptr);

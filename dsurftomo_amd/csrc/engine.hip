@@ -538,7 +538,17 @@ int Engine::bundle_mpl_of(int G, long nb) const
 float Engine::bundle_window() const
 {
     if (bundle_window_opt > 0.0f) return bundle_window_opt;
-    return (bundle_wide && bundle_G_now > 0 && bundle_G_now < 16) ? 1.25f : 0.6f;
+    // (round 5, profiles/r05_ab_windows.log: wide bundles of 16 -- 250 sources: 0.6 / 1.0 / 1.5 / 2.5 cells 134.4 / 129.6 / 131.9 / 133.0 ms;
+    // wide bundles of 8 -- 125 sources: 1.25 / 1.75 / 2.5 / 4.0 cells 97.8 / 96.0 / 95.6 / 111.5 ms)
+    if (bundle_wide && bundle_G_now > 0) return bundle_G_now < 16 ? 1.75f : 1.0f;
+    return 0.6f;
+}
+
+// ... and of the bundles that run 768 threads wide behind the first generation of a large launch (plan_bundles: member flag 2)
+float Engine::bundle_window_tail() const
+{
+    if (bundle_window_opt > 0.0f) return bundle_window_opt;
+    return bundle_threads_b == 768 && bundle_threads() == 256 ? 1.0f : bundle_window();
 }
 
 // Workgroup size of the bundle kernel: the option; 256 threads, three workgroups per CU, as a rule.  Where a bundle has a CU to itself
@@ -585,6 +595,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
       stats[DSA_STAT_MS_DISPERSION] = keep_ms; stats[DSA_STAT_CURVES] = keep_n; }
     std::fill(phase_ticks, phase_ticks + kClockSlots, 0.0);
     release_march_pool();
+    marched_in_tiles = false;
     std::fill(h_unit_flags.begin(), h_unit_flags.end(), (unsigned char)0);      // (per solve: a unit marched by an earlier call with other options is not "marched")
     std::fill(h_unit_tie.begin(), h_unit_tie.end(), 0.0f);
     // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
@@ -659,7 +670,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         }
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
                              detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p,
-                             nbundles ? member_flag.p : nullptr, bundle_window() * cell_c, bundle_max_rounds, stream);
+                             nbundles ? member_flag.p : nullptr, bundle_window() * cell_c, bundle_max_rounds, stream, bundle_window_tail() * cell_c);
         FimLaunch sr = shape_r, sc = shape_c;
         sr.tie = sc.tie = detect ? 1 : 0;
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
@@ -994,6 +1005,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         // each as the first generation's workgroups leave (a bundle of 16 alone on a CU: 106 ms wide against 190 with 256 threads)
         tail.assign(pieces.begin() + res3, pieces.end());
         pieces.resize((size_t)res3);
+        for (const auto& pc : tail) for (int u : pc.second) h_member_flag[(size_t)u] = 2;      // (their own causal window: bundle_window_tail)
         bundles_a = res3; bundles_b = (int)tail.size(); bundle_Gb = G;
         bundle_mpl_b = 4; bundle_threads_b = 768;
     } else if (auto_mpl && bundle_opt == 1 && G >= 8 && nb > res3 && nb < 1500) {

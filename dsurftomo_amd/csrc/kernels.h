@@ -183,7 +183,8 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           const int* d_launch_rank, int32_t* d_tie, float tie_threshold, FimEnds* d_ends_c, const RayDesc* d_rays /* null: no receiver times inside the solve */,
                           const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err,
                           const int* d_member_flag /* null or per unit: 1 = solved inside a bundle */, float window_b /* causal window of the bundles */,
-                          int max_rounds_b /* > 0: round limit of the bundles (tests of the fallback) */, hipStream_t stream);
+                          int max_rounds_b /* > 0: round limit of the bundles (tests of the fallback) */, hipStream_t stream,
+                          float window_t = 0.0f /* > 0: causal window of the members flagged 2 (the wide bundles behind a launch's first generation) */);
 
 // exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), FOUR units per wavefront
 // (a group of sixteen lanes each), unit j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per

@@ -294,7 +294,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
                                 const float* risti_c, float window_r, float window_c, FimProblem* prob_r,
                                 FimProblem* prob_c, int32_t* info, unsigned long long* clocks, const int* __restrict__ launch_rank,
                                 int32_t* tie, float tie_threshold, FimEnds* ends_c, const RayDesc* __restrict__ rays, const float* __restrict__ veln_all,
-                                size_t veln_stride, float dpl, float* out, int32_t* err, const int* __restrict__ member_flag, float window_b, int max_rounds_b)
+                                size_t veln_stride, float dpl, float* out, int32_t* err, const int* __restrict__ member_flag, float window_b, int max_rounds_b, float window_t)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -324,7 +324,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.slow = slow_all + (size_t)sd.period * field_stride; c.risti = risti_c;
     c.seed = b.seed_c + (size_t)s * kSeedC; c.seed_count = b.nseed_c + s; c.seed_cap = kSeedC; c.lists = b.lists_c + (size_t)slot * b.lists_c_stride;
     c.nnx = g.nnx; c.nnz = g.nnz; c.nbx = g.nbx; c.nbz = g.nbz;
-    c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = member ? window_b : window_c;
+    c.ri = g.earth; c.dnx = g.dnx; c.dnz = g.dnz; c.window = member ? (member_flag[s] == 2 && window_t > 0.0f ? window_t : window_b) : window_c;
     // (a bundle whose members' fronts have nothing in common re-evaluates without end: it gives up sixteen times sooner and its chunk goes unit by unit)
     c.max_rounds = member ? (max_rounds_b > 0 ? max_rounds_b : 4 * (g.nnx + g.nnz) + 2048) : 64 * (g.nnx + g.nnz) + 4096;
     c.clocks = clocks ? clocks + (size_t)s * kClockSlots : nullptr;
@@ -349,12 +349,12 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
                           const int* d_launch_rank, int32_t* d_tie, float tie_threshold, FimEnds* d_ends_c, const RayDesc* d_rays,
-                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, const int* d_member_flag, float window_b, int max_rounds_b, hipStream_t stream)
+                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, const int* d_member_flag, float window_b, int max_rounds_b, hipStream_t stream, float window_t)
 {
     if (nsrc <= 0) return;
     hipLaunchKernelGGL(k_make_problems, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all,
                        field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks, d_launch_rank, d_tie, tie_threshold,
-                       d_ends_c, d_rays, d_veln_all, veln_stride, dpl, d_out, d_err, d_member_flag, window_b, max_rounds_b);
+                       d_ends_c, d_rays, d_veln_all, veln_stride, dpl, d_out, d_err, d_member_flag, window_b, max_rounds_b, window_t);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ def main():
         lib.dsa_get_stats.argtypes = [C.c_void_p, C.c_void_p]
     # stage times of the last call (the drop-in's process-wide engine is not exposed; time the stages through an own engine)
     e = E.Engine(0)
+    if os.environ.get("DSA_PROBE_TIES"):
+        e.set_option("exact_ties", int(os.environ["DSA_PROBE_TIES"]))
     vel = np.ascontiguousarray(c["vels"].T)
     for k in range(2):
         t0 = time.perf_counter()
@@ -51,6 +53,7 @@ def main():
         print("stages (own engine) pass %d: dispersion %.1f ms (kernel %.1f, %d curves), maps+kernels %.1f ms, plan %.1f ms (%d units), solve_rows %.1f ms "
               "[fim coarse %.1f refined %.1f stages %.1f rays %.1f rows %.1f]" % (k, 1e3 * (t1 - t0), st["ms_dispersion"], st["curves"], 1e3 * (t2 - t1), 1e3 * (t3 - t2), len(maps),
               1e3 * (t4 - t3), st["ms_fim_coarse"], st["ms_fim_refined"], st["ms_stages"], st["ms_rays"], st["ms_rows"]))
+        print("    tie handling (exact_ties = %s): %d units flagged, %d marched in %.1f ms, largest influence %.3g s" % (os.environ.get("DSA_PROBE_TIES", "default"), st["tie_units"], st["exact_units"], st["ms_exact"], st.get("tie_influence_max", 0.0)))
     e.close()
     ref = L.ref()
     if ref is not None and "--no-ref" not in sys.argv:
