@@ -226,13 +226,16 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         for (int m = 0; m < nmem; ++m) {
             const FimEnds* const E = ends + s_member[m];
             const FimProblem* const pm = problems + s_member[m];
-            GCRec* const W = (GCRec*)E->W;
-            const int cwz0 = E->cwz0, cwx0 = E->cwx0, cwnz = E->cwnz, nw = E->cwnx * cwnz;
+            // pinned nodes: the records of the coarse march window -- or (the refined boxes in bundles) the unit's own tiled records, which the
+            // start-up march pinned: same tiling as the bundle's field, so a record's index is the node's
+            const bool from_records = E->Fpin != nullptr;
+            GCRec* const W = from_records ? (GCRec*)E->Fpin : (GCRec*)E->W;
+            const int cwz0 = E->cwz0, cwx0 = E->cwx0, cwnz = from_records ? 1 : E->cwnz, nw = from_records ? ntile * kTileRecs : E->cwnx * cwnz;
             for (int q = tid; q < nw; q += NT) {
                 const float wt = W[q].T, wk = W[q].tau;
                 if (!t_pinned(wt)) continue;
                 const int lx = q / cwnz, lz = q - lx * cwnz;
-                const int id = rec_index(nbz, cwz0 + lz, cwx0 + lx);
+                const int id = from_records ? q : rec_index(nbz, cwz0 + lz, cwx0 + lx);
                 const int key = id * G + m;
                 const unsigned long long mine = exc_pack(key | kExcPinned, wk);
                 const unsigned mask = (1u << xlog) - 1u;
@@ -1022,6 +1025,56 @@ __global__ void k_interleave_maps(const float* __restrict__ slow_all, size_t fie
     const size_t id = i / (size_t)np;
     const int m = (int)(i - id * (size_t)np);
     slowI[i] = slow_all[(size_t)m * field_stride + id];
+}
+
+// ---- the refined boxes in bundles (round 5) -----------------------------------------------------------------------------------------------
+// slowI[(b * nrec + id) * G + m] = slowness of member m of bundle b at record id, from the member's own tiled slowness (FimProblem::slow)
+template <int G>
+__global__ void k_bundle_refined_slowness(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems, int nrec, float* __restrict__ slowI)
+{
+    const FimBundle* const bd = bundles + blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec * G) return;
+    const int id = i / G, m = i - id * G;
+    const int mm = m < bd->nmem ? m : 0;
+    slowI[((size_t)blockIdx.y * nrec + id) * G + m] = problems[bd->member[mm]].slow[id];
+}
+// the converged members of the bundles back into their (T, tau) records (FimProblem::F), as the unit-by-unit refined solve leaves them: T with the
+// sign bit of a pinned node, tau the acceptance time (the value itself unless the node is in the bundle's exception table)
+template <int G>
+__global__ void k_bundle_export_records(const FimBundle* __restrict__ bundles, const FimProblem* __restrict__ problems, int nrec)
+{
+    const FimBundle* const bd = bundles + blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec * G) return;
+    const int id = i / G, m = i - id * G;
+    if (m >= bd->nmem) return;
+    const float v = bd->B[(size_t)bd->slot * bd->b_stride + (size_t)id * G * DSA_BSTRIDE + m];
+    Rec r{ v, v };
+    if (__builtin_signbit(v)) {
+        bool pinned = false;
+        const float tau = exc_find(bd->exc + (size_t)bd->slot * bd->exc_stride, bd->exc_log2cap, id * G + m, &pinned);
+        r.T = pinned ? v : -v; r.tau = tau;
+    }
+    problems[bd->member[m]].F[id] = r;
+}
+
+void launch_bundle_refined_slowness(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, int nrec, float* d_slowI, hipStream_t stream)
+{
+    if (nbundles <= 0) return;
+    const dim3 grid((unsigned)((nrec * G + 255) / 256), (unsigned)nbundles), block(256);
+    if (G == 16) hipLaunchKernelGGL(k_bundle_refined_slowness<16>, grid, block, 0, stream, d_bundles, d_problems, nrec, d_slowI);
+    else if (G == 8) hipLaunchKernelGGL(k_bundle_refined_slowness<8>, grid, block, 0, stream, d_bundles, d_problems, nrec, d_slowI);
+    else hipLaunchKernelGGL(k_bundle_refined_slowness<4>, grid, block, 0, stream, d_bundles, d_problems, nrec, d_slowI);
+}
+
+void launch_bundle_export_records(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, int nrec, hipStream_t stream)
+{
+    if (nbundles <= 0) return;
+    const dim3 grid((unsigned)((nrec * G + 255) / 256), (unsigned)nbundles), block(256);
+    if (G == 16) hipLaunchKernelGGL(k_bundle_export_records<16>, grid, block, 0, stream, d_bundles, d_problems, nrec);
+    else if (G == 8) hipLaunchKernelGGL(k_bundle_export_records<8>, grid, block, 0, stream, d_bundles, d_problems, nrec);
+    else hipLaunchKernelGGL(k_bundle_export_records<4>, grid, block, 0, stream, d_bundles, d_problems, nrec);
 }
 
 void launch_interleave_maps(const float* d_slow_all, size_t field_stride, int np, float* d_slowI, hipStream_t stream)

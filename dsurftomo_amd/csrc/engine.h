@@ -104,6 +104,20 @@ struct Engine {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
     hipError_t make_stream2();
+    // Round 5: the REFINED boxes of bundled units are solved in bundles too (option bundle_refined, default on): the same member lists as the
+    // coarse bundles, fields of the 129^2 box (1.3 MB per bundle), the members' own refined slowness member-minor, the converged members written back
+    // into their (T, tau) records for the hand-off (kernels.h: FimEnds::Fpin, launch_bundle_*).  The unit-by-unit refined solves took 29 ms of the
+    // headline step: 5 times the coarse bundles' cost per evaluation.
+    int bundle_refined_opt = 1;
+    bool refined_bundles_failed = false;      // a refined bundle ran out of rounds / table space: unit by unit until the maps change
+    bool refined_bundles_now = false;
+    std::vector<FimBundle> h_bundles_r;
+    DevBuf<FimBundle> bundles_r_d;
+    DevBuf<FimEnds> ends_r;
+    DevBuf<float> Br_pool, slowIr;
+    DevBuf<unsigned long long> exc_br;
+    DevBuf<int> lists_br, cand_br;
+    size_t slowIr_off_b = 0;                   // floats from slowIr to the second group's block
     int bundle_pool_opt = 0;           // option bundle_pool: bundle field slots (0 = up to 1024; fewer than the bundles of a launch: recycled like the unit slots)
     DevBuf<float> slowI, B_pool;       // member-minor slowness of all maps; bundle field slots
     bool slowI_ready = false;

@@ -91,7 +91,7 @@ Engine::~Engine()
     rel(coo_col); rel(coo_iw); rel(slabs); rel(coo_rw); rel(rayinfo); rel(G_rw); rel(G_row); rel(G_col);
     rel(geom); rel(pvstore); rel(curves); rel(tper); rel(disp_ws);
     if (stream2) { (void)hipStreamDestroy(stream2); (void)hipEventDestroy(ev_b0); (void)hipEventDestroy(ev_b1); stream2 = nullptr; }
-    rel(cand_b);
+    rel(cand_b); rel(bundles_r_d); rel(ends_r); rel(Br_pool); rel(slowIr); rel(exc_br); rel(lists_br); rel(cand_br);
     rel(lists_c); rel(pool_gen); rel(ends_c); rel(disp_diag); rel(disp_fail_list); rel(X_pool); rel(X_heap); rel(X_tt); rel(X_tp); rel(X_ring); rel(X_free); rel(X_pins); rel(x_starts); rel(x_nstart); rel(x_units); rel(xinfo); rel(tieinfo);
     for (auto& ev : events) if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
@@ -157,7 +157,7 @@ int Engine::finish_maps(int nm)
     planned = false;
     have_maps = true;
     slowI_ready = false;
-    bundles_failed = false;
+    bundles_failed = false; refined_bundles_failed = false;
     if (g.nnx != grown_nnx || g.nnz != grown_nnz) { exc_log2cap_grown = 0; grown_nnx = g.nnx; grown_nnz = g.nnz; }
     return 0;
 }
@@ -668,15 +668,29 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         if (bundle_G > 0 && !bundle_off_chunk) {
             if (plan_bundles(first, n, bundle_G, &nsolo, &nbundles) != 0) return status;
         }
+        const bool refined_b = nbundles > 0 && refined_bundles_now && !bundle_off_chunk;
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
                              detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p,
-                             nbundles ? member_flag.p : nullptr, bundle_window() * cell_c, bundle_max_rounds, stream, bundle_window_tail() * cell_c);
+                             nbundles ? member_flag.p : nullptr, bundle_window() * cell_c, bundle_max_rounds, stream, bundle_window_tail() * cell_c,
+                             refined_b ? ends_r.p : nullptr);
         FimLaunch sr = shape_r, sc = shape_c;
         sr.tie = sc.tie = detect ? 1 : 0;
         launch_refine(g, b, n, velv.p, (size_t)g.nx * g.ny, rbasis.p, stream);
         if (exact_ties != 2) launch_refined_startup(g, b, n, stream);
         HIP_TRY(this, hipEventRecord(events[2], stream));
-        if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
+        if (exact_ties != 2 && refined_b) {
+            // solo units (launch ranks 0 .. nsolo-1) one by one; the bundles' members side by side: member-minor slowness, the bundle kernel on the
+            // boxes (256 threads), the converged members back into their records
+            launch_fim(prob_r.p, nsolo, sr, stream);
+            const int cnt[2] = { bundles_a, nbundles - bundles_a }, GG[2] = { bundle_G, bundle_Gb }, mpl[2] = { bundle_mpl_now, bundles_b > 0 && bundle_threads_b == 256 ? bundle_mpl_b : bundle_mpl_of(bundle_Gb ? bundle_Gb : bundle_G, nbundles) };
+            for (int q = 0; q < 2; ++q) {
+                if (cnt[q] <= 0) continue;
+                const FimBundle* const bq = bundles_r_d.p + (q ? bundles_a : 0);
+                launch_bundle_refined_slowness(bq, cnt[q], GG[q], prob_r.p, kRefRecs, slowIr.p + (q ? slowIr_off_b : 0), stream);
+                launch_fim_bundles(bq, cnt[q], GG[q], 256, prob_r.p, ends_r.p, sr.tile_words, stream, GG[q] == 16 ? 4 : mpl[q], detect);
+                launch_bundle_export_records(bq, cnt[q], GG[q], prob_r.p, kRefRecs, stream);
+            }
+        } else if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         if (exact_ties != 2) {
             launch_handoff(g, b, n, stream);
@@ -784,6 +798,11 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             break;
         }
         if (redo_chunk) continue;
+        if (refined_b) {    // a refined bundle that ran out of rounds or table space: the chunk once more with the refined boxes unit by unit
+            bool bad = false;
+            for (int u = 0; u < n && !bad; ++u) bad = h_member_flag[(size_t)u] && h_info[(size_t)u * 16 + 2] < 0;
+            if (bad) { refined_bundles_failed = true; refined_bundles_now = false; redo_chunk = true; stats[DSA_STAT_RESCANS] += 1; continue; }
+        }
         if (nbundles) {     // a bundle that did not converge under the shared schedule: its chunk once more, every unit by itself
             bool bad = false;
             for (int u = 0; u < n && !bad; ++u) bad = h_member_flag[(size_t)u] && h_info[(size_t)u * 16 + 10] == -1;
@@ -1076,6 +1095,39 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
             bd.member[m] = rank++;
             bd.map[m] = h_src[(size_t)(first + u)].period;
         }
+    }
+    // the same bundles once more for the refined boxes (engine.h: bundle_refined_opt): a slot per bundle, the group's member count per node
+    // (from 128 bundles on: a dozen bundles leave the chip emptier than their 200 unit-by-unit workgroups did -- 12 bundles of 16 at 1025^2: refined stage
+    // 2.1 -> 4.9 ms; 1 000 bundles: 29.1 -> 14.7 ms, profiles/r05_ab_refined_bundles.log; option bundle_refined = 2 forces it for tests)
+    refined_bundles_now = bundle_refined_opt && (nb >= 128 || bundle_refined_opt == 2) && !refined_bundles_failed && exact_ties != 2;
+    if (refined_bundles_now) {
+        const size_t nrec_r = kRefRecs;
+        const int xlog_r0 = exc_log2cap_of(kRefMax, kRefMax);
+        const size_t lists_r_stride = ((size_t)kFimMaskInts * kRefTiles * kRefTiles + 2 + 1) & ~(size_t)1;
+        const size_t cand_cap_r = 65535, cand_stride_r = cand_cap_r + 1;
+        size_t b_tot = 0, x_tot = 0, s_tot = 0;
+        std::vector<size_t> b_off((size_t)nb), x_off((size_t)nb), s_off((size_t)nb);
+        for (int k = 0; k < nb; ++k) {
+            const int GG = k < bundles_a ? G : bundle_Gb, lg = GG == 16 ? 4 : GG == 8 ? 3 : 2;
+            b_off[(size_t)k] = b_tot; x_off[(size_t)k] = x_tot; s_off[(size_t)k] = s_tot;
+            b_tot += (size_t)(GG * DSA_BSTRIDE + 1) * nrec_r; x_tot += (size_t)1 << (xlog_r0 + lg); s_tot += (size_t)GG * nrec_r;
+            if (k + 1 == bundles_a) slowIr_off_b = s_tot;
+        }
+        if (ensure(Br_pool, b_tot) || ensure(exc_br, x_tot) || ensure(lists_br, (size_t)nb * lists_r_stride) || ensure(slowIr, s_tot) || ensure(bundles_r_d, (size_t)nb) ||
+            ensure(ends_r, (size_t)n) || (want_cand && ensure(cand_br, (size_t)nb * cand_stride_r))) return status;
+        h_bundles_r = h_bundles;
+        for (int k = 0; k < nb; ++k) {
+            const int GG = k < bundles_a ? G : bundle_Gb, lg = GG == 16 ? 4 : GG == 8 ? 3 : 2;
+            FimBundle& bd = h_bundles_r[(size_t)k];
+            bd.B = Br_pool.p + b_off[(size_t)k]; bd.b_stride = 0; bd.p_offset = (size_t)GG * DSA_BSTRIDE * nrec_r;
+            bd.exc = exc_br.p + x_off[(size_t)k]; bd.exc_stride = 0; bd.exc_log2cap = xlog_r0 + lg;
+            bd.lists = lists_br.p + (size_t)k * lists_r_stride; bd.lists_stride = 0;
+            bd.slot_busy = nullptr; bd.nslots = 1; bd.slot = 0;
+            bd.slowI = slowIr.p + s_off[(size_t)k]; bd.np = GG;
+            bd.cand = want_cand && tie_list_opt ? cand_br.p + (size_t)k * cand_stride_r : nullptr; bd.cand_stride = 0; bd.cand_cap = (int)cand_cap_r;
+            for (int m = 0; m < kBundleMax; ++m) bd.map[m] = m < GG ? m : 0;
+        }
+        HIP_TRY(this, hipMemcpyAsync(bundles_r_d.p, h_bundles_r.data(), (size_t)nb * sizeof(FimBundle), hipMemcpyHostToDevice, stream));
     }
     HIP_TRY(this, hipMemsetAsync(bpool_gen.p, 0, slots_total * sizeof(int), stream));
     HIP_TRY(this, hipMemcpyAsync(bundles_d.p, h_bundles.data(), (size_t)nb * sizeof(FimBundle), hipMemcpyHostToDevice, stream));
@@ -1460,6 +1512,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "bundle_threads" && (value == 0 || value == 256 || value == 512 || value == 768)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }
     if (n == "bundle_tail" && (value == 0 || value == 1)) { en->bundle_tail_opt = (int)value; return 0; }
+    if (n == "bundle_refined" && (value == 0 || value == 1 || value == 2)) { en->bundle_refined_opt = (int)value; return 0; }
     if (n == "bundle_far_all" && (value == 0 || value == 1)) { en->bundle_far_all = (int)value; return 0; }
     if (n == "bundle_pool" && value >= 0) { en->bundle_pool_opt = (int)value; return 0; }
     if (n == "bundle_members_per_lane" && (value == 0 || value == 4 || value == 2)) { en->bundle_mpl = (int)value; return 0; }

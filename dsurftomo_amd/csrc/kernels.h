@@ -50,6 +50,8 @@ struct FimProblem {
 struct FimEnds {
     const Rec* W;            // window records, (cwnz, cwnx) column-major
     int cwz0, cwx0, cwnz, cwnx;
+    const Rec* Fpin;         // (round 5, the refined boxes solved in bundles) non-null: the unit's tiled (T, tau) records -- the bundle takes its pinned nodes
+                             // from them instead of a window, and k_bundle_export_records writes the converged member back into them
     int* slot_busy;          // recycled field slots: the pool's busy flags (the workgroup claims a free slot by compare-and-swap and
     int nslots;              // clears the flag when done); null: the slot named in the FimProblem is this unit's alone
     float* Tc_pool;          // the pool's arrays: slot q at Tc_pool + q * (tile records of the grid), exc_pool + (q << exc_log2cap),
@@ -184,7 +186,12 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err,
                           const int* d_member_flag /* null or per unit: 1 = solved inside a bundle */, float window_b /* causal window of the bundles */,
                           int max_rounds_b /* > 0: round limit of the bundles (tests of the fallback) */, hipStream_t stream,
-                          float window_t = 0.0f /* > 0: causal window of the members flagged 2 (the wide bundles behind a launch's first generation) */);
+                          float window_t = 0.0f /* > 0: causal window of the members flagged 2 (the wide bundles behind a launch's first generation) */,
+                          FimEnds* d_ends_r = nullptr /* non-null: the refined problems go to d_prob_r by launch rank like the coarse ones, with these ends (Fpin) beside them: the refined boxes of bundled units are solved in bundles too */);
+// the refined boxes in bundles: member-minor slowness of a bundle's members from their own tiled slowness (problems[member].slow), and the converged members
+// back into their (T, tau) records (problems[member].F) for the hand-off
+void launch_bundle_refined_slowness(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, int nrec, float* d_slowI, hipStream_t stream);
+void launch_bundle_export_records(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, int nrec, hipStream_t stream);
 
 // exact mode (exact_kernel.hip): the reference's Fast Marching replayed for the chunk-local units d_units[0..n), FOUR units per wavefront
 // (a group of sixteen lanes each), unit j marching in pool slot j (pool_stride records of 8 bytes per slot; gcap tree slots of 8 bytes per

@@ -294,7 +294,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
                                 const float* risti_c, float window_r, float window_c, FimProblem* prob_r,
                                 FimProblem* prob_c, int32_t* info, unsigned long long* clocks, const int* __restrict__ launch_rank,
                                 int32_t* tie, float tie_threshold, FimEnds* ends_c, const RayDesc* __restrict__ rays, const float* __restrict__ veln_all,
-                                size_t veln_stride, float dpl, float* out, int32_t* err, const int* __restrict__ member_flag, float window_b, int max_rounds_b, float window_t)
+                                size_t veln_stride, float dpl, float* out, int32_t* err, const int* __restrict__ member_flag, float window_b, int max_rounds_b, float window_t, FimEnds* ends_r)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -309,9 +309,16 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     r.clocks = nullptr;
     r.info = info + (size_t)s * 16;
     r.tie = tie ? tie + (size_t)s * 4 : nullptr; r.tie_threshold = tie_threshold;
-    prob_r[s] = r;
     // field slot: the unit's own, or (a pool smaller than the launch) the one its workgroup number selects
     const int rank = launch_rank ? launch_rank[s] : s;
+    if (ends_r) {
+        // (the refined boxes of bundled units are solved in bundles too: the refined problems by launch rank, like the coarse ones -- solo units
+        // first --, each with the records its bundle takes the pinned nodes from)
+        prob_r[rank] = r;
+        FimEnds er{};
+        er.Fpin = r.F;
+        ends_r[rank] = er;
+    } else prob_r[s] = r;
     const bool recycled = b.pool < nsrc;
     const int slot = recycled ? rank % b.pool : s;
     // a member of a bundle (bundle_kernel.hip) is solved inside its bundle's field: it has no slot of its own unless every unit has one
@@ -333,6 +340,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     prob_c[rank] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
     if (ends_c) {
         FimEnds e;
+        e.Fpin = nullptr;
         e.W = b.W_c + (size_t)s * kCWinMax * kCWinMax; e.cwz0 = sd.cwz0; e.cwx0 = sd.cwx0; e.cwnz = sd.cwnz; e.cwnx = sd.cwnx;
         e.slot_busy = recycled && !member ? b.pool_gen : nullptr; e.nslots = b.pool;
         e.Tc_pool = b.T_c; e.exc_pool = b.exc_c; e.lists_pool = b.lists_c; e.lists_stride = (unsigned)b.lists_c_stride;
@@ -349,12 +357,12 @@ void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,
                           const int* d_launch_rank, int32_t* d_tie, float tie_threshold, FimEnds* d_ends_c, const RayDesc* d_rays,
-                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, const int* d_member_flag, float window_b, int max_rounds_b, hipStream_t stream, float window_t)
+                          const float* d_veln_all, size_t veln_stride, float dpl, float* d_out, int32_t* d_err, const int* d_member_flag, float window_b, int max_rounds_b, hipStream_t stream, float window_t, FimEnds* d_ends_r)
 {
     if (nsrc <= 0) return;
     hipLaunchKernelGGL(k_make_problems, dim3((nsrc + 63) / 64), dim3(64), 0, stream, g, b, nsrc, d_slow_all,
                        field_stride, d_risti_c, window_r, window_c, d_prob_r, d_prob_c, d_info, d_clocks, d_launch_rank, d_tie, tie_threshold,
-                       d_ends_c, d_rays, d_veln_all, veln_stride, dpl, d_out, d_err, d_member_flag, window_b, max_rounds_b, window_t);
+                       d_ends_c, d_rays, d_veln_all, veln_stride, dpl, d_out, d_err, d_member_flag, window_b, max_rounds_b, window_t, d_ends_r);
 }
 
 // ---------------------------------------------------------------------------------------------

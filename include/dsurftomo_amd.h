@@ -80,12 +80,13 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *   differently (measured: identical on the headline and checkerboard media, 4 of 262 144 times apart by up to 4.2e-5 s on unrelated random maps)
  *     bundle                   [1]     1 automatic: 16 / 8 / 4 members, whichever the launch-time model promises most for the call's sources and periods,
  *                                      on grids of at least 120 nodes per side (below 400: only launches of at least 384 bundles of 8 or 16) | 0 off | 4, 8, 16
- *     bundle_window_cells      [0]     causal window of the bundles; 0 = 0.6 (1.25 for launches of at most 256 bundles of 8 or 4, which run 768 threads wide)
+ *     bundle_window_cells      [0]     causal window of the bundles; 0 = 0.6 (768 threads wide: 1.0 for bundles of 16, 1.75 for bundles of 8 or 4)
  *     bundle_threads           [0]     256 | 512 | 768; 0 = 256 (three workgroups per CU), 768 beyond 1500 nodes per side and for launches of at most 256 bundles
  *     bundle_members_per_lane  [0]     4 | 2; 0 = four for bundles of 16, two for bundles of 8 / 4 in launches of more than 512
  *     bundle_pool              [0]     bundle field slots; 0 = the bundles resident at a time and an eighth more, within the memory budget
  *     bundle_tail              [1]     a launch of 768 .. 1500 bundles, the ones beyond the first generation (768 = three workgroups per CU): 1 whole and 768 threads
  *                                      wide on a second stream, a CU each, when there are at most 256 of them | 0 cut in halves (256 threads; also beyond 256)
+ *     bundle_refined           [1]     the 129^2 refined boxes of bundled units in bundles too, in launches of at least 128 bundles | 0 unit by unit | 2 always
  *     bundle_max_rounds        [0]     round limit of a bundle; 0 = the solver's own.  A bundle that hits it sends its chunk to the unit-by-unit solve (tests)
  *     bundle_far_all           [0]     1 = every node trip fetches all four outer neighbours (round 4's loads; A/B switch)
  *

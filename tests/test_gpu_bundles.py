@@ -191,6 +191,39 @@ def test_bundles_beyond_the_first_generation(bundles, tail):
     assert nbad == 0
 
 
+@pytest.mark.parametrize("nx,kinds,nsrc,G", [(35, ("checker4", "rough", "smooth", "checker4"), 30, 4), (131, ("smooth",) * 16, 12, 16), (131, ("checker", "rough") * 4, 10, 8)])
+def test_refined_boxes_in_bundles_equal_unit_by_unit(bundles, nx, kinds, nsrc, G):
+    """Round 5 (engine option bundle_refined, default on): the 129^2 refined boxes of a source's periods are solved in bundles like the coarse grids --
+    the members' own refined slowness member-minor, pinned nodes from each member's start-up march, the converged members written back into their
+    (T, tau) records for the hand-off.  Refined snapshots, coarse fields and receiver times must be those of the unit-by-unit refined solve."""
+    e = bundles
+    nper, nrec = len(kinds), 6
+    pv = np.stack([synth.medium(nx, k, p) for p, k in enumerate(kinds)])
+    u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 91)
+    n = nsrc * nper
+    e.set_option("field_pool", -1)
+    e.set_option("bundle", G)
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    out = {}
+    try:
+        for br in (0, 2):                     # (2: also for launches of fewer than 128 bundles, which the default leaves unit by unit)
+            e.set_option("bundle_refined", br)
+            t = e.traveltimes(**u)
+            st = e.stats()
+            assert st["bundled_units"] == n, st
+            pick = list(range(0, n, max(1, n // 24)))
+            out[br] = (t, [e.refined(k) for k in pick], [e.field(k) for k in pick], st["ms_fim_refined"])
+    finally:
+        e.set_option("bundle_refined", 1)
+    assert np.array_equal(bits(out[0][0]), bits(out[2][0]))
+    for (Ta, Sa), (Tb, Sb) in zip(out[0][1], out[2][1]):
+        assert np.array_equal(Sa, Sb) and np.array_equal(bits(Ta), bits(Tb))
+    for Fa, Fb in zip(out[0][2], out[2][2]):
+        assert np.array_equal(bits(Fa), bits(Fb))
+    parity_log.add(f"refined boxes in bundles N={e.nnx} {'/'.join(sorted(set(kinds)))}, {n} units in bundles of {G}: receiver times, {len(out[0][1])} refined snapshots and coarse fields identical to the "
+                   f"unit-by-unit refined solve (refined stage {out[0][3]:.2f} -> {out[2][3]:.2f} ms)")
+
+
 @pytest.mark.parametrize("kind,G", [("checker", 16), ("rough", 16), ("checker4s", 4)])
 def test_tie_census_by_candidate_list_equals_the_sweep(bundles, kind, G):
     """The bundles' tie census (round 5): candidates marked while the bundle iterates and checked against the converged field (option tie_list = 1,
