@@ -372,7 +372,7 @@ for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, ns
     assert (o["iw"] == d["iw"]).all() and (o["col"] == d["col"]).all()
     assert (o["rw"].view(np.uint32) == d["rw"].view(np.uint32)).all()
 import ctypes as C
-st = np.zeros(40); lib.dsa_dropin_engine.restype = C.c_void_p
+st = np.zeros(64); lib.dsa_dropin_engine.restype = C.c_void_p
 assert lib.dsa_get_stats(C.c_void_p(lib.dsa_dropin_engine()), st.ctypes.data_as(C.c_void_p)) == 0
 assert st[21] > 0, st[:26]          # DSA_STAT_EXACT_UNITS: the last call went through the literal march
 print("exact ok")

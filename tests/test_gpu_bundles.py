@@ -138,7 +138,7 @@ for kw in (dict(), dict(kRc=0, kRg=2, kLc=0, kLg=1), dict(nx=20, ny=18, nz=6, ns
     assert (o["dsurf"].view(np.uint32) == d["dsurf"].view(np.uint32)).all()
     assert (o["iw"] == d["iw"]).all() and (o["col"] == d["col"]).all()
     assert (o["rw"].view(np.uint32) == d["rw"].view(np.uint32)).all()
-    st = np.zeros(40)
+    st = np.zeros(64)
     assert lib.dsa_get_stats(C.c_void_p(lib.dsa_dropin_engine()), st.ctypes.data_as(C.c_void_p)) == 0
     assert st[26] == 4 and st[27] > 0 and st[28] > 0, st[:30]          # DSA_STAT_BUNDLE_SIZE, _BUNDLES, _BUNDLED_UNITS
     print("bundles", int(st[27]), "units", int(st[28]), "of", int(st[5]))
@@ -191,11 +191,13 @@ def test_bundles_beyond_the_first_generation(bundles, tail):
     assert nbad == 0
 
 
-@pytest.mark.parametrize("nx,kinds,nsrc,G", [(35, ("checker4", "rough", "smooth", "checker4"), 30, 4), (131, ("smooth",) * 16, 12, 16), (131, ("checker", "rough") * 4, 10, 8)])
+@pytest.mark.parametrize("nx,kinds,nsrc,G", [(35, ("checker4", "rough", "smooth", "checker4"), 30, 4), (131, ("smooth",) * 16, 12, 16), (131, ("checker", "smooth") * 4, 10, 8)])
 def test_refined_boxes_in_bundles_equal_unit_by_unit(bundles, nx, kinds, nsrc, G):
     """Round 5 (engine option bundle_refined, default on): the 129^2 refined boxes of a source's periods are solved in bundles like the coarse grids --
     the members' own refined slowness member-minor, pinned nodes from each member's start-up march, the converged members written back into their
-    (T, tau) records for the hand-off.  Refined snapshots, coarse fields and receiver times must be those of the unit-by-unit refined solve."""
+    (T, tau) records for the hand-off.  Refined snapshots, coarse fields and receiver times must be those of the unit-by-unit refined solve.
+    (Media whose solves repeat bit for bit: on the +-10 % random medium a tie node of the COARSE field can settle in either of its two states from run
+    to run, DESIGN.md "Ties", so two runs of anything differ there by an ulp at a few nodes; the small case keeps a rough period for the refined stage.)"""
     e = bundles
     nper, nrec = len(kinds), 6
     pv = np.stack([synth.medium(nx, k, p) for p, k in enumerate(kinds)])
@@ -224,12 +226,12 @@ def test_refined_boxes_in_bundles_equal_unit_by_unit(bundles, nx, kinds, nsrc, G
                    f"unit-by-unit refined solve (refined stage {out[0][3]:.2f} -> {out[2][3]:.2f} ms)")
 
 
-@pytest.mark.parametrize("kind,G", [("checker", 16), ("rough", 16), ("checker4s", 4)])
+@pytest.mark.parametrize("kind,G", [("checker", 16), ("smooth", 16), ("checker4s", 4)])
 def test_tie_census_by_candidate_list_equals_the_sweep(bundles, kind, G):
     """The bundles' tie census (round 5): candidates marked while the bundle iterates and checked against the converged field (option tie_list = 1,
     default) against the sweep of the whole converged field (tie_list = 0; also what a list that overflows falls back to).  Both must name the same
     units with the same largest influence -- every tie of the converged field is seen by the last evaluation of one of its two nodes -- and the
-    receiver times do not depend on the census at all."""
+    receiver times do not depend on the census at all.  (Media whose solves repeat bit for bit: the two censuses look at two runs.)"""
     e = bundles
     if kind == "checker4s":
         nx, nsrc, nper, nrec, med = 35, 40, 4, 4, "checker4"       # 257^2, forced bundles of 4
@@ -255,7 +257,6 @@ def test_tie_census_by_candidate_list_equals_the_sweep(bundles, kind, G):
     assert np.array_equal(out[1][1] & 1, out[0][1] & 1), (np.nonzero((out[1][1] ^ out[0][1]) & 1)[0][:8], out[1][3], out[0][3])
     assert np.array_equal(bits(out[1][2]), bits(out[0][2]))
     parity_log.add(f"tie census N={e.nnx} {med}, {n} units in bundles of {G}: candidate list and sweep flag the same {out[1][3]} units (largest influence {out[1][2].max():.3g} s)")
-    assert out[1][3] > 0 or kind == "rough" or True
 
 
 def test_small_launch_on_a_rectangular_grid_runs_wide_and_equals_unit_by_unit(bundles):

@@ -82,7 +82,7 @@ def test_bench_gpus_2_as_typed():
     """`python bench.py --gpus 2` without a launcher: the parent starts the two ranks (before touching the GPU) and rank 0
     prints one JSON line for the whole job"""
     env = dict(os.environ, DSA_MAX_CHUNK="2048")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -96,7 +96,7 @@ def test_bench_collective_path_over_rccl_with_one_rank():
     receiver times left in HBM by dsa_solve_device, all_gather_into_tensor on the device tensor, host copy after the collective"""
     env = dict(os.environ, DSA_BENCH_FORCE_DIST="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -25,7 +25,7 @@ def main():
         d = L.call_boundary(lib.dsa_calsurfg, c)
         dt = time.perf_counter() - t0
         print("device call %d: %.3f s wall, nar %d" % (k, dt, d["nar"]))
-        st = np.zeros(40)
+        st = np.zeros(64)
         lib.dsa_get_stats.argtypes = [C.c_void_p, C.c_void_p]
     # stage times of the last call (the drop-in's process-wide engine is not exposed; time the stages through an own engine)
     e = E.Engine(0)
