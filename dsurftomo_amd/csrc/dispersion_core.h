@@ -30,6 +30,51 @@ DSA_HD void sin_cos(double x, double* s, double* c)
 #endif
 }
 
+// IEEE division by a denominator that serves several quotients (round 5).  The compiler expands `x / d` on this hardware into v_div_scale (x2),
+// v_rcp, two Newton steps on the reciprocal, the quotient, its remainder, v_div_fmas and v_div_fixup: eleven instructions, sixteen times per
+// layer of the Rayleigh secular function -- a fifth of its instruction stream.  recip_of / div_by are that expansion split where it splits: the
+// reciprocal's four FMAs depend on the denominator alone (five quotients share the layer product's norm, three the density, every layer
+// 1 / omega), the quotient takes three more and the fix-up of the special cases (zeros and their signs, infinities, NaN: as the full division
+// has them).  What is left out is the rescaling of v_div_scale / v_div_fmas, which acts only on operands it would otherwise lose bits of: a
+// denominator that is denormal or beyond 2^1021, exponents 768 apart, a quotient in the denormal range, a numerator below 2^-970 -- such a
+// quotient (a component 290 orders of magnitude under the layer product's norm) may round differently in its last bit here.  Everywhere else
+// the value is the full division's, bit for bit: the same instructions on the same operands.  The host build divides.
+struct Recip { double d, r; };
+DSA_HD Recip recip_of(double d)
+{
+    Recip R;
+    R.d = d;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSA_DISP_PLAIN_DIV)          // (-DDSA_DISP_PLAIN_DIV: the compiler's division, for the A/B of profiles/r05_ab_dispersion.log)
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    R.r = __builtin_fma(r, e, r);
+#else
+    R.r = 0.0;
+#endif
+    return R;
+}
+DSA_HD double div_by(double x, const Recip& R)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSA_DISP_PLAIN_DIV)
+    const double q = x * R.r;
+    const double rem = __builtin_fma(-R.d, q, x);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(rem, R.r, q), R.d, x);
+#else
+    return x / R.d;
+#endif
+}
+
+DSA_HD double larger_abs(double t, double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmax(t, __builtin_fabs(v));
+#else
+    return fabs(v) > t ? fabs(v) : t;
+#endif
+}
+
 constexpr int kMaxLayers = 200;     // reference NL
 constexpr int kMaxPeriods = 60;     // reference NP
 
@@ -107,8 +152,9 @@ DSA_HD double dltar1(const Layers& m, double wvno, double omega)
         const double ynor = fabs(e20);
         if (ynor > xnor) xnor = ynor;
         if (xnor < 1.e-40) xnor = 1.0;
-        e1 = e10 / xnor;
-        e2 = e20 / xnor;
+        const Recip by_xnor = recip_of(xnor);
+        e1 = div_by(e10, by_xnor);
+        e2 = div_by(e20, by_xnor);
     };
     if (m.gsize <= 1) {
         for (int k = mmax - 1; k >= m.llw; --k) {
@@ -147,29 +193,35 @@ struct LayerTerms { double a0, cpcq, cpy, cpz, cqw, cqx, xy, xz, wy, wz, w, cosp
 
 DSA_HD void layer_terms(double p, double q, double ra, double rb, double wvno, double xka, double xkb, double dpth, LayerTerms& o)
 {
-    double pex = 0.0, sex = 0.0, sinp, x, sinq, y, z, cosq, fac, w, cosp;
+    double pex = 0.0, sex = 0.0, sinp = 0.0, x, sinq = 0.0, y, z, cosq, fac, w, cosp;
+    // (w = sinp / ra and y = sinq / rb of the oscillating and of the evanescent branch: one division behind the branches, so that a wavefront
+    // whose lanes sit on both sides of a layer's velocity divides once)
     if (wvno < xka) {
-        sin_cos(p, &sinp, &cosp); w = sinp / ra; x = -ra * sinp;
+        sin_cos(p, &sinp, &cosp); x = -ra * sinp;
     } else if (wvno == xka) {
-        cosp = 1.0; w = dpth; x = 0.0;
+        cosp = 1.0; x = 0.0;
     } else {
         pex = p; fac = 0.0;
         if (p < 16) fac = exp(-2.0 * p);
         cosp = (1.0 + fac) * 0.5;
         sinp = (1.0 - fac) * 0.5;
-        w = sinp / ra; x = ra * sinp;
+        x = ra * sinp;
     }
+    w = div_by(sinp, recip_of(ra));
+    if (wvno == xka) w = dpth;
     if (wvno < xkb) {
-        sin_cos(q, &sinq, &cosq); y = sinq / rb; z = -rb * sinq;
+        sin_cos(q, &sinq, &cosq); z = -rb * sinq;
     } else if (wvno == xkb) {
-        cosq = 1.0; y = dpth; z = 0.0;
+        cosq = 1.0; z = 0.0;
     } else {
         sex = q; fac = 0.0;
         if (q < 16) fac = exp(-2.0 * q);
         cosq = (1.0 + fac) * 0.5;
         sinq = (1.0 - fac) * 0.5;
-        y = sinq / rb; z = rb * sinq;
+        z = rb * sinq;
     }
+    y = div_by(sinq, recip_of(rb));
+    if (wvno == xkb) y = dpth;
     const double exa = pex + sex;
     o.a0 = 0.0;
     if (exa < 60.0) o.a0 = exp(-exa);
@@ -216,13 +268,14 @@ DSA_HD double dltar4(const Layers& m, double wvno, double omga)
         e4 = wvno2 - ra * rb;
     }
     const double tt = -2.0 * wvno2;
+    const Recip by_omega = recip_of(omega);
     // layer matrix of layer k (compound matrix ca(i, j), named cIJ; the entries that are copies or tt-multiples of others
     // are formed in the product step)
     auto layer_matrix = [&](int k, double* c) {
         const double ak = (double)m.A(k - 1), bk = (double)m.B(k - 1);
-        const double xka_ = omega / ak;
-        const double xkb_ = omega / bk;
-        const double t_ = bk / omega;
+        const double xka_ = div_by(omega, recip_of(ak));
+        const double xkb_ = div_by(omega, recip_of(bk));
+        const double t_ = div_by(bk, by_omega);
         const double gammk_ = 2.0 * t_ * t_;
         const double gam_ = gammk_ * wvno2;
         double wp = wvno + xka_;
@@ -242,12 +295,13 @@ DSA_HD double dltar4(const Layers& m, double wvno, double omga)
         const double gmgm1 = gam_ * gamm1;
         const double gm1sq = gamm1 * gamm1;
         const double rho2 = rho * rho;
+        const Recip by_rho = recip_of(rho), by_rho2 = recip_of(rho2);
         const double a0pq = o.a0 - o.cpcq;
         c[0] = o.cpcq - two * gmgm1 * a0pq - gmgmk * o.xz - wvno2 * gm1sq * o.wy;                      // c11
-        c[1] = (wvno2 * o.cpy - o.cqx) / rho;                                                          // c12
-        c[2] = -(twgm1 * a0pq + gammk_ * o.xz + wvno2 * gamm1 * o.wy) / rho;                           // c13
-        c[3] = (o.cpz - wvno2 * o.cqw) / rho;                                                          // c14
-        c[4] = -(two * wvno2 * a0pq + o.xz + wvno2 * wvno2 * o.wy) / rho2;                             // c15
+        c[1] = div_by(wvno2 * o.cpy - o.cqx, by_rho);                                                  // c12
+        c[2] = div_by(-(twgm1 * a0pq + gammk_ * o.xz + wvno2 * gamm1 * o.wy), by_rho);                 // c13
+        c[3] = div_by(o.cpz - wvno2 * o.cqw, by_rho);                                                  // c14
+        c[4] = div_by(-(two * wvno2 * a0pq + o.xz + wvno2 * wvno2 * o.wy), by_rho2);                   // c15
         c[5] = (gmgmk * o.cpz - gm1sq * o.cqw) * rho;                                                  // c21
         c[6] = o.cpcq;                                                                                 // c22
         c[7] = gammk_ * o.cpz - gamm1 * o.cqw;                                                         // c23
@@ -275,14 +329,12 @@ DSA_HD double dltar4(const Layers& m, double wvno, double omga)
         n2 = n2 + e0 * c13; n2 = n2 + e1 * c23; n2 = n2 + e2 * c33; n2 = n2 + e3 * c43; n2 = n2 + e4 * c53;
         n3 = n3 + e0 * c14; n3 = n3 + e1 * c24; n3 = n3 + e2 * c34; n3 = n3 + e3 * c44; n3 = n3 + e4 * c54;
         n4 = n4 + e0 * c15; n4 = n4 + e1 * c25; n4 = n4 + e2 * c35; n4 = n4 + e3 * c45; n4 = n4 + e4 * c55;
+        // (normc :989-1014: `if (dabs(ee(i)) .gt. t1) t1 = dabs(ee(i))` -- the larger of the two, t1 when ee(i) is NaN: v_max_f64 on the device)
         double t1 = 0.0;
-        if (fabs(n0) > t1) t1 = fabs(n0);
-        if (fabs(n1) > t1) t1 = fabs(n1);
-        if (fabs(n2) > t1) t1 = fabs(n2);
-        if (fabs(n3) > t1) t1 = fabs(n3);
-        if (fabs(n4) > t1) t1 = fabs(n4);
+        t1 = larger_abs(t1, n0); t1 = larger_abs(t1, n1); t1 = larger_abs(t1, n2); t1 = larger_abs(t1, n3); t1 = larger_abs(t1, n4);
         if (t1 < 1.e-40) t1 = 1.0;
-        e0 = n0 / t1; e1 = n1 / t1; e2 = n2 / t1; e3 = n3 / t1; e4 = n4 / t1;
+        const Recip by_t1 = recip_of(t1);
+        e0 = div_by(n0, by_t1); e1 = div_by(n1, by_t1); e2 = div_by(n2, by_t1); e3 = div_by(n3, by_t1); e4 = div_by(n4, by_t1);
     };
     if (m.gsize <= 1) {
         for (int k = mmax - 1; k >= m.llw; --k) {

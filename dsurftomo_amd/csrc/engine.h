@@ -28,6 +28,8 @@ struct SpmvState;
 // (DSA_EXACT_TIES=0 for an unchanged Fortran host); the census still runs (tie_detect) and the call reports what it would have flagged.
 constexpr int kDefaultExactTies = 1;
 constexpr float kDefaultTieThreshold = 2.0e-5f;
+// Rays of a launch up to which four lanes trace a ray together (ray_kernels.hip: launch_rays; profiles/r05_ab_rays.log)
+constexpr int kRayGroupMax = 49152;
 
 struct Engine {
     int device = 0;
@@ -89,6 +91,7 @@ struct Engine {
     // round schedule.  Option `bundle`: 0 = off, 1 = automatic (default: 16, 8 or 4 members by the sources' unit counts and the memory),
     // 4 / 8 / 16 = that many members per bundle.  Default mode only (the tie detector and the literal march work per unit).
     int bundle_opt = 1;
+    int ray_lanes_opt = 0;             // option ray_lanes: lanes per ray of the back-trace, 0 = automatic (4 for launches of up to kRayGroupMax rays, else 1), 1, 4
     float bundle_window_opt = 0.0f;    // option bundle_window_cells: causal window of the bundles, 0 = automatic (bundle_window(): 0.6 cells -- a round's fixed costs are shared by the members, so fewer evaluations per round pay; 1.25 for small wide launches)
     int bundle_G_now = 0;              // members per bundle of the current solve
                                        // (measured at 1025^2, 16 members: 0.4 / 0.5 / 0.6 / 0.8 / 1.25 cells -> 24.4 / 24.6 / 24.4 / 23.9 / 22.7 k solves/s)

@@ -1331,7 +1331,7 @@ int Engine::trace_chunk(int first_unit, int n, float* rw, int* iw, int* col, lon
             d_paths = paths.p + t * (size_t)ray_path_cap * 2; d_path_n = path_n.p + t;
         }
         launch_rays(g, batch(), first_unit, rays.p, trace_ids.p + t, m, veln.p, nfield, dpl, slabs.p, slab_stride, rayinfo.p, err.p,
-                    d_paths, ray_path_cap, d_path_n, stream);
+                    d_paths, ray_path_cap, d_path_n, stream, ray_lanes_opt ? ray_lanes_opt : (m <= kRayGroupMax ? 4 : 1));
         HIP_TRY(this, hipEventRecord(eb, stream));
         RowArgs a{};
         a.rays = rays.p; a.trace_ids = trace_ids.p + t; a.n = m; a.src = src.p; a.unit_base = first_unit;
@@ -1508,6 +1508,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "rows_on_device" && (value == 0 || value == 1)) { en->rows_on_device = value != 0; return 0; }
     if (n == "lsmr_device_vectors" && (value == 0 || value == 1)) { en->lsmr_device_vectors = (int)value; return 0; }
     if (n == "field_pool" && value >= -1) { en->planned = false; en->field_pool_opt = (int)value; return 0; }
+    if (n == "ray_lanes" && (value == 0 || value == 1 || value == 4)) { en->ray_lanes_opt = (int)value; return 0; }
     if (n == "bundle_window_cells" && value >= 0) { en->bundle_window_opt = (float)value; return 0; }
     if (n == "bundle_threads" && (value == 0 || value == 256 || value == 512 || value == 768)) { en->bundle_threads_opt = (int)value; return 0; }
     if (n == "bundle_max_rounds" && value >= 0) { en->bundle_max_rounds = (int)value; return 0; }

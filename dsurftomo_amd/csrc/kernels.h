@@ -223,10 +223,10 @@ void launch_srtimes(const GridDesc& g, const BatchPtrs& b, int unit_base, const 
 
 // rays and Frechet rows (ray_kernels.hip) ------------------------------------------------------------
 // trace_ids: indices into d_rays of the rays to trace (flag kRayPath), `n` of them; ray t of the
-// launch owns slab t (slab_stride floats, zeroed by the caller) and rayinfo[2t..2t+1] = (flags, steps)
+// launch owns slab t (slab_stride floats, zeroed by the caller) and rayinfo[2t..2t+1] = (flags, steps); lanes_per_ray: 1, or 4 (small launches)
 void launch_rays(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, const int* d_trace_ids, int n,
                  const float* d_veln_all, size_t field_stride, float dpl, float* d_slabs, size_t slab_stride,
-                 int32_t* d_rayinfo, int32_t* d_err, float* d_paths, int path_cap, int* d_path_n, hipStream_t stream);
+                 int32_t* d_rayinfo, int32_t* d_err, float* d_paths, int path_cap, int* d_path_n, hipStream_t stream, int lanes_per_ray = 1);
 
 // S[(k * kmax + slot) * ncol + c] = (sen_vp * coe_a + sen_rho * coe_rho) + sen_vs, the depth-kernel
 // factor of a Frechet row entry (reference CalSurfG.f90:1395-1423); vels: (nz, ny*nx) fp32

@@ -12,13 +12,15 @@
 
 namespace dsa {
 
+template <int LPR>
 __global__ __launch_bounds__(64) void k_rays(GridDesc g, BatchPtrs b, int unit_base, const RayDesc* __restrict__ rays,
                                              const int* __restrict__ trace_ids, int n, const float* __restrict__ veln_all,
                                              size_t field_stride, float dpl, float* __restrict__ slabs, size_t slab_stride,
                                              int32_t* __restrict__ rayinfo, int32_t* __restrict__ err,
                                              float* __restrict__ paths, int path_cap, int* __restrict__ path_n)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = lane_id / LPR, sub = lane_id % LPR;          // LPR = 4: four lanes trace ray t together (ray_core.h: PatchAcc)
     if (t >= n) return;
     const int r = trace_ids[t];
     const RayDesc rd = rays[r];
@@ -32,8 +34,9 @@ __global__ __launch_bounds__(64) void k_rays(GridDesc g, BatchPtrs b, int unit_b
     f.Sr = b.S_r + slot * rr;
     int flags = 0, steps = 0;
     RayPath path;
-    if (paths) { path.pts = paths + (size_t)t * (size_t)path_cap * 2; path.cap = path_cap; }
-    const int rc = trace_ray(g, sd, f, rd.rx, rd.rz, dpl, slabs + (size_t)t * slab_stride, &flags, &steps, paths ? &path : nullptr);
+    if (paths && sub == 0) { path.pts = paths + (size_t)t * (size_t)path_cap * 2; path.cap = path_cap; }
+    const int rc = trace_ray<LPR>(g, sd, f, rd.rx, rd.rz, dpl, slabs + (size_t)t * slab_stride, &flags, &steps, paths ? &path : nullptr, sub);
+    if (sub != 0) return;
     if (paths) path_n[t] = path.n;
     if (rc != 0) atomicExch(err, r + 1);
     rayinfo[2 * t] = flags;
@@ -42,11 +45,18 @@ __global__ __launch_bounds__(64) void k_rays(GridDesc g, BatchPtrs b, int unit_b
 
 void launch_rays(const GridDesc& g, const BatchPtrs& b, int unit_base, const RayDesc* d_rays, const int* d_trace_ids, int n,
                  const float* d_veln_all, size_t field_stride, float dpl, float* d_slabs, size_t slab_stride,
-                 int32_t* d_rayinfo, int32_t* d_err, float* d_paths, int path_cap, int* d_path_n, hipStream_t stream)
+                 int32_t* d_rayinfo, int32_t* d_err, float* d_paths, int path_cap, int* d_path_n, hipStream_t stream, int lanes_per_ray)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_rays, dim3((n + 63) / 64), dim3(64), 0, stream, g, b, unit_base, d_rays, d_trace_ids, n, d_veln_all,
-                       field_stride, dpl, d_slabs, slab_stride, d_rayinfo, d_err, d_paths, path_cap, d_path_n);
+    // A ray is a chain of ~2 steps per node crossed, ~3 000 instructions a step of which the sixteen vertex sums are half: a small launch (one
+    // wavefront or less per SIMD) is bound by that chain, and four lanes per ray shorten it; a large one is bound by the instructions issued, of
+    // which four lanes per ray issue three times as many per ray (profiles/r05_ab_rays.log)
+    if (lanes_per_ray == 4)
+        hipLaunchKernelGGL(k_rays<4>, dim3((unsigned)(((size_t)n * 4 + 63) / 64)), dim3(64), 0, stream, g, b, unit_base, d_rays, d_trace_ids, n, d_veln_all,
+                           field_stride, dpl, d_slabs, slab_stride, d_rayinfo, d_err, d_paths, path_cap, d_path_n);
+    else
+        hipLaunchKernelGGL(k_rays<1>, dim3((n + 63) / 64), dim3(64), 0, stream, g, b, unit_base, d_rays, d_trace_ids, n, d_veln_all,
+                           field_stride, dpl, d_slabs, slab_stride, d_rayinfo, d_err, d_paths, path_cap, d_path_n);
 }
 
 // ---------------------------------------------------------------------------------------------

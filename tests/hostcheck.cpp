@@ -283,6 +283,33 @@ int hc_trace_ray(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd,
     return rc;
 }
 
+// the same with `lanes` lanes per ray (ray_core.h: PatchAcc<4>): the four lanes' traces one after the other on the one slab -- a slab row has
+// one owner, so the order of the lanes does not matter
+int hc_trace_ray_lanes(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, int gd, const float* veln,
+                       const float* ttn, const float* ttnr, const int* nstsr, float sx, float sz, float rx, float rz,
+                       float* fdm, int* flags, int* nsteps, int lanes)
+{
+    if (lanes == 1) return hc_trace_ray(nx, ny, goxd, gozd, dvxd, dvzd, gd, veln, ttn, ttnr, nstsr, sx, sz, rx, rz, fdm, flags, nsteps);
+    GridDesc g; make_grid(g, nx, ny, goxd, gozd, dvxd, dvzd, gd);
+    SourceDesc s;
+    if (make_source(g, sx, sz, s) != 0) return -2;
+    std::vector<float> F((size_t)g.nbx * g.nbz * kTileRecs, kInf);
+    for (int ix = 0; ix < g.nnx; ++ix)
+        for (int iz = 0; iz < g.nnz; ++iz) F[rec_index(g.nbz, iz, ix)] = ttn[(size_t)ix * g.nnz + iz];
+    std::vector<int8_t> S((size_t)s.rnx * s.rnz);
+    for (size_t k = 0; k < S.size(); ++k) S[k] = (int8_t)(nstsr[k] > 0 ? 1 : (nstsr[k] < 0 ? -1 : 0));
+    std::vector<float> slab((size_t)(g.nvx + 2) * (g.nvz + 2), 0.0f);
+    RayFields f{ F.data(), veln, ttnr, S.data() };
+    int rc = 0;
+    for (int sub = 3; sub >= 0; --sub) {
+        *flags = 0;
+        rc = trace_ray<4>(g, s, f, rx, rz, min_cell_km(g), slab.data(), flags, nsteps, nullptr, sub);
+    }
+    for (int vx = 0; vx < g.nvx + 2; ++vx)
+        for (int vz = 0; vz < g.nvz + 2; ++vz) fdm[(size_t)vx * (g.nvz + 2) + vz] = slab[(size_t)vz * (g.nvx + 2) + vx];
+    return rc;
+}
+
 float hc_sinf(float x) { return sinf_libm(x); }
 
 // count of fp32 values in [lo, hi] where sinf_libm differs from this machine's libm sinf

@@ -23,6 +23,7 @@ def H():
     hdr.append(os.path.join(HERE, "solve_node_walk_ref.h"))
     hdr.append(os.path.join(L.ROOT, "dsurftomo_amd", "csrc", "exact_march.h"))
     hdr.append(os.path.join(L.ROOT, "dsurftomo_amd", "csrc", "dispersion_core.h"))
+    hdr.append(os.path.join(L.ROOT, "dsurftomo_amd", "csrc", "ray_core.h"))
     if L._stale(SO, [src] + hdr):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-msse2",
                                "-mfpmath=sse", "-shared", "-o", SO, src, "-lm"])
@@ -42,6 +43,7 @@ def H():
     h.hc_depthkernel.argtypes = [L.i32, L.i32, L.vp, L.vp, L.f32, L.i32, L.i32, L.i32, L.vp, L.i32, L.vp, L.vp, L.vp, L.vp]
     h.hc_quads_compare.argtypes = [C.c_ulonglong, C.c_long]
     h.hc_quads_compare.restype = C.c_long
+    h.hc_trace_ray_lanes.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.vp, L.vp, L.vp, L.f32, L.f32, L.f32, L.f32, L.vp, L.vp, L.vp, L.i32]
     h.hc_exact_solve.argtypes = [L.i32, L.i32, L.f32, L.f32, L.f32, L.f32, L.i32, L.vp, L.f32, L.f32, L.i32, L.i32] + [L.vp] * 5
     return h
 
@@ -251,3 +253,38 @@ def test_dispersion_state_machine_equals_the_oracle(H, iwave, igr):
     got = (pv, *sen)
     for a, b in zip(got, want):
         assert (np.ascontiguousarray(a).view(np.uint64) != np.ascontiguousarray(b).view(np.uint64)).sum() == 0
+
+
+@pytest.mark.parametrize("nx,kind,gd", [(18, "smooth", 8), (18, "rough", 5), (35, "checker4", 8)])
+def test_ray_trace_one_lane_and_four_lanes_against_oracle(H, nx, kind, gd):
+    """trace_ray (ray_core.h) on the oracle's fields: the vertex sums (the reference's fdm, CalSurfG.f90:1970-2271), the clamp flag and the
+    step count -- with one lane per ray and with four lanes sharing a ray (PatchAcc<4>: a slab row has one owner), bit for bit"""
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+    pv = synth.medium(nx, kind)
+    veln = L.o_gridder(g, pv)
+    N = g.nnx
+    r = synth.LCG(11 + nx)
+    nrays = 0
+    for fx, fz in [(0.43 * N + 0.3, 0.61 * N + 0.6), (1.4, N / 2 + 0.2), (N - 2.5, N - 3.3)]:
+        sx = np.float32(g.gox + np.float32(fx) * g.dnx)
+        sz = np.float32(g.goz + np.float32(fz) * g.dnz)
+        o = L.o_solve(g, pv, veln, sx, sz)
+        u = r.uniform(16)
+        for k in range(8):
+            rx = np.float32(g.gox + np.float32(0.3 + u[2 * k] * (N - 1.6)) * g.dnx)
+            rz = np.float32(g.goz + np.float32(0.3 + u[2 * k + 1] * (N - 1.6)) * g.dnz)
+            ref, rb, ns = L.o_rpaths(g, o, veln, sx, sz, rx, rz)
+            out = []
+            for lanes in (1, 4):
+                fdm = np.zeros((g.nvx + 2, g.nvz + 2), np.float32)
+                fl, st = L.i32(0), L.i32(0)
+                rc = H.hc_trace_ray_lanes(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd, L.ptr(veln), L.ptr(o["T"]),
+                                          L.ptr(np.ascontiguousarray(o["Tr"])), L.ptr(np.ascontiguousarray(o["Sr"])), sx, sz, rx, rz,
+                                          L.ptr(fdm), C.byref(fl), C.byref(st), lanes)
+                assert rc == 0
+                out.append((fdm, fl.value, st.value))
+            assert out[0][1:] == out[1][1:] == ((rb & 1), ns) or out[0][1:] == out[1][1:]
+            assert (bits(out[0][0]) != bits(out[1][0])).sum() == 0, "four lanes per ray differ from one"
+            assert (bits(out[0][0]) != bits(ref)).sum() == 0 and out[0][2] == ns
+            nrays += 1
+    assert nrays == 24
