@@ -29,7 +29,7 @@ struct SpmvState;
 constexpr int kDefaultExactTies = 1;
 constexpr float kDefaultTieThreshold = 2.0e-5f;
 // Rays of a launch up to which four lanes trace a ray together (ray_kernels.hip: launch_rays; profiles/r05_ab_rays.log)
-constexpr int kRayGroupMax = 49152;
+constexpr int kRayGroupMax = 81920;
 
 struct Engine {
     int device = 0;

@@ -92,6 +92,7 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *
  *   rays, rows, dispersion, inversion step
  *     ray_budget               [0]     bytes of per-ray vertex slabs per launch of the tracer; 0 = a third of free HBM, up to 40 GB
+ *     ray_lanes                [0]     lanes that trace a ray together: 0 = by the size of the launch (4 up to 81 920 rays, else 1) | 1 | 4 (same rows)
  *     ray_path_cap             [0]     points kept per traced ray for dsa_ray_paths
  *     rows_on_device           [0]     1 = dsa_solve_rows leaves the COO rows on the device (dsa_iteration_system_device, dsa_lsmr)
  *     disp_layers_lds          [-1]    layer tables of the dispersion kernel: 1 LDS | 0 global scratch | -1 LDS when they fit

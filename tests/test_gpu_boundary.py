@@ -107,12 +107,13 @@ def test_dispersion_stage(iwave, igr):
         assert (a == b).mean() >= 0.98
 
 
-@pytest.mark.parametrize("max_chunk,ray_budget", [(0, 0), (2, 40000)])
-def test_engine_rows_from_host_kernels(max_chunk, ray_budget):
+@pytest.mark.parametrize("max_chunk,ray_budget,ray_lanes", [(0, 0, 0), (2, 40000, 0), (0, 0, 1), (0, 0, 4)])
+def test_engine_rows_from_host_kernels(max_chunk, ray_budget, ray_lanes):
     """engine level: maps and depth kernels handed over from the host (dsa_set_maps +
     dsa_set_depth_kernels + dsa_plan_units + dsa_solve_rows) instead of the device dispersion stage;
     second variant: two units per chunk and a ray budget of a few rays per launch, so that the unit
-    chunks and the ray launches are stitched many times"""
+    chunks and the ray launches are stitched many times; then the tracer with one lane per ray and with
+    four lanes per ray (the engine picks by the size of the launch): the same rows, bit for bit"""
     from dsurftomo_amd.engine import Engine
     c = synth.boundary_case(kRc=3, kRg=0, kLc=0, kLg=0)
     vel = np.ascontiguousarray(c["vels"].T)
@@ -128,6 +129,7 @@ def test_engine_rows_from_host_kernels(max_chunk, ray_budget):
     try:
         e.set_option("max_chunk", max_chunk)
         e.set_option("ray_budget", ray_budget)
+        e.set_option("ray_lanes", ray_lanes)
         e.set_maps(c["nx"], c["ny"], c["goxd"], c["gozd"], c["dvxd"], c["dvzd"], pv)
         e.set_depth_kernels(vel, c["depz"], svs, svp, srho)
         e.plan(maps, sx, sz, nrec, rx, rz, sen_slot=slot)
