@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdsurftomo_amd.so")
-SOURCES = ["fim_kernel.hip", "bundle_kernel.hip", "exact_kernel.hip", "stage_kernels.hip", "ray_kernels.hip", "disp_kernels.hip", "spmv.hip", "lsmr.hip", "iteration.hip", "engine.hip", "dropin.hip"]
+SOURCES = ["fim_kernel.hip", "bundle_kernel.hip", "exact_kernel.hip", "stage_kernels.hip", "ray_kernels.hip", "disp_kernels.hip", "spmv.hip", "lsmr.hip", "iteration.hip", "engine.hip", "dropin.hip", "selfcheck.hip"]
 HEADERS = ["eikonal_core.h", "source_stage.h", "host_geometry.h", "kernels.h", "engine.h", "ray_core.h", "dispersion_core.h", "spmv_state.h", "exact_march.h", "wave_ops.h", "receiver_core.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]

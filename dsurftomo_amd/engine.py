@@ -68,6 +68,7 @@ def load_library():
     L.dsa_spmv.argtypes = [_vp, _i32, _vp, _vp]
     L.dsa_lsmr.argtypes = [_vp, _vp, _f32, _f32, _f32, _f32, _i32, _i32, _vp] + [_vp] * 7
     L.dsa_debug_field.argtypes = [_vp, _i32, _i32, _vp]
+    L.dsa_selfcheck_divisions.argtypes = [C.c_ulonglong, _i32, _vp, _vp]
     L.dsa_dropin_error.restype = C.c_char_p
     L.dsa_dropin_set_capacity.argtypes = [C.c_longlong]
     L.dsa_aprod_invalidate.argtypes = []
@@ -77,6 +78,18 @@ def load_library():
 
 def _p(a):
     return a.ctypes.data_as(_vp) if a is not None and a.size else None
+
+
+def selfcheck_divisions(seed, millions, exponents8):
+    """device self-check of the hand-expanded divisions (include/dsurftomo_amd.h: dsa_selfcheck_divisions): (fp64 pairs, fp64 quotients that
+    differ from the compiler's division bitwise, fp32 pairs, fp32 quotients that differ)"""
+    L = load_library()
+    ex = np.ascontiguousarray(exponents8, np.int32)
+    out = np.zeros(4, np.uint64)
+    rc = L.dsa_selfcheck_divisions(int(seed), int(millions), _p(ex), _p(out))
+    if rc != 0:
+        raise EngineError("dsa_selfcheck_divisions failed (%d)" % rc)
+    return tuple(int(v) for v in out)
 
 
 class Engine:

@@ -261,6 +261,13 @@ int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence)
 /* rounds the coarse fixed-point solve of each planned unit took in the last dsa_solve (a bundled unit: its bundle's) */
 int dsa_unit_rounds(const dsa_engine* e, int nunits, int* rounds);
 
+/* Device self-check, on no product path (tests/test_gpu_boundary.py): the hand-expanded divisions of the dispersion and ray kernels
+ * (dispersion_core.h: recip_of / div_by; ray_core.h: recipf_of / divf_by) against the compiler's IEEE division on `millions` x 1e6 random operand
+ * pairs per precision, five numerators per denominator, zeros / infinities / NaN among the numerators.  exponents8: unbiased binary exponent
+ * ranges {numerator lo, hi, denominator lo, hi} for fp64, then for fp32.  out4: fp64 pairs, fp64 quotients that differ bitwise, fp32 pairs, fp32
+ * quotients that differ.  Needs no engine; uses the current device. */
+int dsa_selfcheck_divisions(unsigned long long seed, int millions, const int* exponents8, unsigned long long* out4);
+
 /* probe builds only (-DDSA_LEDGER, tools/isa_ledger.py): trip counters of the coarse solve's phases, summed over the units of the last solve */
 int dsa_debug_counters(const dsa_engine* e, double* out24);
 

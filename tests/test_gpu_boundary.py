@@ -424,3 +424,22 @@ def test_dropin_empty_slots_and_sources_without_receivers(lib):
     so = L.call_boundary(L.oracle().dso_synthetic, c, synthetic=True)
     sd = L.call_boundary(lib.dsa_synthetic, c, synthetic=True)
     assert np.abs(so - sd).max() <= 1e-4
+
+
+def test_shared_reciprocal_divisions_are_the_compilers_division():
+    """dispersion_core.h: div_by and ray_core.h: divf_by -- the compiler's expansion of an IEEE division with the reciprocal's refinement shared
+    between the quotients of one denominator -- against `x / d` on the device, bit for bit, over the operand ranges the kernels use them on
+    (and well beyond): 0 differences in 2e8 pairs per precision, zeros, infinities and NaN among the numerators.  Outside those ranges
+    (numerators within 2^53 / 2^23 of the denormal range, where v_div_scale rescales and the hand expansion does not) they may differ in the
+    last bit: counted and reported, not asserted."""
+    from dsurftomo_amd.engine import selfcheck_divisions
+    # fp64: dispersion -- wavenumbers, layer products normalised to 1, densities: exponents -200 .. 200 is generous; fp32: rays -- coordinate
+    # differences in radians (0 or >= 1e-12), travel-time differences, cell sizes 1e-6 .. 1, 6, twice a cell size in km
+    n64, bad64, n32, bad32 = selfcheck_divisions(20261003, 200, [-200, 200, -200, 200, -45, 20, -25, 12])
+    parity_log.add("shared-reciprocal divisions, in-contract ranges: fp64 %d pairs, %d differ; fp32 %d pairs, %d differ" % (n64, bad64, n32, bad32))
+    assert n64 >= 200_000_000 and n32 >= 200_000_000
+    assert bad64 == 0 and bad32 == 0
+    # beyond the contract: tiny numerators
+    m64, wrong64, m32, wrong32 = selfcheck_divisions(7, 20, [-1022, -960, -3, 3, -126, -100, -3, 3])
+    parity_log.add("shared-reciprocal divisions, numerators below 2^-960 / 2^-100 (outside the contract): fp64 %d of %d differ, fp32 %d of %d"
+           % (wrong64, m64, wrong32, m32))
