@@ -141,10 +141,20 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     const size_t rr = (size_t)kRefMax * kRefMax;
     if (tid == 0) { s_best = ~0ull; s_first = 0x7fffffff; }
     __syncthreads();
-    // first open-edge node in acceptance order; exact ties resolved by scan order (ix outer, iz inner)
+    // first open-edge node in acceptance order; exact ties resolved by scan order (ix outer, iz inner: the smallest id).  Round 5: the
+    // lanes walk the box's PERIMETER (2 rnx + 2 rnz positions, the corners twice -- a minimum does not mind) instead of testing all rnx x rnz
+    // nodes for an edge: two passes of 3 trips instead of 65 (stages 12.1 -> 11.4 ms for 16 000 sources)
     if (!ended) {
-        for (int id = tid; id < n; id += 256) {
-            const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
+        const int nper = 2 * sd.rnz + 2 * sd.rnx;
+        auto edge_node = [&](int q, int* iz, int* ix) {
+            if (q < sd.rnz) { *ix = 1; *iz = q + 1; }
+            else if (q < 2 * sd.rnz) { *ix = sd.rnx; *iz = q - sd.rnz + 1; }
+            else if (q < 2 * sd.rnz + sd.rnx) { *iz = 1; *ix = q - 2 * sd.rnz + 1; }
+            else { *iz = sd.rnz; *ix = q - 2 * sd.rnz - sd.rnx + 1; }
+        };
+        for (int q = tid; q < nper; q += 256) {
+            int iz, ix;
+            edge_node(q, &iz, &ix);
             if (!is_open_edge(sd, iz, ix)) continue;
             const Rec r = w.F_r[rec_index(sd.nbz_r, iz - 1, ix - 1)];
             if (!(t_value(r.T) < kInf)) continue;
@@ -153,12 +163,13 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
         __syncthreads();
         const unsigned long long best = s_best;
         if (best != ~0ull)
-            for (int id = tid; id < n; id += 256) {
-                const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
+            for (int q = tid; q < nper; q += 256) {
+                int iz, ix;
+                edge_node(q, &iz, &ix);
                 if (!is_open_edge(sd, iz, ix)) continue;
                 const Rec r = w.F_r[rec_index(sd.nbz_r, iz - 1, ix - 1)];
                 if (!(t_value(r.T) < kInf)) continue;
-                if ((unsigned long long)accept_rank(r.T, r.tau) == best) atomicMin(&s_first, id);
+                if ((unsigned long long)accept_rank(r.T, r.tau) == best) atomicMin(&s_first, (ix - 1) * sd.rnz + (iz - 1));
             }
     }
     __syncthreads();
@@ -167,12 +178,17 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     if (!ended && s_first != 0x7fffffff) { ex = s_first / sd.rnz + 1; ez = s_first % sd.rnz + 1; }
     if (tid == 0) { w.flags[2] = ez; w.flags[3] = ex; }
     float* Tfin = b.Tfin_r + s * rr;
-    for (int id = tid; id < n; id += 256) {
-        const int ix = id / sd.rnz + 1, iz = id % sd.rnz + 1;
-        float t;
-        const int st = handoff_node(g, sd, w, ended, rstar, ez, ex, iz, ix, &t);
-        w.S_r[id] = (int8_t)st;
-        Tfin[id] = t;
+    {   // (ix, iz) of id = tid, tid + 256, ... without a division per node
+        const int dq = 256 / sd.rnz, dr = 256 % sd.rnz;
+        int ix0 = tid / sd.rnz, iz0 = tid % sd.rnz;
+        for (int id = tid; id < n; id += 256) {
+            float t;
+            const int st = handoff_node(g, sd, w, ended, rstar, ez, ex, iz0 + 1, ix0 + 1, &t);
+            w.S_r[id] = (int8_t)st;
+            Tfin[id] = t;
+            iz0 += dr; ix0 += dq;
+            if (iz0 >= sd.rnz) { iz0 -= sd.rnz; ix0 += 1; }
+        }
     }
     // coarse window: everything far, then every 8th refined node, then band promotion
     const int wn = sd.cwnx * sd.cwnz;
