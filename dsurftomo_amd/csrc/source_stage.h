@@ -205,37 +205,65 @@ DSA_HD bool ref_alive(const SourceDesc& s, const SourceScratch& w, uint64_t rsta
     return rk < rstar || (rk == rstar && (ix - 1) * s.rnz + (iz - 1) < eid);
 }
 
-// classify node (iz, ix): returns status (-1, 0, 1) and the value to keep in *tout
+// ref_alive on a record already in hand
+DSA_HD bool ref_alive_rec(const SourceDesc& s, const Rec& r, uint64_t rstar, int eid, int iz, int ix)
+{
+    if (t_pinned(r.T)) return true;
+    const uint64_t rk = accept_rank(r.T, r.tau);
+    return rk < rstar || (rk == rstar && (ix - 1) * s.rnz + (iz - 1) < eid);
+}
+
+// classify node (iz, ix): returns status (-1, 0, 1) and the value to keep in *tout.  (Round 5: the eight stencil records of a node that is
+// not alive are fetched together, before the first is looked at -- the hand-off kernel used to wait for them one after the other.)
 DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScratch& w, int ended,
                         uint64_t rstar, int ez, int ex, int iz, int ix, float* tout)
 {
-    const float raw = w.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)].T;
+    const Rec own = w.F_r[rec_index(s.nbz_r, iz - 1, ix - 1)];
+    const float raw = own.T;
     if (ended) {
         if (t_pinned(raw)) { *tout = t_value(raw); return 0; }
         if (t_value(raw) < kInf) { *tout = raw; return 1; }
         *tout = kInf; return -1;
     }
     const int eid = ex > 0 ? (ex - 1) * s.rnz + (ez - 1) : -1;
-    if (ref_alive(s, w, rstar, eid, iz, ix)) { *tout = t_value(raw); return 0; }
+    if (ref_alive_rec(s, own, rstar, eid, iz, ix)) { *tout = t_value(raw); return 0; }
     // not alive: close iff it touches an alive node; its value is the trial value from the alive
     // set (the edge node that ended the stage is alive but was never propagated)
     Stencil st;
     const int jx[2] = { ix - 1, ix + 1 }, jx2[2] = { ix - 2, ix + 2 };
     const int kz[2] = { iz - 1, iz + 1 }, kz2[2] = { iz - 2, iz + 2 };
-    bool touch = false;
+    const Rec far = { kInf, kInf };
+    Rec rj[2], rj2[2], rk[2], rk2[2];
+    bool ej2[2], ek2[2];
     for (int d = 0; d < 2; ++d) {
         st.ej[d] = jx[d] >= 1 && jx[d] <= s.rnx;
-        st.aj[d] = st.ej[d] && ref_alive(s, w, rstar, eid, iz, jx[d]);
-        st.tj[d] = st.aj[d] ? t_value(w.F_r[rec_index(s.nbz_r, iz - 1, jx[d] - 1)].T) : kInf;
-        const bool o = jx2[d] >= 1 && jx2[d] <= s.rnx && ref_alive(s, w, rstar, eid, iz, jx2[d]);
-        st.oj[d] = o;
-        st.tj2[d] = o ? t_value(w.F_r[rec_index(s.nbz_r, iz - 1, jx2[d] - 1)].T) : kInf;
+        ej2[d] = jx2[d] >= 1 && jx2[d] <= s.rnx;
         st.ek[d] = kz[d] >= 1 && kz[d] <= s.rnz;
-        st.ak[d] = st.ek[d] && ref_alive(s, w, rstar, eid, kz[d], ix);
-        st.tk[d] = st.ak[d] ? t_value(w.F_r[rec_index(s.nbz_r, kz[d] - 1, ix - 1)].T) : kInf;
-        const bool p = kz2[d] >= 1 && kz2[d] <= s.rnz && ref_alive(s, w, rstar, eid, kz2[d], ix);
+        ek2[d] = kz2[d] >= 1 && kz2[d] <= s.rnz;
+        // (a neighbour outside the box reads the node's own record, which exists, and the value is dropped: no branch around a load)
+        rj[d] = w.F_r[rec_index(s.nbz_r, iz - 1, (st.ej[d] ? jx[d] : ix) - 1)];
+        rj2[d] = w.F_r[rec_index(s.nbz_r, iz - 1, (ej2[d] ? jx2[d] : ix) - 1)];
+        rk[d] = w.F_r[rec_index(s.nbz_r, (st.ek[d] ? kz[d] : iz) - 1, ix - 1)];
+        rk2[d] = w.F_r[rec_index(s.nbz_r, (ek2[d] ? kz2[d] : iz) - 1, ix - 1)];
+    }
+    for (int d = 0; d < 2; ++d) {
+        if (!st.ej[d]) rj[d] = far;
+        if (!ej2[d]) rj2[d] = far;
+        if (!st.ek[d]) rk[d] = far;
+        if (!ek2[d]) rk2[d] = far;
+    }
+    bool touch = false;
+    for (int d = 0; d < 2; ++d) {
+        st.aj[d] = st.ej[d] && ref_alive_rec(s, rj[d], rstar, eid, iz, jx[d]);
+        st.tj[d] = st.aj[d] ? t_value(rj[d].T) : kInf;
+        const bool o = ej2[d] && ref_alive_rec(s, rj2[d], rstar, eid, iz, jx2[d]);
+        st.oj[d] = o;
+        st.tj2[d] = o ? t_value(rj2[d].T) : kInf;
+        st.ak[d] = st.ek[d] && ref_alive_rec(s, rk[d], rstar, eid, kz[d], ix);
+        st.tk[d] = st.ak[d] ? t_value(rk[d].T) : kInf;
+        const bool p = ek2[d] && ref_alive_rec(s, rk2[d], rstar, eid, kz2[d], ix);
         st.ok[d] = p;
-        st.tk2[d] = p ? t_value(w.F_r[rec_index(s.nbz_r, kz2[d] - 1, ix - 1)].T) : kInf;
+        st.tk2[d] = p ? t_value(rk2[d].T) : kInf;
         touch = touch || st.aj[d] || st.ak[d];
     }
     if (!touch) { *tout = kInf; return -1; }
