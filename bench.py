@@ -426,7 +426,7 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-SETTLE_STEPS = 6
+SETTLE_STEPS = int(os.environ.get("DSA_BENCH_SETTLE", "6"))       # (tools/profile_bench.sh: 0 for the counter passes, which count one launch)
 
 
 def main():

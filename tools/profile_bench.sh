@@ -12,7 +12,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r -- python3 bench
 for g in "fetch FETCH_SIZE" "write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "busy SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
          "insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "wait SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES"; do
   set -- $g; n=$1; shift
-  timeout 400 rocprofv3 --pmc "$@" -d $OUT/pmc/$n -o r -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > $OUT/$n.log 2>&1
+  DSA_BENCH_SETTLE=0 timeout 400 rocprofv3 --pmc "$@" -d $OUT/pmc/$n -o r -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > $OUT/$n.log 2>&1
 done
 {
   echo "== kernel trace (rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline)"; grep '"metric"' $OUT/trace.log | cut -c1-600
