@@ -153,6 +153,7 @@ struct Engine {
     int tie_list_opt = 1;              // option tie_list: 1 = the bundles mark tie candidates as they iterate and the census looks at those only; 0 = the census sweeps the converged field (A/B; also the fallback of a list that overflows)
     int tie_detect = 1;                // option tie_detect: exact_ties = 0 runs the detector too and reports the units it would have flagged (no second solve)
     int exact_lds_slots = 0;           // tree slots kept in LDS per marching unit (8 bytes each, made odd); 0 = by the number of units marching (.. 4799)
+    int exact_heap_blocked = 1;        // option exact_heap_blocked: the march's tree beyond its LDS part in blocks of three levels (exact_kernel.hip: xg_gi): 0 never, 1 batches that fill the chip, 2 whenever the LDS part is whole levels
     int exact_pool = 0;                // units marching at a time (0 = by free memory, at most exact_pool_max)
     size_t exact_pool_max = 16384;     // option exact_pool_max: four units per wavefront, sixteen wavefronts per CU (measured at 1025^2: 10 240 units 1 500, 12 288 1 600, 16 384 1 700 solves/s)
     DevBuf<unsigned> X_pool;                     // per marching unit: one packed word per node of the whole grid (exact_kernel.hip)

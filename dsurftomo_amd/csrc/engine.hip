@@ -1146,14 +1146,17 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
     (void)n;
     // (a tree holds at most 65 535 nodes -- sixteen levels, one per lane of a unit's group; narrow bands are a few times nnx + nnz)
     const int gcap_max = std::min(16 * (g.nnx + g.nnz) + 4096, 65534);
-    size_t per = nrec_c * 4 + (size_t)gcap_max * 8 + exact_start_bytes() + 4;      // (one packed word per node, exact_kernel.hip)
+    // (the tree's global part: slot by slot, or -- whole levels in LDS -- in blocks of three levels, whose last generation is allocated whole)
+    size_t heap_bytes = (size_t)gcap_max * 8;
+    if (exact_heap_blocked) for (int l = 6; l <= 12; ++l) heap_bytes = std::max(heap_bytes, exact_heap_blocked_entries((1 << l) - 1, std::min(gcap_max, 65534 - ((1 << l) - 1)) & ~1) * 8);
+    size_t per = nrec_c * 4 + heap_bytes + exact_start_bytes() + 4;      // (one packed word per node, exact_kernel.hip)
     // Pooled tiles (round 5, kernels.h XTiles): a times-only batch whose whole fields would not all fit marches in pooled tiles -- tcap tiles of
     // 8 x 8 nodes per unit (the band and what lies within a tile of it: a few times the tiles along the grid's perimeter) instead of a word per
     // node.  At 4097^2: 3.2 MB per unit instead of 67, so the batch is bounded by exact_pool_max, not by memory.  Option exact_tiles: 0 automatic,
     // 1 always (times-only calls), -1 never; exact_tile_cap: tiles per unit, 0 = 8 (nbx + nbz).
     const int ntile = g.nbx * g.nbz;
     const int tcap = exact_tile_cap > 0 ? exact_tile_cap : std::min(65000, std::max(512, 8 * (g.nbx + g.nbz)));
-    const size_t per_tiles = exact_tile_unit_bytes(ntile, tcap) + (size_t)gcap_max * 8 + exact_start_bytes() + 4;
+    const size_t per_tiles = exact_tile_unit_bytes(ntile, tcap) + heap_bytes + exact_start_bytes() + 4;
     bool tiles = false;
     if (may_pool_tiles && receivers && !compact && exact_tiles_opt >= 0 && tcap < ntile) {
         if (exact_tiles_opt == 1) tiles = true;
@@ -1207,9 +1210,19 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
         lcap = (int)std::min<long>(std::min<long>(fit, 4L * (g.nnx + g.nnz) + 1023), 4799);
     }
     lcap = std::max(63, lcap) | 1;
+    // (round 5) a batch that fills the chip -- twelve wavefronts or more per CU: the march is then bound by the fabric and by issue together,
+    // profiles/r05_pmc_march_full_load.txt -- keeps whole levels in LDS and stores the tree's global part in blocks of three levels
+    // (exact_kernel.hip: xg_gi): 16 000 units at 1025^2 1 956 -> 2 137 solves/s.  A smaller batch waits for its own instructions, and the
+    // block arithmetic is more of them: 4 096 units 1 244 -> 1 120, 1 536 units at 4097^2 26.8 -> 23.8 (profiles/r05_ab_march_heap.log).
+    // Option exact_heap_blocked: 0 never, 1 as above, 2 whenever the LDS part is whole levels (tests).
+    int lb = 0;
+    const bool full = ((pool + 3) / 4 + 255) / 256 >= 12;
+    if (exact_heap_blocked == 1 && full && exact_lds_slots <= 0 && lcap < 4 * (g.nnx + g.nnz) + 1023) { int l = 6; while ((2 << l) - 1 <= lcap) ++l; lcap = (1 << l) - 1; }
+    if (((exact_heap_blocked == 1 && full) || exact_heap_blocked == 2) && ((lcap + 1) & lcap) == 0) { while ((1 << lb) < lcap + 1) ++lb; }
     const int gcap = std::min(gcap_max, 65534 - lcap) & ~1;
+    const size_t gstride = lb ? exact_heap_blocked_entries(lcap, gcap) : (size_t)gcap;
     if (exact_lds_bytes(lcap) > 156 * 1024) { fail(DSA_ERR_ARGUMENT, "exact_lds_slots %d needs more than 156 KB of LDS (four units per wavefront)", lcap); return DSA_ERR_ARGUMENT; }
-    if (ensure(X_heap, pool * (size_t)gcap) || ensure(x_starts, pool * (exact_start_bytes() / 8)) || ensure(x_nstart, pool)) return status;
+    if (ensure(X_heap, pool * gstride) || ensure(x_starts, pool * (exact_start_bytes() / 8)) || ensure(x_nstart, pool)) return status;
     XTiles xt{};
     if (tiles) {
         if (ensure(X_tt, pool * exact_tile_table_entries(ntile)) || ensure(X_tp, pool * (size_t)tcap * 64) || ensure(X_ring, pool * (size_t)tcap) || ensure(X_free, pool * (size_t)tcap) ||
@@ -1223,7 +1236,7 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
         const int m = (int)std::min(pool, xl.size() - k);
         const XReceivers rc{ rays.p, veln.p, nfield, dpl, out.p, err.p };
         launch_exact(g, batch(), x_units.p + k, m, slow.p, nrec_c, risti_c.p, X_pool.p, nrec_c, X_heap.p, gcap, lcap, x_starts.p, x_nstart.p, xinfo.p, clocks.p,
-                     receivers ? &rc : nullptr, compact, stream, tiles ? &xt : nullptr);
+                     receivers ? &rc : nullptr, compact, stream, tiles ? &xt : nullptr, (int)gstride, lb);
     }
     HIP_TRY(this, hipGetLastError());
     std::vector<int32_t> h_x((size_t)n * 4);
@@ -1523,7 +1536,8 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "tie_detect" && (value == 0 || value == 1)) { en->tie_detect = (int)value; return 0; }
     if (n == "tie_list" && (value == 0 || value == 1)) { en->tie_list_opt = (int)value; return 0; }
     if (n == "disp_failure_log" && value >= 0 && value <= 65536) { en->disp_failure_log = (int)value; return 0; }
-    if (n == "exact_lds_slots" && (value == 0 || (value >= 64 && value <= 4975))) { en->exact_lds_slots = (int)value; return 0; }
+    if (n == "exact_heap_blocked" && (value == 0 || value == 1 || value == 2)) { en->exact_heap_blocked = (int)value; return 0; }
+    if (n == "exact_lds_slots" && (value == 0 || (value >= 63 && value <= 4975))) { en->exact_lds_slots = (int)value; return 0; }
     if (n == "exact_tiles" && (value == -1 || value == 0 || value == 1)) { en->exact_tiles_opt = (int)value; return 0; }
     if (n == "exact_tile_cap" && (value == 0 || (value >= 64 && value <= 65000))) { en->exact_tile_cap = (int)value; return 0; }
     if (n == "exact_pool" && value >= 0 && value <= 65535) { en->exact_pool = (int)value; return 0; }

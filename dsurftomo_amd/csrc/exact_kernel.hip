@@ -62,6 +62,7 @@ struct XG {                                  // the march of one unit; every lan
     DSA_LDS XEntry* hl; DSA_GLB XEntry* hg;
     DSA_LDS XEntry* sc;                      // sixteen entries of LDS scratch: the levels of the tree beyond lcap, three at a time (xg_pop_root)
     int lcap, gcap;
+    int lb;                                  // > 0: lcap = 2^lb - 1 and the global part of the tree is stored in BLOCKS (xg_gi); 0: slot by slot
     int ntr, err;
     unsigned pops;
     XEntry last;                             // tree[ntr], fetched at the end of the step before: the entry the next removal of the root sinks
@@ -126,12 +127,32 @@ typedef float xf2 __attribute__((ext_vector_type(2)));
 typedef float xf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ XEntry xg_entry(xf2 v) { return XEntry{ v.x, __float_as_int(v.y) }; }
 __device__ __forceinline__ xf2 xg_vec(XEntry e) { xf2 v; v.x = e.key; v.y = __int_as_float(e.id); return v; }
+// Where slot s > lcap of the tree lies in the unit's global part (in entries).  Round 5: with lcap = 2^lb - 1 (whole levels in LDS) the
+// levels beyond are stored three at a time -- the fourteen descendants of a node p of level lb - 1 + 3 g (children, grandchildren, great-
+// grandchildren) share one 128-byte line, in the order of the little tree the removal of the root walks (position = index in p's
+// fifteen-node subtree - 2) -- so that a trip of the walk down, and the three nearest ancestors an update looks at, are one line instead of
+// three: at full load the march moves 14 lines per accept, most of them tree entries (profiles/r05_pmc_march_full_load.txt).
+// Lines of generation g follow those of the generations before: 2^(lb-1) (1 + 8 + ... + 8^(g-1)) of them.
+__device__ __forceinline__ unsigned xg_line(const XG& m, unsigned p, int gq)
+{
+    return ((0x49249249u & ((1u << (3 * gq)) - 1u)) << (m.lb - 1)) + (p - (1u << (m.lb - 1 + 3 * gq)));
+}
+__device__ __forceinline__ unsigned xg_gi(const XG& m, int s)
+{
+    if (m.lb == 0) return (unsigned)(s - m.lcap - 1);
+    const int t = (31 - __builtin_clz((unsigned)s)) - m.lb;          // level beyond the LDS part: 0, 1, 2, ...
+    const int gq = (t * 11) >> 5;                                     // t / 3
+    const int sh = t - 3 * gq + 1;
+    const unsigned p = (unsigned)s >> sh;
+    const unsigned li = ((unsigned)s & ((1u << sh) - 1u)) | (1u << sh);
+    return (xg_line(m, p, gq) << 4) + li - 2u;
+}
 // slot s of the tree; the lanes of a group may ask for different slots.  The LDS read is unconditional (slot 1 stands in for a slot
 // beyond the LDS part), the global one sits behind a branch the whole wavefront skips when no lane needs it
 __device__ __forceinline__ XEntry xg_get(const XG& m, int s)
 {
     xf2 v = *(DSA_LDS const xf2*)(m.hl + (s <= m.lcap ? s : 1));
-    if (s > m.lcap) v = *(DSA_GLB const xf2*)(m.hg + (s - m.lcap - 1));
+    if (s > m.lcap) v = *(DSA_GLB const xf2*)(m.hg + xg_gi(m, s));
     return xg_entry(v);
 }
 // entry into slot s of the tree for the lanes with `on`; the lanes hold different (slot, entry) pairs.  LDS slot 0 is nobody's: lanes that
@@ -139,7 +160,7 @@ __device__ __forceinline__ XEntry xg_get(const XG& m, int s)
 __device__ __forceinline__ void xg_put_tree(XG& m, bool on, int s, XEntry e)
 {
     *(DSA_LDS xf2*)(m.hl + ((on && s <= m.lcap) ? s : 0)) = xg_vec(e);
-    if (on && s > m.lcap) *(DSA_GLB xf2*)(m.hg + (s - m.lcap - 1)) = xg_vec(e);
+    if (on && s > m.lcap) *(DSA_GLB xf2*)(m.hg + xg_gi(m, s)) = xg_vec(e);
 }
 // ... and the node's status (reference nsts: its slot)
 template <int MD> __device__ __forceinline__ void xg_put_status(XG& m, bool on, int s, XEntry e)
@@ -268,7 +289,11 @@ __device__ __forceinline__ XPop xg_pop_root(XG& m, int gl)
         const int d = gl < 2 ? 1 : gl < 6 ? 2 : 3, off = gl - ((1 << d) - 2);
         const int slot = (tpp << d) + off;
         xf2 v; v.x = kInf; v.y = 0.0f;
-        if (gl < 14 && slot <= m.ntr) v = *(DSA_GLB const xf2*)(m.hg + (slot - m.lcap - 1));
+        // (blocked: tpp stands at level lb - 1 + 3 g -- the walk enters this loop from the last LDS level and goes on three levels at a time --
+        // and its fourteen descendants are the first fourteen entries of its line)
+        unsigned gi = (unsigned)(slot - m.lcap - 1);
+        if (m.lb) { const int lp = 31 - __builtin_clz((unsigned)tpp); gi = (xg_line(m, (unsigned)tpp, ((lp - m.lb + 1) * 11) >> 5) << 4) + (unsigned)gl; }
+        if (gl < 14 && slot <= m.ntr) v = *(DSA_GLB const xf2*)(m.hg + gi);
         *(DSA_LDS xf2*)(m.sc + (gl < 14 ? (1 << d) + off : gl - 14)) = v;
         int lpc = 2;
         while (lpc < 16 && tpc <= m.ntr) DSA_XG_LEVEL(*(DSA_LDS const xf4*)(m.sc + lpc), lpc = 2 * (lpc + (right ? 1 : 0));)
@@ -570,7 +595,7 @@ template <bool REFINED, bool POOLED = false>
 __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const int* __restrict__ units, int n, const float* __restrict__ slow_all,
                                                size_t field_stride, const float* __restrict__ risti_c, unsigned* pool, size_t pool_stride,
                                                XEntry* heap_pool, int gcap, int lcap, const XStart* __restrict__ starts, const int* __restrict__ nstart,
-                                               int32_t* xinfo, unsigned long long* clk, XTilePool tpool)
+                                               int32_t* xinfo, unsigned long long* clk, XTilePool tpool, int gstride, int lb)
 {
     extern __shared__ unsigned char x_lds[];
     const int lane = threadIdx.x, grp = lane >> 4;
@@ -582,7 +607,7 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
     m.hl = (DSA_LDS XEntry*)x_lds + (size_t)grp * (size_t)(lcap + 1);
     m.sc = (DSA_LDS XEntry*)x_lds + (size_t)4 * (size_t)(lcap + 1) + (size_t)grp * 16;
     m.last = XEntry{ 0.0f, 0 };
-    m.lcap = lcap; m.hg = (DSA_GLB XEntry*)(heap_pool + (size_t)(live ? slot : 0) * gcap); m.gcap = gcap;
+    m.lcap = lcap; m.hg = (DSA_GLB XEntry*)(heap_pool + (size_t)(live ? slot : 0) * (size_t)gstride); m.gcap = gcap; m.lb = lb;
     m.ntr = 0; m.err = 0; m.pops = 0u; m.ri = g.earth;
     m.F = nullptr; m.P = nullptr;
     m.tt = nullptr; m.tp = nullptr; m.ring = nullptr; m.freestk = nullptr; m.pins = nullptr; m.tcap = 0; m.bump = 0; m.nfree = 0; m.rh = 0; m.rt = 0; m.nbx = g.nbx;
@@ -835,6 +860,23 @@ __global__ __launch_bounds__(64) void k_xreceivers(GridDesc g, BatchPtrs b, cons
     }
 }
 
+// entries of a unit's global tree part in the blocked layout (xg_gi): whole lines up to the one that holds slot lcap + gcap
+size_t exact_heap_blocked_entries(int lcap, int gcap)
+{
+    int lb = 0;
+    while ((1 << lb) < lcap + 1) ++lb;
+    const unsigned smax = (unsigned)(lcap + gcap);
+    int lev = 31;
+    while (!((smax >> lev) & 1u)) --lev;
+    const int t = lev - lb, gq = t < 0 ? 0 : t / 3;
+    // every line of the generations before the last one's, and of that one up to the parent of slot smax at the generation's deepest level
+    size_t lines = ((size_t)(0x49249249u & ((1u << (3 * gq)) - 1u)) << (lb - 1));
+    const unsigned plev = (unsigned)(lb - 1 + 3 * gq);
+    const unsigned pmax = t < 0 ? (1u << plev) : std::min<unsigned>((2u << plev) - 1u, std::max<unsigned>(smax >> (t - 3 * gq + 1), 1u << plev));
+    // (a shallower row of the same generation reaches further to the right than the deepest one: take the whole generation when it has more than one row)
+    lines += (t - 3 * gq > 0 ? (size_t)1 << plev : (size_t)(pmax - (1u << plev)) + 1);
+    return lines * 16;
+}
 size_t exact_lds_bytes(int lcap) { return (size_t)4 * (size_t)(lcap + 1 + 16) * sizeof(XEntry); }
 size_t exact_start_bytes() { return (size_t)kXStage * sizeof(XStart); }
 // pooled tiles, per marching unit: the tile table (two bytes per tile of the grid, a multiple of sixteen bytes), tcap tiles of 256 bytes, the ring
@@ -844,9 +886,11 @@ size_t exact_tile_unit_bytes(int ntile, int tcap) { return exact_tile_table_entr
 
 void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int n, const float* d_slow_all, size_t field_stride,
                   const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
-                  int32_t* d_xinfo, unsigned long long* d_clocks, const XReceivers* rc, bool compact_copy, hipStream_t stream, const XTiles* tiles)
+                  int32_t* d_xinfo, unsigned long long* d_clocks, const XReceivers* rc, bool compact_copy, hipStream_t stream, const XTiles* tiles,
+                  int gstride, int lb)
 {
     if (n <= 0) return;
+    if (gstride <= 0) { gstride = gcap; lb = 0; }
     const size_t lds = exact_lds_bytes(lcap);
     if (lds > 48 * 1024) {   // (per device: set every time)
         (void)hipFuncSetAttribute((const void*)k_xmarch<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -865,14 +909,14 @@ void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int
     if (tiles && rc) hipLaunchKernelGGL(k_xpins, dim3(n), dim3(64), 0, stream, g, b, d_units, rc->rays, tp);
     const int waves = (n + 3) / 4;
     hipLaunchKernelGGL((k_xmarch<true, false>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp);
+                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb);
     hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (unsigned*)d_pool, pool_stride, (XStart*)d_starts, d_nstart, tiles ? 1 : 0);
     if (tiles)
         hipLaunchKernelGGL((k_xmarch<false, true>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp);
+                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb);
     else
         hipLaunchKernelGGL((k_xmarch<false, false>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp);
+                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb);
     if (compact_copy && !tiles) hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, nrec);
     if (rc) hipLaunchKernelGGL(k_xreceivers, dim3(n), dim3(64), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, rc->rays, rc->veln_all, rc->veln_stride,
                                rc->dpl, rc->out, rc->err, tp);

@@ -199,6 +199,7 @@ void launch_bundle_export_records(const FimBundle* d_bundles, int nbundles, int 
 // launches: reset, refined march, snapshot + hand-off, coarse march, then the compact copy and / or the batch's receiver times.
 // xinfo[4 u ..]: accepts of the refined / coarse stage, error code (1 tree capacity)
 size_t exact_lds_bytes(int lcap);
+size_t exact_heap_blocked_entries(int lcap, int gcap);
 size_t exact_start_bytes();
 // (round 5) POOLED TILES for times-only calls on large grids: a marching unit keeps only the 8x8-node tiles its narrow band has touched and not yet
 // left behind (exact_kernel.hip: xg_tile_*), tcap of them, instead of a word per node of the whole grid -- 2.6 MB instead of 67 MB at 4097^2.  The
@@ -213,7 +214,8 @@ void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int
                   const float* d_risti_c, void* d_pool, size_t pool_stride, void* d_heap_pool, int gcap, int lcap, void* d_starts, int* d_nstart,
                   int32_t* d_xinfo, unsigned long long* d_clocks /* probe builds (DSA_X_CLOCKS): cycle counts per phase of the accept step */,
                   const XReceivers* receivers /* null: no receiver times here */, bool compact_copy /* the units' compact fields into BatchPtrs::T_c */, hipStream_t stream,
-                  const XTiles* tiles = nullptr /* pooled tiles on the propagation grid (times-only calls: needs `receivers`, no compact copy) */);
+                  const XTiles* tiles = nullptr /* pooled tiles on the propagation grid (times-only calls: needs `receivers`, no compact copy) */,
+                  int gstride = 0 /* entries per unit in d_heap_pool; 0: gcap */, int lb = 0 /* > 0: lcap = 2^lb - 1, global tree part in blocks (exact_heap_blocked_entries) */);
 
 // receivers: one thread per ray; reference srtimes (CalSurfG.f90:1636-1759)
 // RayDesc::src is a global unit index; unit_base is the first unit held by the batch arrays

@@ -55,7 +55,8 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *     exact_ties               [1]     0 fixed point only | 1 fixed point + tie census + the reference's march for the flagged units | 2 the march for every unit
  *     tie_threshold            [2e-5]  seconds: the influence on its node's value a tie must have to flag its unit; 0 = any tie
  *     tie_detect               [1]     exact_ties = 0 runs the census too and reports what it would have flagged (DSA_STAT_TIE_UNITS, dsa_unit_ties); 0 = off
- *     exact_lds_slots          [0]     tree slots kept in LDS per marching unit, 64 .. 4975 (made odd); 0 = what lets every wavefront of a batch be resident
+ *     exact_lds_slots          [0]     tree slots kept in LDS per marching unit, 63 .. 4975 (made odd); 0 = what lets every wavefront of a batch be resident
+ *     exact_heap_blocked       [1]     the march's tree beyond its LDS part stored in blocks of three levels: 0 never | 1 batches that fill the chip (>= 12 wavefronts per CU) | 2 whenever the LDS part is whole levels
  *     exact_pool               [0]     units marching at a time, up to 65535; 0 = by free memory, at most exact_pool_max
  *     exact_pool_max           [16384] 4 .. 32768
  *     exact_tiles              [0]     times-only calls: 0 = the march keeps pooled 8x8-node tiles per unit instead of whole fields when whole fields would bound the

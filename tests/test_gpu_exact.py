@@ -30,9 +30,14 @@ def exact(engine):
     yield engine          # (conftest's _product_defaults puts the options back before the next test)
 
 
-@pytest.mark.parametrize("nx,kind,gd,lds", [(18, "homog", 8, 2048), (35, "checker4", 8, 64), (35, "smooth", 5, 2048), (35, "rough", 8, 300), (35, "homog", 8, 2048)])
+@pytest.mark.parametrize("nx,kind,gd,lds", [(18, "homog", 8, 2048), (35, "checker4", 8, 64), (35, "smooth", 5, 2048), (35, "rough", 8, 300), (35, "homog", 8, 2048),
+                                            (35, "checker4", 8, -63), (35, "rough", 8, -127), (35, "smooth", 8, -255), (18, "rough", 8, -63)])
 def test_literal_march_is_the_oracle_bit_for_bit(exact, nx, kind, gd, lds):
+    """lds: tree slots kept in LDS; a negative value: that many (2^k - 1: whole levels) with the tree's global part in BLOCKS of three levels
+    (exact_kernel.hip: xg_gi; the engine does this by itself only for batches that fill the chip)"""
     e = exact
+    e.set_option("exact_heap_blocked", 2 if lds < 0 else 0)
+    lds = abs(lds)
     srcs = positions(nx, gd, FRAC)
     g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
     pv = synth.medium(nx, kind)

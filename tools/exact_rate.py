@@ -17,6 +17,7 @@ e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
 u = synth.units(nx, units // nper, nper, 32)
 n = units // nper * nper
 e.set_option('exact_ties', 2)
+if os.environ.get('DSA_HEAP_BLOCKED'): e.set_option('exact_heap_blocked', int(os.environ['DSA_HEAP_BLOCKED']))      # 0: the tree's global part slot by slot
 first = True
 for l in lds:
     for p in pools:
