@@ -11,10 +11,11 @@ is one pass of the hot path over the whole set: 16 000 solves (refine + two fixe
 plus 512 000 receiver times.  Velocity maps and source/receiver descriptors are resident in HBM
 before the timed region; the receiver times come back to the host inside it.
 
-With N > 1 the 16 000 units are split into N contiguous slices (whole periods per rank, the loop
-nest of CalSurfG.f90:1144-1145), every rank solves its slice, and the receiver-time vector is
-completed on every rank by an RCCL all-gather: total work is fixed ("strong" scaling, as
-configs[3] states).  `python bench.py --gpus N` without a launcher starts the N ranks itself (one
+With N > 1 the 16 000 units are split by SOURCES: rank r takes sources r, r + N, ... with all their
+periods (the units of the loop nest of CalSurfG.f90:1144-1145 are independent; a source's periods
+stay on one rank so that ranks keep whole bundles), every rank solves its share, and the
+receiver-time vector is completed on every rank by an RCCL all-gather and put into the reference's
+order: total work is fixed ("strong" scaling, as configs[3] states).  `python bench.py --gpus N` without a launcher starts the N ranks itself (one
 child process per GPU, before anything in the parent touches the GPU).
 
 Prints ONE JSON line on rank 0.

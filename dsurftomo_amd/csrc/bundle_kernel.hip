@@ -220,6 +220,11 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             sc[BC_SLOWN] = 0; sc[BC_FARALL] = bd->far_all ? 1 : 0;
             if (TIE && bd->cand) *(bd->cand + (size_t)my_slot * bd->cand_stride) = 0;
         }
+        if (TIE && bd->cand) {          // the census' "looked at" bits, kTieSeenBits per node record (behind the candidate list)
+            BGV4* const seen4 = (BGV4*)(bd->cand + (size_t)my_slot * bd->cand_stride + ((bd->cand_cap + 4) & ~3));
+            const BV4 zero4 = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int i = tid; i < ntile * (kTileRecs * kTieSeenBits / 128); i += NT) seen4[i] = zero4;
+        }
         __threadfence_block();
         __syncthreads();
         typedef __attribute__((address_space(1))) const Rec GCRec;
@@ -345,6 +350,15 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         if (TIE) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) tied = tied || (h.in[q] && c < kInf && c == h.near_tau[q]);
+            // (round 6) ... or an exceptional outer node was accepted at the very clock of one of the near neighbours: the second kind of tie
+            // (eikonal_core.h: solve_node_t<true>, the outer probe) -- a superset, the census' second look decides
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ko = h.outer_tau[q];
+                if (!(h.in_outer[q] && ko < kInf && ko != t_value(h.outer[q]))) continue;
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) tied = tied || (h.in[q2] && ko == h.near_tau[q2]);
+            }
         }
         ++evals;
         if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return tied;
@@ -370,11 +384,16 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         return tied;
     };
     // the tie census' second look (TIE): member mo of node id in the converged field, evaluated once more with the detector's walk
+    unsigned* const seen_g = (TIE && bd->cand) ? (unsigned*)(bd->cand + (size_t)my_slot * bd->cand_stride + ((bd->cand_cap + 4) & ~3)) : nullptr;
     auto tie_member = [&](int id, int mo) {
         if (mo >= nmem) return;
         int iz, ix;
         coords(id, &iz, &ix);
         if (ix >= nnx || iz >= nnz) return;
+        if (seen_g) {       // every (node, member) pair once: the list names a node as often as its evaluations ended on a tie, the sweep once per tied side
+            const unsigned bit = (unsigned)id * (unsigned)kTieSeenBits + (unsigned)mo;
+            if (atomicOr(&seen_g[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))) return;
+        }
         Hood h;
         float t_old, k_old;
         load_hood(id, mo, ix, iz, h, &t_old, &k_old);
@@ -384,12 +403,16 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
         (void)solve_node_t<true>(h, slown, geom, &k, &ti);
         const FimProblem* const pm = problems + s_member[mo];
-        if (ti >= 0.0f && pm->tie && ti > pm->tie_threshold) { atomicAdd((unsigned*)pm->tie, 1u); atomicMax((unsigned*)pm->tie + 1, bf2u(ti)); }
+        if (ti >= 0.0f && pm->tie) {
+            if (ti > 0.0f) { atomicAdd((unsigned*)pm->tie + 2, 1u); atomicAdd((unsigned*)pm->tie + 3, (unsigned)(fminf(ti, 1.0f) * (1.0f / kTieSumUnit))); }
+            else atomicAdd((unsigned*)pm->tie + 5, 1u);         // (a tie whose tied neighbour changes nothing at this node)
+            if (ti > pm->tie_threshold) { atomicAdd((unsigned*)pm->tie, 1u); atomicMax((unsigned*)pm->tie + 1, bf2u(ti)); }
+        }
     };
     int* const wq = slowq + wave * kSlowQ;              // the wave's queue of (node << 4 | member) left to the slow pass
     int qn = 0;
     int cn = 0;                                         // (TIE) tie candidates of the half-round, kept from the queue's top end downwards
-    int* const cand_g = (TIE && bd->cand) ? bd->cand + (size_t)my_slot * bd->cand_stride : nullptr;
+    int* const cand_g = (TIE && bd->cand && bd->cand_list) ? bd->cand + (size_t)my_slot * bd->cand_stride : nullptr;
     // a candidate per lane with `on` (wave-uniform control flow): into the LDS list while it has room beside the slow queue, else the count alone
     // grows -- the flush then reports more candidates than the list holds and the census sweeps the field
     bool clost = false;                                 // (a candidate found no room beside the slow queue: the bundle's list counts as overflowed)
@@ -403,10 +426,15 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
     };
     auto cand_flush = [&]() {          // (behind the half-round's slow pass: qn is 0 again)
         if (!cn || !cand_g) { cn = 0; clost = false; return; }
-        int base = 0;
-        if (lane == 0) base = atomicAdd(cand_g, clost ? bd->cand_cap + 1 : cn);
+        // (the count saturates just above the capacity: a medium that ties everywhere overflows the list every half-round, and a counter that kept
+        // adding would wrap -- ADVICE r05; the census reads "more than cand_cap" as overflow and sweeps the field)
+        int base = -1;
+        if (lane == 0) {
+            if (clost) (void)atomicMax(cand_g, bd->cand_cap + 1);
+            else if (__hip_atomic_load(cand_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= bd->cand_cap) base = atomicAdd(cand_g, cn);
+        }
         base = __builtin_amdgcn_readfirstlane(base);
-        if (!clost) for (int i = lane; i < cn; i += 64) if (base + i < bd->cand_cap) cand_g[1 + base + i] = wq[kSlowQ - 1 - i];
+        if (!clost && base >= 0) for (int i = lane; i < cn; i += 64) if (base + i < bd->cand_cap) cand_g[1 + base + i] = wq[kSlowQ - 1 - i];
         cn = 0; clost = false;
     };
 
@@ -846,7 +874,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         int cq = 0;
         bool lost = false;                     // (a trip with more ties than the queue holds: every member of the bundle counts as tied)
         const int ncand = cand_g ? __hip_atomic_load(cand_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;      // (counted by atomics at the L2: not through this CU's L1)
-        const bool by_list = cand_g && ncand <= bd->cand_cap;
+        const bool by_list = cand_g && ncand >= 0 && ncand <= bd->cand_cap;
         auto census_flush = [&]() {          // (the one call site of the second look)
             lost = lost || cq > kSlowQ;
             cq = cq < kSlowQ ? cq : kSlowQ;
@@ -871,12 +899,24 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                     coords(id, &iz, &ix);
                     rec_stencil(nbz, id, nid);
                     const unsigned mb = (unsigned)mo * 4u;
-                    const float a = fabsf(*(BGF32*)(Bb + (unsigned)id * GB + mb));
+                    const float raw = *(BGF32*)(Bb + (unsigned)id * GB + mb);
+                    const float a = fabsf(raw);
                     if (a < kInf) {
-                        if (ix > 0 && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[0] * GB + mb))) still |= 1u;
-                        if (ix + 1 < nnx && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[1] * GB + mb))) still |= 2u;
-                        if (iz > 0 && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[2] * GB + mb))) still |= 4u;
-                        if (iz + 1 < nnz && a == fabsf(*(BGF32*)(Bb + (unsigned)nid[3] * GB + mb))) still |= 8u;
+                        // (round 6) the walk's tie is against the neighbour's ACCEPTANCE time: where that is not the value -- an exceptional node
+                        // (sign bit) among the node, its near and its outer neighbours -- the values cannot tell, and the second look decides by itself
+                        const bool in0 = ix > 0, in1 = ix + 1 < nnx, in2 = iz > 0, in3 = iz + 1 < nnz;
+                        const float v0 = in0 ? *(BGF32*)(Bb + (unsigned)nid[0] * GB + mb) : kInf, v1 = in1 ? *(BGF32*)(Bb + (unsigned)nid[1] * GB + mb) : kInf;
+                        const float v2 = in2 ? *(BGF32*)(Bb + (unsigned)nid[2] * GB + mb) : kInf, v3 = in3 ? *(BGF32*)(Bb + (unsigned)nid[3] * GB + mb) : kInf;
+                        if (in0 && a == fabsf(v0)) still |= 1u;
+                        if (in1 && a == fabsf(v1)) still |= 2u;
+                        if (in2 && a == fabsf(v2)) still |= 4u;
+                        if (in3 && a == fabsf(v3)) still |= 8u;
+                        bool exc = __builtin_signbit(raw) || __builtin_signbit(v0) || __builtin_signbit(v1) || __builtin_signbit(v2) || __builtin_signbit(v3);
+                        if (ix > 1) exc = exc || __builtin_signbit(*(BGF32*)(Bb + (unsigned)nid[4] * GB + mb));
+                        if (ix + 2 < nnx) exc = exc || __builtin_signbit(*(BGF32*)(Bb + (unsigned)nid[5] * GB + mb));
+                        if (iz > 1) exc = exc || __builtin_signbit(*(BGF32*)(Bb + (unsigned)nid[6] * GB + mb));
+                        if (iz + 2 < nnz) exc = exc || __builtin_signbit(*(BGF32*)(Bb + (unsigned)nid[7] * GB + mb));
+                        if (exc) still |= 16u;             // (the node itself goes to the second look; no partner is named)
                     }
                 }
                 if (__any(still != 0u)) {
@@ -943,6 +983,35 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         cq += __popcll(bal);
                     }
                 }
+                // (round 6) an exceptional node -- accepted later than its value: the sign bit -- ties by its acceptance time, which the values
+                // above cannot show: the node and the eight nodes whose walks look at it go to the second look (0.02 % of a field's nodes)
+                unsigned xm = 0u;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) if (__builtin_signbit(own[k][m]) && fabsf(own[k][m]) < kInf) xm |= 1u << m;
+                if (__any(xm != 0u)) {
+                    int iz, ix, nid[8];
+                    coords(idv[k], &iz, &ix);
+                    rec_stencil(nbz, idv[k], nid);
+                    // (bit q: stencil node q lies inside the grid; a rare path: plain loops, the words picked by shifts, nothing unrolled)
+                    const unsigned inq = (ix > 0 ? 1u : 0u) | (ix + 1 < nnx ? 2u : 0u) | (iz > 0 ? 4u : 0u) | (iz + 1 < nnz ? 8u : 0u) |
+                                         (ix > 1 ? 16u : 0u) | (ix + 2 < nnx ? 32u : 0u) | (iz > 1 ? 64u : 0u) | (iz + 2 < nnz ? 128u : 0u);
+#pragma nounroll
+                    for (int m = 0; m < 4; ++m) {
+                        if (!__any(((xm >> m) & 1u) != 0u)) continue;
+#pragma nounroll
+                        for (int q = -1; q < 8; ++q) {
+                            if (cq + 64 > kSlowQ) census_flush();
+                            const bool on = ((xm >> m) & 1u) != 0u && (q < 0 || ((inq >> q) & 1u) != 0u);
+                            int node = idv[k];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) node = q == j ? nid[j] : node;
+                            const unsigned long long bal = __ballot(on);
+                            const int pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
+                            if (on && pos < kSlowQ) wq[pos] = (node << 4) | (csub * 4 + m);
+                            cq += __popcll(bal);
+                        }
+                    }
+                }
             }
         }
         census_flush();
@@ -956,7 +1025,8 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         const FimEnds* const E = ends + s_member[m];
         const FimProblem* const pm = problems + s_member[m];
         if (tid == 0) {
-            pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = m == 0 ? freezes : 0;      // (a statistic: a frozen 2-cycle sits an ulp or two from a tie state, which the census below sees or not by its own rule)
+            pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = m == 0 ? freezes : 0;      // (the statistic, counted once per bundle)
+            if (TIE && pm->tie) pm->tie[4] = freezes;                                      // (every member knows its bundle froze a cycle: a frozen 2-cycle sits an ulp or two from a tie state)
             if (failed && pm->info[2] != -2) pm->info[2] = -1;
             if (sc[BC_OVERFLOW]) pm->info[2] = -2;
         }

@@ -411,19 +411,34 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
     }
 #endif
     bool probing = false;               // TIE: the trip after a tie
+    // (round 6) TIE, the second kind of tie: an OUTER node accepted at the very clock of the neighbour taken in last (ko == tnow: only an
+    // exceptional outer node -- accepted later than its value -- can be, a regular one lies below its near node's time).  Whether it was alive
+    // when the reference evaluated this node for the last time -- second order or first in that direction -- is the tree's choice again; the
+    // walk here counts it as not alive (ko < tnow).  The probe evaluates the stopped walk's last trip once more with such outer nodes alive.
+    bool oprobe = false, odone = false;
     float c_keep = 0.0f, tnow_keep = 0.0f;
     if (TIE) *tie_out = -1.0f;
     for (;;) {
         if (!first) {
             const float nk = key[0];
+            bool take = true;
             if (!(nk < kInf && c > nk)) {
-                if (!(TIE && nk < kInf && c == nk)) break;
-                probing = true; c_keep = c; tnow_keep = tnow;     // an exact tie: one more trip with the tied neighbour alive
+                bool otie = false;
+                if (TIE && !odone && c < kInf) {
+                    for (int q = 0; q < 4; ++q) otie = otie || (((alive >> q) & 1u) && ko[q] == tnow && ko[q] != 0.0f && tn[q] > t2[q]);
+                }
+                if (otie) { oprobe = true; odone = true; c_keep = c; take = false; }
+                else {
+                    if (!(TIE && nk < kInf && c == nk)) break;
+                    probing = true; c_keep = c; tnow_keep = tnow;     // an exact tie: one more trip with the tied neighbour alive
+                }
             }
-            alive |= 1u << idx[0];
-            tnow = nk;
-            key[0] = key[1]; key[1] = key[2]; key[2] = key[3]; key[3] = kInf;
-            idx[0] = idx[1]; idx[1] = idx[2]; idx[2] = idx[3];
+            if (take) {
+                alive |= 1u << idx[0];
+                tnow = nk;
+                key[0] = key[1]; key[1] = key[2]; key[2] = key[3]; key[3] = kInf;
+                idx[0] = idx[1]; idx[1] = idx[2]; idx[2] = idx[3];
+            }
         }
         first = false;
         DSA_LEDGER_COUNT(13, "walk_body");
@@ -431,7 +446,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
         bool sw[4];
         float P[4];
         for (int q = 0; q < 4; ++q) {
-            const bool o = ko[q] < tnow || ko[q] == 0.0f;                // outer node alive (0: alive before any march)
+            const bool o = ko[q] < tnow || ko[q] == 0.0f || (TIE && oprobe && ko[q] == tnow);      // outer node alive (0: alive before any march)
             sw[q] = ((alive >> q) & 1u) && o && tn[q] > t2[q];
             P[q] = fmaf(4.0f, tn[q], -t2[q]);                            // 4 t - t2 (4 t is exact)
         }
@@ -482,7 +497,8 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
             best = (trav < best) ? trav : best;
         }
         c = best;
-        if (TIE && probing) { *tie_out = fabsf(c - c_keep); c = c_keep; tnow = tnow_keep; break; }
+        if (TIE && oprobe) { *tie_out = fabsf(c - c_keep); c = c_keep; oprobe = false; continue; }      // (back to the top: the walk stops again, now for good or on a tie of the first kind)
+        if (TIE && probing) { const float ti = fabsf(c - c_keep); *tie_out = ti > *tie_out ? ti : *tie_out; c = c_keep; tnow = tnow_keep; break; }
     }
     DSA_LEDGER_COUNT(15, "solve_epilogue");
     *tau_out = (c > tnow) ? c : tnow;

@@ -28,6 +28,12 @@ struct SpmvState;
 // (DSA_EXACT_TIES=0 for an unchanged Fortran host); the census still runs (tie_detect) and the call reports what it would have flagged.
 constexpr int kDefaultExactTies = 1;
 constexpr float kDefaultTieThreshold = 2.0e-5f;
+// (round 6) the census keeps the SUM and the COUNT of a unit's tie influences beside the largest one; the defaults of the rule that uses them
+// are set from the scans under profiles/r06_tie_*: 0 = that part of the rule is off
+constexpr float kDefaultTieSumThreshold = 0.0f;
+constexpr int kDefaultTieCountThreshold = 0;
+constexpr int kDefaultTieFrozenBundles = 0;
+constexpr int kDefaultTieMapStrict = 1;
 // Rays of a launch up to which four lanes trace a ray together (ray_kernels.hip: launch_rays; profiles/r05_ab_rays.log)
 constexpr int kRayGroupMax = 81920;
 
@@ -169,6 +175,15 @@ struct Engine {
     std::vector<unsigned char> h_unit_flags;     // per planned unit after a solve: bit 0 tie met, bit 1 solved by the exact mode
     std::vector<int> h_unit_rounds;               // rounds of the unit's coarse solve (of its bundle's, for a bundled unit)
     std::vector<float> h_unit_tie;               // largest tie influence of the unit (s)
+    std::vector<float> h_unit_tie_sum;           // (round 6) sum of the influences of the unit's ties (s) ...
+    std::vector<int> h_unit_tie_count;           // ... and how many had one; cycles the unit (its bundle) froze
+    std::vector<int> h_unit_froze;
+    float tie_sum_threshold = kDefaultTieSumThreshold;      // option tie_sum_threshold: a unit whose ties' influences add up to more than this (s) is flagged; 0 = off
+    int tie_count_threshold = kDefaultTieCountThreshold;    // option tie_count_threshold: ... or that holds more ties with an influence than this; 0 = off
+    int tie_frozen_bundles = kDefaultTieFrozenBundles;      // option tie_frozen_bundles: 1 = every member of a bundle that froze a cycle is flagged
+    int tie_map_strict = kDefaultTieMapStrict;              // option tie_map_strict: on a map where some unit holds a tie above tie_threshold, every unit holding a tie with any influence is flagged
+    int tie_verdict(int unit, const int32_t* tie_words, const int32_t* info16, bool member);
+    std::vector<char> tie_verdicts(int first, int n, const int32_t* tie_words, const int32_t* info16, bool bundled);
     int run_exact(int first, int n, const std::vector<int>& local_units, bool receivers, bool compact, bool may_pool_tiles = false);
     DevBuf<int8_t> S_r, cinit;
     DevBuf<int16_t> rst, cst;
@@ -237,7 +252,7 @@ struct Engine {
     SpmvState* spmv = nullptr;         // device copy of a COO matrix for dsa_spmv (spmv.hip)
     int lsmr_device_vectors = 0;       // dsa_lsmr: 1 = vectors and ordered reductions on the device, 0 = on the host (lsmr.hip)
 
-    double stats[40] = {};
+    double stats[DSA_STAT_COUNT + 2] = {};
 
     ~Engine();
     void fail(int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));

@@ -449,9 +449,10 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, PS * nrec_c) || ensure(exc_c, PS << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
         ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * kClockSlots) ||
-        ensure(tieinfo, C * 4) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
+        ensure(tieinfo, C * kTieWords) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
     h_unit_flags.assign((size_t)nunits, 0);
     h_unit_tie.assign((size_t)nunits, 0.0f);
+    h_unit_tie_sum.assign((size_t)nunits, 0.0f); h_unit_tie_count.assign((size_t)nunits, 0); h_unit_froze.assign((size_t)nunits, 0);
     h_unit_rounds.assign((size_t)nunits, 0);
     HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
@@ -575,6 +576,55 @@ BatchPtrs Engine::batch() const
     return b;
 }
 
+// The census' verdict on one unit (round 6): the unit's tie record (kernels.h: kTieWords, the refined stage's half first) and solve info into the
+// per-unit arrays dsa_unit_ties / dsa_unit_tie_sums report; true = the unit goes to the march (exact_ties = 1) / counts as flagged (exact_ties = 0).
+// Flag rule: a tie whose influence exceeds tie_threshold (counted by the kernels), OR the influences of all its ties adding up to more than
+// tie_sum_threshold, OR more than tie_count_threshold ties with an influence, OR a frozen cycle (unit-by-unit solves: always; members of a
+// bundle that froze one: option tie_frozen_bundles).
+// The verdicts of one launch (units first .. first + n - 1).  Round 6: a map on which some unit holds a tie above tie_threshold is TIE-PRONE -- a medium with
+// sharp contrasts, where second-order stencils switch along ridges and a one-ulp difference grows downstream (profiles/r06_tie_*: the units the
+// per-unit rule leaves alone end beyond 1e-4 s at a rate of ~1 in 10 000 there, whatever their own largest, summed or counted influences; on a map
+// without such a tie none of 16 000 did) -- and on a tie-prone map every unit that holds a tie with any influence at all goes to the march
+// (option tie_map_strict, default on).  The maps are judged launch by launch: a call that fits one launch -- the rule -- is judged as a whole.
+std::vector<char> Engine::tie_verdicts(int first, int n, const int32_t* tie_words, const int32_t* info16, bool bundled)
+{
+    std::vector<char> fl((size_t)n, 0);
+    std::vector<char> prone((size_t)std::max(nmaps, 1), 0);
+    for (int u = 0; u < n; ++u) {
+        const bool member = bundled && h_member_flag[(size_t)u] != 0;
+        const int code = tie_verdict(first + u, tie_words + (size_t)u * kTieWords, info16 + (size_t)u * 16, member);
+        fl[(size_t)u] = code != 0;
+        const int p = h_src[(size_t)(first + u)].period;
+        if (code == 2 && p >= 0 && p < nmaps) prone[(size_t)p] = 1;
+    }
+    if (tie_map_strict)
+        for (int u = 0; u < n; ++u) {
+            const int p = h_src[(size_t)(first + u)].period;
+            if (!fl[(size_t)u] && p >= 0 && p < nmaps && prone[(size_t)p] && h_unit_tie_count[(size_t)(first + u)] > 0) { fl[(size_t)u] = 1; stats[DSA_STAT_TIE_UNITS_STRICT] += 1.0; }
+        }
+    for (char c : prone) stats[DSA_STAT_TIE_PRONE_MAPS] += c ? 1.0 : 0.0;
+    for (int u = 0; u < n; ++u) if (!fl[(size_t)u] && h_unit_tie_count[(size_t)(first + u)] > 0) stats[DSA_STAT_TIE_UNITS_TIED] += 1.0;
+    return fl;
+}
+
+// returns 0: not flagged, 1: flagged, 2: flagged by a tie above tie_threshold (what makes the unit's map tie-prone)
+int Engine::tie_verdict(int unit, const int32_t* t, const int32_t* inf, bool member)
+{
+    const int h = kTieWords / 2;
+    float a, c2;
+    std::memcpy(&a, t + 1, 4); std::memcpy(&c2, t + h + 1, 4);
+    h_unit_tie[(size_t)unit] = std::max(a, c2);
+    const double sum = ((double)(uint32_t)t[3] + (double)(uint32_t)t[h + 3]) * (double)kTieSumUnit;
+    const long cnt = (long)(uint32_t)t[2] + (long)(uint32_t)t[h + 2];
+    h_unit_tie_sum[(size_t)unit] = (float)sum;
+    h_unit_tie_count[(size_t)unit] = (int)std::min<long>(cnt, 0x7fffffff);
+    const int froze = inf[3] + inf[11] + (member ? t[4] + t[h + 4] : 0);
+    h_unit_froze[(size_t)unit] = froze;
+    const bool frozen = inf[3] > 0 || (!member && inf[11] > 0) || (member && tie_frozen_bundles && (t[4] > 0 || t[h + 4] > 0));
+    if (t[0] > 0 || t[h] > 0) return 2;
+    return (frozen || (tie_sum_threshold > 0.0f && sum > (double)tie_sum_threshold) || (tie_count_threshold > 0 && cnt > tie_count_threshold)) ? 1 : 0;
+}
+
 int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, long long* nar)
 {
     if (!planned) { fail(DSA_ERR_STATE, "solve: call dsa_plan first"); return DSA_ERR_STATE; }
@@ -598,6 +648,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
     marched_in_tiles = false;
     std::fill(h_unit_flags.begin(), h_unit_flags.end(), (unsigned char)0);      // (per solve: a unit marched by an earlier call with other options is not "marched")
     std::fill(h_unit_tie.begin(), h_unit_tie.end(), 0.0f);
+    std::fill(h_unit_tie_sum.begin(), h_unit_tie_sum.end(), 0.0f); std::fill(h_unit_tie_count.begin(), h_unit_tie_count.end(), 0); std::fill(h_unit_froze.begin(), h_unit_froze.end(), 0);
     // units per launch: with recycled field slots a launch takes every unit the per-unit arrays hold; when the fields are needed after
     // the solve (rays and rows, the exact mode, keep_fields) a launch takes one unit per slot
     // (round 5: exact_ties = 1 runs like exact_ties = 0 -- recycled slots, receiver times from the solve's own field -- and the units the
@@ -669,6 +720,8 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             if (plan_bundles(first, n, bundle_G, &nsolo, &nbundles) != 0) return status;
         }
         const bool refined_b = nbundles > 0 && refined_bundles_now && !bundle_off_chunk;
+        // (what the bundles hold, recorded now: a memory-bound march below gives the bundle buffers back before the statistic is written)
+        const double bundle_mb = nbundles ? (double)(B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4 + slowI.cap * 4 + cand_b.cap * 4 + Br_pool.cap * 4 + exc_br.cap * 8 + lists_br.cap * 4 + cand_br.cap * 4 + slowIr.cap * 4) / 1.0e6 : 0.0;
         launch_make_problems(g, b, n, slow.p, nrec_c, risti_c.p, window_r, window_c, prob_r.p, prob_c.p, info.p, clocks.p, launch_rank.p,
                              detect ? tieinfo.p : nullptr, tie_threshold, ends_c.p, fused_times ? rays.p : nullptr, veln.p, nfield, dpl, out.p, err.p,
                              nbundles ? member_flag.p : nullptr, bundle_window() * cell_c, bundle_max_rounds, stream, bundle_window_tail() * cell_c,
@@ -716,19 +769,21 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             std::vector<int> xl;
             if (exact_ties == 2) { xl.resize((size_t)n); for (int u = 0; u < n; ++u) xl[(size_t)u] = u; }
             else {
-                std::vector<int32_t> h_tie((size_t)n * 4), h_inf((size_t)n * 16);
-                HIP_TRY(this, hipMemcpyAsync(h_tie.data(), tieinfo.p, (size_t)n * 16, hipMemcpyDeviceToHost, stream));
+                std::vector<int32_t> h_tie((size_t)n * kTieWords), h_inf((size_t)n * 16);
+                HIP_TRY(this, hipMemcpyAsync(h_tie.data(), tieinfo.p, (size_t)n * kTieWords * 4, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(this, hipMemcpyAsync(h_inf.data(), info.p, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(this, hipStreamSynchronize(stream));
-                for (int u = 0; u < n; ++u) {
-                    const int32_t* t = &h_tie[(size_t)u * 4];
-                    float a, c2;
-                    std::memcpy(&a, t + 1, 4); std::memcpy(&c2, t + 3, 4);
-                    h_unit_tie[(size_t)(first + u)] = std::max(a, c2);
-                    // (a frozen cycle of a unit-by-unit solve flags its unit; inside a bundle the census of the converged field decides, bundle_kernel.hip)
+                //  a chunk that is about to be solved again -- exception table overflow, a refined or a coarse bundle that gave up: the
+                // checks behind the receivers below -- is not marched now: its flagged units would march twice and keep flags of the abandoned attempt
+                bool will_redo = false;
+                for (int u = 0; u < n && !will_redo; ++u) {
+                    const int32_t* fi = &h_inf[(size_t)u * 16];
                     const bool member = nbundles > 0 && h_member_flag[(size_t)u] != 0;
-                    const bool frozen = h_inf[(size_t)u * 16 + 3] > 0 || (!member && h_inf[(size_t)u * 16 + 11] > 0);
-                    if (t[0] > 0 || t[2] > 0 || frozen) { h_unit_flags[(size_t)(first + u)] |= 1; xl.push_back(u); }
+                    will_redo = fi[10] == -2 || (refined_b && member && fi[2] < 0) || (member && fi[10] == -1);
+                }
+                if (!will_redo) {
+                    const std::vector<char> fl = tie_verdicts(first, n, h_tie.data(), h_inf.data(), nbundles > 0);
+                    for (int u = 0; u < n; ++u) if (fl[(size_t)u]) { h_unit_flags[(size_t)(first + u)] |= 1; xl.push_back(u); }
                 }
                 stats[DSA_STAT_TIE_UNITS] += (double)xl.size();
             }
@@ -754,7 +809,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         h_info.resize((size_t)n * 16);
         h_flags.resize((size_t)n * 4);
         std::vector<int32_t> h_tie0;
-        if (exact_ties == 0 && detect) { h_tie0.resize((size_t)n * 4); HIP_TRY(this, hipMemcpyAsync(h_tie0.data(), tieinfo.p, (size_t)n * 16, hipMemcpyDeviceToHost, stream)); }
+        if (exact_ties == 0 && detect) { h_tie0.resize((size_t)n * kTieWords); HIP_TRY(this, hipMemcpyAsync(h_tie0.data(), tieinfo.p, (size_t)n * kTieWords * 4, hipMemcpyDeviceToHost, stream)); }
         HIP_TRY(this, hipMemcpyAsync(h_info.data(), info.p, (size_t)n * 16 * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(this, hipMemcpyAsync(h_flags.data(), flags.p, (size_t)n * 4 * 4, hipMemcpyDeviceToHost, stream));
         if (dsurf && r1 > r0) {
@@ -815,8 +870,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                 continue;
             }
             stats[DSA_STAT_BUNDLES] += nbundles; stats[DSA_STAT_BUNDLED_UNITS] += n - nsolo;
-            stats[DSA_STAT_FOOTPRINT_MB] = std::max(stats[DSA_STAT_FOOTPRINT_MB], ((double)pool_slots * (double)per_slot_bytes + (double)chunk * (double)per_unit_bytes +
-                                                    (double)(B_pool.cap * 4 + exc_b.cap * 8 + lists_b.cap * 4 + slowI.cap * 4)) / 1.0e6);
+            stats[DSA_STAT_FOOTPRINT_MB] = std::max(stats[DSA_STAT_FOOTPRINT_MB], ((double)pool_slots * (double)per_slot_bytes + (double)chunk * (double)per_unit_bytes) / 1.0e6 + bundle_mb);
         }
         for (int u = 0; u < n; ++u) {
             const int32_t* fi = &h_info[(size_t)u * 16];
@@ -834,15 +888,8 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             stats[DSA_STAT_FREEZES] += fi[3] + fi[11];
         }
         if (!h_tie0.empty()) {      // exact_ties = 0: what the detector saw is reported, nothing is solved again
-            for (int u = 0; u < n; ++u) {
-                const int32_t* t = &h_tie0[(size_t)u * 4];
-                float a, c2;
-                std::memcpy(&a, t + 1, 4); std::memcpy(&c2, t + 3, 4);
-                h_unit_tie[(size_t)(first + u)] = std::max(a, c2);
-                const bool member = nbundles > 0 && h_member_flag[(size_t)u] != 0;
-                const bool frozen = h_info[(size_t)u * 16 + 3] > 0 || (!member && h_info[(size_t)u * 16 + 11] > 0);
-                if (t[0] > 0 || t[2] > 0 || frozen) { h_unit_flags[(size_t)(first + u)] |= 1; stats[DSA_STAT_TIE_UNITS] += 1.0; stats[DSA_STAT_TIE_UNITS_LEFT] += 1.0; }
-            }
+            const std::vector<char> fl = tie_verdicts(first, n, h_tie0.data(), h_info.data(), nbundles > 0);
+            for (int u = 0; u < n; ++u) if (fl[(size_t)u]) { h_unit_flags[(size_t)(first + u)] |= 1; stats[DSA_STAT_TIE_UNITS] += 1.0; stats[DSA_STAT_TIE_UNITS_LEFT] += 1.0; }
         }
         for (int u = 0; u < n; ++u) stats[DSA_STAT_TIE_INFLUENCE_MAX] = std::max(stats[DSA_STAT_TIE_INFLUENCE_MAX], (double)h_unit_tie[(size_t)(first + u)]);
         last_chunk_first = first;                               // the per-unit arrays (refined snapshots, ...) of this chunk stay resident ...
@@ -1069,7 +1116,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     bundle_slots = gr[0].slots;
     // tie candidates per bundle slot (the census' list, bundle_kernel.hip): an eighth of the field's nodes, at least 65 535 entries
     const bool want_cand = exact_ties == 1 || (exact_ties == 0 && tie_detect);
-    const size_t cand_cap = std::max<size_t>(65535, nrec_c / 8), cand_stride = cand_cap + 1;
+    const size_t cand_cap = std::max<size_t>(65535, nrec_c / 8), cand_stride = ((cand_cap + 4) & ~(size_t)3) + nrec_c * kTieSeenBits / 32;
     if (want_cand && ensure(cand_b, slots_total * cand_stride)) return status;
     if (ensure(B_pool, b_total) || ensure(exc_b, exc_total) || ensure(lists_b, slots_total * lists_c_stride) || ensure(bpool_gen, slots_total) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
@@ -1086,7 +1133,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         bd.lists = lists_b.p + r.slot0 * lists_c_stride; bd.lists_stride = lists_c_stride;
         bd.slot_busy = r.slots < r.count ? bpool_gen.p + r.slot0 : nullptr; bd.nslots = r.slots; bd.slot = r.slots < r.count ? 0 : kk;
         bd.slowI = slowI.p; bd.np = nmaps; bd.far_all = bundle_far_all;
-        bd.cand = want_cand && tie_list_opt ? cand_b.p + r.slot0 * cand_stride : nullptr; bd.cand_stride = cand_stride; bd.cand_cap = (int)cand_cap;
+        bd.cand = want_cand ? cand_b.p + r.slot0 * cand_stride : nullptr; bd.cand_stride = cand_stride; bd.cand_cap = (int)cand_cap; bd.cand_list = tie_list_opt;
         bd.nmem = (int)mem.size();
         for (int m = 0; m < kBundleMax; ++m) { bd.member[m] = 0; bd.map[m] = 0; }
         for (int m = 0; m < bd.nmem; ++m) {
@@ -1104,7 +1151,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         const size_t nrec_r = kRefRecs;
         const int xlog_r0 = exc_log2cap_of(kRefMax, kRefMax);
         const size_t lists_r_stride = ((size_t)kFimMaskInts * kRefTiles * kRefTiles + 2 + 1) & ~(size_t)1;
-        const size_t cand_cap_r = 65535, cand_stride_r = cand_cap_r + 1;
+        const size_t cand_cap_r = 65535, cand_stride_r = ((cand_cap_r + 4) & ~(size_t)3) + nrec_r * kTieSeenBits / 32;
         size_t b_tot = 0, x_tot = 0, s_tot = 0;
         std::vector<size_t> b_off((size_t)nb), x_off((size_t)nb), s_off((size_t)nb);
         for (int k = 0; k < nb; ++k) {
@@ -1124,7 +1171,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
             bd.lists = lists_br.p + (size_t)k * lists_r_stride; bd.lists_stride = 0;
             bd.slot_busy = nullptr; bd.nslots = 1; bd.slot = 0;
             bd.slowI = slowIr.p + s_off[(size_t)k]; bd.np = GG;
-            bd.cand = want_cand && tie_list_opt ? cand_br.p + (size_t)k * cand_stride_r : nullptr; bd.cand_stride = 0; bd.cand_cap = (int)cand_cap_r;
+            bd.cand = want_cand ? cand_br.p + (size_t)k * cand_stride_r : nullptr; bd.cand_stride = 0; bd.cand_cap = (int)cand_cap_r; bd.cand_list = tie_list_opt;
             for (int m = 0; m < kBundleMax; ++m) bd.map[m] = m < GG ? m : 0;
         }
         HIP_TRY(this, hipMemcpyAsync(bundles_r_d.p, h_bundles_r.data(), (size_t)nb * sizeof(FimBundle), hipMemcpyHostToDevice, stream));
@@ -1188,7 +1235,10 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
             auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
             HIP_TRY(this, hipStreamSynchronize(stream));
             if (stream2) HIP_TRY(this, hipStreamSynchronize(stream2));
-            release(B_pool); release(exc_b); release(lists_b);
+            // (the candidate lists and the refined boxes' bundle buffers go with them -- GBs at 4097^2 --, and nothing may launch the
+            // bundle descriptors that still point there: plan_bundles builds them again for the next chunk or call)
+            release(B_pool); release(exc_b); release(lists_b); release(cand_b); release(Br_pool); release(exc_br); release(lists_br); release(cand_br); release(slowIr);
+            bundles_a = bundles_b = 0; h_bundles.clear(); h_bundles_r.clear();
             HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
             pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.80 * (double)(free_b + have)) / per));
         }
@@ -1534,6 +1584,10 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "exact_ties" && (value == 0 || value == 1 || value == 2)) { en->exact_ties = (int)value; return 0; }
     if (n == "tie_threshold" && value >= 0) { en->tie_threshold = (float)value; return 0; }
     if (n == "tie_detect" && (value == 0 || value == 1)) { en->tie_detect = (int)value; return 0; }
+    if (n == "tie_sum_threshold" && value >= 0) { en->tie_sum_threshold = (float)value; return 0; }
+    if (n == "tie_count_threshold" && value >= 0) { en->tie_count_threshold = (int)value; return 0; }
+    if (n == "tie_frozen_bundles" && (value == 0 || value == 1)) { en->tie_frozen_bundles = (int)value; return 0; }
+    if (n == "tie_map_strict" && (value == 0 || value == 1)) { en->tie_map_strict = (int)value; return 0; }
     if (n == "tie_list" && (value == 0 || value == 1)) { en->tie_list_opt = (int)value; return 0; }
     if (n == "disp_failure_log" && value >= 0 && value <= 65536) { en->disp_failure_log = (int)value; return 0; }
     if (n == "exact_heap_blocked" && (value == 0 || value == 1 || value == 2)) { en->exact_heap_blocked = (int)value; return 0; }
@@ -1742,6 +1796,19 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
     const Engine* en = reinterpret_cast<const Engine*>(e);
     if (clamped) *clamped = en->rays_clamped;
     if (first_unit) *first_unit = en->first_clamped_unit;
+    return 0;
+}
+
+int dsa_unit_tie_sums(const dsa_engine* e, int nunits, int* count, float* sum, int* frozen)
+{
+    if (!e) return DSA_ERR_ARGUMENT;
+    const Engine* en = reinterpret_cast<const Engine*>(e);
+    if (nunits < 0 || (size_t)nunits > en->h_unit_tie_sum.size()) return DSA_ERR_ARGUMENT;
+    for (int u = 0; u < nunits; ++u) {
+        if (count) count[u] = en->h_unit_tie_count[(size_t)u];
+        if (sum) sum[u] = en->h_unit_tie_sum[(size_t)u];
+        if (frozen) frozen[u] = en->h_unit_froze[(size_t)u];
+    }
     return 0;
 }
 

@@ -565,6 +565,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
 #endif
     unsigned tie_n = 0;                                      // TIE: evaluations that ended on an exact tie with influence, and the largest influence
     float tie_max = 0.0f;
+    unsigned tie_any = 0, tie_sum = 0;                       // ... with any influence at all, and their sum (kTieSumUnit): evaluations of the iteration, transient ties among them
 #ifdef DSA_PASSA_CLOCKS
     unsigned long long sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tsub = wall_clock64();
 #define DSA_TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = wall_clock64(); sub[k] += t1_ - tsub; tsub = t1_; } while (0)
@@ -1052,6 +1053,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
                         float tie;
                         c = solve_node_t<true>(h, slow_at(id), geom, &k, &tie DSA_LEDGER_PASS);
                         if (tie > p.tie_threshold) { ++tie_n; tie_max = fmaxf(tie_max, tie); }
+                        if (tie > 0.0f) { ++tie_any; tie_sum += (unsigned)(fminf(tie, 1.0f) * (1.0f / kTieSumUnit)); }
                     } else c = solve_node_t<false>(h, slow_at(id), geom, &k, nullptr DSA_LEDGER_PASS);
 #ifdef DSA_PROBE_EXTRA_READ
                     if (COMPACT) {   // bandwidth probe: one more cold line per evaluated node group (the slowness half a grid away); result unused
@@ -1176,6 +1178,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DSA_FIM_WAVE
         const unsigned tn = wave_sum(tie_n);
         const float tm = -wave_min(-tie_max);
         if (lane == 0 && tn) { atomicAdd((unsigned*)p.tie, tn); atomicMax((unsigned*)p.tie + 1, f2u(tm)); }
+        const unsigned ta = wave_sum(tie_any), ts = wave_sum(tie_sum);
+        if (lane == 0 && ta) { atomicAdd((unsigned*)p.tie + 2, ta); atomicAdd((unsigned*)p.tie + 3, ts); }
     }
 #ifdef DSA_BARRIER_CLOCKS
     if (p.clocks && lane == 0) {

@@ -14,6 +14,11 @@ struct RayDesc { int src; float rx, rz; float sin_rx; int data; int flags; };   
 constexpr int kRayTime = 1, kRayPath = 2;
 
 constexpr int kClockSlots = 32;     // probe counters per unit (FimProblem::clocks)
+// The tie record of a unit (FimProblem::tie): kTieWords int32, the refined stage's half first.  A tie's influence enters the sum as
+// min(influence, 1 s) / kTieSumUnit, saturating at 2^32 - 1 (4.3 s of influences: nothing that matters is that large).
+constexpr int kTieWords = 12;
+constexpr float kTieSumUnit = 0x1p-30f;
+constexpr int kTieSeenBits = 16;   // (= kBundleMax)
 
 // One fixed-point problem: a travel-time field on an (nnz, nnx) grid stored as tiled (T, tau)
 // records (eikonal_core.h).  The records carry the boundary condition: pinned nodes (sign bit of T)
@@ -36,7 +41,9 @@ struct FimProblem {
     int max_rounds;
     unsigned long long* clocks;   // optional, kClockSlots u64: [0..7] phase clocks of thread 0 (wall_clock64 ticks) + list sizes; [8..31] trip counters of DSA_LEDGER builds
     int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [3] stall freezes, [4..5] evaluations (u64)
-    int32_t* tie;          // tie detector (kernels launched with FimLaunch::tie): [0] evaluations that ended on an exact tie whose influence exceeds tie_threshold, [1] largest influence (float bits)
+    int32_t* tie;          // tie detector (kernels launched with FimLaunch::tie), kTieWords / 2 words per stage: [0] ties whose influence exceeds tie_threshold, [1] largest influence (float bits),
+                           // [2] ties with any influence at all, [3] the sum of the influences in units of kTieSumUnit (round 6: sub-threshold ties add up along a front),
+                           // [4] cycles the unit's bundle froze (bundle kernel), [5] ties without an influence on their node (bundle kernel's census)
     float tie_threshold;
 };
 
@@ -122,7 +129,8 @@ struct FimBundle {
     int np;
     int* cand;                    // slot 0: tie candidates of the bundle (TIE kernels): [0] their number, then (node << 4 | member) words; null: none kept (the census sweeps the field)
     size_t cand_stride;           //         ints per slot
-    int cand_cap;                 //         entries per slot
+    int cand_cap;                 //         entries per slot; behind them kTieSeenBits bits per node record: the (node, member) pairs the census has looked at (each once)
+    int cand_list;                // 1: the round loop lists candidates; 0: the census sweeps the converged field (option tie_list = 0, A/B)
     int far_all;                  // 1: pass A asks for all four outer neighbours of every node (option bundle_far_all; A/B of round 5's upwind-only loads)
     int nmem;
     int member[kBundleMax];       // indices into the launch's FimProblem / FimEnds arrays (grid, seeds, window records, receivers, info)

@@ -324,7 +324,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     r.max_rounds = 64 * (sd.rnx + sd.rnz) + 4096;
     r.clocks = nullptr;
     r.info = info + (size_t)s * 16;
-    r.tie = tie ? tie + (size_t)s * 4 : nullptr; r.tie_threshold = tie_threshold;
+    r.tie = tie ? tie + (size_t)s * kTieWords : nullptr; r.tie_threshold = tie_threshold;
     // field slot: the unit's own, or (a pool smaller than the launch) the one its workgroup number selects
     const int rank = launch_rank ? launch_rank[s] : s;
     if (ends_r) {
@@ -352,7 +352,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.max_rounds = member ? (max_rounds_b > 0 ? max_rounds_b : 4 * (g.nnx + g.nnz) + 2048) : 64 * (g.nnx + g.nnz) + 4096;
     c.clocks = clocks ? clocks + (size_t)s * kClockSlots : nullptr;
     c.info = info + (size_t)s * 16 + 8;
-    c.tie = tie ? tie + (size_t)s * 4 + 2 : nullptr; c.tie_threshold = tie_threshold;
+    c.tie = tie ? tie + (size_t)s * kTieWords + kTieWords / 2 : nullptr; c.tie_threshold = tie_threshold;
     prob_c[rank] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
     if (ends_c) {
         FimEnds e;
@@ -365,7 +365,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
         ends_c[rank] = e;
     }
     for (int q = 0; q < 16; ++q) info[(size_t)s * 16 + q] = 0;
-    if (tie) for (int q = 0; q < 4; ++q) tie[(size_t)s * 4 + q] = 0;
+    if (tie) for (int q = 0; q < kTieWords; ++q) tie[(size_t)s * kTieWords + q] = 0;
     if (clocks) for (int q = 0; q < kClockSlots; ++q) clocks[(size_t)s * kClockSlots + q] = 0ull;      // probe builds accumulate into them
 }
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DSA_LIB_PATH") or os.path.join(_HERE, "libdsurftomo_a
 
 STAT_NAMES = ("ms_total", "ms_fim_coarse", "ms_fim_refined", "ms_stages", "launches_fim_coarse", "units",
               "rounds_max", "evals_total", "chunk", "rescans", "freezes", "rays", "ray_steps", "rays_clamped",
-              "ms_rays", "ms_rows", "nar", "ms_dispersion", "curves", "changes_total", "tie_units", "exact_units", "exact_pops", "ms_exact", "field_slots", "footprint_mb", "bundle_size", "bundles", "bundled_units", "bundle_slots", "bundle_threads", "tie_units_left", "tie_influence_max", "exact_pool", "exact_tiles")
+              "ms_rays", "ms_rows", "nar", "ms_dispersion", "curves", "changes_total", "tie_units", "exact_units", "exact_pops", "ms_exact", "field_slots", "footprint_mb", "bundle_size", "bundles", "bundled_units", "bundle_slots", "bundle_threads", "tie_units_left", "tie_influence_max", "exact_pool", "exact_tiles", "tie_units_strict", "tie_prone_maps", "tie_units_tied")
 
 _f32, _i32, _vp = C.c_float, C.c_int, C.c_void_p
 _lib = None
@@ -62,6 +62,7 @@ def load_library():
     L.dsa_get_stats.argtypes = [_vp, _vp]
     L.dsa_unit_ties.argtypes = [_vp, _i32, _vp, _vp]
     L.dsa_unit_rounds.argtypes = [_vp, _i32, _vp]
+    L.dsa_unit_tie_sums.argtypes = [_vp, _i32, _vp, _vp, _vp]
     L.dsa_debug_counters.argtypes = [_vp, _vp]
     L.dsa_ray_paths.argtypes = [_vp, _vp, _vp, _vp]
     L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]
@@ -302,6 +303,13 @@ class Engine:
         fl = np.zeros(n, np.int32); inf = np.zeros(n, np.float32)
         self._check(self._L.dsa_unit_ties(self._h, n, _p(fl), _p(inf)))
         return fl, inf
+
+    def unit_tie_sums(self):
+        """per unit of the last solve: ties with an influence, the sum of their influences (s), cycles frozen by the unit or its bundle"""
+        n = len(self._nrec_of_plan)
+        cnt = np.zeros(n, np.int32); sm = np.zeros(n, np.float32); fr = np.zeros(n, np.int32)
+        self._check(self._L.dsa_unit_tie_sums(self._h, n, _p(cnt), _p(sm), _p(fr)))
+        return cnt, sm, fr
 
     def unit_rounds(self):
         """rounds of each unit's coarse solve in the last solve"""

@@ -259,6 +259,10 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  * dsa_unit_ties: per planned unit of the last solve, flags (bit 0: holds a tie above the threshold, bit 1: solved by the march) and the largest
  * tie influence in seconds (either array may be NULL). */
 int dsa_unit_ties(const dsa_engine* e, int nunits, int* flags, float* influence);
+/* (round 6) what else the census keeps per planned unit of the last solve: how many of the unit's ties have an influence at all, the sum of those
+ * influences in seconds (sub-threshold ties add up along a front: options tie_sum_threshold / tie_count_threshold flag by them), and the cycles
+ * the unit -- or, for a bundled unit, its bundle -- froze (option tie_frozen_bundles).  Any array may be NULL. */
+int dsa_unit_tie_sums(const dsa_engine* e, int nunits, int* count, float* sum, int* frozen);
 /* rounds the coarse fixed-point solve of each planned unit took in the last dsa_solve (a bundled unit: its bundle's) */
 int dsa_unit_rounds(const dsa_engine* e, int nunits, int* rounds);
 
@@ -284,6 +288,10 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_TIE_INFLUENCE_MAX,    /* largest tie influence met (seconds) */
        DSA_STAT_EXACT_POOL,           /* units the last march held side by side */
        DSA_STAT_EXACT_TILES,          /* > 0: it marched in pooled tiles, that many 8x8-node tiles per unit */
+       DSA_STAT_TIE_UNITS_STRICT,     /* (round 6) of DSA_STAT_TIE_UNITS: flagged only because their map is tie-prone (option tie_map_strict) */
+       DSA_STAT_TIE_PRONE_MAPS,       /* maps on which some unit held a tie above tie_threshold, summed over the call's launches */
+       DSA_STAT_TIE_UNITS_TIED,       /* units that stayed with the fixed point although the census found a tie with an influence in them: their times are the
+                                         reference's to ~1e-4 s statistically, not by construction (DESIGN.md "Ties") */
        DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 
