@@ -141,6 +141,7 @@ struct Engine {
     size_t bundle_room(size_t free_b) const;
     bool grow_unit_pool();
     void release_march_pool();
+    bool march_pool_kept = false, released_bundles_for_march = false;      // (exact_ties = 1: the marching pool stays allocated between calls when the device has room, run_exact)
     int bundle_threads() const;
     float bundle_window() const;
     float bundle_window_tail() const;

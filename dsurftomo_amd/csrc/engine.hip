@@ -158,7 +158,7 @@ int Engine::finish_maps(int nm)
     have_maps = true;
     slowI_ready = false;
     bundles_failed = false; refined_bundles_failed = false;
-    if (g.nnx != grown_nnx || g.nnz != grown_nnz) { exc_log2cap_grown = 0; grown_nnx = g.nnx; grown_nnz = g.nnz; }
+    if (g.nnx != grown_nnx || g.nnz != grown_nnz) { exc_log2cap_grown = 0; grown_nnx = g.nnx; grown_nnz = g.nnz; march_pool_kept = false; }      // (another grid: a kept marching pool is of the wrong size)
     return 0;
 }
 
@@ -479,9 +479,11 @@ hipError_t Engine::make_stream2()
 void Engine::release_march_pool()
 {
     if (exact_ties == 2 || (!X_pool.cap && !X_tp.cap)) return;
+    if (exact_ties == 1 && march_pool_kept) return;          // (round 6: kept by the last march because the device had room for it beside everything else)
     (void)hipStreamSynchronize(stream);
     auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
     release(X_pool); release(X_heap); release(X_tt); release(X_tp); release(X_ring); release(X_free); release(X_pins);
+    march_pool_kept = false;
 }
 
 // The unit field pool back to its regular size (four times the resident workgroups, within the plan's budget) when plan() had cut it
@@ -1220,6 +1222,7 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
     }
     if (tiles) per = per_tiles;
     marched_in_tiles = tiles;
+    released_bundles_for_march = false;
     size_t pool = (size_t)exact_pool;
     if (!pool) {
         // units marching at a time: as many as 80 % of the free memory holds, at most exact_pool_max (four units per wavefront; at 4097^2 the
@@ -1239,6 +1242,7 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
             // bundle descriptors that still point there: plan_bundles builds them again for the next chunk or call)
             release(B_pool); release(exc_b); release(lists_b); release(cand_b); release(Br_pool); release(exc_br); release(lists_br); release(cand_br); release(slowIr);
             bundles_a = bundles_b = 0; h_bundles.clear(); h_bundles_r.clear();
+            released_bundles_for_march = true;
             HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
             pool = std::min<size_t>(exact_pool_max, std::max<size_t>(1, (size_t)(0.80 * (double)(free_b + have)) / per));
         }
@@ -1301,9 +1305,16 @@ int Engine::run_exact(int first, int n, const std::vector<int>& xl, bool receive
     stats[DSA_STAT_EXACT_UNITS] += (double)xl.size();
     if (exact_ties == 1) {
         // the march's pool was sized from what the fixed point's buffers left (or took their place, above): it goes back, so that the next
-        // call's bundles find the memory this call's found (exact_ties = 2 keeps its pool: nothing else wants the memory there)
-        auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
-        release(X_pool); release(X_heap); release(X_tt); release(X_tp); release(X_ring); release(X_free); release(X_pins);
+        // call's bundles find the memory this call's found (exact_ties = 2 keeps its pool: nothing else wants the memory there) -- unless
+        // (round 6) the device holds it with room to spare beside the bundles and the unit pool (a third of the memory still free: 1025^2),
+        // where giving back and allocating 70 GB again on every call of a tie-prone medium cost seconds (profiles/r06_march_pool.log)
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(this, hipMemGetInfo(&free_b, &total_b));
+        march_pool_kept = released_bundles_for_march ? false : free_b * 3 > total_b;
+        if (!march_pool_kept) {
+            auto release = [](auto& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; };
+            release(X_pool); release(X_heap); release(X_tt); release(X_tp); release(X_ring); release(X_free); release(X_pins);
+        }
     }
     return 0;
 }

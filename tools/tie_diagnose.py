@@ -65,8 +65,25 @@ for k in look:
     F0 = e.field(p).copy()
     K0 = np.abs(e.debug_field(p, 1)) if solo else None          # acceptance times (unit-by-unit solve only)
     st0 = e.stats()
+    R0, S0 = e.refined(p)
+    c0, s0, f0 = e.unit_tie_sums()
     e.set_option("exact_ties", 2); e.plan(**su); ax = e.solve().reshape(nper, nrec)
     FX = e.field(p).copy()
+    RX, SX = e.refined(p)
+    # the refined box's snapshot at the hand-off (the reference's ttnr / nstsr, CalSurfG.f90:1287): where do the two modes' differ?
+    both = np.isfinite(R0) & np.isfinite(RX)
+    dR = np.where(both, np.abs(R0.astype(np.float64) - RX.astype(np.float64)), 0.0)
+    nst = int((S0 != SX).sum())
+    print(f"\n--- unit {k}: refined snapshot {R0.shape}: statuses differ at {nst} nodes, times at {int((R0 != RX).sum() - (~both & (np.isinf(R0) == np.isinf(RX))).sum())} (largest {dR.max():.3g} s); "
+          f"ties with an influence the census counted in this unit (both stages): {int(c0[p])}, their sum {s0[p]:.3g} s")
+    if nst:
+        w = np.argwhere(S0 != SX)[:6]
+        print("    status differences (ix, iz, fixed point -> march, T fixed point, T march): " + "; ".join(f"({a},{b}) {S0[a, b]}->{SX[a, b]} {R0[a, b]:.7f} {RX[a, b]:.7f}" for a, b in w))
+    if (R0 != RX).any():
+        w = np.argwhere((R0 != RX) & both)
+        if len(w):
+            o2 = np.argsort(RX[w[:, 0], w[:, 1]])[:6]
+            print("    earliest time differences (ix, iz, T march, T fixed point, status march): " + "; ".join(f"({w[q, 0]},{w[q, 1]}) {RX[w[q, 0], w[q, 1]]:.8f} {R0[w[q, 0], w[q, 1]]:.8f} {SX[w[q, 0], w[q, 1]]}" for q in o2))
     dd = np.abs(a0[p].astype(np.float64) - ax[p].astype(np.float64))
     print(f"\n=== unit {k} (source {s}, period {p}): stage-1 receiver error {d[k] if march_all else float('nan'):.4g} s, census influence {infl[k]:.3g} s; alone in a bundle of {int(st0['bundle_size'])}: "
           f"receiver error {dd.max():.4g} s, census flag {int(fl[p] & 1)} influence {inf[p]:.3g}, same times as in the full call: {bool((a0[p] == t0[k]).all())}")
