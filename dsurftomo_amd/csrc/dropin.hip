@@ -85,14 +85,16 @@ Layout make_layout(int kRc, int kRg, int kLc, int kLg, int kmax, bool clobber)
 }
 
 long long g_tie_units = 0, g_tie_left = 0, g_tie_marched = 0;      // tie census of the last drop-in call (dsa_dropin_tie_diagnostics)
+long long g_tie_tied = 0, g_tie_prone = 0, g_tie_strict = 0;       // (round 6: dsa_dropin_tie_census)
 float g_tie_influence = 0.0f;
-void tie_reset() { g_tie_units = g_tie_left = g_tie_marched = 0; g_tie_influence = 0.0f; }
+void tie_reset() { g_tie_units = g_tie_left = g_tie_marched = g_tie_tied = g_tie_prone = g_tie_strict = 0; g_tie_influence = 0.0f; }
 void tie_collect(dsa_engine* e)
 {
     double st[DSA_STAT_COUNT + 8];
     if (dsa_get_stats(e, st) != 0) return;
     g_tie_units += (long long)st[DSA_STAT_TIE_UNITS]; g_tie_left += (long long)st[DSA_STAT_TIE_UNITS_LEFT]; g_tie_marched += (long long)st[DSA_STAT_EXACT_UNITS];
     g_tie_influence = std::max(g_tie_influence, (float)st[DSA_STAT_TIE_INFLUENCE_MAX]);
+    g_tie_tied += (long long)st[DSA_STAT_TIE_UNITS_TIED]; g_tie_prone += (long long)st[DSA_STAT_TIE_PRONE_MAPS]; g_tie_strict += (long long)st[DSA_STAT_TIE_UNITS_STRICT];
 }
 
 int g_rbint_notes = 0;                // diagnostics of the last dsa_calsurfg call (dsa_dropin_diagnostics)
@@ -344,6 +346,16 @@ int dsa_dropin_dispersion_failure(int index, int* info, double* vals, float* tab
 // Tie census of the last dsa_calsurfg / dsa_synthetic call (all its engines): units that hold an exact time tie with an influence above the
 // threshold, how many of them were left to the fixed point (exact_ties = 0: their travel times may differ from the reference's Fast Marching by
 // more than 1e-4 s) and how many were solved again by the reference's march (exact_ties = 1), and the largest influence met.
+// (round 6) ... and what the per-unit rule cannot see: units that stayed with the fixed point although they hold a tie with a (small) influence -- their
+// times are the reference's to 1e-4 s by measurement, not by construction --, the maps found tie-prone and the units marched because of their map.
+int dsa_dropin_tie_census(long long* tied_units_left, long long* tie_prone_maps, long long* flagged_by_map)
+{
+    if (tied_units_left) *tied_units_left = g_tie_tied;
+    if (tie_prone_maps) *tie_prone_maps = g_tie_prone;
+    if (flagged_by_map) *flagged_by_map = g_tie_strict;
+    return 0;
+}
+
 int dsa_dropin_tie_diagnostics(long long* flagged_units, long long* left_to_fixed_point, long long* marched_units, float* largest_influence)
 {
     if (flagged_units) *flagged_units = g_tie_units;

@@ -624,6 +624,7 @@ int Engine::tie_verdict(int unit, const int32_t* t, const int32_t* inf, bool mem
     h_unit_froze[(size_t)unit] = froze;
     const bool frozen = inf[3] > 0 || (!member && inf[11] > 0) || (member && tie_frozen_bundles && (t[4] > 0 || t[h + 4] > 0));
     if (t[0] > 0 || t[h] > 0) return 2;
+    if (t[6] > 0) return 1;            // (a rank tie at the hand-off that changes what the coarse grid receives: k_handoff's probe)
     return (frozen || (tie_sum_threshold > 0.0f && sum > (double)tie_sum_threshold) || (tie_count_threshold > 0 && cnt > tie_count_threshold)) ? 1 : 0;
 }
 
@@ -748,7 +749,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         } else if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         if (exact_ties != 2) {
-            launch_handoff(g, b, n, stream);
+            launch_handoff(g, b, n, stream, detect ? tieinfo.p : nullptr, tie_threshold);
             launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
         }
         HIP_TRY(this, hipEventRecord(events[4], stream));

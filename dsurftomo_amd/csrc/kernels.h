@@ -16,7 +16,7 @@ constexpr int kRayTime = 1, kRayPath = 2;
 constexpr int kClockSlots = 32;     // probe counters per unit (FimProblem::clocks)
 // The tie record of a unit (FimProblem::tie): kTieWords int32, the refined stage's half first.  A tie's influence enters the sum as
 // min(influence, 1 s) / kTieSumUnit, saturating at 2^32 - 1 (4.3 s of influences: nothing that matters is that large).
-constexpr int kTieWords = 12;
+constexpr int kTieWords = 16;
 constexpr float kTieSumUnit = 0x1p-30f;
 constexpr int kTieSeenBits = 16;   // (= kBundleMax)
 
@@ -43,7 +43,8 @@ struct FimProblem {
     int32_t* info;         // 8 ints: [0] rounds, [1] rescans, [2] -1 = no convergence, [3] stall freezes, [4..5] evaluations (u64)
     int32_t* tie;          // tie detector (kernels launched with FimLaunch::tie), kTieWords / 2 words per stage: [0] ties whose influence exceeds tie_threshold, [1] largest influence (float bits),
                            // [2] ties with any influence at all, [3] the sum of the influences in units of kTieSumUnit (round 6: sub-threshold ties add up along a front),
-                           // [4] cycles the unit's bundle froze (bundle kernel), [5] ties without an influence on their node (bundle kernel's census)
+                           // [4] cycles the unit's bundle froze (bundle kernel), [5] ties without an influence on their node (bundle kernel's census),
+                           // [6] (refined half) rank ties at the hand-off that change a STATUS the coarse grid receives (k_handoff's probe), [7] spare
     float tie_threshold;
 };
 
@@ -184,7 +185,7 @@ constexpr int kSeedC = kCWinMax * kCWinMax + 4 * kCWinMax;    // every node of t
 void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_velv_all, size_t velv_stride,
                    const float* d_rbasis, hipStream_t stream);
 void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);
-void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);
+void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream, int32_t* d_tie = nullptr /* the units' tie records: the hand-off probes its rank ties */, float tie_threshold = 0.0f);
 void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                          size_t field_stride, const float* d_risti_c, hipStream_t stream);
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,

@@ -50,6 +50,10 @@ module dsa_bindings
       integer(c_long_long) :: flagged, left, marched
       real(c_float) :: influence
     end function
+    integer(c_int) function dsa_dropin_tie_census(tied, prone, bymap) bind(C, name='dsa_dropin_tie_census')
+      import :: c_int, c_long_long
+      integer(c_long_long) :: tied, prone, bymap
+    end function
     integer(c_int) function dsa_dropin_dispersion_failure(index, info, vals, table, c) bind(C, name='dsa_dropin_dispersion_failure')
       import :: c_int, c_double, c_float
       integer(c_int), value :: index
@@ -102,16 +106,17 @@ subroutine CalSurfG(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf, &
   call dsa_report_ties('CalSurfG')
 end subroutine
 
-! Not a message of the reference: one line on unit 6 when a call left travel-time fields with exact time ties to the fixed-point solve
-! (DSA_EXACT_TIES=0 in the environment).  With the default (exact_ties = 1) such fields are solved again by the reference's own march and
-! nothing is written.
+! Not messages of the reference: one line on unit 6 when a call left travel-time fields with exact time ties above the threshold to the
+! fixed-point solve (DSA_EXACT_TIES=0 in the environment; with the default such fields are solved again by the reference's own march), and one
+! line when fields with ties BELOW the threshold kept the fixed-point times (the default mode's caveat; DSA_TIE_NOTE=0 silences it).
 subroutine dsa_report_ties(where)
   use dsa_bindings
   implicit none
   character(len=*), intent(in) :: where
-  integer(c_long_long) :: nflag, nleft, nmarch
+  integer(c_long_long) :: nflag, nleft, nmarch, ntied, nprone, nbymap
   real(c_float) :: infl
-  integer :: rc
+  integer :: rc, stat
+  character(len=16) :: note
   rc = dsa_dropin_tie_diagnostics(nflag, nleft, nmarch, infl)
   if (rc /= 0) return
   if (nleft > 0) then
@@ -119,6 +124,15 @@ subroutine dsa_report_ties(where)
       ' (period, source) travel-time fields hold exact time ties (largest influence ', infl, &
       ' s) and were left to the fixed-point solve (DSA_EXACT_TIES=0): they may differ from Fast Marching by more than 1e-4 s'
   endif
+  ! (round 6) the default mode's own caveat: fields whose ties all stay below the threshold keep the fixed-point solve's times -- the reference's
+  ! to 1e-4 s by measurement, not by construction (one-ulp differences can grow along a ridge of the field).  One line, unless DSA_TIE_NOTE=0.
+  rc = dsa_dropin_tie_census(ntied, nprone, nbymap)
+  if (rc /= 0 .or. ntied <= 0) return
+  call get_environment_variable('DSA_TIE_NOTE', note, status=stat)
+  if (stat == 0 .and. trim(note) == '0') return
+  write(6,'(a,a,a,i0,a)') ' dsurftomo_amd (', where, '): ', ntied, &
+    ' (period, source) travel-time fields hold exact time ties of small influence and keep the fixed-point times: within 1e-4 s of' // &
+    ' Fast Marching by measurement, not by construction (DSA_EXACT_TIES=2: the reference''s bits; DSA_TIE_NOTE=0: no note)'
 end subroutine
 
 ! The reference's non-fatal messages, written where and how it writes them.

@@ -355,6 +355,10 @@ int dsa_dropin_diagnostics(int* rbint_notes, long long* disp_count, int* disp_fi
  * than 1e-4 s; the shim writes one line about it to unit 6) and how many were solved again by the reference's march (exact_ties = 1, the default);
  * the largest influence met, in seconds.  Any pointer may be NULL. */
 int dsa_dropin_tie_diagnostics(long long* flagged_units, long long* left_to_fixed_point, long long* marched_units, float* largest_influence);
+/* (round 6) the same call's units that stayed with the fixed point although the census found a tie with a (sub-threshold) influence in them -- within 1e-4 s
+ * of the reference by measurement, not by construction: the shim writes one line about them unless DSA_TIE_NOTE=0 --, the maps found tie-prone (a unit on
+ * them holds a tie above the threshold; summed over the call's launches) and the units marched because of their map (option tie_map_strict). */
+int dsa_dropin_tie_census(long long* tied_units_left, long long* tie_prone_maps, long long* flagged_by_map);
 /* dsa_dispersion_failure of the last dsa_calsurfg call (environment DSA_DISP_FAILURE_LOG = N switches the log on): the shim then writes
  * the reference's unit-66 block once per failing surfdisp96 call, layer table included */
 int dsa_dropin_dispersion_failure(int index, int* info, double* vals, float* table, double* c);
