@@ -749,7 +749,11 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         } else if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         if (exact_ties != 2) {
+#ifdef DSA_NO_HANDOFF_PROBE      // (A/B switch)
+            launch_handoff(g, b, n, stream);
+#else
             launch_handoff(g, b, n, stream, detect ? tieinfo.p : nullptr, tie_threshold);
+#endif
             launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
         }
         HIP_TRY(this, hipEventRecord(events[4], stream));

@@ -129,24 +129,17 @@ void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hip
 
 // ---------------------------------------------------------------------------------------------
 // K2c: hand-off, one workgroup per source
-// (round 6) tie: the units' tie records (kernels.h kTieWords, the refined half) or null.  A node whose acceptance rank TIES with the terminating node's was
-// accepted before it or not as the reference's tree had it -- ref_alive guesses by scan order.  The probe: such nodes are collected, and the hand-off's
-// outputs that reach the coarse grid (every kSgdl-th node of the box: status and time) are evaluated once more with the tied node's answer inverted; a
-// changed time is the tie's influence (counted like the census' ties: any / sum / above the threshold), a changed STATUS on the lattice counts in word [6]
-// and flags the unit by itself (Engine::tie_verdict).
-__global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b, int32_t* tie, float tie_threshold)
+__global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
 {
     __shared__ unsigned long long s_best;
     __shared__ int s_first;
-    constexpr int kTiedMax = 8;
-    __shared__ int s_tied[kTiedMax], s_ntied;
     const int s = blockIdx.x, tid = threadIdx.x;
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
     const int ended = w.flags[0];
     const int n = sd.rnx * sd.rnz;
     const size_t rr = (size_t)kRefMax * kRefMax;
-    if (tid == 0) { s_best = ~0ull; s_first = 0x7fffffff; s_ntied = 0; }
+    if (tid == 0) { s_best = ~0ull; s_first = 0x7fffffff; }
     __syncthreads();
     // first open-edge node in acceptance order; exact ties resolved by scan order (ix outer, iz inner: the smallest id).  Round 5: the
     // lanes walk the box's PERIMETER (2 rnx + 2 rnz positions, the corners twice -- a minimum does not mind) instead of testing all rnx x rnz
@@ -193,40 +186,8 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b, int32_
             const int st = handoff_node(g, sd, w, ended, rstar, ez, ex, iz0 + 1, ix0 + 1, &t);
             w.S_r[id] = (int8_t)st;
             Tfin[id] = t;
-            if (tie && !ended && ex > 0 && id != (ex - 1) * sd.rnz + (ez - 1)) {      // a rank tie with the terminating node: the probe's business
-                const Rec r = w.F_r[rec_index(sd.nbz_r, iz0, ix0)];
-                if (!t_pinned(r.T) && t_value(r.T) < kInf && accept_rank(r.T, r.tau) == rstar) { const int k = atomicAdd(&s_ntied, 1); if (k < kTiedMax) s_tied[k] = id; }
-            }
             iz0 += dr; ix0 += dq;
             if (iz0 >= sd.rnz) { iz0 -= sd.rnz; ix0 += 1; }
-        }
-    }
-    __syncthreads();
-    if (tie && s_ntied > 0) {
-        // the probe (see the head of the kernel): thread z of the first nine looks at the tied node (z = 0) or one of its eight stencil nodes
-        const int nt = s_ntied < kTiedMax ? s_ntied : kTiedMax;
-        int32_t* const tr = tie + (size_t)s * kTieWords;
-        if (s_ntied > kTiedMax && tid == 0) atomicAdd(tr + 6, 1);
-        for (int k = 0; k < nt; ++k) {
-            const int yid = s_tied[k], yx = yid / sd.rnz + 1, yz = yid % sd.rnz + 1;
-            if (tid < 9) {
-                const int dx = tid == 1 ? -1 : tid == 2 ? 1 : tid == 5 ? -2 : tid == 6 ? 2 : 0, dz = tid == 3 ? -1 : tid == 4 ? 1 : tid == 7 ? -2 : tid == 8 ? 2 : 0;
-                const int zx = yx + dx, zz = yz + dz;
-                // (only what reaches the coarse grid counts: the nodes the hand-off injects, below)
-                if (zx >= 1 && zx <= sd.rnx && zz >= 1 && zz <= sd.rnz && (zx - 1) % kSgdl == 0 && (zz - 1) % kSgdl == 0) {
-                    float t1;
-                    const int st1 = handoff_node(g, sd, w, ended, rstar, ez, ex, zz, zx, &t1, yid);
-                    const int zid = (zx - 1) * sd.rnz + (zz - 1);
-                    const int st0 = w.S_r[zid];
-                    const float t0 = Tfin[zid];
-                    if (st1 != st0) atomicAdd(tr + 6, 1);
-                    else if (st0 >= 0 && t1 != t0) {
-                        const float ti = fabsf(t1 - t0);
-                        atomicAdd((unsigned*)tr + 2, 1u); atomicAdd((unsigned*)tr + 3, (unsigned)(fminf(ti, 1.0f) * (1.0f / kTieSumUnit)));
-                        if (ti > tie_threshold) { atomicAdd((unsigned*)tr, 1u); atomicMax((unsigned*)tr + 1, __float_as_uint(ti)); }
-                    }
-                }
-            }
         }
     }
     // coarse window: everything far, then every 8th refined node, then band promotion
@@ -261,10 +222,66 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b, int32_
     }
 }
 
+// (round 6) The hand-off's tie probe, a kernel of its own behind k_handoff (one workgroup per source; it only reads what k_handoff left).  A node of the box
+// whose acceptance rank TIES with the terminating node's was accepted before it or not as the reference's tree had it -- ref_alive guesses by scan order.
+// Such nodes are collected, and the hand-off's outputs that reach the coarse grid (every kSgdl-th node of the box: status and time) are evaluated once more
+// with the tied node's answer inverted: a changed time is the tie's influence (counted into the unit's tie record like the census' ties: any / sum / above
+// the threshold), a changed STATUS on the lattice counts in word [6] of the record's refined half and flags the unit by itself (Engine::tie_verdict).
+__global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, int32_t* tie, float tie_threshold)
+{
+    constexpr int kTiedMax = 8;
+    __shared__ int s_tied[kTiedMax], s_ntied;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const SourceDesc sd = b.src[s];
+    SourceScratch w = scratch_of(b, s);
+    const int ended = w.flags[0], ez = w.flags[2], ex = w.flags[3];
+    if (tid == 0) s_ntied = 0;
+    __syncthreads();
+    if (ended || ex <= 0) return;                    // (uniform: the refined stage ended by itself, or no open edge was reached -- no terminating node, no tie with it)
+    const int n = sd.rnx * sd.rnz, eid = (ex - 1) * sd.rnz + (ez - 1);
+    const Rec er = w.F_r[rec_index(sd.nbz_r, ez - 1, ex - 1)];
+    const uint64_t rstar = accept_rank(er.T, er.tau);
+    {
+        const int dq = 256 / sd.rnz, dr = 256 % sd.rnz;
+        int ix0 = tid / sd.rnz, iz0 = tid % sd.rnz;
+        for (int id = tid; id < n; id += 256) {
+            const Rec r = w.F_r[rec_index(sd.nbz_r, iz0, ix0)];
+            if (id != eid && !t_pinned(r.T) && t_value(r.T) < kInf && accept_rank(r.T, r.tau) == rstar) { const int k = atomicAdd(&s_ntied, 1); if (k < kTiedMax) s_tied[k] = id; }
+            iz0 += dr; ix0 += dq;
+            if (iz0 >= sd.rnz) { iz0 -= sd.rnz; ix0 += 1; }
+        }
+    }
+    __syncthreads();
+    if (s_ntied == 0 || tid >= 9) return;
+    const float* Tfin = b.Tfin_r + (size_t)s * kRefMax * kRefMax;
+    int32_t* const tr = tie + (size_t)s * kTieWords;
+    if (s_ntied > kTiedMax && tid == 0) atomicAdd(tr + 6, 1);
+    const int nt = s_ntied < kTiedMax ? s_ntied : kTiedMax;
+    // thread z of the first nine looks at the tied node (z = 0) or at one of its eight stencil nodes
+    const int dx = tid == 1 ? -1 : tid == 2 ? 1 : tid == 5 ? -2 : tid == 6 ? 2 : 0, dz = tid == 3 ? -1 : tid == 4 ? 1 : tid == 7 ? -2 : tid == 8 ? 2 : 0;
+    for (int k = 0; k < nt; ++k) {
+        const int yid = s_tied[k], zx = yid / sd.rnz + 1 + dx, zz = yid % sd.rnz + 1 + dz;
+        // (only what reaches the coarse grid counts: the nodes k_handoff injects)
+        if (!(zx >= 1 && zx <= sd.rnx && zz >= 1 && zz <= sd.rnz && (zx - 1) % kSgdl == 0 && (zz - 1) % kSgdl == 0)) continue;
+        float t1;
+        const int st1 = handoff_node(g, sd, w, 0, rstar, ez, ex, zz, zx, &t1, yid);
+        const int zid = (zx - 1) * sd.rnz + (zz - 1);
+        const int st0 = w.S_r[zid];
+        const float t0 = Tfin[zid];
+        if (st1 != st0) atomicAdd(tr + 6, 1);
+        else if (st0 >= 0 && t1 != t0) {
+            const float ti = fabsf(t1 - t0);
+            atomicAdd((unsigned*)tr + 2, 1u); atomicAdd((unsigned*)tr + 3, (unsigned)(fminf(ti, 1.0f) * (1.0f / kTieSumUnit)));
+            if (ti > tie_threshold) { atomicAdd((unsigned*)tr, 1u); atomicMax((unsigned*)tr + 1, __float_as_uint(ti)); }
+        }
+    }
+}
+
 void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream, int32_t* d_tie, float tie_threshold)
 {
     if (nsrc <= 0) return;
-    hipLaunchKernelGGL(k_handoff, dim3(nsrc), dim3(256), 0, stream, g, b, d_tie, tie_threshold);
+    hipLaunchKernelGGL(k_handoff, dim3(nsrc), dim3(256), 0, stream, g, b);
+    if (d_tie) hipLaunchKernelGGL(k_handoff_probe, dim3(nsrc), dim3(256), 0, stream, g, b, d_tie, tie_threshold);
 }
 
 // ---------------------------------------------------------------------------------------------
