@@ -55,6 +55,7 @@ template <> struct BMem<2> { typedef BV2 V; typedef __attribute__((address_space
 // 2^28: Engine::choose_bundle_size / fits), pass B fetches those, and a member whose own upwind side is not among them (fronts that
 // collide right there) goes through the slow queue, which reads everything.  A direction whose two near times are both unreached, or
 // closer than a quarter of the causal window (the members' fronts may order them differently), keeps both sides.
+constexpr unsigned kCandAlways = 0x80000000u;      // (round 6) a listed tie candidate (node << 4 | member) that goes to the census' second look whatever the field's values say (record indices stay below 2^27: Engine::choose_bundle_size / fits)
 constexpr int kFarShift = 28;
 __device__ __forceinline__ unsigned far_sides(float lo, float hi, float margin)
 {
@@ -343,23 +344,12 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         float k = kInf;
         const float slown = *(BGCF32*)(slowb + (unsigned)id * npb + (unsigned)s_map[mo] * 4u);
         const NodeGeom geom = { p.ri, risti[ix], p.dnx, p.dnz };
-        const float c = solve_node_t<false>(h, slown, geom, &k, nullptr);
-        // (TIE) a candidate of the census: the value equals a near neighbour's acceptance time -- every walk that stops at an exact tie does
-        // (the list may hold more than the ties: the converged field decides)
-        bool tied = false;
-        if (TIE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tied = tied || (h.in[q] && c < kInf && c == h.near_tau[q]);
-            // (round 6) ... or an exceptional outer node was accepted at the very clock of one of the near neighbours: the second kind of tie
-            // (eikonal_core.h: solve_node_t<true>, the outer probe) -- a superset, the census' second look decides
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float ko = h.outer_tau[q];
-                if (!(h.in_outer[q] && ko < kInf && ko != t_value(h.outer[q]))) continue;
-#pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) tied = tied || (h.in[q2] && ko == h.near_tau[q2]);
-            }
-        }
+        // (TIE) a candidate of the census: the detector's walk says so -- it stopped at an exact tie, an exceptional outer node was accepted at the clock of
+        // the neighbour taken in last, or the node took a neighbour in that its raised key may not have waited for (eikonal_core.h: solve_node_t<true>; same
+        // value and acceptance time as the plain walk).  The list may hold more than the converged field's ties: the census' second look decides.
+        float ti = -1.0f;
+        const float c = TIE ? solve_node_t<true>(h, slown, geom, &k, &ti) : solve_node_t<false>(h, slown, geom, &k, nullptr);
+        const bool tied = TIE && ti >= 0.0f;
         ++evals;
         if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return tied;
         float newv = c;
@@ -797,7 +787,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                 const int e = base + lane < qn ? wq[base + lane] : -1;
                 bool tied = false;
                 if (e >= 0) tied = slow_member(e >> 4, e & 15, half, stale, evals, nchanged, hv_lane, kmin_lane, smin_lane);
-                if (TIE && cand_g) cand_push(tied, e);
+                if (TIE && cand_g) cand_push(tied, (int)((unsigned)e | kCandAlways));      // (the detector's walk found it: not a matter of equal values, the second look decides)
             }
             qn = 0;
             if (TIE) cand_flush();
@@ -890,11 +880,13 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             // second look; a wave takes 64 candidates at a time
             for (int i0 = wave * 64; i0 < ncand; i0 += NW * 64) {
                 const int i = i0 + lane;
-                const int e = i < ncand ? cand_g[1 + i] : -1;
+                const unsigned eraw = i < ncand ? (unsigned)cand_g[1 + i] : ~0u;
+                const int e = eraw == ~0u ? -1 : (int)(eraw & ~kCandAlways);
                 unsigned still = 0u;               // bit q: near neighbour q carries the member's value
                 int nid[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
                 if (e >= 0) {
                     const int id = e >> 4, mo = e & 15;
+                    if (eraw & kCandAlways) still |= 16u;
                     int iz, ix;
                     coords(id, &iz, &ix);
                     rec_stencil(nbz, id, nid);

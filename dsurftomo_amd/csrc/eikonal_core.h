@@ -417,7 +417,14 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
     // walk here counts it as not alive (ko < tnow).  The probe evaluates the stopped walk's last trip once more with such outer nodes alive.
     bool oprobe = false, odone = false;
     float c_keep = 0.0f, tnow_keep = 0.0f;
-    if (TIE) *tie_out = -1.0f;
+    // (round 6) TIE, the third kind: a RAISED KEY.  The reference's updtree moves an entry towards the root only (CalSurfG.f90:899-920): when an update makes a
+    // trial value LARGER (second-order stencils switching on) the entry stays where its smaller key put it, the tree is no heap there any more, and the node
+    // may be accepted before its key's turn -- before a neighbour whose acceptance time lies between the smallest key the node ever had (cmin) and its
+    // current one.  The walk here takes that neighbour in (it orders by acceptance times); whether the reference did is its tree's layout again.  The first
+    // such neighbour is noted with the value the node would have been accepted with (c_amb); the influence is what the rest of the walk changes.
+    float cmin = kInf, c_amb = 0.0f;
+    bool amb = false;
+    if (TIE) { *tie_out = -1.0f; cmin = c; }
     for (;;) {
         if (!first) {
             const float nk = key[0];
@@ -434,6 +441,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
                 }
             }
             if (take) {
+                if (TIE && !amb && !probing && cmin < nk) { amb = true; c_amb = c; }
                 alive |= 1u << idx[0];
                 tnow = nk;
                 key[0] = key[1]; key[1] = key[2]; key[2] = key[3]; key[3] = kInf;
@@ -499,7 +507,9 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
         c = best;
         if (TIE && oprobe) { *tie_out = fabsf(c - c_keep); c = c_keep; oprobe = false; continue; }      // (back to the top: the walk stops again, now for good or on a tie of the first kind)
         if (TIE && probing) { const float ti = fabsf(c - c_keep); *tie_out = ti > *tie_out ? ti : *tie_out; c = c_keep; tnow = tnow_keep; break; }
+        if (TIE) cmin = c < cmin ? c : cmin;
     }
+    if (TIE && amb) { const float ti = fabsf(c - c_amb); *tie_out = ti > *tie_out ? ti : *tie_out; }
     DSA_LEDGER_COUNT(15, "solve_epilogue");
     *tau_out = (c > tnow) ? c : tnow;
     return c;

@@ -945,7 +945,7 @@ int Engine::choose_bundle_size(int step, long* solo_units)
     auto slot_bytes = [&](int G) { int lg = G == 16 ? 4 : G == 8 ? 3 : 2; return (size_t)(G * DSA_BSTRIDE + 1) * nrec_c * 4 + ((size_t)8 << (exc_log2cap + lg)) + lists_c_stride * 4; };
     auto fits = [&](int G) {
         if ((unsigned long long)nrec_c * (unsigned long long)G * 4ull * DSA_BSTRIDE >= (1ull << 32)) return false;          // 32-bit byte offsets inside a bundle field
-        if (nrec_c >= ((size_t)1 << 28)) return false;                                                          // (record indices share the ready-list word with the far-load code)
+        if (nrec_c >= ((size_t)1 << 27)) return false;                                                          // (record indices share the ready-list word with the far-load code, and -- shifted by four -- the tie candidates' word with a flag bit)
         if ((unsigned long long)nrec_c * (unsigned long long)G >= (1ull << 30)) return false;                // exception keys
         if ((unsigned long long)nrec_c * (unsigned long long)nmaps * 4ull >= (1ull << 32)) return false;      // ... and inside the member-minor slowness
         const long nb = std::min<long>(bundles_with(G), (long)step);

@@ -55,6 +55,10 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *     exact_ties               [1]     0 fixed point only | 1 fixed point + tie census + the reference's march for the flagged units | 2 the march for every unit
  *     tie_threshold            [2e-5]  seconds: the influence on its node's value a tie must have to flag its unit; 0 = any tie
  *     tie_detect               [1]     exact_ties = 0 runs the census too and reports what it would have flagged (DSA_STAT_TIE_UNITS, dsa_unit_ties); 0 = off
+ *     tie_map_strict           [1]     on a map where some unit holds a tie above tie_threshold, every unit holding a tie with any influence is flagged; 0 = the per-unit rule alone
+ *     tie_sum_threshold        [0]     seconds: a unit whose ties' influences add up to more than this is flagged; 0 = off (measured: separates nothing, see dsa_unit_tie_sums)
+ *     tie_count_threshold      [0]     a unit holding more ties with an influence than this is flagged; 0 = off
+ *     tie_frozen_bundles       [0]     1 = every member of a bundle that froze a cycle is flagged (a unit-by-unit solve that froze one always is)
  *     exact_lds_slots          [0]     tree slots kept in LDS per marching unit, 63 .. 4975 (made odd); 0 = what lets every wavefront of a batch be resident
  *     exact_heap_blocked       [1]     the march's tree beyond its LDS part stored in blocks of three levels: 0 never | 1 batches that fill the chip (>= 12 wavefronts per CU) | 2 whenever the LDS part is whole levels
  *     exact_pool               [0]     units marching at a time, up to 65535; 0 = by free memory, at most exact_pool_max
@@ -245,12 +249,21 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
 /* Exact time ties (DESIGN.md "Ties").  The fixed-point solve lands on the reference's Fast-Marching travel times except downstream of bit-equal
  * times of two neighbouring narrow-band nodes, where the reference's own answer depends on the layout of its binary tree (CalSurfG.f90:417-485,
  * :768-921).  Option "exact_ties":
- *   1 (default)  fixed point, then a census of the converged fields: a node holds a tie when a near neighbour carries its value bit for bit; the tie's
- *                influence is what taking the tied neighbour into the node's stencil would change; a unit with an influence above "tie_threshold" is
- *                solved again by the reference's march itself, replayed on the device four units per wavefront -- its field, refined snapshot and
- *                receiver times are then the reference's bit for bit.  A heuristic, not a bound: sub-threshold ties can add up along a front.
+ *   1 (default)  fixed point, then a census of the converged fields.  A node holds a tie when a near neighbour's ACCEPTANCE time equals its value bit for
+ *                bit (for all but ~0.02 % of the nodes that is the neighbour's value), or -- round 6 -- when an exceptional outer node was accepted at
+ *                the very clock of the neighbour taken in last, or when a node of the refined box ranks equal with the node that ended the refined
+ *                stage (the hand-off's probe); the tie's influence is what deciding it the other way changes at the node.  Flagged and solved again by
+ *                the reference's march itself (four units per wavefront; field, refined snapshot and receiver times then the reference's bit for bit):
+ *                  - a unit holding a tie whose influence exceeds "tie_threshold";
+ *                  - "tie_map_strict" (on): on a map where some unit holds such a tie -- a tie-prone medium: sharp contrasts, second-order stencils
+ *                    switching along ridges, where a one-ulp difference grows downstream -- every unit holding a tie with ANY influence.
+ *                What stays with the fixed point: units without a tie (measured: bit-identical to the reference, 0 of ~10 000 such units differ), and --
+ *                on maps where no tie reaches the threshold -- units holding ties of an ulp or two: within 1e-4 s of the reference BY MEASUREMENT
+ *                (worst of 80 000 units x 32 receivers on the headline medium: 8.8e-5 s), not by construction (DSA_STAT_TIE_UNITS_TIED counts them, the
+ *                shim says so once per call).  No rule on a unit's own ties -- largest, summed, counted influence -- separates the rare unit that ends
+ *                beyond 1e-4 s from the thousands that do not (profiles/r06_tie_rule_scan_*.log).
  *                Cost: a few per cent where nothing is flagged; a flagged unit costs one march (sequential accepts, ~2.3 us each: 35 ms at 121^2,
- *                2.4 s at 1025^2, a minute at 4097^2 -- the same for one unit or thousands side by side);
+ *                2.4 s at 1025^2, a minute at 4097^2 -- the same for one unit or thousands side by side): a tie-prone medium runs at the march's rate;
  *   2            every unit by the march (the guarantee; ~2 000 solves/s at 1025^2 with 16 000 units in flight, ~50 at 4097^2);
  *   0            the fixed point alone; the census still runs ("tie_detect") and DSA_STAT_TIE_UNITS / DSA_STAT_TIE_UNITS_LEFT / dsa_unit_ties say
  *                which units a default call would have marched.
