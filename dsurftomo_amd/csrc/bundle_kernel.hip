@@ -221,10 +221,10 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             sc[BC_SLOWN] = 0; sc[BC_FARALL] = bd->far_all ? 1 : 0;
             if (TIE && bd->cand) *(bd->cand + (size_t)my_slot * bd->cand_stride) = 0;
         }
-        if (TIE && bd->cand) {          // the census' "looked at" bits, kTieSeenBits per node record (behind the candidate list)
+        if (TIE && bd->cand) {          // the census' "looked at" set: a hash table of kTieSeenSlots (node, member) keys behind the candidate list
             BGV4* const seen4 = (BGV4*)(bd->cand + (size_t)my_slot * bd->cand_stride + ((bd->cand_cap + 4) & ~3));
             const BV4 zero4 = { 0.0f, 0.0f, 0.0f, 0.0f };
-            for (int i = tid; i < ntile * (kTileRecs * kTieSeenBits / 128); i += NT) seen4[i] = zero4;
+            for (int i = tid; i < kTieSeenSlots / 4; i += NT) seen4[i] = zero4;
         }
         __threadfence_block();
         __syncthreads();
@@ -347,9 +347,24 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         // (TIE) a candidate of the census: the detector's walk says so -- it stopped at an exact tie, an exceptional outer node was accepted at the clock of
         // the neighbour taken in last, or the node took a neighbour in that its raised key may not have waited for (eikonal_core.h: solve_node_t<true>; same
         // value and acceptance time as the plain walk).  The list may hold more than the converged field's ties: the census' second look decides.
-        float ti = -1.0f;
-        const float c = TIE ? solve_node_t<true>(h, slown, geom, &k, &ti) : solve_node_t<false>(h, slown, geom, &k, nullptr);
-        const bool tied = TIE && ti >= 0.0f;
+        // (TIE) a candidate of the census -- the list may hold more than the converged field's ties, the second look decides: the value equals a near
+        // neighbour's acceptance time (every walk that stops at an exact tie does); an exceptional outer node was accepted at the very clock of a near
+        // neighbour (the detector's outer probe); the walk took a neighbour in that a raised key may not have waited for (solve_node_t<false, true>
+        // notes it).  [The detector's own walk here, solve_node_t<true>, said the same and cost 7.6 ms of the headline's 348.]
+        float amb = -1.0f;
+        const float c = TIE ? solve_node_t<false, true>(h, slown, geom, &k, &amb) : solve_node_t<false>(h, slown, geom, &k, nullptr);
+        bool tied = TIE && amb >= 0.0f;
+        if (TIE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tied = tied || (h.in[q] && c < kInf && c == h.near_tau[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ko = h.outer_tau[q];
+                if (!(h.in_outer[q] && ko < kInf && ko != t_value(h.outer[q]))) continue;
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) tied = tied || (h.in[q2] && ko == h.near_tau[q2]);
+            }
+        }
         ++evals;
         if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return tied;
         float newv = c;
@@ -380,9 +395,18 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         int iz, ix;
         coords(id, &iz, &ix);
         if (ix >= nnx || iz >= nnz) return;
-        if (seen_g) {       // every (node, member) pair once: the list names a node as often as its evaluations ended on a tie, the sweep once per tied side
-            const unsigned bit = (unsigned)id * (unsigned)kTieSeenBits + (unsigned)mo;
-            if (atomicOr(&seen_g[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))) return;
+        if (seen_g) {
+            // every (node, member) pair once -- the list names a node as often as its evaluations ended on a tie, the sweep once per tied side --: its key
+            // goes into a small open-addressing table (a bitmap over the field cost 2.1 MB of clearing per bundle, 2.7 ms of the headline step).  A key
+            // that finds no room within eight probes (a medium with tens of thousands of ties per bundle) is looked at again: the largest influence
+            // does not mind, the count and the sum then count that pair more than once.
+            const unsigned key = (unsigned)id * 16u + (unsigned)mo + 1u;
+            unsigned hs = (key * 2654435761u) >> (32 - kTieSeenLog2);
+            for (int n = 0; n < 8; ++n, hs = (hs + 1u) & (unsigned)(kTieSeenSlots - 1)) {
+                const unsigned old = atomicCAS(&seen_g[hs], 0u, key);
+                if (old == key) return;
+                if (old == 0u) break;
+            }
         }
         Hood h;
         float t_old, k_old;
@@ -1018,7 +1042,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         const FimProblem* const pm = problems + s_member[m];
         if (tid == 0) {
             pm->info[0] = rounds; pm->info[1] = 0; pm->info[3] = m == 0 ? freezes : 0;      // (the statistic, counted once per bundle)
-            if (TIE && pm->tie) pm->tie[4] = freezes;                                      // (every member knows its bundle froze a cycle: a frozen 2-cycle sits an ulp or two from a tie state)
+            if (TIE && pm->tie) { pm->tie[4] = freezes; pm->tie[7] = cand_g ? __hip_atomic_load(cand_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1; }      // ([7]: candidates the bundle listed -- above cand_cap: the census swept the field)                                      // (every member knows its bundle froze a cycle: a frozen 2-cycle sits an ulp or two from a tie state)
             if (failed && pm->info[2] != -2) pm->info[2] = -1;
             if (sc[BC_OVERFLOW]) pm->info[2] = -2;
         }

@@ -348,9 +348,12 @@ struct Hood {
 #define DSA_LEDGER_PASS
 #define DSA_LEDGER_COUNT(k, name) do { } while (0)
 #endif
-template <bool TIE>
+// AMBONLY (with TIE = false; round 6): the plain walk that only NOTES a raised-key ambiguity (below) -- *tie_out = 0 when it met one, -1 otherwise --
+// without the detector's probes: what the bundle kernel's slow pass marks its census candidates by (the full detector there cost 2.3 % of the kernel).
+template <bool TIE, bool AMBONLY = false>
 DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* tau_out, float* tie_out DSA_LEDGER_PARAM)
 {
+    constexpr bool KEYS = TIE || AMBONLY;          // (the running minimum of the node's keys is kept)
     DSA_LEDGER_COUNT(10, "solve_prologue");
     float tn[4], t2[4], ko[4], key[4];
     int idx[4] = { 0, 1, 2, 3 };
@@ -424,7 +427,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
     // such neighbour is noted with the value the node would have been accepted with (c_amb); the influence is what the rest of the walk changes.
     float cmin = kInf, c_amb = 0.0f;
     bool amb = false;
-    if (TIE) { *tie_out = -1.0f; cmin = c; }
+    if (KEYS) { *tie_out = -1.0f; cmin = c; }
     for (;;) {
         if (!first) {
             const float nk = key[0];
@@ -441,7 +444,7 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
                 }
             }
             if (take) {
-                if (TIE && !amb && !probing && cmin < nk) { amb = true; c_amb = c; }
+                if (KEYS && !amb && !probing && cmin < nk) { amb = true; c_amb = c; }
                 alive |= 1u << idx[0];
                 tnow = nk;
                 key[0] = key[1]; key[1] = key[2]; key[2] = key[3]; key[3] = kInf;
@@ -507,9 +510,10 @@ DSA_HD float solve_node_t(const Hood& h, float slown, const NodeGeom& g, float* 
         c = best;
         if (TIE && oprobe) { *tie_out = fabsf(c - c_keep); c = c_keep; oprobe = false; continue; }      // (back to the top: the walk stops again, now for good or on a tie of the first kind)
         if (TIE && probing) { const float ti = fabsf(c - c_keep); *tie_out = ti > *tie_out ? ti : *tie_out; c = c_keep; tnow = tnow_keep; break; }
-        if (TIE) cmin = c < cmin ? c : cmin;
+        if (KEYS) cmin = c < cmin ? c : cmin;
     }
     if (TIE && amb) { const float ti = fabsf(c - c_amb); *tie_out = ti > *tie_out ? ti : *tie_out; }
+    if (AMBONLY && amb) *tie_out = 0.0f;
     DSA_LEDGER_COUNT(15, "solve_epilogue");
     *tau_out = (c > tnow) ? c : tnow;
     return c;

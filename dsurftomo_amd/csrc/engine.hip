@@ -452,7 +452,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(tieinfo, C * kTieWords) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
     h_unit_flags.assign((size_t)nunits, 0);
     h_unit_tie.assign((size_t)nunits, 0.0f);
-    h_unit_tie_sum.assign((size_t)nunits, 0.0f); h_unit_tie_count.assign((size_t)nunits, 0); h_unit_froze.assign((size_t)nunits, 0);
+    h_unit_tie_sum.assign((size_t)nunits, 0.0f); h_unit_tie_count.assign((size_t)nunits, 0); h_unit_froze.assign((size_t)nunits, 0); h_unit_cand.assign((size_t)nunits, 0);
     h_unit_rounds.assign((size_t)nunits, 0);
     HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
@@ -602,7 +602,8 @@ std::vector<char> Engine::tie_verdicts(int first, int n, const int32_t* tie_word
     if (tie_map_strict)
         for (int u = 0; u < n; ++u) {
             const int p = h_src[(size_t)(first + u)].period;
-            if (!fl[(size_t)u] && p >= 0 && p < nmaps && prone[(size_t)p] && h_unit_tie_count[(size_t)(first + u)] > 0) { fl[(size_t)u] = 1; stats[DSA_STAT_TIE_UNITS_STRICT] += 1.0; }
+            // (a member of a bundle that froze a cycle counts here too: a frozen 2-cycle sits an ulp from a tie state the census of the frozen field cannot see)
+            if (!fl[(size_t)u] && p >= 0 && p < nmaps && prone[(size_t)p] && (h_unit_tie_count[(size_t)(first + u)] > 0 || h_unit_froze[(size_t)(first + u)] > 0)) { fl[(size_t)u] = 1; stats[DSA_STAT_TIE_UNITS_STRICT] += 1.0; }
         }
     for (char c : prone) stats[DSA_STAT_TIE_PRONE_MAPS] += c ? 1.0 : 0.0;
     for (int u = 0; u < n; ++u) if (!fl[(size_t)u] && h_unit_tie_count[(size_t)(first + u)] > 0) stats[DSA_STAT_TIE_UNITS_TIED] += 1.0;
@@ -622,9 +623,10 @@ int Engine::tie_verdict(int unit, const int32_t* t, const int32_t* inf, bool mem
     h_unit_tie_count[(size_t)unit] = (int)std::min<long>(cnt, 0x7fffffff);
     const int froze = inf[3] + inf[11] + (member ? t[4] + t[h + 4] : 0);
     h_unit_froze[(size_t)unit] = froze;
+    h_unit_cand[(size_t)unit] = t[h + 7];
     const bool frozen = inf[3] > 0 || (!member && inf[11] > 0) || (member && tie_frozen_bundles && (t[4] > 0 || t[h + 4] > 0));
     if (t[0] > 0 || t[h] > 0) return 2;
-    if (t[6] > 0) return 1;            // (a rank tie at the hand-off that changes what the coarse grid receives: k_handoff's probe)
+    if (t[6] > 0 || t[h + 6] > 0) return 1;            // (a rank tie at the hand-off that changes what the coarse grid receives: k_handoff_probe; a band march that left its tree no heap: k_coarse_march)
     return (frozen || (tie_sum_threshold > 0.0f && sum > (double)tie_sum_threshold) || (tie_count_threshold > 0 && cnt > tie_count_threshold)) ? 1 : 0;
 }
 
@@ -754,7 +756,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
 #else
             launch_handoff(g, b, n, stream, detect ? tieinfo.p : nullptr, tie_threshold);
 #endif
-            launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream);
+            launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream, detect ? tieinfo.p : nullptr);
         }
         HIP_TRY(this, hipEventRecord(events[4], stream));
         if (exact_ties != 2) {
@@ -1123,7 +1125,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
     bundle_slots = gr[0].slots;
     // tie candidates per bundle slot (the census' list, bundle_kernel.hip): an eighth of the field's nodes, at least 65 535 entries
     const bool want_cand = exact_ties == 1 || (exact_ties == 0 && tie_detect);
-    const size_t cand_cap = std::max<size_t>(65535, nrec_c / 8), cand_stride = ((cand_cap + 4) & ~(size_t)3) + nrec_c * kTieSeenBits / 32;
+    const size_t cand_cap = std::max<size_t>(65535, nrec_c / 8), cand_stride = ((cand_cap + 4) & ~(size_t)3) + kTieSeenSlots;
     if (want_cand && ensure(cand_b, slots_total * cand_stride)) return status;
     if (ensure(B_pool, b_total) || ensure(exc_b, exc_total) || ensure(lists_b, slots_total * lists_c_stride) || ensure(bpool_gen, slots_total) ||
         ensure(bundles_d, (size_t)nb) || ensure(member_flag, (size_t)n) || ensure(slowI, (size_t)nmaps * nrec_c)) return status;
@@ -1158,7 +1160,7 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         const size_t nrec_r = kRefRecs;
         const int xlog_r0 = exc_log2cap_of(kRefMax, kRefMax);
         const size_t lists_r_stride = ((size_t)kFimMaskInts * kRefTiles * kRefTiles + 2 + 1) & ~(size_t)1;
-        const size_t cand_cap_r = 65535, cand_stride_r = ((cand_cap_r + 4) & ~(size_t)3) + nrec_r * kTieSeenBits / 32;
+        const size_t cand_cap_r = 65535, cand_stride_r = ((cand_cap_r + 4) & ~(size_t)3) + kTieSeenSlots;
         size_t b_tot = 0, x_tot = 0, s_tot = 0;
         std::vector<size_t> b_off((size_t)nb), x_off((size_t)nb), s_off((size_t)nb);
         for (int k = 0; k < nb; ++k) {
@@ -1824,6 +1826,7 @@ int dsa_unit_tie_sums(const dsa_engine* e, int nunits, int* count, float* sum, i
         if (count) count[u] = en->h_unit_tie_count[(size_t)u];
         if (sum) sum[u] = en->h_unit_tie_sum[(size_t)u];
         if (frozen) frozen[u] = en->h_unit_froze[(size_t)u];
+        if (getenv("DSA_DEBUG_CAND") && count) count[u] = en->h_unit_cand[(size_t)u];      // (probe: the bundle's candidate count in place of the tie count)
     }
     return 0;
 }

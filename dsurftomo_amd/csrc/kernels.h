@@ -18,7 +18,7 @@ constexpr int kClockSlots = 32;     // probe counters per unit (FimProblem::cloc
 // min(influence, 1 s) / kTieSumUnit, saturating at 2^32 - 1 (4.3 s of influences: nothing that matters is that large).
 constexpr int kTieWords = 16;
 constexpr float kTieSumUnit = 0x1p-30f;
-constexpr int kTieSeenBits = 16;   // (= kBundleMax)
+constexpr int kTieSeenLog2 = 14, kTieSeenSlots = 1 << kTieSeenLog2;   // the census' set of (node, member) pairs it has looked at: an open-addressing table per bundle slot, behind the candidate list
 
 // One fixed-point problem: a travel-time field on an (nnz, nnx) grid stored as tiled (T, tau)
 // records (eikonal_core.h).  The records carry the boundary condition: pinned nodes (sign bit of T)
@@ -44,7 +44,7 @@ struct FimProblem {
     int32_t* tie;          // tie detector (kernels launched with FimLaunch::tie), kTieWords / 2 words per stage: [0] ties whose influence exceeds tie_threshold, [1] largest influence (float bits),
                            // [2] ties with any influence at all, [3] the sum of the influences in units of kTieSumUnit (round 6: sub-threshold ties add up along a front),
                            // [4] cycles the unit's bundle froze (bundle kernel), [5] ties without an influence on their node (bundle kernel's census),
-                           // [6] (refined half) rank ties at the hand-off that change a STATUS the coarse grid receives (k_handoff's probe), [7] spare
+                           // [6] refined half: rank ties at the hand-off that change a STATUS the coarse grid receives (k_handoff_probe); coarse half: the band march left its tree no heap (k_coarse_march), [7] tie candidates the unit's bundle listed (bundle kernel; a statistic)
     float tie_threshold;
 };
 
@@ -130,7 +130,7 @@ struct FimBundle {
     int np;
     int* cand;                    // slot 0: tie candidates of the bundle (TIE kernels): [0] their number, then (node << 4 | member) words; null: none kept (the census sweeps the field)
     size_t cand_stride;           //         ints per slot
-    int cand_cap;                 //         entries per slot; behind them kTieSeenBits bits per node record: the (node, member) pairs the census has looked at (each once)
+    int cand_cap;                 //         entries per slot; behind them kTieSeenSlots words: the (node, member) pairs the census has looked at (each once)
     int cand_list;                // 1: the round loop lists candidates; 0: the census sweeps the converged field (option tie_list = 0, A/B)
     int far_all;                  // 1: pass A asks for all four outer neighbours of every node (option bundle_far_all; A/B of round 5's upwind-only loads)
     int nmem;
@@ -187,7 +187,7 @@ void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float*
 void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);
 void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream, int32_t* d_tie = nullptr /* the units' tie records: the hand-off probes its rank ties */, float tie_threshold = 0.0f);
 void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
-                         size_t field_stride, const float* d_risti_c, hipStream_t stream);
+                         size_t field_stride, const float* d_risti_c, hipStream_t stream, int32_t* d_tie = nullptr /* the units' tie records: a band march that leaves its tree no heap says so */);
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                           size_t field_stride, const float* d_risti_c, float window_r, float window_c,
                           FimProblem* d_prob_r, FimProblem* d_prob_c, int32_t* d_info, unsigned long long* d_clocks,

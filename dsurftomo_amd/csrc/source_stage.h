@@ -304,6 +304,42 @@ DSA_HD void band_march_run(MarchView& m, const SourceDesc& s, SourceScratch& w, 
     }
     if (m.error) w.flags[1] = 16 + m.error;
 }
+// (round 6) The fixed point takes over from the band march on the assumption that from here on the reference accepts in the order of the keys -- true
+// while its tree is a heap.  It need not be one when the last injected node has gone: an update that RAISED a key during the band march (updtree only
+// moves an entry towards the root, CalSurfG.f90:899-920) leaves that entry above smaller ones, and the nodes beneath it are accepted late -- a node
+// with time 0.2933 s after its neighbour with 0.2952 s in the case that showed it (profiles/r06_tie_diagnose_band_tree.log: 3.9e-4 s at the next
+// node, no tie anywhere).  So the serial march goes on, accept by accept, until the tree is a heap again (at most kBandExtra accepts, and only
+// while the root's neighbours lie inside the march's window); a tree that is still no heap then is reported (the unit is flagged for the march).
+constexpr int kBandExtra = 96;
+// slots s0, s0 + stride, ... of the tree: no entry smaller than its parent?
+DSA_HD bool mv_heap_valid(MarchView& m, int s0, int stride)
+{
+    bool ok = true;
+    for (int sl = s0; sl <= m.ntr; sl += stride) ok = ok && !(mv_key(m, sl) < mv_key(m, sl >> 1));      // (s0 >= 2)
+    return ok;
+}
+// the root's four neighbours (those inside the grid) lie inside the march's window: an accept of the root cannot run into the window's edge
+DSA_HD bool mv_root_inside(const MarchView& m)
+{
+    const int ix = hp_ix(m.heap[1]), iz = hp_iz(m.heap[1]);
+    bool ok = true;
+    if (ix - 1 >= 1) ok = ok && mv_inwin(m, iz, ix - 1);
+    if (ix + 1 <= m.nnx) ok = ok && mv_inwin(m, iz, ix + 1);
+    if (iz - 1 >= 1) ok = ok && mv_inwin(m, iz - 1, ix);
+    if (iz + 1 <= m.nnz) ok = ok && mv_inwin(m, iz + 1, ix);
+    return ok;
+}
+// the serial form (host tools / CPU checks; the device kernel checks the tree with a whole wavefront): returns 1 when the tree is left no heap
+DSA_HD int band_march_settle(MarchView& m)
+{
+    for (int extra = 0; m.ntr > 1 && m.error == 0; ++extra) {
+        if (mv_heap_valid(m, 2, 1)) return 0;
+        if (extra >= kBandExtra || !mv_root_inside(m)) return 1;
+        if (!mv_accept_root(m)) return 1;
+    }
+    return 0;
+}
+
 // window node q after the march: alive -> pinned (tau: accept number of the march, 0 for the hand-off's alive nodes), else unreached
 DSA_HD void band_march_finish_node(const SourceScratch& w, Rec* W, int q)
 {
@@ -326,6 +362,7 @@ DSA_HD void coarse_band_march(const GridDesc& g, const SourceDesc& s, SourceScra
             if (w.cst[q] > 0) { w.cinit[q] = 1; ++ninit; mv_add(m, s.cwz0 + lz + 1, s.cwx0 + lx + 1); }
         }
     band_march_run(m, s, w, ninit);
+    (void)band_march_settle(m);
     for (int q = 0; q < s.cwnx * s.cwnz; ++q) band_march_finish_node(w, W, q);
 }
 

@@ -290,7 +290,7 @@ void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t
 // (a few dozen accept steps) on lane 0.  [Round 1 ran everything on one lane per source: four serial sweeps of the window in
 // global memory, 5.8 ms for the 449 sources of the Taipei example and 10 ms for any number up to 16 000.]
 __global__ __launch_bounds__(64) void k_coarse_march(GridDesc g, BatchPtrs b, int nsrc, const float* __restrict__ slow_all,
-                                                     size_t field_stride, const float* __restrict__ risti_c)
+                                                     size_t field_stride, const float* __restrict__ risti_c, int32_t* tie)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= nsrc) return;
@@ -325,6 +325,27 @@ __global__ __launch_bounds__(64) void k_coarse_march(GridDesc g, BatchPtrs b, in
     __threadfence_block();
     if (lane == 0) band_march_run(m, sd, w, ninit);
     __threadfence_block();
+    // (round 6, source_stage.h: band_march_settle) on with the serial march until the tree is a heap: the wavefront checks the tree, lane 0 accepts
+    {
+        int left = 0;
+        for (int extra = 0;; ++extra) {
+            m.ntr = __shfl(m.ntr, 0); m.error = __shfl(m.error, 0);
+            if (m.ntr <= 1 || m.error) break;
+            const bool valid = __all(mv_heap_valid(m, 2 + lane, 64));
+            if (valid) break;
+            int go = 0;
+            if (lane == 0) go = (extra < kBandExtra && mv_root_inside(m)) ? 1 : 0;
+            go = __shfl(go, 0);
+            if (!go) { left = 1; break; }
+            if (lane == 0 && !mv_accept_root(m)) m.error = m.error ? m.error : 1;
+            __threadfence_block();
+        }
+        if (lane == 0) {
+            if (m.error && !w.flags[1]) w.flags[1] = 16 + m.error;
+            if (left && tie) atomicAdd(tie + (size_t)s * kTieWords + kTieWords / 2 + 6, 1);
+        }
+    }
+    __threadfence_block();
     // pinning: the window's alive nodes get their sign bit; the coarse solve carries them into its field slot and exception table (FimEnds)
     for (int q = lane; q < nw; q += 64) band_march_finish_node(w, W, q);
     // seeds of the fixed-point solve: every node of the grid that is not itself pinned and has a pinned neighbour; they lie in the
@@ -355,10 +376,10 @@ __global__ __launch_bounds__(64) void k_coarse_march(GridDesc g, BatchPtrs b, in
 }
 
 void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
-                         size_t field_stride, const float* d_risti_c, hipStream_t stream)
+                         size_t field_stride, const float* d_risti_c, hipStream_t stream, int32_t* d_tie)
 {
     if (nsrc <= 0) return;
-    hipLaunchKernelGGL(k_coarse_march, dim3(nsrc), dim3(64), 0, stream, g, b, nsrc, d_slow_all, field_stride, d_risti_c);
+    hipLaunchKernelGGL(k_coarse_march, dim3(nsrc), dim3(64), 0, stream, g, b, nsrc, d_slow_all, field_stride, d_risti_c, d_tie);
 }
 
 // ---------------------------------------------------------------------------------------------

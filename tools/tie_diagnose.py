@@ -56,6 +56,8 @@ def sub_units(s):
 
 
 e.set_option("bundle", 0 if solo else 16 if nper >= 16 else 8 if nper >= 8 else 4)
+for kv in [o for o in os.environ.get("DSA_DIAG_OPTS", "").split(",") if o]:      # (more engine options for stage 2, e.g. bundle_refined=2: the refined boxes of the lone bundle in a bundle too)
+    e.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 for k in look:
     s, p = k % nsrc, k // nsrc
     su = sub_units(s)
@@ -100,14 +102,17 @@ for k in look:
     x, z = int(ix[0]), int(iz[0])
     for name, F in (("march", FX), ("fixed point", F0)):
         print(f"  neighbourhood of ({x},{z}) in the {name} field (rows ix-2..ix+2, columns iz-2..iz+2), as float bits relative to the node's own:")
-        for dx in range(-2, 3):
+        for dx in range(-3, 4):
             row = []
-            for dz in range(-2, 3):
+            for dz in range(-3, 4):
                 xx, zz = x + dx, z + dz
                 if 0 <= xx < F.shape[0] and 0 <= zz < F.shape[1]:
                     mark = ""
                     if K0 is not None and F is F0 and K0[xx, zz] != F0[xx, zz]:
-                        mark = f"*tau{int(np.int64(K0[xx, zz].view(np.int32)) - np.int64(F[x, z].view(np.int32))):+d}"      # an exceptional node: accepted later than its value
+                        if K0[xx, zz] < 1e-20:
+                            mark = f"#{int(round(float(K0[xx, zz]) / 1e-30))}"          # pinned by the serial band march: its accept number (0: alive at the hand-off)
+                        else:
+                            mark = f"*tau{int(np.int64(K0[xx, zz].view(np.int32)) - np.int64(F[x, z].view(np.int32))):+d}"      # an exceptional node: accepted later than its value
                     row.append(f"{F[xx, zz]:.6f}({int(np.int64(F[xx, zz].view(np.int32)) - np.int64(F[x, z].view(np.int32))):+d}){mark}")
                 else:
                     row.append("outside")

@@ -19,7 +19,10 @@ CONFIGS = [(131, 1000, 16, "checker"), (131, 1000, 16, "rough"), (131, 500, 16, 
 e = Engine(0)
 tot = {}
 t_start = time.time()
+only = [int(v) for v in os.environ.get("DSA_FUZZ_ONLY", "").split(",") if v]      # (indices into CONFIGS: one call again, with the same seed)
 for ci, (nx, nsrc, nper, kind) in enumerate(CONFIGS):
+    if only and ci not in only:
+        continue
     for call in range(ncalls):
         seed = seed0 + 17 * ci + call
         pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)])
@@ -34,15 +37,16 @@ for ci, (nx, nsrc, nper, kind) in enumerate(CONFIGS):
         marched = (fl & 2) != 0
         d = np.abs(t1.astype(np.float64) - tx.astype(np.float64)).max(axis=1)
         left = ~marched
-        clean = left & (cnt == 0)
+        clean = left & (cnt == 0) & (fr == 0)
         rec = dict(units=n, marched=int(marched.sum()), marched_differ=int((d[marched] > 0).sum()), left=int(left.sum()), left_tied=int((left & (cnt > 0)).sum()),
                    escapees=int((d[left] > 1e-4).sum()), beyond_5e5=int((d[left] > 5e-5).sum()), worst=float(d[left].max()) if left.any() else 0.0,
-                   clean=int(clean.sum()), clean_differ=int((d[clean] > 0).sum()), clean_worst=float(d[clean].max()) if clean.any() else 0.0)
+                   clean=int(clean.sum()), clean_differ=int((d[clean] > 0).sum()), clean_worst=float(d[clean].max()) if clean.any() else 0.0,
+                   froze=int((fr > 0).sum()), left_froze_differ=int((d[left & (fr > 0)] > 0).sum()))
         print(f"N={e.nnx:5d} {kind:8s} seed+{seed}: {n} units, {int(st['tie_prone_maps'])}/{nper} maps tie-prone, marched {rec['marched']} (not bit-identical to exact_ties=2: {rec['marched_differ']}); "
               f"left to the fixed point {rec['left']} (holding a tie with an influence {rec['left_tied']}): beyond 1e-4 s {rec['escapees']}, beyond 5e-5 {rec['beyond_5e5']}, worst {rec['worst']:.3g} s; "
-              f"no tie seen {rec['clean']}, of them not bit-identical {rec['clean_differ']} (worst {rec['clean_worst']:.3g} s) | {n / (st['ms_total'] / 1e3):.0f} solves/s", flush=True)
+              f"no tie seen {rec['clean']}, of them not bit-identical {rec['clean_differ']} (worst {rec['clean_worst']:.3g} s); units whose bundle froze a cycle {rec['froze']} (left alone and not bit-identical: {rec['left_froze_differ']}) | {n / (st['ms_total'] / 1e3):.0f} solves/s", flush=True)
         grp = "smooth" if kind == "smooth" else "tie-prone"
-        t = tot.setdefault(grp, dict(units=0, marched=0, marched_differ=0, left=0, left_tied=0, escapees=0, beyond_5e5=0, worst=0.0, clean=0, clean_differ=0, clean_worst=0.0))
+        t = tot.setdefault(grp, dict(units=0, marched=0, marched_differ=0, left=0, left_tied=0, escapees=0, beyond_5e5=0, worst=0.0, clean=0, clean_differ=0, clean_worst=0.0, froze=0, left_froze_differ=0))
         for k2 in rec:
             t[k2] = max(t[k2], rec[k2]) if k2 in ("worst", "clean_worst") else t[k2] + rec[k2]
 for grp, t in tot.items():
