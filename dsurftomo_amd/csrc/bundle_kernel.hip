@@ -348,22 +348,19 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
         // the neighbour taken in last, or the node took a neighbour in that its raised key may not have waited for (eikonal_core.h: solve_node_t<true>; same
         // value and acceptance time as the plain walk).  The list may hold more than the converged field's ties: the census' second look decides.
         // (TIE) a candidate of the census -- the list may hold more than the converged field's ties, the second look decides: the value equals a near
-        // neighbour's acceptance time (every walk that stops at an exact tie does); an exceptional outer node was accepted at the very clock of a near
-        // neighbour (the detector's outer probe); the walk took a neighbour in that a raised key may not have waited for (solve_node_t<false, true>
-        // notes it).  [The detector's own walk here, solve_node_t<true>, said the same and cost 7.6 ms of the headline's 348.]
+        // neighbour's acceptance time (every walk that stops at an exact tie does).  The other kinds of tie involve an exceptional node and are found
+        // behind the loop from the exception table (the census); marking them here -- the detector's own walk, or the plain walk noting raised keys and a
+        // check of the outer nodes' acceptance times -- cost 7.6 / 14 ms of the headline's 335 (profiles/r06_ab_census.log).
         float amb = -1.0f;
+#ifdef DSA_BUNDLE_MARK_RAISED_KEYS      // (the slow pass notes raised keys itself: +7 ms on the headline's 335; without it they are found where the node ends exceptional)
         const float c = TIE ? solve_node_t<false, true>(h, slown, geom, &k, &amb) : solve_node_t<false>(h, slown, geom, &k, nullptr);
+#else
+        const float c = solve_node_t<false>(h, slown, geom, &k, nullptr);
+#endif
         bool tied = TIE && amb >= 0.0f;
         if (TIE) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) tied = tied || (h.in[q] && c < kInf && c == h.near_tau[q]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float ko = h.outer_tau[q];
-                if (!(h.in_outer[q] && ko < kInf && ko != t_value(h.outer[q]))) continue;
-#pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) tied = tied || (h.in[q2] && ko == h.near_tau[q2]);
-            }
         }
         ++evals;
         if (bf2u(c) == bf2u(t_old) && bf2u(k) == bf2u(k_old)) return tied;
@@ -943,6 +940,40 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         const unsigned long long bal = __ballot(on);
                         const int pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
                         if (on && pos < kSlowQ) wq[pos] = ((q < 0 ? (e >> 4) : nid[q < 0 ? 0 : q]) << 4) | (e & 15);
+                        cq += __popcll(bal);
+                    }
+                }
+            }
+            // (round 6) the ties that values do not show -- against the acceptance time of an EXCEPTIONAL node (accepted later than its value), among them
+            // the outer node accepted at the clock of the neighbour taken in last -- are found from the other end: the bundle's exception table names
+            // every exceptional (node, member) there ever was (a few thousand); those that still are go to the second look with the eight nodes whose
+            // walks look at them.  [Marking them in the round loop's slow pass instead cost 4 ms of the headline's 335: profiles/r06_ab_census.log.]
+            {
+                const int xn = 1 << xlog;
+                for (int i0 = wave * 64; i0 < xn; i0 += NW * 64) {
+                    const unsigned long long en = *exc_at((unsigned)(i0 + lane));      // (xn is a multiple of 64 * NW or the loop's last trip reads inside the table: xn >= 1024)
+                    const int kx = exc_key(en);
+                    bool on = i0 + lane < xn && kx != -1 && !(kx & kExcPinned);
+                    const int key = kx & 0x3fffffff, id = on ? key / G : 0, mo = on ? key - id * G : 0;
+                    int iz = 0, ix = 0, nid[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                    if (on) {
+                        coords(id, &iz, &ix);
+                        on = ix < nnx && iz < nnz && mo < nmem && __builtin_signbit(*(BGF32*)(Bb + (unsigned)id * GB + (unsigned)mo * 4u));      // (still exceptional)
+                        rec_stencil(nbz, id, nid);
+                    }
+                    if (!__any(on)) continue;
+                    const unsigned inq = (ix > 0 ? 1u : 0u) | (ix + 1 < nnx ? 2u : 0u) | (iz > 0 ? 4u : 0u) | (iz + 1 < nnz ? 8u : 0u) |
+                                         (ix > 1 ? 16u : 0u) | (ix + 2 < nnx ? 32u : 0u) | (iz > 1 ? 64u : 0u) | (iz + 2 < nnz ? 128u : 0u);
+#pragma nounroll
+                    for (int q = -1; q < 8; ++q) {
+                        if (cq + 64 > kSlowQ) census_flush();
+                        const bool push = on && (q < 0 || ((inq >> q) & 1u) != 0u);
+                        int node = id;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) node = q == j ? nid[j] : node;
+                        const unsigned long long bal = __ballot(push);
+                        const int pos = cq + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (push && pos < kSlowQ) wq[pos] = (node << 4) | mo;
                         cq += __popcll(bal);
                     }
                 }
