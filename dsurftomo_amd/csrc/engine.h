@@ -183,6 +183,7 @@ struct Engine {
     float tie_sum_threshold = kDefaultTieSumThreshold;      // option tie_sum_threshold: a unit whose ties' influences add up to more than this (s) is flagged; 0 = off
     int tie_count_threshold = kDefaultTieCountThreshold;    // option tie_count_threshold: ... or that holds more ties with an influence than this; 0 = off
     int tie_frozen_bundles = kDefaultTieFrozenBundles;      // option tie_frozen_bundles: 1 = every member of a bundle that froze a cycle is flagged
+    int bundle_order_opt = 0;          // option bundle_order: 0 = the first generation's bundles longest first | 1 = bundles of similar length on one CU (plan_bundles)
     int tie_map_strict = kDefaultTieMapStrict;              // option tie_map_strict: on a map where some unit holds a tie above tie_threshold, every unit holding a tie with any influence is flagged
     int tie_verdict(int unit, const int32_t* tie_words, const int32_t* info16, bool member);
     std::vector<char> tie_verdicts(int first, int n, const int32_t* tie_words, const int32_t* info16, bool bundled);

@@ -1097,6 +1097,21 @@ int Engine::plan_bundles(int first, int n, int G, int* nsolo_out, int* nbundles_
         nb = bundles_a + bundles_b;
         *nbundles_out = nb;
     }
+    if (bundle_order_opt && bundles_b > 0 && bundle_threads_b == 768 && (int)pieces.size() == res3) {
+        // Round 6, option bundle_order (A/B switch, default 0): which bundles share a CU.  If the first generation's 768 workgroups went out round robin --
+        // k, k + 256 and k + 512 on one CU -- "longest first" would give every CU a long, a middle and a short bundle, and the wide tail, whose workgroups
+        // need whole CUs, could only start when the generation is all but over; position p holding rank 3 (p mod 256) + p / 256 would then put bundles of
+        // similar length on one CU.  Measured (profiles/r06_ab_bundle_order.log): 350.4 ms against 342.0 -- the dispatcher fills a CU with CONSECUTIVE
+        // workgroups, "longest first" already is the grouped order (the rocprof trace shows the tail starting with the generation and ending 84 ms after it),
+        // and the permutation un-groups it.
+        std::vector<std::pair<float, std::vector<int>>> perm((size_t)res3);
+        const int ncu = res3 / 3;
+        for (int p2 = 0; p2 < res3; ++p2) {
+            const int rank2 = bundle_order_opt == 1 ? 3 * (p2 % ncu) + p2 / ncu : p2;
+            perm[(size_t)p2] = pieces[(size_t)rank2];
+        }
+        if (bundle_order_opt == 1) pieces.swap(perm);
+    }
     h_launch_rank.assign((size_t)n, 0);
     for (int r = 0; r < nsolo; ++r) h_launch_rank[(size_t)solo[(size_t)r].second] = r;
     size_t free_b = 0, total_b = 0;
@@ -1606,6 +1621,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "tie_count_threshold" && value >= 0) { en->tie_count_threshold = (int)value; return 0; }
     if (n == "tie_frozen_bundles" && (value == 0 || value == 1)) { en->tie_frozen_bundles = (int)value; return 0; }
     if (n == "tie_map_strict" && (value == 0 || value == 1)) { en->tie_map_strict = (int)value; return 0; }
+    if (n == "bundle_order" && (value == 0 || value == 1 || value == 2 || value == 3)) { en->bundle_order_opt = (int)value; return 0; }
     if (n == "tie_list" && (value == 0 || value == 1)) { en->tie_list_opt = (int)value; return 0; }
     if (n == "disp_failure_log" && value >= 0 && value <= 65536) { en->disp_failure_log = (int)value; return 0; }
     if (n == "exact_heap_blocked" && (value == 0 || value == 1 || value == 2)) { en->exact_heap_blocked = (int)value; return 0; }

@@ -208,17 +208,19 @@ DSA_HD bool ref_alive(const SourceDesc& s, const SourceScratch& w, uint64_t rsta
 // ref_alive on a record already in hand
 // (round 6: `flip` -- the scan index of a node whose rank ties with the terminating node's, or -1 -- inverts that node's answer: the hand-off's tie probe,
 // k_handoff, evaluates the snapshot both ways to measure what the reference's tree decided there and this rule can only guess)
+template <bool FLIP = false>
 DSA_HD bool ref_alive_rec(const SourceDesc& s, const Rec& r, uint64_t rstar, int eid, int iz, int ix, int flip = -1)
 {
     if (t_pinned(r.T)) return true;
     const uint64_t rk = accept_rank(r.T, r.tau);
     const int id = (ix - 1) * s.rnz + (iz - 1);
     const bool alive = rk < rstar || (rk == rstar && id < eid);
-    return id == flip ? !alive : alive;
+    return (FLIP && id == flip) ? !alive : alive;
 }
 
 // classify node (iz, ix): returns status (-1, 0, 1) and the value to keep in *tout.  (Round 5: the eight stencil records of a node that is
 // not alive are fetched together, before the first is looked at -- the hand-off kernel used to wait for them one after the other.)
+template <bool FLIP = false>
 DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScratch& w, int ended,
                         uint64_t rstar, int ez, int ex, int iz, int ix, float* tout, int flip = -1)
 {
@@ -230,7 +232,7 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
         *tout = kInf; return -1;
     }
     const int eid = ex > 0 ? (ex - 1) * s.rnz + (ez - 1) : -1;
-    if (ref_alive_rec(s, own, rstar, eid, iz, ix, flip)) { *tout = t_value(raw); return 0; }
+    if (ref_alive_rec<FLIP>(s, own, rstar, eid, iz, ix, flip)) { *tout = t_value(raw); return 0; }
     // not alive: close iff it touches an alive node; its value is the trial value from the alive
     // set (the edge node that ended the stage is alive but was never propagated)
     Stencil st;
@@ -258,14 +260,14 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
     }
     bool touch = false;
     for (int d = 0; d < 2; ++d) {
-        st.aj[d] = st.ej[d] && ref_alive_rec(s, rj[d], rstar, eid, iz, jx[d], flip);
+        st.aj[d] = st.ej[d] && ref_alive_rec<FLIP>(s, rj[d], rstar, eid, iz, jx[d], flip);
         st.tj[d] = st.aj[d] ? t_value(rj[d].T) : kInf;
-        const bool o = ej2[d] && ref_alive_rec(s, rj2[d], rstar, eid, iz, jx2[d], flip);
+        const bool o = ej2[d] && ref_alive_rec<FLIP>(s, rj2[d], rstar, eid, iz, jx2[d], flip);
         st.oj[d] = o;
         st.tj2[d] = o ? t_value(rj2[d].T) : kInf;
-        st.ak[d] = st.ek[d] && ref_alive_rec(s, rk[d], rstar, eid, kz[d], ix, flip);
+        st.ak[d] = st.ek[d] && ref_alive_rec<FLIP>(s, rk[d], rstar, eid, kz[d], ix, flip);
         st.tk[d] = st.ak[d] ? t_value(rk[d].T) : kInf;
-        const bool p = ek2[d] && ref_alive_rec(s, rk2[d], rstar, eid, kz2[d], ix, flip);
+        const bool p = ek2[d] && ref_alive_rec<FLIP>(s, rk2[d], rstar, eid, kz2[d], ix, flip);
         st.ok[d] = p;
         st.tk2[d] = p ? t_value(rk2[d].T) : kInf;
         touch = touch || st.aj[d] || st.ak[d];

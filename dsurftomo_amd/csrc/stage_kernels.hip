@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, 
         // (only what reaches the coarse grid counts: the nodes k_handoff injects)
         if (!(zx >= 1 && zx <= sd.rnx && zz >= 1 && zz <= sd.rnz && (zx - 1) % kSgdl == 0 && (zz - 1) % kSgdl == 0)) continue;
         float t1;
-        const int st1 = handoff_node(g, sd, w, 0, rstar, ez, ex, zz, zx, &t1, yid);
+        const int st1 = handoff_node<true>(g, sd, w, 0, rstar, ez, ex, zz, zx, &t1, yid);
         const int zid = (zx - 1) * sd.rnz + (zz - 1);
         const int st0 = w.S_r[zid];
         const float t0 = Tfin[zid];
