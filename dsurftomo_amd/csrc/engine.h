@@ -179,7 +179,6 @@ struct Engine {
     std::vector<float> h_unit_tie_sum;           // (round 6) sum of the influences of the unit's ties (s) ...
     std::vector<int> h_unit_tie_count;           // ... and how many had one; cycles the unit (its bundle) froze
     std::vector<int> h_unit_froze;
-    std::vector<int> h_unit_cand;                // tie candidates the unit's bundle listed (a statistic; DSA_DEBUG_CAND)
     float tie_sum_threshold = kDefaultTieSumThreshold;      // option tie_sum_threshold: a unit whose ties' influences add up to more than this (s) is flagged; 0 = off
     int tie_count_threshold = kDefaultTieCountThreshold;    // option tie_count_threshold: ... or that holds more ties with an influence than this; 0 = off
     int tie_frozen_bundles = kDefaultTieFrozenBundles;      // option tie_frozen_bundles: 1 = every member of a bundle that froze a cycle is flagged

@@ -452,7 +452,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(tieinfo, C * kTieWords) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
     h_unit_flags.assign((size_t)nunits, 0);
     h_unit_tie.assign((size_t)nunits, 0.0f);
-    h_unit_tie_sum.assign((size_t)nunits, 0.0f); h_unit_tie_count.assign((size_t)nunits, 0); h_unit_froze.assign((size_t)nunits, 0); h_unit_cand.assign((size_t)nunits, 0);
+    h_unit_tie_sum.assign((size_t)nunits, 0.0f); h_unit_tie_count.assign((size_t)nunits, 0); h_unit_froze.assign((size_t)nunits, 0);
     h_unit_rounds.assign((size_t)nunits, 0);
     HIP_TRY(this, hipMemsetAsync(out.p, 0, std::max<size_t>(ndata, 1) * sizeof(float), stream));     // data indices without a kRayTime ray read as 0
     if (nr) HIP_TRY(this, hipMemcpyAsync(rays.p, h_rays.data(), nr * sizeof(RayDesc), hipMemcpyHostToDevice, stream));
@@ -623,7 +623,6 @@ int Engine::tie_verdict(int unit, const int32_t* t, const int32_t* inf, bool mem
     h_unit_tie_count[(size_t)unit] = (int)std::min<long>(cnt, 0x7fffffff);
     const int froze = inf[3] + inf[11] + (member ? t[4] + t[h + 4] : 0);
     h_unit_froze[(size_t)unit] = froze;
-    h_unit_cand[(size_t)unit] = t[h + 7];
     const bool frozen = inf[3] > 0 || (!member && inf[11] > 0) || (member && tie_frozen_bundles && (t[4] > 0 || t[h + 4] > 0));
     if (t[0] > 0 || t[h] > 0) return 2;
     if (t[6] > 0 || t[h + 6] > 0) return 1;            // (a rank tie at the hand-off that changes what the coarse grid receives: k_handoff_probe; a band march that left its tree no heap: k_coarse_march)
@@ -751,11 +750,7 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         } else if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         if (exact_ties != 2) {
-#ifdef DSA_NO_HANDOFF_PROBE      // (A/B switch)
-            launch_handoff(g, b, n, stream);
-#else
             launch_handoff(g, b, n, stream, detect ? tieinfo.p : nullptr, tie_threshold);
-#endif
             launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream, detect ? tieinfo.p : nullptr);
         }
         HIP_TRY(this, hipEventRecord(events[4], stream));
@@ -1842,7 +1837,6 @@ int dsa_unit_tie_sums(const dsa_engine* e, int nunits, int* count, float* sum, i
         if (count) count[u] = en->h_unit_tie_count[(size_t)u];
         if (sum) sum[u] = en->h_unit_tie_sum[(size_t)u];
         if (frozen) frozen[u] = en->h_unit_froze[(size_t)u];
-        if (getenv("DSA_DEBUG_CAND") && count) count[u] = en->h_unit_cand[(size_t)u];      // (probe: the bundle's candidate count in place of the tie count)
     }
     return 0;
 }
