@@ -950,10 +950,21 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
             // walks look at them.  [Marking them in the round loop's slow pass instead cost 4 ms of the headline's 335: profiles/r06_ab_census.log.]
             {
                 const int xn = 1 << xlog;
-                for (int i0 = wave * 64; i0 < xn; i0 += NW * 64) {
-                    const unsigned long long en = *exc_at((unsigned)(i0 + lane));      // (xn is a multiple of 64 * NW or the loop's last trip reads inside the table: xn >= 1024)
+#ifndef DSA_XU
+#define DSA_XU 4
+#endif
+                constexpr int XU = DSA_XU;        // (entries per lane and trip, fetched together: the table is 98 % empty and the walk is the latency of its loads)
+                for (int i00 = wave * 64 * XU; i00 < xn; i00 += NW * 64 * XU) {
+                  unsigned long long env[XU];
+#pragma unroll
+                  for (int xu = 0; xu < XU; ++xu) env[xu] = i00 + xu * 64 + lane < xn ? *exc_at((unsigned)(i00 + xu * 64 + lane)) : kExcEmpty;
+#pragma unroll
+                  for (int xu = 0; xu < XU; ++xu) {
+                    const int i0 = i00 + xu * 64;
+                    const unsigned long long en = env[xu];
                     const int kx = exc_key(en);
                     bool on = i0 + lane < xn && kx != -1 && !(kx & kExcPinned);
+                    if (!__any(on)) continue;
                     const int key = kx & 0x3fffffff, id = on ? key / G : 0, mo = on ? key - id * G : 0;
                     int iz = 0, ix = 0, nid[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
                     if (on) {
@@ -976,6 +987,7 @@ __global__ __launch_bounds__(NT) DSA_BUNDLE_OCC(G, NT, MPL) void k_fim_bundle(co
                         if (push && pos < kSlowQ) wq[pos] = (node << 4) | mo;
                         cq += __popcll(bal);
                     }
+                  }
                 }
             }
         }

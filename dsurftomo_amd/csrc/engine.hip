@@ -605,6 +605,15 @@ std::vector<char> Engine::tie_verdicts(int first, int n, const int32_t* tie_word
             // (a member of a bundle that froze a cycle counts here too: a frozen 2-cycle sits an ulp from a tie state the census of the frozen field cannot see)
             if (!fl[(size_t)u] && p >= 0 && p < nmaps && prone[(size_t)p] && (h_unit_tie_count[(size_t)(first + u)] > 0 || h_unit_froze[(size_t)(first + u)] > 0)) { fl[(size_t)u] = 1; stats[DSA_STAT_TIE_UNITS_STRICT] += 1.0; }
         }
+    if (getenv("DSA_DEBUG_TIES")) {      // (probe: what flagged the launch's units)
+        long big = 0, hand = 0, band = 0, froze = 0, any = 0;
+        const int h = kTieWords / 2;
+        for (int u = 0; u < n; ++u) {
+            const int32_t* t = tie_words + (size_t)u * kTieWords;
+            big += t[0] > 0 || t[h] > 0; hand += t[6] > 0; band += t[h + 6] > 0; froze += h_unit_froze[(size_t)(first + u)] > 0; any += fl[(size_t)u] != 0;
+        }
+        fprintf(stderr, "dsa ties: %d units: flagged %ld (a tie above the threshold %ld, hand-off status %ld, band march's tree %ld, frozen cycle %ld)\n", n, any, big, hand, band, froze);
+    }
     for (char c : prone) stats[DSA_STAT_TIE_PRONE_MAPS] += c ? 1.0 : 0.0;
     for (int u = 0; u < n; ++u) if (!fl[(size_t)u] && h_unit_tie_count[(size_t)(first + u)] > 0) stats[DSA_STAT_TIE_UNITS_TIED] += 1.0;
     return fl;

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
 // whose acceptance rank TIES with the terminating node's was accepted before it or not as the reference's tree had it -- ref_alive guesses by scan order.
 // Such nodes are collected, and the hand-off's outputs that reach the coarse grid (every kSgdl-th node of the box: status and time) are evaluated once more
 // with the tied node's answer inverted: a changed time is the tie's influence (counted into the unit's tie record like the census' ties: any / sum / above
-// the threshold), a changed STATUS on the lattice counts in word [6] of the record's refined half and flags the unit by itself (Engine::tie_verdict).
+// the threshold), a changed STATUS on the lattice counts as a tie with an influence (no amount); more ties than the probe holds count in word [6] of the
+// record's refined half, which flags the unit by itself (Engine::tie_verdict).
 __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, int32_t* tie, float tie_threshold)
 {
     constexpr int kTiedMax = 8;
@@ -268,7 +269,11 @@ __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, 
         const int zid = (zx - 1) * sd.rnz + (zz - 1);
         const int st0 = w.S_r[zid];
         const float t0 = Tfin[zid];
-        if (st1 != st0) atomicAdd(tr + 6, 1);
+        // (a changed STATUS: a tie with an influence nobody has measured -- counted, so that a tie-prone map sends the unit to the march; not a flag by itself:
+        // a source on a symmetry axis of a laterally homogeneous model -- the Taipei example's first iteration: one station, 22 of its 26 periods -- ties
+        // like this by construction, the scan-order rule is right there in 20 of the 22 and without consequence in the other two, and a march would
+        // double the call's time)
+        if (st1 != st0) atomicAdd((unsigned*)tr + 2, 1u);
         else if (st0 >= 0 && t1 != t0) {
             const float ti = fabsf(t1 - t0);
             atomicAdd((unsigned*)tr + 2, 1u); atomicAdd((unsigned*)tr + 3, (unsigned)(fminf(ti, 1.0f) * (1.0f / kTieSumUnit)));
