@@ -257,9 +257,10 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  *                  - a unit holding a tie whose influence exceeds "tie_threshold";
  *                  - "tie_map_strict" (on): on a map where some unit holds such a tie -- a tie-prone medium: sharp contrasts, second-order stencils
  *                    switching along ridges, where a one-ulp difference grows downstream -- every unit holding a tie with ANY influence.
- *                What stays with the fixed point: units without a tie (measured: bit-identical to the reference, 0 of ~10 000 such units differ), and --
- *                on maps where no tie reaches the threshold -- units holding ties of an ulp or two: within 1e-4 s of the reference BY MEASUREMENT
- *                (worst of 80 000 units x 32 receivers on the headline medium: 8.8e-5 s), not by construction (DSA_STAT_TIE_UNITS_TIED counts them, the
+ *                What stays with the fixed point: units without a tie (measured: bit-identical to the reference but for 5 of 83 000 such units, off by an
+ *                ulp at a receiver: DESIGN.md "Ties", known residuals), and -- on maps where no tie reaches the threshold -- units holding ties of an
+ *                ulp or two: within 1e-4 s of the reference BY MEASUREMENT (worst of 256 000 smooth-medium units x 32 receivers: 8.8e-5 s), not by
+ *                construction (DSA_STAT_TIE_UNITS_TIED counts them, the
  *                shim says so once per call).  No rule on a unit's own ties -- largest, summed, counted influence -- separates the rare unit that ends
  *                beyond 1e-4 s from the thousands that do not (profiles/r06_tie_rule_scan_*.log).
  *                Cost: a few per cent where nothing is flagged; a flagged unit costs one march (sequential accepts, ~2.3 us each: 35 ms at 121^2,
