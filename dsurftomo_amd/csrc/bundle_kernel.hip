@@ -1178,6 +1178,11 @@ __global__ void k_bundle_export_records(const FimBundle* __restrict__ bundles, c
     if (i >= nrec * G) return;
     const int id = i / G, m = i - id * G;
     if (m >= bd->nmem) return;
+    // (round 6) a unit whose serial start-up march ended the refined stage by itself (a source in the last cell before an open edge) has nothing for the
+    // fixed point to do, and its records hold that march's trial values, which the hand-off reads: they stay.  [Overwritten by the bundle's empty field
+    // they left the hand-off without a band, the coarse solve without a seed, and the call returned zeros for the unit -- silently: tools/edge_probe.py.]
+    const FimProblem* const pm = problems + bd->member[m];
+    if (pm->ended && *pm->ended) return;
     const float v = bd->B[(size_t)bd->slot * bd->b_stride + (size_t)id * G * DSA_BSTRIDE + m];
     Rec r{ v, v };
     if (__builtin_signbit(v)) {
@@ -1185,7 +1190,7 @@ __global__ void k_bundle_export_records(const FimBundle* __restrict__ bundles, c
         const float tau = exc_find(bd->exc + (size_t)bd->slot * bd->exc_stride, bd->exc_log2cap, id * G + m, &pinned);
         r.T = pinned ? v : -v; r.tau = tau;
     }
-    problems[bd->member[m]].F[id] = r;
+    pm->F[id] = r;
 }
 
 void launch_bundle_refined_slowness(const FimBundle* d_bundles, int nbundles, int G, const FimProblem* d_problems, int nrec, float* d_slowI, hipStream_t stream)

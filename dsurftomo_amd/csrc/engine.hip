@@ -890,6 +890,10 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
             if (fi[10] == -3) { fail(DSA_ERR_INTERNAL, "unit %d: no free field slot within the wait bound (pool of %d slots, claimed by compare-and-swap: a pool smaller than the resident workgroups on very long solves, or corrupted busy flags; set option field_pool = -1 for a slot per unit)", first + u, pool_slots); return DSA_ERR_INTERNAL; }
             if (fi[2] < 0 || fi[10] == -1) { fail(DSA_ERR_INTERNAL, "unit %d: fixed-point solve did not converge (rounds %d/%d)", first + u, fi[0], fi[8]); return DSA_ERR_INTERNAL; }
             if (h_flags[(size_t)u * 4 + 1]) { fail(DSA_ERR_INTERNAL, "unit %d: serial march guard %d (1/17 window, 2/18 tree, 32 exception table)", first + u, h_flags[(size_t)u * 4 + 1]); return DSA_ERR_INTERNAL; }
+            // (a coarse solve that never ran a round is NOT an error: for some sources in the last cell before a high edge the reference's own start-up
+            // march ends with nothing alive and its field stays zero -- tests/tools/fuzz_parity.py "degenerate in the reference" --, and the engine
+            // returns the same zeros.  The one case of round 6 that looked the same and was a bug -- refined boxes in bundles overwriting the records of
+            // a unit whose start-up march had ended the refined stage -- is covered by tests/test_gpu_bundles.py.)
             stats[DSA_STAT_ROUNDS_MAX] = std::max(stats[DSA_STAT_ROUNDS_MAX], (double)fi[8]);
             h_unit_rounds[(size_t)(first + u)] = fi[8];
             unsigned long long ev;

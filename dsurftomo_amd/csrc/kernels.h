@@ -46,6 +46,8 @@ struct FimProblem {
                            // [4] cycles the unit's bundle froze (bundle kernel), [5] ties without an influence on their node (bundle kernel's census),
                            // [6] refined half: more rank ties at the hand-off than the probe holds (k_handoff_probe); coarse half: the band march left its tree no heap (k_coarse_march), [7] tie candidates the unit's bundle listed (bundle kernel; a statistic)
     float tie_threshold;
+    const int32_t* ended;  // refined problems: the unit's flag "the serial start-up march ended the refined stage by itself" (SourceScratch::flags[0]) -- its records then
+                           // hold the march's own trial values, which nothing may overwrite (round 6: k_bundle_export_records did); coarse problems: null
 };
 
 // What the COARSE solve does around its fixed point: the workgroup owns its unit's field slot from the first store to the last read.

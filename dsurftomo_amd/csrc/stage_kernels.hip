@@ -407,6 +407,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     r.clocks = nullptr;
     r.info = info + (size_t)s * 16;
     r.tie = tie ? tie + (size_t)s * kTieWords : nullptr; r.tie_threshold = tie_threshold;
+    r.ended = b.flags + (size_t)s * 4;
     // field slot: the unit's own, or (a pool smaller than the launch) the one its workgroup number selects
     const int rank = launch_rank ? launch_rank[s] : s;
     if (ends_r) {
@@ -435,6 +436,7 @@ __global__ void k_make_problems(GridDesc g, BatchPtrs b, int nsrc, const float* 
     c.clocks = clocks ? clocks + (size_t)s * kClockSlots : nullptr;
     c.info = info + (size_t)s * 16 + 8;
     c.tie = tie ? tie + (size_t)s * kTieWords + kTieWords / 2 : nullptr; c.tie_threshold = tie_threshold;
+    c.ended = nullptr;
     prob_c[rank] = c;      // workgroup launch_rank[s] solves unit s: the longest solves start first
     if (ends_c) {
         FimEnds e;

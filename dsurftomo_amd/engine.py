@@ -62,7 +62,8 @@ def load_library():
     L.dsa_get_stats.argtypes = [_vp, _vp]
     L.dsa_unit_ties.argtypes = [_vp, _i32, _vp, _vp]
     L.dsa_unit_rounds.argtypes = [_vp, _i32, _vp]
-    L.dsa_unit_tie_sums.argtypes = [_vp, _i32, _vp, _vp, _vp]
+    if hasattr(L, "dsa_unit_tie_sums"):          # (absent from libraries of rounds 1-5: same-box A/B runs against an old build, DSA_LIB_PATH)
+        L.dsa_unit_tie_sums.argtypes = [_vp, _i32, _vp, _vp, _vp]
     L.dsa_debug_counters.argtypes = [_vp, _vp]
     L.dsa_ray_paths.argtypes = [_vp, _vp, _vp, _vp]
     L.dsa_spmv_load.argtypes = [_vp, _i32, _i32, C.c_longlong, _vp, _vp, _vp]

@@ -510,3 +510,37 @@ def test_two_members_per_lane_variant_equals_four(bundles):
         assert np.array_equal(bits(out[(2, G)][0]), bits(out[(4, G)][0])), G
         assert np.array_equal(bits(out[(2, G)][1]), bits(out[(4, G)][1])), G
     parity_log.add(f"bundles, two members per lane: {n} units (ragged period sets), sizes 16 / 8 / 4: receiver times and all {out[(2, 16)][1].size} field nodes identical to four members per lane")
+
+
+def test_refined_bundles_keep_the_records_of_a_unit_whose_startup_march_ended_the_stage(bundles):
+    """Round 6: a source in the last cell before an open edge of its refined box -- the serial start-up march meets the reference's exit after five
+    accepts and the refined stage is over before the fixed point starts (SourceScratch::flags[0]); the unit's records then hold that march's trial
+    values.  With the refined boxes solved in bundles, k_bundle_export_records overwrote them with the bundle's empty field: no band at the hand-off,
+    no seed for the coarse solve, and the call returned ZEROS for the unit without an error (every call of >= 128 bundles; found by a fuzz with sources
+    up to the grid's edge).  The source of that run, its 16 periods, refined boxes forced into a bundle: the march's times, bit for bit."""
+    e = bundles
+    nx, nper, nrec = 35, 16, 32
+    sx, sz = synth.sources(nx, 1000, inner=1.0, seed=synth.SEED + 1585)
+    k = 622
+    N = synth.nprop(nx)
+    gox, goz, dnx, dnz = synth.grid_origin(nx)
+    assert (sx[k] - gox) / dnx > N - 2                   # (the last cell)
+    idx = (k + 1 + np.arange(nrec)) % 1000
+    u = dict(map_index=np.arange(nper, dtype=np.int32), scx=np.full(nper, sx[k], np.float32), scz=np.full(nper, sz[k], np.float32),
+             nrec=np.full(nper, nrec, np.int32), rcx=np.tile(sx[idx], nper), rcz=np.tile(sz[idx], nper))
+    pv = np.stack([synth.medium(nx, "checker4", p) for p in range(nper)])
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+    e.set_option("exact_ties", 2)
+    tx = e.traveltimes(**u).reshape(nper, nrec)
+    assert tx.min() > 0.0
+    e.set_option("exact_ties", 0); e.set_option("bundle", 16)
+    out = []
+    for refined in (1, 2):
+        e.set_option("bundle_refined", refined)
+        t = e.traveltimes(**u).reshape(nper, nrec)
+        out.append(t)
+        assert t.min() > 0.0, "a unit came back without times"
+    d = np.abs(out[1].astype(np.float64) - tx.astype(np.float64)).max()
+    parity_log.add(f"refined boxes in a bundle, a source in the grid's last cell (the start-up march ends the refined stage): 16 units x {nrec} receivers, "
+                   f"max |dt| against the march {d:.3g} s, refined boxes unit by unit {np.abs(out[0].astype(np.float64) - tx).max():.3g} s")
+    assert (out[0].view(np.uint32) == out[1].view(np.uint32)).all() and d <= 1e-4

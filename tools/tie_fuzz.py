@@ -10,6 +10,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import synth
 from dsurftomo_amd.engine import Engine
 
+if os.environ.get("DSA_FUZZ_INNER"):      # (sources over this fraction of the grid instead of the inner 90 %: 1.0 puts some on the very edge)
+    _inner = float(os.environ["DSA_FUZZ_INNER"]); _src = synth.sources
+    synth.sources = lambda nx, nsrc, gd=8, inner=0.90, seed=synth.SEED: _src(nx, nsrc, gd, _inner, seed)
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 ncalls = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 nrec = 32
