@@ -44,7 +44,7 @@ struct FimProblem {
     int32_t* tie;          // tie detector (kernels launched with FimLaunch::tie), kTieWords / 2 words per stage: [0] ties whose influence exceeds tie_threshold, [1] largest influence (float bits),
                            // [2] ties with any influence at all, [3] the sum of the influences in units of kTieSumUnit (round 6: sub-threshold ties add up along a front),
                            // [4] cycles the unit's bundle froze (bundle kernel), [5] ties without an influence on their node (bundle kernel's census),
-                           // [6] refined half: more rank ties at the hand-off than the probe holds (k_handoff_probe); coarse half: the band march left its tree no heap (k_coarse_march), [7] tie candidates the unit's bundle listed (bundle kernel; a statistic)
+                           // [6] refined half: rank ties at the hand-off that change a STATUS the coarse grid receives, or more of them than the probe holds (k_handoff_probe); coarse half: the band march left its tree no heap (k_coarse_march), [7] tie candidates the unit's bundle listed (bundle kernel; a statistic)
     float tie_threshold;
     const int32_t* ended;  // refined problems: the unit's flag "the serial start-up march ended the refined stage by itself" (SourceScratch::flags[0]) -- its records then
                            // hold the march's own trial values, which nothing may overwrite (round 6: k_bundle_export_records did); coarse problems: null

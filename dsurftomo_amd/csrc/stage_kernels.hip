@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
 // whose acceptance rank TIES with the terminating node's was accepted before it or not as the reference's tree had it -- ref_alive guesses by scan order.
 // Such nodes are collected, and the hand-off's outputs that reach the coarse grid (every kSgdl-th node of the box: status and time) are evaluated once more
 // with the tied node's answer inverted: a changed time is the tie's influence (counted into the unit's tie record like the census' ties: any / sum / above
-// the threshold), a changed STATUS on the lattice counts as a tie with an influence (no amount); more ties than the probe holds count in word [6] of the
-// record's refined half, which flags the unit by itself (Engine::tie_verdict).
+// the threshold); a changed STATUS on the lattice, or more ties than the probe holds, counts in word [6] of the record's refined half, which flags the
+// unit by itself (Engine::tie_verdict) -- except in a laterally homogeneous box, where such ties are the grid's symmetry and only count.
 __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, int32_t* tie, float tie_threshold)
 {
     constexpr int kTiedMax = 8;
@@ -253,7 +253,28 @@ __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, 
         }
     }
     __syncthreads();
-    if (s_ntied == 0 || tid >= 9) return;
+    if (s_ntied == 0) return;
+    // (a laterally homogeneous box -- a 1-D starting model: every map of the Taipei example's first iteration -- ties like this BY SYMMETRY, one station of
+    // that example in 22 of its 26 periods; there the scan-order rule is the reference's behaviour, checked bit for bit, and a changed status only counts)
+    __shared__ unsigned s_smin, s_smax;          // (positive floats order like their bit patterns)
+    if (tid == 0) { s_smin = 0x7f800000u; s_smax = 0u; }
+    __syncthreads();
+    {
+        unsigned lo = 0x7f800000u, hi = 0u;
+        const int dq = 256 / sd.rnz, dr = 256 % sd.rnz;
+        int ix0 = tid / sd.rnz, iz0 = tid % sd.rnz;
+        for (int id = tid; id < n; id += 256) {
+            const unsigned v = __float_as_uint(w.slow_r[rec_index(sd.nbz_r, iz0, ix0)]);
+            lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+            iz0 += dr; ix0 += dq;
+            if (iz0 >= sd.rnz) { iz0 -= sd.rnz; ix0 += 1; }
+        }
+        atomicMin(&s_smin, lo); atomicMax(&s_smax, hi);
+    }
+    __syncthreads();
+    // (homogeneous up to the rounding of the B-spline weights that dice a constant map: a few ulps)
+    const bool homogeneous = __uint_as_float(s_smax) - __uint_as_float(s_smin) <= 1.0e-5f * __uint_as_float(s_smin);
+    if (tid >= 9) return;
     const float* Tfin = b.Tfin_r + (size_t)s * kRefMax * kRefMax;
     int32_t* const tr = tie + (size_t)s * kTieWords;
     if (s_ntied > kTiedMax && tid == 0) atomicAdd(tr + 6, 1);
@@ -269,11 +290,9 @@ __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, 
         const int zid = (zx - 1) * sd.rnz + (zz - 1);
         const int st0 = w.S_r[zid];
         const float t0 = Tfin[zid];
-        // (a changed STATUS: a tie with an influence nobody has measured -- counted, so that a tie-prone map sends the unit to the march; not a flag by itself:
-        // a source on a symmetry axis of a laterally homogeneous model -- the Taipei example's first iteration: one station, 22 of its 26 periods -- ties
-        // like this by construction, the scan-order rule is right there in 20 of the 22 and without consequence in the other two, and a march would
-        // double the call's time)
-        if (st1 != st0) atomicAdd((unsigned*)tr + 2, 1u);
+        // (a changed STATUS on the lattice: the coarse grid starts from another band -- on small grids, where the box is a good part of the field, 2e-4 to
+        // 4.5e-4 s at a receiver (profiles/r06_tie_fuzz_symmetric_sources.log) --: the unit is flagged, word [6]; in a homogeneous box it only counts)
+        if (st1 != st0) { if (homogeneous) atomicAdd((unsigned*)tr + 2, 1u); else atomicAdd(tr + 6, 1); }
         else if (st0 >= 0 && t1 != t0) {
             const float ti = fabsf(t1 - t0);
             atomicAdd((unsigned*)tr + 2, 1u); atomicAdd((unsigned*)tr + 3, (unsigned)(fminf(ti, 1.0f) * (1.0f / kTieSumUnit)));

@@ -13,6 +13,17 @@ from dsurftomo_amd.engine import Engine
 if os.environ.get("DSA_FUZZ_INNER"):      # (sources over this fraction of the grid instead of the inner 90 %: 1.0 puts some on the very edge)
     _inner = float(os.environ["DSA_FUZZ_INNER"]); _src = synth.sources
     synth.sources = lambda nx, nsrc, gd=8, inner=0.90, seed=synth.SEED: _src(nx, nsrc, gd, _inner, seed)
+if os.environ.get("DSA_FUZZ_SNAP"):       # (a third of the sources exactly on a node line in x, a third in z -- some on a node: symmetric fronts, exact ties by construction)
+    _src2 = synth.sources
+    def _snapped(nx, nsrc, gd=8, inner=0.90, seed=synth.SEED):
+        sx, sz = _src2(nx, nsrc, gd, inner, seed)
+        gox, goz, dnx, dnz = synth.grid_origin(nx, gd)
+        fx = (sx - gox) / dnx; fz = (sz - goz) / dnz
+        k = np.arange(nsrc)
+        fx = np.where(k % 3 == 0, np.round(fx), fx); fz = np.where(k % 3 != 2, fz, np.round(fz)); fz = np.where(k % 9 == 0, np.round(fz), fz)
+        return (gox + fx.astype(np.float32) * dnx).astype(np.float32), (goz + fz.astype(np.float32) * dnz).astype(np.float32)
+    synth.sources = _snapped
+DICING = int(os.environ.get("DSA_FUZZ_DICING", "8"))
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 ncalls = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 nrec = 32
@@ -29,9 +40,9 @@ for ci, (nx, nsrc, nper, kind) in enumerate(CONFIGS):
     for call in range(ncalls):
         seed = seed0 + 17 * ci + call
         pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)])
-        u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + seed)
+        u = synth.units(nx, nsrc, nper, nrec, gd=DICING, seed=synth.SEED + seed)
         n = nsrc * nper
-        e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv, dicing=DICING)
         e.set_option("exact_ties", 2); e.plan(**u); tx = e.solve().reshape(n, nrec)
         e.set_option("exact_ties", 1); e.plan(**u); t1 = e.solve().reshape(n, nrec)
         st = e.stats()
