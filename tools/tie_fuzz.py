@@ -30,6 +30,8 @@ nrec = 32
 #          nx   sources periods medium
 CONFIGS = [(131, 1000, 16, "checker"), (131, 1000, 16, "rough"), (131, 500, 16, "wild"), (67, 1000, 16, "checker"), (67, 1000, 16, "rough"), (35, 1000, 16, "checker4"),
            (35, 1000, 16, "rough"), (131, 1000, 16, "smooth"), (67, 1000, 16, "smooth"), (35, 1000, 16, "smooth")]
+if os.environ.get("DSA_FUZZ_SMALL"):      # (the sizes DSurfTomo's users run: 121^2 .. 193^2)
+    CONFIGS = [(18, 1000, 16, "smooth"), (18, 1000, 16, "checker4"), (18, 1000, 16, "rough"), (27, 1000, 16, "smooth"), (27, 1000, 16, "checker4"), (27, 1000, 16, "homog"), (18, 1000, 16, "homog")]
 e = Engine(0)
 tot = {}
 t_start = time.time()
@@ -59,7 +61,7 @@ for ci, (nx, nsrc, nper, kind) in enumerate(CONFIGS):
         print(f"N={e.nnx:5d} {kind:8s} seed+{seed}: {n} units, {int(st['tie_prone_maps'])}/{nper} maps tie-prone, marched {rec['marched']} (not bit-identical to exact_ties=2: {rec['marched_differ']}); "
               f"left to the fixed point {rec['left']} (holding a tie with an influence {rec['left_tied']}): beyond 1e-4 s {rec['escapees']}, beyond 5e-5 {rec['beyond_5e5']}, worst {rec['worst']:.3g} s; "
               f"no tie seen {rec['clean']}, of them not bit-identical {rec['clean_differ']} (worst {rec['clean_worst']:.3g} s); units whose bundle froze a cycle {rec['froze']} (left alone and not bit-identical: {rec['left_froze_differ']}) | {n / (st['ms_total'] / 1e3):.0f} solves/s", flush=True)
-        grp = "smooth" if kind == "smooth" else "tie-prone"
+        grp = "smooth" if kind in ("smooth", "homog") else "tie-prone"
         t = tot.setdefault(grp, dict(units=0, marched=0, marched_differ=0, left=0, left_tied=0, escapees=0, beyond_5e5=0, worst=0.0, clean=0, clean_differ=0, clean_worst=0.0, froze=0, left_froze_differ=0))
         for k2 in rec:
             t[k2] = max(t[k2], rec[k2]) if k2 in ("worst", "clean_worst") else t[k2] + rec[k2]
