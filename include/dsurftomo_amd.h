@@ -256,10 +256,14 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  *                the reference's march itself (four units per wavefront; field, refined snapshot and receiver times then the reference's bit for bit):
  *                  - a unit holding a tie whose influence exceeds "tie_threshold";
  *                  - "tie_map_strict" (on): on a map where some unit holds such a tie -- a tie-prone medium: sharp contrasts, second-order stencils
- *                    switching along ridges, where a one-ulp difference grows downstream -- every unit holding a tie with ANY influence.
+ *                    switching along ridges, where a one-ulp difference grows downstream -- every unit holding a tie with ANY influence;
+ *                  - a unit in which the hand-off's tie decides whether a node the coarse grid receives is alive (a difference of first order, not
+ *                    an ulp) -- except where the refined box's slowness does not vary along x (a 1-D model: the two choices are mirror images);
+ *                  - a unit whose band march could not leave its tree a heap, or whose bundle froze a cycle ("tie_frozen_bundles").
  *                What stays with the fixed point: units without a tie (measured: bit-identical to the reference but for 5 of 83 000 such units, off by an
  *                ulp at a receiver: DESIGN.md "Ties", known residuals), and -- on maps where no tie reaches the threshold -- units holding ties of an
- *                ulp or two: within 1e-4 s of the reference BY MEASUREMENT (worst of 256 000 smooth-medium units x 32 receivers: 8.8e-5 s), not by
+ *                ulp or two: within 1e-4 s of the reference BY MEASUREMENT (about 450 000 smooth-medium units x 32 receivers: worst 5.7e-6 s at 121^2-193^2,
+ *                9.5e-5 s at 1025^2 -- the margin shrinks with the grid: 1.7e-4 s seen at 4097^2, where mode 2 or tie_threshold = 0 is the answer), not by
  *                construction (DSA_STAT_TIE_UNITS_TIED counts them, the
  *                shim says so once per call).  No rule on a unit's own ties -- largest, summed, counted influence -- separates the rare unit that ends
  *                beyond 1e-4 s from the thousands that do not (profiles/r06_tie_rule_scan_*.log).
