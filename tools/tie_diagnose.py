@@ -8,8 +8,9 @@ is) that set the difference off sits there.  No oracle involved: exact_ties = 2 
    python3 tools/tie_diagnose.py [nx] [sources] [periods] [medium] [seed offset] [units to look at]"""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import synth
+import fuzz_sources; fuzz_sources.install()      # (DSA_FUZZ_INNER, DSA_FUZZ_SNAP: the sources of a tie_fuzz.py call again)
 from dsurftomo_amd.engine import Engine
 
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 131

@@ -6,23 +6,11 @@ differ from the march (what the census does not see).  No oracle involved.
    python3 tools/tie_fuzz.py [first seed offset] [calls per medium]"""
 import sys, os, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import synth
 from dsurftomo_amd.engine import Engine
 
-if os.environ.get("DSA_FUZZ_INNER"):      # (sources over this fraction of the grid instead of the inner 90 %: 1.0 puts some on the very edge)
-    _inner = float(os.environ["DSA_FUZZ_INNER"]); _src = synth.sources
-    synth.sources = lambda nx, nsrc, gd=8, inner=0.90, seed=synth.SEED: _src(nx, nsrc, gd, _inner, seed)
-if os.environ.get("DSA_FUZZ_SNAP"):       # (a third of the sources exactly on a node line in x, a third in z -- some on a node: symmetric fronts, exact ties by construction)
-    _src2 = synth.sources
-    def _snapped(nx, nsrc, gd=8, inner=0.90, seed=synth.SEED):
-        sx, sz = _src2(nx, nsrc, gd, inner, seed)
-        gox, goz, dnx, dnz = synth.grid_origin(nx, gd)
-        fx = (sx - gox) / dnx; fz = (sz - goz) / dnz
-        k = np.arange(nsrc)
-        fx = np.where(k % 3 == 0, np.round(fx), fx); fz = np.where(k % 3 != 2, fz, np.round(fz)); fz = np.where(k % 9 == 0, np.round(fz), fz)
-        return (gox + fx.astype(np.float32) * dnx).astype(np.float32), (goz + fz.astype(np.float32) * dnz).astype(np.float32)
-    synth.sources = _snapped
+import fuzz_sources; fuzz_sources.install()      # (DSA_FUZZ_INNER, DSA_FUZZ_SNAP: where the sources go)
 DICING = int(os.environ.get("DSA_FUZZ_DICING", "8"))
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 ncalls = int(sys.argv[2]) if len(sys.argv) > 2 else 1
