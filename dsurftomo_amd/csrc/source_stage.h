@@ -273,6 +273,24 @@ DSA_HD int handoff_node(const GridDesc& g, const SourceDesc& s, const SourceScra
         touch = touch || st.aj[d] || st.ak[d];
     }
     if (!touch) { *tout = kInf; return -1; }
+    // The reference's trial value of a node in the narrow band is the one fouds2 wrote at the LAST acceptance of one of its near neighbours (:431-485:
+    // only the four near neighbours of an accepted node are evaluated again) -- from the nodes alive THEN.  An outer neighbour accepted after that
+    // never reached this node's value.  In key order that cannot matter (an outer node accepted later than the near one in front of it is not smaller,
+    // so the second-order leg is not taken either way); it does where the march ran out of key order: the source cell's corners, accepted by the
+    // start-up march under their raised keys (a corner at 0.0092 s third, its neighbour at 0.0050 s sixth: the node beyond the corner keeps the
+    // first-order value of accept 3).  So an outer node counts only if it was accepted no later than the last of the alive near neighbours
+    // (accept_rank orders pinned nodes by their accept numbers, ahead of every other node).
+    {
+        uint64_t rlast = 0;
+        for (int d = 0; d < 2; ++d) {
+            const uint64_t a = st.aj[d] ? accept_rank(rj[d].T, rj[d].tau) : 0, c = st.ak[d] ? accept_rank(rk[d].T, rk[d].tau) : 0;
+            rlast = a > rlast ? a : rlast; rlast = c > rlast ? c : rlast;
+        }
+        for (int d = 0; d < 2; ++d) {
+            if (st.oj[d] && accept_rank(rj2[d].T, rj2[d].tau) > rlast) { st.oj[d] = false; st.tj2[d] = kInf; }
+            if (st.ok[d] && accept_rank(rk2[d].T, rk2[d].tau) > rlast) { st.ok[d] = false; st.tk2[d] = kInf; }
+        }
+    }
     NodeGeom ng = { g.earth, w.risti_r[ix - 1], s.rdnx, s.rdnz };
     *tout = fouds2(st, w.slow_r[rec_index(s.nbz_r, iz - 1, ix - 1)], ng);
     if (iz == ez && ix == ex) return 0;

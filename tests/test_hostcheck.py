@@ -119,6 +119,32 @@ def test_stencil_bitwise_against_oracle(H):
     assert nmis == 0
 
 
+def test_trial_value_behind_a_corner_accepted_out_of_key_order(H):
+    """Round 6 (tools/tie_fuzz.py, sources on node lines up to the grid's edge): a node of the refined box's narrow band whose near neighbour is a
+    corner of the source cell accepted under a raised key (third, at 0.0092 s) while the node behind that corner (0.0050 s) was accepted sixth --
+    the reference's trial value is the FIRST-order one fouds2 wrote at accept 3 (CalSurfG.f90:431-485: only near neighbours are evaluated again);
+    the hand-off took the alive set at the exit and got the second-order value, 3 ulps lower, 4.6e-5 s downstream.  Snapshot (trial values
+    included) and coarse field against the oracle, bit for bit."""
+    nx, gd = 67, 8
+    g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
+    pv = synth.medium(nx, "checker", 9)
+    veln = L.o_gridder(g, pv)
+    N = g.nnx
+    sx = np.float32(g.gox + np.float32(57.881752) * g.dnx)
+    sz = np.float32(g.goz + np.float32(511.79425) * g.dnz)
+    o = L.o_solve(g, pv, veln, sx, sz)
+    T = np.zeros((N, N), np.float32); Tr = np.zeros(129 * 129, np.float32); Sr = np.zeros(129 * 129, np.int32)
+    it = np.zeros((N, N), np.float32); is_ = np.zeros((N, N), np.int32); box = np.zeros(6, np.int32); st = np.zeros(4, np.int64)
+    assert H.hc_solve_source(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd, L.ptr(pv), sx, sz, L.ptr(T), L.ptr(Tr),
+                             L.ptr(Sr), L.ptr(it), L.ptr(is_), L.ptr(box), L.ptr(st)) == 0
+    n = box[4] * box[5]
+    Trh = Tr[:n].reshape(box[4], box[5]); Srh = Sr[:n].reshape(box[4], box[5])
+    assert (np.sign(o["Sr"]).clip(-1, 1) != np.sign(Srh).clip(-1, 1)).sum() == 0
+    known = o["Sr"] >= 0                                        # alive nodes and the narrow band's trial values
+    assert (bits(Trh[known]) != bits(o["Tr"][known])).sum() == 0
+    assert (bits(T) != bits(o["T"])).sum() == 0
+
+
 @pytest.mark.parametrize("nx,kind,gd", [(18, "homog", 8), (18, "smooth", 8), (18, "smooth", 5), (35, "checker4", 8)])
 def test_pipeline_against_oracle(H, nx, kind, gd):
     g = L.grid(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, gd)
