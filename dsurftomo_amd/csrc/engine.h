@@ -34,6 +34,7 @@ constexpr float kDefaultTieSumThreshold = 0.0f;
 constexpr int kDefaultTieCountThreshold = 0;
 constexpr int kDefaultTieFrozenBundles = 0;
 constexpr int kDefaultTieMapStrict = 1;
+constexpr float kTieUlpsAt1025 = 26.0f;      // what a receiver time of the fixed point differs by from the reference's downstream of one-ulp ties, at most, in ulps, on grids up to 1025 nodes per side (measured: 25; Engine::tie_verdicts)
 // Rays of a launch up to which four lanes trace a ray together (ray_kernels.hip: launch_rays; profiles/r05_ab_rays.log)
 constexpr int kRayGroupMax = 81920;
 
@@ -183,6 +184,11 @@ struct Engine {
     int tie_count_threshold = kDefaultTieCountThreshold;    // option tie_count_threshold: ... or that holds more ties with an influence than this; 0 = off
     int tie_frozen_bundles = kDefaultTieFrozenBundles;      // option tie_frozen_bundles: 1 = every member of a bundle that froze a cycle is flagged
     int bundle_order_opt = 0;          // option bundle_order: 0 = the first generation's bundles longest first | 1 = bundles of similar length on one CU (plan_bundles)
+    int tie_scale_guard = 1;           // option tie_scale_guard: units whose time scale lies outside the measured envelope of the fixed point's tie errors are marched when they hold a tie (Engine::tie_verdicts)
+    float tie_tolerance = 1.0e-4f;     // option tie_tolerance: the bar the envelope is held against (s)
+    std::vector<float> h_unit_reach_km;                    // per planned unit: great-circle distance to its farthest receiver (plan)
+    std::vector<float> map_mean_slow;                      // per map: mean slowness of its vertices (set_maps)
+    void mean_slowness_of_maps(const float* hv, size_t nv, int nm);
     int tie_map_strict = kDefaultTieMapStrict;              // option tie_map_strict: on a map where some unit holds a tie above tie_threshold, every unit holding a tie with any influence is flagged
     int tie_verdict(int unit, const int32_t* tie_words, const int32_t* info16, bool member);
     std::vector<char> tie_verdicts(int first, int n, const int32_t* tie_words, const int32_t* info16, bool bundled);

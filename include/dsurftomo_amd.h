@@ -259,11 +259,16 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  *                    switching along ridges, where a one-ulp difference grows downstream -- every unit holding a tie with ANY influence;
  *                  - a unit in which the hand-off's tie decides whether a node the coarse grid receives is alive (a difference of first order, not
  *                    an ulp) -- except where the refined box's slowness does not vary along x (a 1-D model: the two choices are mirror images);
- *                  - a unit whose band march could not leave its tree a heap, or whose bundle froze a cycle ("tie_frozen_bundles").
+ *                  - a unit whose band march could not leave its tree a heap, or whose bundle froze a cycle ("tie_frozen_bundles");
+ *                  - "tie_scale_guard" (on): a unit holding a tie whose times lie outside the MEASURED ENVELOPE.  Downstream of one-ulp ties the fixed
+ *                    point's field differs from the reference's by a number of ulps of the travel time that grows with the grid -- at a receiver at
+ *                    most 25 ulps on grids up to 1025 nodes per side (2 M fuzzed units), 35 at 2049^2, 110 at 4097^2 -- so against the absolute bar
+ *                    ("tie_tolerance", 1e-4 s) it is the size of the times that decides: a unit whose farthest receiver (great-circle distance x the
+ *                    map's mean slowness) lies at 64 s or beyond on grids up to 1025^2 -- 32 s at 2049^2, 16 s at 4097^2 -- is marched.
  *                What stays with the fixed point: units without a tie (measured: bit-identical to the reference but for 5 of 83 000 such units, off by an
  *                ulp at a receiver: DESIGN.md "Ties", known residuals), and -- on maps where no tie reaches the threshold -- units holding ties of an
  *                ulp or two: within 1e-4 s of the reference BY MEASUREMENT (about 450 000 smooth-medium units x 32 receivers: worst 5.7e-6 s at 121^2-193^2,
- *                9.5e-5 s at 1025^2 -- the margin shrinks with the grid: 1.7e-4 s seen at 4097^2, where mode 2 or tie_threshold = 0 is the answer), not by
+ *                9.5e-5 s at 1025^2 with times of 32-64 s: the envelope the scale guard above holds the call to), not by
  *                construction (DSA_STAT_TIE_UNITS_TIED counts them, the
  *                shim says so once per call).  No rule on a unit's own ties -- largest, summed, counted influence -- separates the rare unit that ends
  *                beyond 1e-4 s from the thousands that do not (profiles/r06_tie_rule_scan_*.log).
@@ -310,6 +315,8 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
        DSA_STAT_TIE_PRONE_MAPS,       /* maps on which some unit held a tie above tie_threshold, summed over the call's launches */
        DSA_STAT_TIE_UNITS_TIED,       /* units that stayed with the fixed point although the census found a tie with an influence in them: their times are the
                                          reference's to ~1e-4 s statistically, not by construction (DESIGN.md "Ties") */
+       DSA_STAT_TIE_UNITS_BY_SCALE,   /* of DSA_STAT_TIE_UNITS: flagged because they hold a tie and their travel times lie outside the envelope in which the
+                                         fixed point's tie errors were measured to stay within the tolerance (option tie_scale_guard) */
        DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 

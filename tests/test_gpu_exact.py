@@ -285,3 +285,38 @@ def test_a_unit_without_a_tie_carries_the_marchs_bits(exact, nx, kind, seed, nsr
         ok = ok and bool((seen | same).all())
     parity_log.add(f"census N={e.nnx} {kind} source {src} ({what}): " + " | ".join(lines))
     assert ok, (what, lines)
+
+
+def test_units_outside_the_measured_envelope_are_marched(exact):
+    """Option tie_scale_guard (round 6): downstream of one-ulp ties the fixed point's receiver times differ from the reference's by up to 25 ulps on
+    grids up to 1025 nodes per side -- within 1e-4 s only while the times stay below 64 s -- and by more on larger grids (2049^2 smooth medium: 207 of
+    8 000 units beyond 1e-4 s, worst 2.7e-4 s, none of them flagged by a tie rule: profiles/r06_tie_scale_guard.log).  A unit that holds a tie and whose
+    time scale (reach x the map's mean slowness) lies outside that envelope goes to the march.  (a) 257^2, the bar lowered to 2e-6 s: every unit with a
+    tie is marched by its time scale, the rest holds no tie; (b) 2049^2, the default bar: the same; both bit-identical to exact_ties = 2."""
+    e = exact
+    for nx, nsrc, nper, nrec, tol in ((35, 64, 4, 8, 2e-6), (259, 4, 2, 4, 1e-4)):
+        u = synth.units(nx, nsrc, nper, nrec, seed=synth.SEED + 77)
+        pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+        e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv)
+        e.set_option("exact_ties", 2)
+        tx = e.traveltimes(**u)
+        e.set_option("exact_ties", 1); e.set_option("tie_tolerance", tol)
+        t1 = e.traveltimes(**u)
+        st = e.stats()
+        flags, _ = e.unit_ties()
+        cnt, _, fr = e.unit_tie_sums()
+        marched = (flags & 2) != 0
+        n = nsrc * nper
+        assert st["tie_units_by_scale"] > 0 and st["tie_units_tied"] == 0
+        assert ((cnt > 0) <= marched).all()                     # every unit that holds a tie went to the march
+        assert (bits(t1.reshape(n, nrec)[marched]) == bits(tx.reshape(n, nrec)[marched])).all()
+        worst = float(np.abs(t1.astype(np.float64) - tx.astype(np.float64)).max())
+        assert worst <= TOL
+        # the guard off: the same call leaves its tied units to the fixed point
+        e.set_option("tie_scale_guard", 0)
+        e.traveltimes(**u)
+        st0 = e.stats()
+        e.set_option("tie_scale_guard", 1)
+        assert st0["tie_units_by_scale"] == 0 and st0["tie_units_tied"] > 0
+        parity_log.add(f"scale guard N={e.nnx} smooth, bar {tol:g} s: {int(marched.sum())} of {n} units marched ({int(st['tie_units_by_scale'])} by the size of their times), "
+                       f"worst |dt| against exact_ties = 2 {worst:.3g} s; guard off: {int(st0['tie_units_tied'])} tied units left to the fixed point")

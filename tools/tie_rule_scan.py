@@ -66,6 +66,6 @@ fl1, _ = e.unit_ties()
 marched = (fl1 & 2) != 0
 d1 = np.abs(t1.astype(np.float64) - tx.astype(np.float64)).max(axis=1)
 print(f"   DEFAULT MODE (exact_ties = 1, tie_threshold 2e-5, tie_map_strict on): {n / (st1['ms_total'] / 1e3):.0f} solves/s ({st1['ms_total']:.0f} ms, march {st1['ms_exact']:.0f} ms); marched {int(marched.sum())} units ({100.0 * marched.mean():.2f} %), "
-      f"{int(st1['tie_units_strict'])} of them by their map, {int(st1['tie_prone_maps'])} maps tie-prone; marched units not bit-identical to exact_ties = 2: {int((d1[marched] > 0).sum())}; "
+      f"{int(st1['tie_units_strict'])} of them by their map, {int(st1.get('tie_units_by_scale', 0))} by the size of their times, {int(st1['tie_prone_maps'])} maps tie-prone; marched units not bit-identical to exact_ties = 2: {int((d1[marched] > 0).sum())}; "
       f"units left to the fixed point: worst {d1[~marched].max() if (~marched).any() else 0.0:.4g} s, beyond 1e-4 s {int((d1[~marched] > 1e-4).sum())}, beyond 5e-5 {int((d1[~marched] > 5e-5).sum())}, holding a tie with an influence {int(st1['tie_units_tied'])}")
 e.close()
