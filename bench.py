@@ -157,7 +157,7 @@ def exact_secondary(eng, with_reference=True):
         d = np.abs(t1.astype(np.float64) - tx.astype(np.float64)).max(axis=1)
         left_beyond = int((d[~marched] > TOL).sum())
         out["exact_ties1"] = {"mode": "exact_ties=1 (the default): fixed point + census of its exact ties, literal march for the flagged units (a tie above tie_threshold 2e-5 s; on a map where some unit holds one, every unit holding a tie with any influence)",
-                              "tie_prone_maps": int(st1.get("tie_prone_maps", 0)), "flagged_by_their_map": int(st1.get("tie_units_strict", 0)),
+                              "tie_prone_maps": int(st1.get("tie_prone_maps", 0)), "flagged_by_their_map": int(st1.get("tie_units_strict", 0)), "flagged_for_the_size_of_their_times": int(st1.get("tie_units_by_scale", 0)),
                               "units_left_alone_holding_a_tie_with_an_influence": int(st1.get("tie_units_tied", 0)),
                               "solves_per_s": round(n / (st1["ms_total"] / 1e3), 1), "ms": round(st1["ms_total"], 1), "ms_march": round(st1["ms_exact"], 1), "ms_first_call": round(first_ms, 1),
                               "flagged_fraction": round(float(marched.mean()), 4), "flagged_units": int(marched.sum()),
@@ -662,11 +662,14 @@ def main():
                                      "influence exceeds tie_threshold (2e-5 s), and (tie_map_strict) every unit holding a tie with any influence on a map where some unit holds such a tie",
                              "census_flagged_units_last_step": int(st.get("tie_units", 0)), "marched_units_last_step": int(st.get("exact_units", 0)),
                              "tie_prone_maps_last_step": int(st.get("tie_prone_maps", 0)),
+                             "marched_for_the_size_of_their_times_last_step": int(st.get("tie_units_by_scale", 0)),
                              "units_left_to_the_fixed_point_holding_a_tie_with_an_influence": int(st.get("tie_units_tied", 0)),
                              "largest_tie_influence_s": float(st.get("tie_influence_max", 0.0)),
                              "note": "no tie on these maps reaches tie_threshold (largest: one or two ulps of the travel time), so nothing is marched; the units that hold such "
                                      "small ties stay with the fixed point, whose times are the reference's to 1e-4 s by measurement, not by construction: "
-                                     "secondary.headline_all_receivers checks every receiver time of the call against exact_ties = 2"},
+                                     "secondary.headline_all_receivers checks every receiver time of the call against exact_ties = 2.  The measurement behind it is an envelope -- at "
+                                     "most 25 ulps of the travel time at a receiver on grids up to 1025^2, i.e. within 1e-4 s while the times stay below 64 s, as this call's do; a unit "
+                                     "that holds a tie and lies outside (longer paths, larger grids) is marched (option tie_scale_guard; DESIGN.md 'Ties')"},
         }
         if not args.no_cpu_baseline:
             # N = 1: the bounded CPU baseline (its times are the parity reference).  N > 1: no baseline line (contract), but the
