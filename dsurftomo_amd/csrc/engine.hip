@@ -396,7 +396,7 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
             const int data = (data_first ? data_first[u] : h_src[u].first_ray) + k;
             if (data < 0 || (k == 0 && u > 0 && h_src[u - 1].nrec > 0 && data < h_rays[h_src[u - 1].first_ray].data)) { fail(DSA_ERR_ARGUMENT, "plan: data indices must be non-negative and non-decreasing (unit %d)", u); return DSA_ERR_ARGUMENT; }
             h_rays[r] = RayDesc{ u, rx, rz, sinf(rx), data, fl };
-            if (fl & kRayTime) {      // the unit's reach: the great-circle distance to its farthest receiver (km; the scale of its travel times, tie_verdicts)
+            if (fl & (kRayTime | kRayPath)) {      // the unit's reach: the great-circle distance to its farthest receiver (km; the scale of its travel times, tie_verdicts)
                 const float dc = rx - h_src[u].scx, dl = (rz - h_src[u].scz) * sinf(0.5f * (rx + h_src[u].scx));
                 const float km = g.earth * sqrtf(dc * dc + dl * dl);
                 if (km > h_unit_reach_km[(size_t)u]) h_unit_reach_km[(size_t)u] = km;
