@@ -630,7 +630,7 @@ std::vector<char> Engine::tie_verdicts(int first, int n, const int32_t* tie_word
     // Against the absolute bar that is a statement about the TIMES: a unit whose farthest receiver lies beyond
     // tie_tolerance / (26 ulps x max(N, 1025) / 1025) -- 64 s on grids up to 1025^2, 32 s at 2049^2, 16 s at 4097^2 -- is outside what was
     // measured, and is marched if it holds a tie with any influence, like a unit on a tie-prone map.  The unit's time scale: its reach (plan) x the
-    // mean slowness of its map (option tie_scale_guard, default on).
+    // mean slowness of its map, plus a tenth (option tie_scale_guard, default on).
     if (tie_scale_guard && exact_ties != 2) {
         const float N = (float)std::max(g.nnx, g.nnz);
         const float ulps = kTieUlpsAt1025 * std::max(N, 1025.0f) / 1025.0f;
@@ -639,7 +639,8 @@ std::vector<char> Engine::tie_verdicts(int first, int n, const int32_t* tie_word
             const size_t gu = (size_t)(first + u);
             if (!(h_unit_tie_count[gu] > 0 || h_unit_froze[gu] > 0)) continue;
             const int p = h_src[gu].period;
-            const float t_scale = h_unit_reach_km[gu] * (p >= 0 && p < (int)map_mean_slow.size() ? map_mean_slow[(size_t)p] : hmin_slow);
+            // (raised by a tenth: a path may run through parts of the map slower than its average)
+            const float t_scale = 1.1f * h_unit_reach_km[gu] * (p >= 0 && p < (int)map_mean_slow.size() ? map_mean_slow[(size_t)p] : hmin_slow);
             int e2 = 0;
             (void)std::frexp(std::max(t_scale, 1e-30f), &e2);            // t_scale in [2^(e2-1), 2^e2): ulp = 2^(e2-24)
             if (ulps * std::ldexp(1.0f, e2 - 24) > tie_tolerance) { fl[(size_t)u] = 1; stats[DSA_STAT_TIE_UNITS_BY_SCALE] += 1.0; }
