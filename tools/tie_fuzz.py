@@ -12,6 +12,7 @@ from dsurftomo_amd.engine import Engine
 
 import fuzz_sources; fuzz_sources.install()      # (DSA_FUZZ_INNER, DSA_FUZZ_SNAP: where the sources go)
 DICING = int(os.environ.get("DSA_FUZZ_DICING", "8"))
+VSCALE = float(os.environ.get("DSA_FUZZ_VSCALE", "1"))      # every velocity times this: 0.8 puts the far units of the 1025^2 calls beyond 64 s -- the edge of the default mode's envelope (tie_scale_guard)
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 ncalls = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 nrec = 32
@@ -29,7 +30,7 @@ for ci, (nx, nsrc, nper, kind) in enumerate(CONFIGS):
         continue
     for call in range(ncalls):
         seed = seed0 + 17 * ci + call
-        pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)])
+        pv = np.stack([synth.medium(nx, kind, p) for p in range(nper)]) * VSCALE
         u = synth.units(nx, nsrc, nper, nrec, gd=DICING, seed=synth.SEED + seed)
         n = nsrc * nper
         e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv, dicing=DICING)
