@@ -625,7 +625,7 @@ std::vector<char> Engine::tie_verdicts(int first, int n, const int32_t* tie_word
             if (!fl[(size_t)u] && p >= 0 && p < nmaps && prone[(size_t)p] && (h_unit_tie_count[(size_t)(first + u)] > 0 || h_unit_froze[(size_t)(first + u)] > 0)) { fl[(size_t)u] = 1; stats[DSA_STAT_TIE_UNITS_STRICT] += 1.0; }
         }
     // The validated envelope of "small ties stay with the fixed point" (round 6, late).  What the fixed point's field differs by from the reference's
-    // downstream of one-ulp ties is a number of ULPS of the travel time, growing with the grid: at most 25 ulps at a receiver on grids up to 1025
+    // downstream of one-ulp ties is a number of ULPS of the travel time, growing with the grid: at most 26 ulps at a receiver on grids up to 1025
     // nodes per side (2 M fuzzed units: 9.5e-5 s at 32-64 s), 35 at 2049^2 (2.7e-4 s), 110 at 4097^2 (1.7e-3 s; profiles/r06_tie_scale_*.log).
     // Against the absolute bar that is a statement about the TIMES: a unit whose farthest receiver lies beyond
     // tie_tolerance / (26 ulps x max(N, 1025) / 1025) -- 64 s on grids up to 1025^2, 32 s at 2049^2, 16 s at 4097^2 -- is outside what was
