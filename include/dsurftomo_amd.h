@@ -56,6 +56,9 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *     tie_threshold            [2e-5]  seconds: the influence on its node's value a tie must have to flag its unit; 0 = any tie
  *     tie_detect               [1]     exact_ties = 0 runs the census too and reports what it would have flagged (DSA_STAT_TIE_UNITS, dsa_unit_ties); 0 = off
  *     tie_map_strict           [1]     on a map where some unit holds a tie above tie_threshold, every unit holding a tie with any influence is flagged; 0 = the per-unit rule alone
+ *     tie_scale_guard          [1]     a unit that holds a tie and whose travel times lie outside the envelope in which the fixed point's tie errors were measured to stay
+ *                                      within tie_tolerance (26 ulps of the time on grids up to 1025 nodes per side, growing with the grid beyond) is flagged; 0 = off
+ *     tie_tolerance            [1e-4]  seconds: the bar that envelope is held to (a lower value marches more units)
  *     tie_sum_threshold        [0]     seconds: a unit whose ties' influences add up to more than this is flagged; 0 = off (measured: separates nothing, see dsa_unit_tie_sums)
  *     tie_count_threshold      [0]     a unit holding more ties with an influence than this is flagged; 0 = off
  *     tie_frozen_bundles       [0]     1 = every member of a bundle that froze a cycle is flagged (a unit-by-unit solve that froze one always is)
