@@ -34,6 +34,7 @@ constexpr float kDefaultTieSumThreshold = 0.0f;
 constexpr int kDefaultTieCountThreshold = 0;
 constexpr int kDefaultTieFrozenBundles = 0;
 constexpr int kDefaultTieMapStrict = 1;
+constexpr int kHandoffReplayCap = 64;        // units of a launch whose refined box the hand-off may march literally (the rest of such units are flagged: the whole unit marched)
 constexpr float kTieUlpsAt1025 = 26.0f;      // what a receiver time of the fixed point differs by from the reference's downstream of one-ulp ties, at most, in ulps, on grids up to 1025 nodes per side (measured: 26 = 9.92e-5 s at 32-64 s, the worst of 2.2 M fuzzed units; Engine::tie_verdicts)
 // Rays of a launch up to which four lanes trace a ray together (ray_kernels.hip: launch_rays; profiles/r05_ab_rays.log)
 constexpr int kRayGroupMax = 81920;
@@ -87,6 +88,9 @@ struct Engine {
     // field slots of the coarse solve (kernels.h: FimEnds): T_c, exc_c and lists_c hold `pool_slots` slots; a launch with more units than
     // slots recycles them (only when nobody needs the fields afterwards: no rows, no exact mode, no keep_fields)
     DevBuf<int> lists_c, pool_gen;
+    DevBuf<int32_t> replay_list;       // (round 6) units whose refined box is marched literally behind the hand-off's probe: [0] count, [1 ..] units (kernels.h launch_handoff)
+    DevBuf<unsigned char> replay_scratch;
+    int handoff_replay = 1;            // option handoff_replay: 1 = as above; 0 = a hand-off tie that changes what the coarse grid receives flags the unit (the whole unit marched)
     DevBuf<FimEnds> ends_c;
     size_t lists_c_stride = 0;
     int pool_slots = 0;

@@ -468,7 +468,8 @@ int Engine::plan(int nunits, const int* map_index, const float* scx, const float
         ensure(rst, C * kRWin * kRWin) || ensure(cst, C * kCWinMax * kCWinMax) || ensure(cinit, C * kCWinMax * kCWinMax) ||
         ensure(heap, C * kHeapCap) || ensure(flags, C * 4) || ensure(T_c, PS * nrec_c) || ensure(exc_c, PS << exc_log2cap) || ensure(W_c, C * kCWinMax * kCWinMax) ||
         ensure(seed_c, C * kSeedC) || ensure(nseed_c, C) || ensure(launch_rank, C) || ensure(prob_r, C) || ensure(prob_c, C) || ensure(info, C * 16) || ensure(clocks, C * kClockSlots) ||
-        ensure(tieinfo, C * kTieWords) || ensure(xinfo, C * 4) || ensure(x_units, C)) return status;
+        ensure(tieinfo, C * kTieWords) || ensure(xinfo, C * 4) || ensure(x_units, C) ||
+        ensure(replay_list, kHandoffReplayCap + 1) || ensure(replay_scratch, (size_t)kHandoffReplayCap * handoff_replay_bytes())) return status;
     h_unit_flags.assign((size_t)nunits, 0);
     h_unit_tie.assign((size_t)nunits, 0.0f);
     h_unit_tie_sum.assign((size_t)nunits, 0.0f); h_unit_tie_count.assign((size_t)nunits, 0); h_unit_froze.assign((size_t)nunits, 0);
@@ -800,7 +801,9 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
         } else if (exact_ties != 2) launch_fim(prob_r.p, n, sr, stream);
         HIP_TRY(this, hipEventRecord(events[3], stream));
         if (exact_ties != 2) {
-            launch_handoff(g, b, n, stream, detect ? tieinfo.p : nullptr, tie_threshold);
+            const bool replay = detect && handoff_replay;
+            if (replay) HIP_TRY(this, hipMemsetAsync(replay_list.p, 0, sizeof(int32_t), stream));
+            launch_handoff(g, b, n, stream, detect ? tieinfo.p : nullptr, tie_threshold, replay ? replay_list.p : nullptr, kHandoffReplayCap, replay_scratch.p, xinfo.p);
             launch_coarse_march(g, b, n, slow.p, nrec_c, risti_c.p, stream, detect ? tieinfo.p : nullptr);
         }
         HIP_TRY(this, hipEventRecord(events[4], stream));
@@ -826,7 +829,10 @@ int Engine::solve(float* dsurf, float* rw, int* iw, int* col, long long cap, lon
                 std::vector<int32_t> h_tie((size_t)n * kTieWords), h_inf((size_t)n * 16);
                 HIP_TRY(this, hipMemcpyAsync(h_tie.data(), tieinfo.p, (size_t)n * kTieWords * 4, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(this, hipMemcpyAsync(h_inf.data(), info.p, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
+                int32_t h_replayed = 0;
+                if (handoff_replay) HIP_TRY(this, hipMemcpyAsync(&h_replayed, replay_list.p, 4, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(this, hipStreamSynchronize(stream));
+                stats[DSA_STAT_HANDOFFS_REPLAYED] += (double)std::min<int32_t>(h_replayed, kHandoffReplayCap);
                 //  a chunk that is about to be solved again -- exception table overflow, a refined or a coarse bundle that gave up: the
                 // checks behind the receivers below -- is not marched now: its flagged units would march twice and keep flags of the abandoned attempt
                 bool will_redo = false;
@@ -1671,6 +1677,7 @@ int dsa_set_option(dsa_engine* e, const char* name, double value)
     if (n == "tie_frozen_bundles" && (value == 0 || value == 1)) { en->tie_frozen_bundles = (int)value; return 0; }
     if (n == "tie_map_strict" && (value == 0 || value == 1)) { en->tie_map_strict = (int)value; return 0; }
     if (n == "tie_scale_guard" && (value == 0 || value == 1)) { en->tie_scale_guard = (int)value; return 0; }
+    if (n == "handoff_replay" && (value == 0 || value == 1)) { en->handoff_replay = (int)value; return 0; }
     if (n == "tie_tolerance" && value > 0) { en->tie_tolerance = (float)value; return 0; }
     if (n == "bundle_order" && (value == 0 || value == 1 || value == 2 || value == 3)) { en->bundle_order_opt = (int)value; return 0; }
     if (n == "tie_list" && (value == 0 || value == 1)) { en->tie_list_opt = (int)value; return 0; }

@@ -595,9 +595,11 @@ template <bool REFINED, bool POOLED = false>
 __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const int* __restrict__ units, int n, const float* __restrict__ slow_all,
                                                size_t field_stride, const float* __restrict__ risti_c, unsigned* pool, size_t pool_stride,
                                                XEntry* heap_pool, int gcap, int lcap, const XStart* __restrict__ starts, const int* __restrict__ nstart,
-                                               int32_t* xinfo, unsigned long long* clk, XTilePool tpool, int gstride, int lb)
+                                               int32_t* xinfo, unsigned long long* clk, XTilePool tpool, int gstride, int lb, const int* n_dev)
 {
     extern __shared__ unsigned char x_lds[];
+    if (n_dev) { const int c = *n_dev; n = c < n ? c : n; }      // (the hand-off's replay list: its length is known to the device only)
+    if (n <= 0) return;
     const int lane = threadIdx.x, grp = lane >> 4;
     const bool lead = (lane & 15) == 0;
     const int slot = blockIdx.x * 4 + grp;
@@ -698,9 +700,10 @@ __global__ __launch_bounds__(64) void k_xmarch(GridDesc g, BatchPtrs b, const in
 
 // every record far, value 0 (the reference's nsts = -1): the refined boxes of the batch's units and their pool slots (pooled tiles: the
 // tile tables -- no tile touched -- and the bitmaps of the tiles that must stay, filled by k_xpins)
-__global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restrict__ units, unsigned* pool, size_t pool_stride, int nrec, XTilePool tpool)
+__global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restrict__ units, unsigned* pool, size_t pool_stride, int nrec, XTilePool tpool, const int* n_dev)
 {
     const int slot = blockIdx.y;
+    if (n_dev && slot >= *n_dev) return;
     const int s = units[slot];
     const uint4 v = { 0u, 0xffffffffu, 0u, 0xffffffffu };              // two records {0.0f, -1}
     const uint4 far4 = { kXFar, kXFar, kXFar, kXFar };                 // four packed records (or eight tile-table entries kTNone)
@@ -714,6 +717,7 @@ __global__ __launch_bounds__(256) void k_xfill(BatchPtrs b, const int* __restric
         for (size_t i = t; i < tpool.pins_stride; i += step) pins[i] = 0u;
         return;
     }
+    if (!pool) return;                 // (the refined boxes alone: launch_refined_replay)
     uint4* const Fc = (uint4*)(pool + (size_t)slot * pool_stride);
     for (size_t i = t; i < (size_t)nrec / 4; i += step) Fc[i] = far4;
 }
@@ -905,21 +909,35 @@ void launch_exact(const GridDesc& g, const BatchPtrs& b, const int* d_units, int
         tp.freestk = (unsigned short*)tiles->freestk; tp.pins = (unsigned*)tiles->pins; tp.pins_stride = ((size_t)ntile + 31) / 32; tp.tcap = tiles->tcap;
     }
     const int fill_blocks = (int)std::min<size_t>(((size_t)nrec / 2 + 255) / 256, 64);
-    hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (unsigned*)d_pool, pool_stride, nrec, tp);
+    hipLaunchKernelGGL(k_xfill, dim3(fill_blocks, n), dim3(256), 0, stream, b, d_units, (unsigned*)d_pool, pool_stride, nrec, tp, (const int*)nullptr);
     if (tiles && rc) hipLaunchKernelGGL(k_xpins, dim3(n), dim3(64), 0, stream, g, b, d_units, rc->rays, tp);
     const int waves = (n + 3) / 4;
     hipLaunchKernelGGL((k_xmarch<true, false>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb);
+                       (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb, (const int*)nullptr);
     hipLaunchKernelGGL(k_xhandoff, dim3(n), dim3(64), 0, stream, g, b, d_units, (unsigned*)d_pool, pool_stride, (XStart*)d_starts, d_nstart, tiles ? 1 : 0);
     if (tiles)
         hipLaunchKernelGGL((k_xmarch<false, true>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb);
+                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb, (const int*)nullptr);
     else
         hipLaunchKernelGGL((k_xmarch<false, false>), dim3(waves), dim3(64), lds, stream, g, b, d_units, n, d_slow_all, field_stride, d_risti_c, (unsigned*)d_pool, pool_stride,
-                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb);
+                           (XEntry*)d_heap_pool, gcap, lcap, (const XStart*)d_starts, (const int*)d_nstart, d_xinfo, d_clocks, tp, gstride, lb, (const int*)nullptr);
     if (compact_copy && !tiles) hipLaunchKernelGGL(k_xfinish, dim3(fill_blocks, n), dim3(256), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, nrec);
     if (rc) hipLaunchKernelGGL(k_xreceivers, dim3(n), dim3(64), 0, stream, g, b, d_units, (const unsigned*)d_pool, pool_stride, rc->rays, rc->veln_all, rc->veln_stride,
                                rc->dpl, rc->out, rc->err, tp);
+}
+
+// (round 6, last) the refined boxes of the units the hand-off's probe listed (d_list[0] = how many, known to the device only; d_list[1 ..] = the units),
+// by the march: the records b.F_r of those units hold the march's (T, status) afterwards (kernels.h launch_handoff; stage_kernels.hip k_handoff_replay
+// turns them into a refined stage that ended by itself).  A unit's tree: 1023 slots in LDS, `gcap` more at d_heap + slot * gcap.
+void launch_refined_replay(const GridDesc& g, const BatchPtrs& b, const int32_t* d_list, int cap, void* d_heap, int gcap, int32_t* d_xinfo, hipStream_t stream)
+{
+    if (cap <= 0) return;
+    const int lcap = 1023;
+    const size_t lds = exact_lds_bytes(lcap);
+    XTilePool tp{};
+    hipLaunchKernelGGL(k_xfill, dim3(64, cap), dim3(256), 0, stream, b, (const int*)(d_list + 1), (unsigned*)nullptr, (size_t)0, 0, tp, (const int*)d_list);
+    hipLaunchKernelGGL((k_xmarch<true, false>), dim3((cap + 3) / 4), dim3(64), lds, stream, g, b, (const int*)(d_list + 1), cap, (const float*)nullptr, (size_t)0, (const float*)nullptr,
+                       (unsigned*)nullptr, (size_t)0, (XEntry*)d_heap, gcap, lcap, (const XStart*)nullptr, (const int*)nullptr, d_xinfo, (unsigned long long*)nullptr, tp, gcap, 0, (const int*)d_list);
 }
 
 }  // namespace dsa

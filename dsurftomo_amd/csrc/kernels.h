@@ -187,7 +187,12 @@ constexpr int kSeedC = kCWinMax * kCWinMax + 4 * kCWinMax;    // every node of t
 void launch_refine(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_velv_all, size_t velv_stride,
                    const float* d_rbasis, hipStream_t stream);
 void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream);
-void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream, int32_t* d_tie = nullptr /* the units' tie records: the hand-off probes its rank ties */, float tie_threshold = 0.0f);
+void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream, int32_t* d_tie = nullptr /* the units' tie records: the hand-off probes its rank ties */, float tie_threshold = 0.0f,
+                    int32_t* d_replay = nullptr /* [0] count (zeroed by the caller), [1 ..] units whose refined box is marched literally: k_handoff_replay */, int replay_cap = 0,
+                    void* d_replay_scratch = nullptr /* replay_cap x handoff_replay_bytes() */, int32_t* d_xinfo = nullptr /* four words per unit: the replayed marches' accepts and guards */);
+constexpr int kReplayHeap = 4096;                    // tree slots of a replayed refined march beyond its LDS part (narrow bands of a 129^2 box: a few hundred)
+constexpr size_t handoff_replay_bytes() { return (size_t)kReplayHeap * 8; }      // per listed unit: tree entries
+void launch_refined_replay(const GridDesc& g, const BatchPtrs& b, const int32_t* d_list, int cap, void* d_heap, int gcap, int32_t* d_xinfo, hipStream_t stream);     // exact_kernel.hip
 void launch_coarse_march(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,
                          size_t field_stride, const float* d_risti_c, hipStream_t stream, int32_t* d_tie = nullptr /* the units' tie records: a band march that leaves its tree no heap says so */);
 void launch_make_problems(const GridDesc& g, const BatchPtrs& b, int nsrc, const float* d_slow_all,

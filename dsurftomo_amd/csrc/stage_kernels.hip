@@ -2,6 +2,7 @@
 // source_stage.h, and the receiver gather.  See kernels.h for the data layout.
 #include "kernels.h"
 #include "receiver_core.h"
+#include "exact_march.h"
 
 namespace dsa {
 
@@ -129,11 +130,10 @@ void launch_refined_startup(const GridDesc& g, const BatchPtrs& b, int nsrc, hip
 
 // ---------------------------------------------------------------------------------------------
 // K2c: hand-off, one workgroup per source
-__global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
+// the hand-off of ONE unit by the threads of a workgroup (k_handoff: 256 of them; k_handoff_replay: 64)
+__device__ __forceinline__ void handoff_unit(const GridDesc& g, const BatchPtrs& b, int s, unsigned long long& s_best, int& s_first)
 {
-    __shared__ unsigned long long s_best;
-    __shared__ int s_first;
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const SourceDesc sd = b.src[s];
     SourceScratch w = scratch_of(b, s);
     const int ended = w.flags[0];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
             else if (q < 2 * sd.rnz + sd.rnx) { *iz = 1; *ix = q - 2 * sd.rnz + 1; }
             else { *iz = sd.rnz; *ix = q - 2 * sd.rnz - sd.rnx + 1; }
         };
-        for (int q = tid; q < nper; q += 256) {
+        for (int q = tid; q < nper; q += nt) {
             int iz, ix;
             edge_node(q, &iz, &ix);
             if (!is_open_edge(sd, iz, ix)) continue;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
         __syncthreads();
         const unsigned long long best = s_best;
         if (best != ~0ull)
-            for (int q = tid; q < nper; q += 256) {
+            for (int q = tid; q < nper; q += nt) {
                 int iz, ix;
                 edge_node(q, &iz, &ix);
                 if (!is_open_edge(sd, iz, ix)) continue;
@@ -179,9 +179,9 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     if (tid == 0) { w.flags[2] = ez; w.flags[3] = ex; }
     float* Tfin = b.Tfin_r + s * rr;
     {   // (ix, iz) of id = tid, tid + 256, ... without a division per node
-        const int dq = 256 / sd.rnz, dr = 256 % sd.rnz;
+        const int dq = nt / sd.rnz, dr = nt % sd.rnz;
         int ix0 = tid / sd.rnz, iz0 = tid % sd.rnz;
-        for (int id = tid; id < n; id += 256) {
+        for (int id = tid; id < n; id += nt) {
             float t;
             const int st = handoff_node(g, sd, w, ended, rstar, ez, ex, iz0 + 1, ix0 + 1, &t);
             w.S_r[id] = (int8_t)st;
@@ -193,10 +193,10 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     // coarse window: everything far, then every 8th refined node, then band promotion
     const int wn = sd.cwnx * sd.cwnz;
     Rec* W = b.W_c + (size_t)s * kCWinMax * kCWinMax;           // records of the coarse march window, (cwnz, cwnx) column-major
-    for (int q = tid; q < wn; q += 256) { w.cst[q] = -1; W[q] = Rec{ kInf, kInf }; }
+    for (int q = tid; q < wn; q += nt) { w.cst[q] = -1; W[q] = Rec{ kInf, kInf }; }
     __syncthreads();
     const int bxn = (sd.rnx - 1) / kSgdl + 1, bzn = (sd.rnz - 1) / kSgdl + 1;
-    for (int q = tid; q < bxn * bzn; q += 256) {
+    for (int q = tid; q < bxn * bzn; q += nt) {
         const int l = (q / bzn) * kSgdl + 1, k = (q % bzn) * kSgdl + 1;
         const int cz = sd.vnt + (k - 1) / kSgdl, cx = sd.vnl + (l - 1) / kSgdl;
         const int id = (l - 1) * sd.rnz + (k - 1);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     __syncthreads();
     // alive nodes that touch a far node go back into the band. A promoted node reads as "not far"
     // before and after, so concurrent promotion is order independent.
-    for (int q = tid; q < bxn * bzn; q += 256) {
+    for (int q = tid; q < bxn * bzn; q += nt) {
         const int cx = sd.vnl + q / bzn, cz = sd.vnt + q % bzn;
         int16_t* me = &w.cst[(cx - 1 - sd.cwx0) * sd.cwnz + (cz - 1 - sd.cwz0)];
         if (*me != 0) continue;
@@ -222,13 +222,20 @@ __global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
     }
 }
 
+__global__ __launch_bounds__(256) void k_handoff(GridDesc g, BatchPtrs b)
+{
+    __shared__ unsigned long long s_best;
+    __shared__ int s_first;
+    handoff_unit(g, b, blockIdx.x, s_best, s_first);
+}
+
 // (round 6) The hand-off's tie probe, a kernel of its own behind k_handoff (one workgroup per source; it only reads what k_handoff left).  A node of the box
 // whose acceptance rank TIES with the terminating node's was accepted before it or not as the reference's tree had it -- ref_alive guesses by scan order.
 // Such nodes are collected, and the hand-off's outputs that reach the coarse grid (every kSgdl-th node of the box: status and time) are evaluated once more
 // with the tied node's answer inverted: a changed time is the tie's influence (counted into the unit's tie record like the census' ties: any / sum / above
 // the threshold); a changed STATUS on the lattice, or more ties than the probe holds, counts in word [6] of the record's refined half, which flags the
 // unit by itself (Engine::tie_verdict) -- except in a laterally homogeneous box, where such ties are the grid's symmetry and only count.
-__global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, int32_t* tie, float tie_threshold)
+__global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, int32_t* tie, float tie_threshold, int32_t* replay, int replay_cap)
 {
     constexpr int kTiedMax = 8;
     __shared__ int s_tied[kTiedMax], s_ntied;
@@ -277,10 +284,29 @@ __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, 
     if (tid >= 9) return;
     const float* Tfin = b.Tfin_r + (size_t)s * kRefMax * kRefMax;
     int32_t* const tr = tie + (size_t)s * kTieWords;
-    if (s_ntied > kTiedMax && tid == 0) atomicAdd(tr + 6, 1);
     const int nt = s_ntied < kTiedMax ? s_ntied : kTiedMax;
     // thread z of the first nine looks at the tied node (z = 0) or at one of its eight stencil nodes
     const int dx = tid == 1 ? -1 : tid == 2 ? 1 : tid == 5 ? -2 : tid == 6 ? 2 : 0, dz = tid == 3 ? -1 : tid == 4 ? 1 : tid == 7 ? -2 : tid == 8 ? 2 : 0;
+    if (replay && !homogeneous) {
+        // (round 6, last) A tie that changes what the coarse grid receives is not guessed at and not flagged: the unit goes on a list, and
+        // k_handoff_replay marches its refined box literally (129^2 nodes: the reference's own tree decides) and hands off from that.  A full list,
+        // or a homogeneous box (the symmetric ties of a 1-D model: counted below), keeps the old way.
+        bool change = s_ntied > kTiedMax;
+        for (int k = 0; k < nt && !change; ++k) {
+            const int yid = s_tied[k], zx = yid / sd.rnz + 1 + dx, zz = yid % sd.rnz + 1 + dz;
+            if (!(zx >= 1 && zx <= sd.rnx && zz >= 1 && zz <= sd.rnz && (zx - 1) % kSgdl == 0 && (zz - 1) % kSgdl == 0)) continue;
+            float t1;
+            const int st1 = handoff_node<true>(g, sd, w, 0, rstar, ez, ex, zz, zx, &t1, yid);
+            const int zid = (zx - 1) * sd.rnz + (zz - 1);
+            change = st1 != w.S_r[zid] || (st1 >= 0 && t1 != Tfin[zid]);
+        }
+        if (!__any(change)) return;
+        int slot = 0;
+        if (tid == 0) slot = atomicAdd(replay, 1);
+        slot = __shfl(slot, 0);
+        if (slot < replay_cap) { if (tid == 0) replay[1 + slot] = s; return; }
+    }
+    if (s_ntied > kTiedMax && tid == 0) atomicAdd(tr + 6, 1);
     for (int k = 0; k < nt; ++k) {
         const int yid = s_tied[k], zx = yid / sd.rnz + 1 + dx, zz = yid % sd.rnz + 1 + dz;
         // (only what reaches the coarse grid counts: the nodes k_handoff injects)
@@ -301,11 +327,48 @@ __global__ __launch_bounds__(256) void k_handoff_probe(GridDesc g, BatchPtrs b, 
     }
 }
 
-void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream, int32_t* d_tie, float tie_threshold)
+// (round 6, last) The refined box of a listed unit by the reference's march itself (exact_kernel.hip: launch_refined_replay, k_xmarch<refined> on the unit's
+// own records: ~16 000 accepts at 2.3 us); its state then replaces the fixed point's records in the form of a refined stage that ended by itself
+// (alive nodes pinned, the narrow band's trial values as they stand: handoff_node's first branch), and the hand-off runs again.  What the coarse grid
+// receives is then the reference's, whatever its tree decided about the nodes that rank equal with the terminating one.  A march that runs out of tree
+// slots leaves the hand-off as it was and flags the unit (word [6]).
+static_assert(sizeof(XRec) == sizeof(Rec) && sizeof(XEntry) == 8, "the march's records lie where the fixed point's do");
+
+__global__ __launch_bounds__(64) void k_handoff_replay(GridDesc g, BatchPtrs b, const int32_t* replay, int replay_cap, const int32_t* xinfo, int32_t* tie)
+{
+    __shared__ unsigned long long s_best;
+    __shared__ int s_first;
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int cnt = replay[0] < replay_cap ? replay[0] : replay_cap;
+    if (j >= cnt) return;
+    const int s = replay[1 + j];
+    const SourceDesc sd = b.src[s];
+    SourceScratch w = scratch_of(b, s);
+    // (a march that ran out of tree slots: the hand-off stays as the fixed point left it and the unit is flagged -- marched whole)
+    if (xinfo[4 * s + 2]) { if (lane == 0) atomicAdd(tie + (size_t)s * kTieWords + 6, 1); return; }
+    for (int ix = 0; ix < sd.rnx; ++ix)
+        for (int iz = lane; iz < sd.rnz; iz += 64) {
+            const int id = rec_index(sd.nbz_r, iz, ix);
+            const XRec r = reinterpret_cast<const XRec*>(w.F_r)[id];
+            w.F_r[id] = r.st == 0 ? Rec{ -r.T, r.T } : r.st > 0 ? Rec{ r.T, r.T } : Rec{ kInf, kInf };
+        }
+    if (lane == 0) w.flags[0] = 1;
+    __threadfence_block();
+    __syncthreads();
+    handoff_unit(g, b, s, s_best, s_first);
+}
+
+void launch_handoff(const GridDesc& g, const BatchPtrs& b, int nsrc, hipStream_t stream, int32_t* d_tie, float tie_threshold, int32_t* d_replay, int replay_cap, void* d_replay_scratch,
+                    int32_t* d_xinfo)
 {
     if (nsrc <= 0) return;
     hipLaunchKernelGGL(k_handoff, dim3(nsrc), dim3(256), 0, stream, g, b);
-    if (d_tie) hipLaunchKernelGGL(k_handoff_probe, dim3(nsrc), dim3(256), 0, stream, g, b, d_tie, tie_threshold);
+    const bool replay = d_tie && d_replay && replay_cap > 0 && d_replay_scratch && d_xinfo;
+    if (d_tie) hipLaunchKernelGGL(k_handoff_probe, dim3(nsrc), dim3(256), 0, stream, g, b, d_tie, tie_threshold, replay ? d_replay : nullptr, replay_cap);
+    if (replay) {
+        launch_refined_replay(g, b, d_replay, replay_cap, d_replay_scratch, kReplayHeap, d_xinfo, stream);
+        hipLaunchKernelGGL(k_handoff_replay, dim3(replay_cap), dim3(64), 0, stream, g, b, (const int32_t*)d_replay, replay_cap, (const int32_t*)d_xinfo, d_tie);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

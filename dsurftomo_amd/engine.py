@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DSA_LIB_PATH") or os.path.join(_HERE, "libdsurftomo_a
 
 STAT_NAMES = ("ms_total", "ms_fim_coarse", "ms_fim_refined", "ms_stages", "launches_fim_coarse", "units",
               "rounds_max", "evals_total", "chunk", "rescans", "freezes", "rays", "ray_steps", "rays_clamped",
-              "ms_rays", "ms_rows", "nar", "ms_dispersion", "curves", "changes_total", "tie_units", "exact_units", "exact_pops", "ms_exact", "field_slots", "footprint_mb", "bundle_size", "bundles", "bundled_units", "bundle_slots", "bundle_threads", "tie_units_left", "tie_influence_max", "exact_pool", "exact_tiles", "tie_units_strict", "tie_prone_maps", "tie_units_tied", "tie_units_by_scale")
+              "ms_rays", "ms_rows", "nar", "ms_dispersion", "curves", "changes_total", "tie_units", "exact_units", "exact_pops", "ms_exact", "field_slots", "footprint_mb", "bundle_size", "bundles", "bundled_units", "bundle_slots", "bundle_threads", "tie_units_left", "tie_influence_max", "exact_pool", "exact_tiles", "tie_units_strict", "tie_prone_maps", "tie_units_tied", "tie_units_by_scale", "handoffs_replayed")
 
 _f32, _i32, _vp = C.c_float, C.c_int, C.c_void_p
 _lib = None

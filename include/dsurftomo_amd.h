@@ -59,6 +59,8 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *     tie_scale_guard          [1]     a unit that holds a tie and whose travel times lie outside the envelope in which the fixed point's tie errors were measured to stay
  *                                      within tie_tolerance (26 ulps of the time on grids up to 1025 nodes per side, growing with the grid beyond) is flagged; 0 = off
  *     tie_tolerance            [1e-4]  seconds: the bar that envelope is held to (a lower value marches more units)
+ *     handoff_replay           [1]     a unit in which a node ranks equal with the one that ended the refined stage, and the choice changes what the coarse grid receives, has its
+ *                                      refined box (<= 129^2 nodes) marched literally and is handed off from that (up to 64 units a launch); 0 = such a unit is flagged (marched whole)
  *     tie_sum_threshold        [0]     seconds: a unit whose ties' influences add up to more than this is flagged; 0 = off (measured: separates nothing, see dsa_unit_tie_sums)
  *     tie_count_threshold      [0]     a unit holding more ties with an influence than this is flagged; 0 = off
  *     tie_frozen_bundles       [0]     1 = every member of a bundle that froze a cycle is flagged (a unit-by-unit solve that froze one always is)
@@ -320,6 +322,8 @@ enum { DSA_STAT_MS_TOTAL = 0, DSA_STAT_MS_FIM_COARSE, DSA_STAT_MS_FIM_REFINED, D
                                          reference's to ~1e-4 s statistically, not by construction (DESIGN.md "Ties") */
        DSA_STAT_TIE_UNITS_BY_SCALE,   /* of DSA_STAT_TIE_UNITS: flagged because they hold a tie and their travel times lie outside the envelope in which the
                                          fixed point's tie errors were measured to stay within the tolerance (option tie_scale_guard) */
+       DSA_STAT_HANDOFFS_REPLAYED,    /* units whose refined box was marched literally behind the hand-off's probe (a node ranking equal with the one that ended the refined
+                                         stage changed what the coarse grid receives: the reference's own tree decides; option handoff_replay) */
        DSA_STAT_COUNT };
 int dsa_get_stats(const dsa_engine* e, double* out /* DSA_STAT_COUNT + 8: counters, then 8 phase-clock sums (probe builds) */);
 

@@ -33,7 +33,7 @@ def pytest_terminal_summary(terminalreporter):
 # the product's defaults of the options tests change (csrc/engine.h: kDefaultExactTies, kDefaultTieThreshold); every GPU test starts from them
 PRODUCT_DEFAULTS = (("exact_ties", 1), ("tie_threshold", 2e-5), ("tie_detect", 1), ("bundle", 1), ("bundle_pool", 0), ("field_pool", 0), ("max_chunk", 0),
                     ("exact_lds_slots", 0), ("exact_pool", 0), ("bundle_members_per_lane", 0), ("bundle_threads", 0), ("bundle_far_all", 0), ("bundle_tail", 1), ("tie_list", 1), ("exact_tiles", 0), ("exact_tile_cap", 0), ("bundle_refined", 1), ("ray_lanes", 0), ("exact_heap_blocked", 1),
-                    ("tie_map_strict", 1), ("tie_scale_guard", 1), ("tie_tolerance", 1e-4), ("tie_sum_threshold", 0), ("tie_count_threshold", 0), ("tie_frozen_bundles", 0))
+                    ("tie_map_strict", 1), ("tie_scale_guard", 1), ("handoff_replay", 1), ("tie_tolerance", 1e-4), ("tie_sum_threshold", 0), ("tie_count_threshold", 0), ("tie_frozen_bundles", 0))
 
 
 @pytest.fixture(autouse=True)

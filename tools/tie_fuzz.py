@@ -47,7 +47,7 @@ for ci, (nx, nsrc, nper, kind) in enumerate(CONFIGS):
                    escapees=int((d[left] > 1e-4).sum()), beyond_5e5=int((d[left] > 5e-5).sum()), worst=float(d[left].max()) if left.any() else 0.0,
                    clean=int(clean.sum()), clean_differ=int((d[clean] > 0).sum()), clean_worst=float(d[clean].max()) if clean.any() else 0.0,
                    froze=int((fr > 0).sum()), left_froze_differ=int((d[left & (fr > 0)] > 0).sum()))
-        print(f"N={e.nnx:5d} {kind:8s} seed+{seed}: {n} units, {int(st['tie_prone_maps'])}/{nper} maps tie-prone, marched {rec['marched']} ({int(st.get('tie_units_by_scale', 0))} by the size of their times; not bit-identical to exact_ties=2: {rec['marched_differ']}); "
+        print(f"N={e.nnx:5d} {kind:8s} seed+{seed}: {n} units, {int(st['tie_prone_maps'])}/{nper} maps tie-prone, marched {rec['marched']} ({int(st.get('tie_units_by_scale', 0))} by the size of their times; refined boxes replayed at the hand-off {int(st.get('handoffs_replayed', 0))}; not bit-identical to exact_ties=2: {rec['marched_differ']}); "
               f"left to the fixed point {rec['left']} (holding a tie with an influence {rec['left_tied']}): beyond 1e-4 s {rec['escapees']}, beyond 5e-5 {rec['beyond_5e5']}, worst {rec['worst']:.3g} s; "
               f"no tie seen {rec['clean']}, of them not bit-identical {rec['clean_differ']} (worst {rec['clean_worst']:.3g} s); units whose bundle froze a cycle {rec['froze']} (left alone and not bit-identical: {rec['left_froze_differ']}) | {n / (st['ms_total'] / 1e3):.0f} solves/s", flush=True)
         grp = "smooth" if kind in ("smooth", "homog") else "tie-prone"
