@@ -320,3 +320,44 @@ def test_units_outside_the_measured_envelope_are_marched(exact):
         assert st0["tie_units_by_scale"] == 0 and st0["tie_units_tied"] > 0
         parity_log.add(f"scale guard N={e.nnx} smooth, bar {tol:g} s: {int(marched.sum())} of {n} units marched ({int(st['tie_units_by_scale'])} by the size of their times), "
                        f"worst |dt| against exact_ties = 2 {worst:.3g} s; guard off: {int(st0['tie_units_tied'])} tied units left to the fixed point")
+
+
+def test_a_tie_at_the_hand_off_is_resolved_by_the_refined_march(exact):
+    """Option handoff_replay (round 6): a node of the refined box that ranks equal with the node that ended the refined stage was alive at the exit or not as
+    the reference's tree had it; where that changes what the coarse grid receives (a status or a time at a lattice node) the refined box is marched
+    literally and the hand-off starts from that state -- the unit stays with the fixed point.  The call of tools/tie_fuzz.py that showed 4.5e-4 s when such
+    changes were only counted (161^2, dicing 5, a third of the sources on node lines, sources up to the edge): with the replay nothing is marched and every
+    receiver time is within the bar of exact_ties = 2; without it the same units are flagged and marched."""
+    import sys
+    sys.path.insert(0, os.path.join(L.ROOT, "tools"))
+    import fuzz_sources
+    keep, env = synth.sources, {k: os.environ.get(k) for k in ("DSA_FUZZ_SNAP", "DSA_FUZZ_INNER")}
+    os.environ["DSA_FUZZ_SNAP"] = "1"; os.environ["DSA_FUZZ_INNER"] = "1.0"
+    try:
+        fuzz_sources.install()
+        nx, nsrc, nper, nrec, gd = 35, 1000, 16, 32, 5
+        u = synth.units(nx, nsrc, nper, nrec, gd=gd, seed=synth.SEED + 2253)
+    finally:
+        synth.sources = keep
+        for k, v in env.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    e = exact
+    pv = np.stack([synth.medium(nx, "smooth", p) for p in range(nper)])
+    e.set_maps(nx, nx, synth.GOXD, synth.GOZD, synth.DVD, synth.DVD, pv, dicing=gd)
+    n = nsrc * nper
+    e.set_option("exact_ties", 2); e.plan(**u); tx = e.solve().reshape(n, nrec)
+    e.set_option("exact_ties", 1); e.plan(**u); t1 = e.solve().reshape(n, nrec)
+    st = e.stats()
+    d = np.abs(t1.astype(np.float64) - tx.astype(np.float64)).max(axis=1)
+    assert st["handoffs_replayed"] >= 1 and st["exact_units"] == 0
+    assert d.max() <= TOL
+    e.set_option("handoff_replay", 0); e.plan(**u); t0 = e.solve().reshape(n, nrec)
+    st0 = e.stats()
+    flags, _ = e.unit_ties()
+    marched = (flags & 2) != 0
+    assert st0["handoffs_replayed"] == 0 and st0["exact_units"] >= 1
+    # the units the old way marches are the reference's bits; the replay leaves the same units within the bar (and, where no other tie is met, on the same bits)
+    same = (bits(t1[marched]) == bits(tx[marched])).all(axis=1)
+    parity_log.add(f"hand-off replay N={e.nnx} smooth, dicing 5, sources on node lines: {int(st['handoffs_replayed'])} refined boxes marched, 0 units marched whole (without the replay: {int(st0['exact_units'])}); "
+                   f"worst |dt| against exact_ties = 2 {d.max():.3g} s; of the {int(marched.sum())} units the old way marches {int(same.sum())} are bit-identical to the march after the replay")
