@@ -262,8 +262,9 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  *                  - a unit holding a tie whose influence exceeds "tie_threshold";
  *                  - "tie_map_strict" (on): on a map where some unit holds such a tie -- a tie-prone medium: sharp contrasts, second-order stencils
  *                    switching along ridges, where a one-ulp difference grows downstream -- every unit holding a tie with ANY influence;
- *                  - a unit in which the hand-off's tie decides whether a node the coarse grid receives is alive (a difference of first order, not
- *                    an ulp) -- except where the refined box's slowness does not vary along x (a 1-D model: the two choices are mirror images);
+ *                  - (a tie at the hand-off that changes what the coarse grid receives -- a difference of first order, not an ulp -- is not flagged but
+ *                    resolved: the refined box is marched literally and handed off again, "handoff_replay"; only a full list of such units, 64 a launch,
+ *                    flags the rest; where the refined box's slowness does not vary along x -- a 1-D model: the two choices are mirror images -- it counts);
  *                  - a unit whose band march could not leave its tree a heap, or whose bundle froze a cycle ("tie_frozen_bundles");
  *                  - "tie_scale_guard" (on): a unit holding a tie whose times lie outside the MEASURED ENVELOPE.  Downstream of one-ulp ties the fixed
  *                    point's field differs from the reference's by a number of ulps of the travel time that grows with the grid -- at a receiver at
