@@ -60,7 +60,7 @@ int dsa_set_memory_budget(dsa_engine* e, size_t bytes);
  *                                      within tie_tolerance (26 ulps of the time on grids up to 1025 nodes per side, growing with the grid beyond) is flagged; 0 = off
  *     tie_tolerance            [1e-4]  seconds: the bar that envelope is held to (a lower value marches more units)
  *     handoff_replay           [1]     a unit in which a node ranks equal with the one that ended the refined stage, and the choice changes what the coarse grid receives, has its
- *                                      refined box (<= 129^2 nodes) marched literally and is handed off from that (up to 64 units a launch); 0 = such a unit is flagged (marched whole)
+ *                                      refined box (<= 129^2 nodes) marched literally and is handed off from that (up to 256 units a launch); 0 = such a unit is flagged (marched whole)
  *     tie_sum_threshold        [0]     seconds: a unit whose ties' influences add up to more than this is flagged; 0 = off (measured: separates nothing, see dsa_unit_tie_sums)
  *     tie_count_threshold      [0]     a unit holding more ties with an influence than this is flagged; 0 = off
  *     tie_frozen_bundles       [0]     1 = every member of a bundle that froze a cycle is flagged (a unit-by-unit solve that froze one always is)
@@ -263,7 +263,7 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  *                  - "tie_map_strict" (on): on a map where some unit holds such a tie -- a tie-prone medium: sharp contrasts, second-order stencils
  *                    switching along ridges, where a one-ulp difference grows downstream -- every unit holding a tie with ANY influence;
  *                  - (a tie at the hand-off that changes what the coarse grid receives -- a difference of first order, not an ulp -- is not flagged but
- *                    resolved: the refined box is marched literally and handed off again, "handoff_replay"; only a full list of such units, 64 a launch,
+ *                    resolved: the refined box is marched literally and handed off again, "handoff_replay"; only a full list of such units, 256 a launch,
  *                    flags the rest; where the refined box's slowness does not vary along x -- a 1-D model: the two choices are mirror images -- it counts);
  *                  - a unit whose band march could not leave its tree a heap, or whose bundle froze a cycle ("tie_frozen_bundles");
  *                  - "tie_scale_guard" (on): a unit holding a tie whose times lie outside the MEASURED ENVELOPE.  Downstream of one-ulp ties the fixed
