@@ -668,7 +668,7 @@ def main():
                              "note": "no tie on these maps reaches tie_threshold (largest: one or two ulps of the travel time), so nothing is marched; the units that hold such "
                                      "small ties stay with the fixed point, whose times are the reference's to 1e-4 s by measurement, not by construction: "
                                      "secondary.headline_all_receivers checks every receiver time of the call against exact_ties = 2.  The measurement behind it is an envelope -- at "
-                                     "most 26 ulps of the travel time at a receiver on grids up to 1025^2, i.e. within 1e-4 s while the times stay below 64 s, as this call's do; a unit "
+                                     "most 26 ulps of the travel time at a receiver on grids up to 1025^2 in all but about one unit in 400 000 (36 ulps seen), i.e. within 1e-4 s while the times stay below 64 s, as this call's do; a unit "
                                      "that holds a tie and lies outside (longer paths, larger grids) is marched (option tie_scale_guard; DESIGN.md 'Ties')"},
         }
         if not args.no_cpu_baseline:

@@ -35,7 +35,7 @@ constexpr int kDefaultTieCountThreshold = 0;
 constexpr int kDefaultTieFrozenBundles = 0;
 constexpr int kDefaultTieMapStrict = 1;
 constexpr int kHandoffReplayCap = 256;       // units of a launch whose refined box the hand-off may march literally (the rest of such units are flagged: the whole unit marched)
-constexpr float kTieUlpsAt1025 = 26.0f;      // what a receiver time of the fixed point differs by from the reference's downstream of one-ulp ties, at most, in ulps, on grids up to 1025 nodes per side (measured: 26 = 9.92e-5 s at 32-64 s, the worst of 2.2 M fuzzed units; Engine::tie_verdicts)
+constexpr float kTieUlpsAt1025 = 26.0f;      // what a receiver time of the fixed point differs by from the reference's downstream of one-ulp ties, at most, in ulps, on grids up to 1025 nodes per side (measured: 26 = 9.92e-5 s at 32-64 s, the worst of the first 2.2 M fuzzed units; two units of the next 0.7 M reached 36 and 27: not a bound; Engine::tie_verdicts)
 // Rays of a launch up to which four lanes trace a ray together (ray_kernels.hip: launch_rays; profiles/r05_ab_rays.log)
 constexpr int kRayGroupMax = 81920;
 

@@ -268,7 +268,8 @@ int dsa_ray_diagnostics(const dsa_engine* e, long long* clamped, int* first_unit
  *                  - a unit whose band march could not leave its tree a heap, or whose bundle froze a cycle ("tie_frozen_bundles");
  *                  - "tie_scale_guard" (on): a unit holding a tie whose times lie outside the MEASURED ENVELOPE.  Downstream of one-ulp ties the fixed
  *                    point's field differs from the reference's by a number of ulps of the travel time that grows with the grid -- at a receiver at
- *                    most 26 ulps on grids up to 1025 nodes per side (2.2 M fuzzed units; the worst, 9.92e-5 s, meets the bar with no margin: lower "tie_tolerance" for one), 35 at 2049^2, 110 at 4097^2 -- so against the absolute bar
+ *                    most 26 ulps on grids up to 1025 nodes per side in 2.2 M fuzzed units (9.92e-5 s), 36 and 27 ulps in two units of the next 0.7 M (1.37e-4 s, 1.03e-4 s: at 1025^2 with
+ *                    times of 32-64 s about one unit in 400 000 ends beyond the bar -- the tolerance is statistical there; lower "tie_tolerance" for a margin), 35 at 2049^2, 110 at 4097^2 -- so against the absolute bar
  *                    ("tie_tolerance", 1e-4 s) it is the size of the times that decides: a unit whose farthest receiver (great-circle distance x the
  *                    map's mean slowness) lies at 64 s or beyond on grids up to 1025^2 -- 32 s at 2049^2, 16 s at 4097^2 -- is marched.
  *                What stays with the fixed point: units without a tie (measured: bit-identical to the reference but for 5 of 83 000 such units, off by an
